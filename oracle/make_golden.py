@@ -1,0 +1,400 @@
+"""Generates tests/golden/*.pt from the REAL reference (build container only).
+
+    python oracle/make_golden.py            # rewrites every fixture
+
+Each fixture is plain data: inputs, reference-format checkpoints (args + state_dict) and the
+outputs / gradients the reference produced.  Tests then check (a) the oracle restatement and
+(b) the HIP product path against them, so the GPU box never needs /root/reference.
+Fixture ids follow SURVEY.md section 8c (G1..G10).
+"""
+import copy
+import math
+import os
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import refharness  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
+INTRINSIC = [[615.1436, 0.0, 315.3623, 0.0], [0.0, 615.4991, 251.5415, 0.0], [0.0, 0.0, 1.0, 0.0]]
+
+
+def save(name, obj):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + '.pt')
+    torch.save(obj, path)
+    print(f'{name}: {os.path.getsize(path) / 1024:.0f} KiB')
+
+
+def cam_dict(c):
+    return {'K': c.intrinsic.detach().clone(), 'viewport': c.viewport.detach().clone(),
+            'log_q': c.log_quaternion.detach().clone(), 't': c.translation.detach().clone(),
+            'z_span': c.z_span, 'width': c.width, 'height': c.height}
+
+
+def rand_cameras(lf, n, zoomed_size=None, dist=None, seed=0):
+    from latentfusion.modules.geometry import Camera
+    g = torch.Generator().manual_seed(seed)
+    log_q = torch.randn(n, 3, generator=g) * 0.7
+    t = torch.cat((torch.randn(n, 2, generator=g) * 0.05, 1.0 + 0.2 * torch.rand(n, 1, generator=g)), 1)
+    K = torch.tensor(INTRINSIC).unsqueeze(0).expand(n, -1, -1).clone()
+    cam = Camera(K, None, log_quaternion=log_q, translation=t)
+    if zoomed_size is not None:
+        cam = cam.zoom(None, zoomed_size, dist)
+    return cam
+
+
+def syn_ckpts(lf, S, C, fuser='gru', seed=0, **ph_kw):
+    from latentfusion.recon.models import Sculptor, Photographer
+    from latentfusion.recon import fusion
+    torch.manual_seed(seed)
+    img = [[16, 32], [32, 16]]
+    sc = Sculptor(in_size=S, image_config=img, camera_config=[C, C], object_config=[C, C],
+                  projection_type='factor', input_color=True, input_depth=False, input_mask=True,
+                  scale_mode='nearest').eval()
+    kw = dict(in_size=S, image_config=img, camera_config=[C, C], object_config=[], projection_type='factor',
+              predict_depth=True, predict_mask=True, scale_mode='nearest')
+    kw.update(ph_kw)
+    ph = Photographer(**kw).eval()
+    fu = fusion.get_fuser(fuser, C, 1.0).eval()
+    # perturb the zero-initialised biases so that bias handling is actually pinned
+    for m in (sc, ph, fu):
+        for k, p in m.named_parameters():
+            if k.endswith('bias'):
+                p.data.normal_(0, 0.1)
+    return sc, fu, ph
+
+
+def ck(module):
+    d = module.create_checkpoint()
+    d = {k: (copy.deepcopy(v) if k != 'state_dict' else {n: t.clone() for n, t in v.items()})
+         for k, v in d.items()}
+    return d
+
+
+def synth_obs(lf, V, seed):
+    """SURVEY section 8d synthetic observation."""
+    from latentfusion.modules.geometry import Camera
+    from latentfusion.observation import Observation
+    from latentfusion import three
+    torch.manual_seed(seed)
+    q = three.orientation.evenly_distributed_quats(V)
+    t = torch.tensor([[0.0, 0.0, 1.0]]).expand(V, -1)
+    E = three.to_extrinsic_matrix(t, q)
+    K = torch.tensor(INTRINSIC).unsqueeze(0).expand(V, -1, -1).clone()
+    cam = Camera(K, E)
+    color = torch.rand(V, 3, 480, 640)
+    yy, xx = torch.meshgrid(torch.arange(480.0), torch.arange(640.0), indexing='ij')
+    disc = (((xx - 315) ** 2 + (yy - 251) ** 2) <= 150 ** 2).float()
+    mask = disc.view(1, 1, 480, 640).expand(V, -1, -1, -1).clone()
+    depth = (1.0 + 0.1 * torch.rand(V, 1, 480, 640)) * mask
+    return Observation(color, depth, mask, cam)
+
+
+def obs_dict(o, lite=False):
+    """lite: drop the colour frame (unused by the pose loss) and store the mask as bool."""
+    if lite:
+        return {'color': None, 'depth': o.depth.clone(), 'mask': o.mask.bool(), 'cam': cam_dict(o.camera)}
+    return {'color': o.color.clone(), 'depth': o.depth.clone(), 'mask': o.mask.clone(), 'cam': cam_dict(o.camera)}
+
+
+# ---------------------------------------------------------------------------------------------
+def g1_camera(lf):
+    from latentfusion.three import quaternion as Q
+    from latentfusion import three
+    cam = rand_cameras(lf, 5, seed=1)
+    cam.viewport = torch.tensor([[100., 80, 420, 400], [0, 0, 640, 480], [50.5, 20.25, 300, 270],
+                                 [-30, -40, 500, 490], [200, 100, 456, 356]])
+    g = torch.Generator().manual_seed(2)
+    qa, qb = torch.randn(6, 4, generator=g), torch.randn(6, 4, generator=g)
+    rot = Q.quat_to_mat(qa)
+    depth = 0.5 + torch.rand(5, 1, 6, 7, generator=g)
+    zcam = cam.zoom(None, 32, 2.5)
+    small = torch.rand(5, 1, 16, 16, generator=g)
+    un_n, _ = zcam.uncrop(small, scale_mode='nearest')
+    un_b, _ = zcam.uncrop(small, scale_mode='bilinear')
+    torch.manual_seed(7)
+    edq = three.orientation.evenly_distributed_quats(8)
+    torch.manual_seed(7)
+    edq_hu = three.orientation.evenly_distributed_quats(6, hemisphere=True, upright=True)
+    save('g1_camera', {
+        'cam': cam_dict(cam), 'quaternion': cam.quaternion.clone(), 'R': cam.rotation_matrix.clone(),
+        'obj_to_cam': cam.obj_to_cam.clone(), 'cam_to_obj': cam.cam_to_obj.clone(),
+        'znear': cam.znear.clone(), 'zfar': cam.zfar.clone(), 'position': cam.position.clone(),
+        'zoom_viewport': zcam.viewport.clone(), 'depth': depth,
+        'depth_norm': cam.normalize_depth(depth), 'depth_denorm': cam.denormalize_depth(depth * 2 - 1),
+        'qa': qa, 'qb': qb, 'qmul': Q.qmul(qa, qb), 'qa_mat': rot, 'mat_to_quat': Q.mat_to_quat(rot),
+        'qlog': Q.qlog(qa), 'qexp3': Q.qexp(qa[:, 1:]), 'angdist': Q.angular_distance(qa, qb),
+        'small': small, 'uncrop_nearest': un_n[:, :, ::4, ::4].clone(), 'uncrop_bilinear': un_b[:, :, ::4, ::4].clone(),
+        'edq_seed': 7, 'edq8': edq, 'edq6_hemi_upright': edq_hu,
+    })
+    # full-resolution crop fixture separately (input image is large): use a low-res frame instead
+    from latentfusion.modules.geometry import Camera
+    cam2 = Camera(cam.intrinsic * torch.tensor([[[0.1], [0.1], [1.0]]]), None, log_quaternion=cam.log_quaternion,
+                  translation=cam.translation, width=64, height=48)
+    img2 = torch.rand(5, 2, 48, 64, generator=g)
+    c_b, zc2 = cam2.zoom(img2, 16, 2.5, scale_mode='bilinear')
+    c_n, _ = cam2.zoom(img2, 16, 2.5, scale_mode='nearest')
+    save('g1_zoom', {'cam': cam_dict(cam2), 'img': img2, 'crop_bilinear': c_b, 'crop_nearest': c_n,
+                     'zoom_viewport': zc2.viewport.clone(), 'target_size': 16, 'target_dist': 2.5})
+
+
+def g2_resample(lf):
+    from latentfusion.modules.geometry import CameraToObjectTransform, ObjectToCameraTransform
+    B, C, S = 3, 3, 8
+    cam = rand_cameras(lf, B, zoomed_size=S, dist=2.0, seed=3)
+    g = torch.Generator().manual_seed(4)
+    out = {'cam': cam_dict(cam), 'cube_size': 1.0}
+    for name, T in (('o2c', ObjectToCameraTransform(1.0)), ('c2o', CameraToObjectTransform(1.0))):
+        vol = torch.randn(B, C, S, S, S, generator=g, requires_grad=True)
+        w = torch.randn(B, C, S, S, S, generator=g)
+        # The reference's C2O divides pixel coords in place (geometry.py:636), so it is NOT
+        # differentiable w.r.t. the camera; only O2C gets camera gradients.
+        want_cam_grad = name == 'o2c'
+        cam.log_quaternion = cam.log_quaternion.detach().requires_grad_(want_cam_grad)
+        cam.translation = cam.translation.detach().requires_grad_(want_cam_grad)
+        cam.viewport = cam.viewport.detach().requires_grad_(want_cam_grad)
+        y = T(vol, cam)
+        (y * w).sum().backward()
+        out[name] = {'vol': vol.detach().clone(), 'w': w, 'out': y.detach().clone(), 'g_vol': vol.grad.clone()}
+        if want_cam_grad:
+            out[name].update({'g_log_q': cam.log_quaternion.grad.clone(), 'g_t': cam.translation.grad.clone(),
+                              'g_viewport': cam.viewport.grad.clone()})
+    save('g2_resample', out)
+
+
+def g3_block(lf):
+    from latentfusion.modules.blocks import Block
+    from latentfusion.modules import EqualizedConv2d, EqualizedConv3d
+    g = torch.Generator().manual_seed(5)
+    out = {}
+    for dims, conv in ((3, EqualizedConv3d), (2, EqualizedConv2d)):
+        for mode, factor in (('nearest', 1.0), ('nearest', 2.0), ('bilinear', 0.5), ('bilinear', 2.0)):
+            torch.manual_seed(6)
+            m = mode
+            if dims == 3 and mode == 'bilinear':
+                m = 'trilinear'
+            blk = Block(5, 7, conv_module=conv, scale_factor=factor, scale_mode=m).eval()
+            for k, p in blk.named_parameters():
+                if k.endswith('bias'):
+                    p.data.normal_(0, 0.1)
+            x = torch.randn(2, 5, *([8] * dims), generator=g, requires_grad=True)
+            y = blk(x)
+            w = torch.randn(y.shape, generator=g)
+            (y * w).sum().backward()
+            out[f'{dims}d_{mode}_{factor}'] = {
+                'sd': {k: v.detach().clone() for k, v in blk.state_dict().items()}, 'x': x.detach().clone(),
+                'w': w, 'y': y.detach().clone(), 'g_x': x.grad.clone(),
+                'g_w1': blk.conv1.module.weight.grad.clone(), 'g_b1': blk.conv1.bias.grad.clone(),
+                'scale': factor, 'mode': mode}
+    save('g3_block', out)
+
+
+def g4_fusers(lf):
+    from latentfusion.recon import fusion
+    from latentfusion.modules.geometry import Camera
+    g = torch.Generator().manual_seed(8)
+    V, C, S = 3, 4, 8
+    z = torch.randn(1, V, C, S, S, S, generator=g)
+    cam = rand_cameras(lf, V, zoomed_size=S, dist=2.0, seed=9)
+    out = {'z': z, 'cam': cam_dict(cam)}
+    for pool in ('mean', 'max', 'abs_max', 'median'):
+        f = fusion.get_fuser('pool:' + pool, C, 1.0)
+        out['pool_' + pool] = f(z, None, None, cam)[0].clone()
+    out['concat'] = fusion.get_fuser('concat', C, 1.0)(z, None, None, cam)[0].clone()
+    for kind in ('gru', 'lstm'):
+        torch.manual_seed(10)
+        f = fusion.get_fuser(kind, C, 1.0).eval()
+        for k, p in f.named_parameters():
+            if k.endswith('bias'):
+                p.data.normal_(0, 0.1)
+        with torch.no_grad():
+            out[kind] = {'ck': ck(f), 'out': f(z, None, None, cam)[0].clone()}
+    torch.manual_seed(11)
+    f = fusion.get_fuser('blend', C, 1.0, block_config=[[5, 8], [8, 4]]).eval()
+    zmid = torch.randn(1, V, C, S, S, S, generator=g)
+    with torch.no_grad():
+        out['blend'] = {'ck': ck(f), 'z_cam_mid': zmid, 'out': f(z, [zmid], None, cam)[0].clone()}
+    save('g4_fusers', out)
+
+
+def g5_decode(lf):
+    S, C, N = 16, 8, 3
+    out = {}
+    variants = {'factor': {}, 'sum': {'projection_type': 'sum'},
+                'occlusion': {'occlusion_config': [[9, 8], [8, 8]], 'object_config': [C, C]}}
+    for name, kw in variants.items():
+        _, _, ph = syn_ckpts(lf, S, C, seed=12, **kw)
+        if name == 'sum':
+            # 'sum' leaves C channels for the decoder; image_config[0][0] must equal C
+            from latentfusion.recon.models import Photographer
+            torch.manual_seed(12)
+            ph = Photographer(in_size=S, image_config=[[C, 16], [16, 8]], camera_config=[C, C], object_config=[],
+                              projection_type='sum', scale_mode='nearest').eval()
+        dist = lf.recon.utils.optimal_camera_dist(615.4991, S, 0.5, slack=128 / S)
+        cam = rand_cameras(lf, N, zoomed_size=S, dist=dist, seed=13)
+        cam.log_quaternion = cam.log_quaternion.detach().requires_grad_(True)
+        cam.translation = cam.translation.detach().requires_grad_(True)
+        cam.viewport = cam.viewport.detach().requires_grad_(True)
+        g = torch.Generator().manual_seed(14)
+        z_obj = torch.randn(1, 1, C, S, S, S, generator=g)
+        y, lat, zd = ph.decode(z_obj, cam, return_latent=True, apply_mask=True)
+        wd = torch.randn(y['depth_logits'].shape, generator=g)
+        wm = torch.randn(y['mask_logits'].shape, generator=g)
+        ((y['depth_logits'] * wd).sum() + (y['mask_logits'] * wm).sum()).backward()
+        out[name] = {'ck': ck(ph), 'cam': cam_dict(cam), 'z_obj': z_obj, 'wd': wd, 'wm': wm,
+                     'y': {k: v.detach().clone() for k, v in y.items()}, 'latent': lat.detach().clone(),
+                     'z_depth': None if zd is None else zd.detach().clone(),
+                     'g_log_q': cam.log_quaternion.grad.clone(), 'g_t': cam.translation.grad.clone(),
+                     'g_viewport': cam.viewport.grad.clone()}
+    save('g5_decode', out)
+
+
+def g6_loss(lf):
+    from latentfusion.pose.estimation import default_pose_loss
+    from latentfusion.observation import Observation
+    N, S = 3, 16
+    target = synth_obs(lf, 1, seed=15)
+    # make some invalid pixels: mask>0.1 but depth==0
+    target.depth[:, :, 240:260, 300:340] = 0.0
+    dist = lf.recon.utils.optimal_camera_dist(615.4991, S, 0.5, slack=128 / S)
+    cam = rand_cameras(lf, N, zoomed_size=S, dist=dist, seed=16)
+    cam.viewport = (cam.viewport * torch.tensor([[1.0, 1.0, 0.6, 0.6]]) + torch.tensor([[150.0, 100, 0, 0]])) \
+        .detach().requires_grad_(True)
+    cam.translation = cam.translation.detach().requires_grad_(True)
+    g = torch.Generator().manual_seed(17)
+    depth_n = (torch.rand(N, 1, S, S, generator=g) * 2 - 1).requires_grad_(True)
+    logits = (torch.randn(N, 1, S, S, generator=g) * 3).requires_grad_(True)
+    z_depth = cam.denormalize_depth(depth_n)
+    ld = default_pose_loss(target, z_depth, logits, cam)
+    wts = {'depth': 1.0, 'ov_depth': 0.3, 'iou': 0.7, 'mask': 0.5}
+    total = sum(wts[k] * v for k, v in ld.items())
+    total.mean().backward()
+    save('g6_loss', {'target': obs_dict(target, lite=True), 'cam': cam_dict(cam), 'depth_n': depth_n.detach().clone(),
+                     'logits': logits.detach().clone(), 'weights': wts,
+                     'loss': {k: v.detach().clone() for k, v in ld.items()},
+                     'g_depth_n': depth_n.grad.clone(), 'g_logits': logits.grad.clone(),
+                     'g_viewport': cam.viewport.grad.clone(), 'g_t': cam.translation.grad.clone()})
+
+
+def _model(lf, S, C, fuser, seed):
+    from latentfusion.recon.inference import LatentFusionModel
+    sc, fu, ph = syn_ckpts(lf, S, C, fuser=fuser, seed=seed)
+    dist = lf.recon.utils.optimal_camera_dist(615.4991, S, 0.5, slack=128 / S)
+    return LatentFusionModel(sc, fu, ph, dist, 'cpu'), (ck(sc), ck(fu), ck(ph)), dist
+
+
+def g7_g10_loop(lf):
+    from latentfusion.pose import estimation, utils as pu
+    import tomli
+    S, C, V, N = 16, 8, 4, 8
+    for fuser in ('gru', 'pool:mean'):
+        tag = fuser.replace(':', '_')
+        model, cks, dist = _model(lf, S, C, fuser, seed=20)
+        ref_obs = synth_obs(lf, V, seed=21)
+        target = synth_obs(lf, 1, seed=22)
+        z_obj = model.build_latent_object(ref_obs)
+        pre = model.preprocess_observation(ref_obs)
+        # G10: encode
+        save(f'g10_encode_{tag}', {'sculptor': cks[0], 'fuser': cks[1], 'camera_dist': dist,
+                                   'obs_pre': {'color': pre.color.clone(), 'depth': pre.depth.clone(),
+                                               'mask': pre.mask.clone(), 'cam': cam_dict(pre.camera)},
+                                   'z_obj': z_obj.clone()})
+        if fuser != 'gru':
+            continue
+        # raw->preprocessed pin for Observation.zoom/prepare/normalize (small crop of inputs is enough)
+        with open('/root/reference/configs/adam_quick.toml', 'rb') as f:
+            cfg = tomli.load(f)
+        cfg['args']['num_iters'] = 10
+        torch.manual_seed(23)
+        init = pu.sample_cameras_with_estimate(N, target.camera)
+        est = estimation.load_from_config(copy.deepcopy(cfg), model, track_stats=True, return_camera_history=True)
+        best, stats, hist = est.estimate(z_obj, target, camera=init)
+        save('g7_adam_trace', {
+            'sculptor': cks[0], 'fuser': cks[1], 'photographer': cks[2], 'camera_dist': dist, 'cfg': cfg,
+            'z_obj': z_obj.clone(), 'target': obs_dict(target, lite=True), 'init': cam_dict(init), 'init_seed': 23,
+            'rank_loss': stats['rank_loss'].clone(), 'depth_loss': stats['depth_loss'].clone(),
+            'ov_depth_loss': stats['ov_depth_loss'].clone(), 'iou_loss': stats['iou_loss'].clone(),
+            'mask_loss': stats['mask_loss'].clone(),
+            'argmin': torch.argmin(stats['rank_loss'], dim=1),
+            'hist_log_q': torch.stack([c.log_quaternion for _, c in hist]),
+            'hist_t': torch.stack([c.translation for _, c in hist]),
+            'best': cam_dict(best)})
+        # G8: one cross-entropy refine step with injected sample cameras
+        torch.manual_seed(24)
+        cams = pu.sample_cameras_with_estimate(6, target.camera, hemisphere=True, upright=True)
+        ce = estimation.CrossEntropyPoseEstimator(
+            model=model, num_samples=24, num_elites=5, num_iters=3, num_gmm_components=2, learning_rate=0.9,
+            sample_flipped=True, ranking_size=4, loss_weights={'depth': 1.0, 'ov_depth': 0.2, 'iou': 0.1, 'mask': 0.3})
+        from latentfusion.modules.geometry import Camera
+        allc = Camera.cat([cams, pu.flip_camera(cams, axis=(0.0, 0.0, 1.0)), pu.flip_camera(cams, axis=(0.0, 1.0, 0.0)),
+                           pu.flip_camera(cams, axis=(1.0, 0.0, 0.0))])
+        zd, zl, _, zc = ce._render_observation(z_obj, allc)
+        ld = ce.loss_func(target, zd, zl, zc)
+        loss = sum(estimation.weigh_losses(ld, ce.loss_weights).values())
+        save('g8_ce_step', {'cams': cam_dict(cams), 'all_cams': cam_dict(allc), 'zoom_viewport': zc.viewport.clone(),
+                            'loss': loss.clone(), 'order': torch.argsort(loss), 'weights': dict(ce.loss_weights),
+                            'depth_crop': zd.clone(), 'mask_logits_crop': zl.clone()})
+
+
+def g9_ibr(lf):
+    from latentfusion import ibr
+    S, C = 16, 8
+    _, _, ph = syn_ckpts(lf, S, C, seed=30)
+    dist = lf.recon.utils.optimal_camera_dist(615.4991, S, 0.5, slack=128 / S)
+    cam_in = rand_cameras(lf, 3, zoomed_size=S, dist=dist, seed=31)
+    cam_out = rand_cameras(lf, 2, zoomed_size=S, dist=dist, seed=32)
+    g = torch.Generator().manual_seed(33)
+    z_obj = torch.randn(1, 1, C, S, S, S, generator=g)
+    img = torch.rand(1, 3, 3, S, S, generator=g)
+    with torch.no_grad():
+        y, lat = ibr.render_latent_ibr2(ph, z_obj, cam_in, cam_out, img, p=0.5, apply_mask=True)
+        y_in, _, _ = ph.decode(z_obj, cam_in, apply_mask=True)
+        y_out, _, _ = ph.decode(z_obj, cam_out, apply_mask=True)
+        reproj, dreproj = ibr.reproject_views(img[0], y_in['depth'][0], y_out['depth'][0], cam_in, cam_out)
+    save('g9_ibr', {'ck': ck(ph), 'cam_in': cam_dict(cam_in), 'cam_out': cam_dict(cam_out), 'z_obj': z_obj,
+                    'image_in': img, 'color': y['color'].clone(), 'depth': y['depth'].clone(),
+                    'image_reproj': reproj.clone(), 'depth_reproj': dreproj.clone()})
+
+
+def g0_preprocess(lf):
+    """Observation.zoom/prepare/normalize on a low-resolution frame (observation.py:225-273)."""
+    from latentfusion.modules.geometry import Camera
+    from latentfusion.observation import Observation
+    g = torch.Generator().manual_seed(40)
+    V = 2
+    K = torch.tensor(INTRINSIC).unsqueeze(0).expand(V, -1, -1).clone()
+    K[:, :2] *= 0.125
+    cam = Camera(K, None, log_quaternion=torch.randn(V, 3, generator=g) * 0.5,
+                 translation=torch.tensor([[0.02, -0.01, 1.0], [0.0, 0.03, 1.1]]), width=80, height=60)
+    color = torch.rand(V, 3, 60, 80, generator=g)
+    mask = (torch.rand(V, 1, 60, 80, generator=g) > 0.4).float()
+    depth = (0.9 + 0.3 * torch.rand(V, 1, 60, 80, generator=g))
+    obs = Observation(color, depth, mask, cam)
+    z = obs.zoom(2.0, 16)
+    p = z.prepare()
+    n = p.normalize()
+    save('g0_preprocess', {'obs': obs_dict(obs), 'target_dist': 2.0, 'target_size': 16,
+                           'zoom': obs_dict(z), 'prepare': obs_dict(p), 'normalize': obs_dict(n)})
+
+
+def main():
+    lf = refharness.load_reference()
+    import latentfusion.recon.utils  # noqa
+    torch.set_num_threads(8)
+    g0_preprocess(lf)
+    g1_camera(lf)
+    g2_resample(lf)
+    g3_block(lf)
+    g4_fusers(lf)
+    g5_decode(lf)
+    g6_loss(lf)
+    g7_g10_loop(lf)
+    g9_ibr(lf)
+
+
+if __name__ == '__main__':
+    main()

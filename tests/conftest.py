@@ -1,0 +1,40 @@
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'oracle')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def pytest_collection_modifyitems(config, items):
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason='no GPU in this container')
+    for item in items:
+        if 'gpu' in item.keywords:
+            item.add_marker(skip)
+
+
+def load_golden(name):
+    return torch.load(os.path.join(GOLDEN, name + '.pt'), weights_only=False)
+
+
+@pytest.fixture(scope='session')
+def golden():
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = load_golden(name)
+        return cache[name]
+    return get
