@@ -1,0 +1,143 @@
+/*
+ * lf_hip.h -- C ABI of liblf_hip.so: the MI355X (gfx950) kernels behind the LatentFusion
+ * reconstruct-and-render hot path.
+ *
+ * The reference (NVlabs/latentfusion) has no FFI layer: its hot path is a chain of ATen calls
+ * issued from nn.Module.forward.  Each entry point below replaces one such chain; the
+ * reference call sites are cited per function as latentfusion/<file>:<lines>.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 data unless stated otherwise;
+ *   - activations are channels-last: volumes [N][D][H][W][C], images [N][H][W][C]
+ *     (the Python host mirror converts from/to the reference's NCDHW at its API boundary);
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued, never synchronised;
+ *   - return value: 0 on success, a positive hipError_t from the launch, or a negative
+ *     LF_E* code for rejected arguments (nothing is launched in that case);
+ *   - no function keeps a pointer past its return; no hidden allocations: scratch space is
+ *     passed in explicitly (see lf_*_scratch_bytes).
+ */
+#ifndef LF_HIP_H
+#define LF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LF_ABI_VERSION 1
+
+#define LF_EINVAL   (-1)   /* bad size / flag combination            */
+#define LF_EALIGN   (-2)   /* pointer or channel count not aligned   */
+#define LF_ENOSPC   (-3)   /* scratch buffer too small               */
+
+/* epilogue flags of the conv entry points */
+#define LF_EPI_LRELU     1u   /* y = max(y, slope*y)                                         */
+#define LF_EPI_PIXELNORM 2u   /* y = y / sqrt(mean_c(y^2) + eps); also writes the norm       */
+
+/* grid-map kinds of the 3-D resampler */
+#define LF_MAP_O2C 0   /* bilinear polynomial map (ObjectToCameraTransform)                  */
+#define LF_MAP_C2O 1   /* projective map (CameraToObjectTransform)                           */
+#define LF_MAP_COEFS 20 /* floats per sample in the coefficient block of either kind         */
+
+int lf_abi_version(void);
+
+/* Name of the device the library is running on (for logs); returns 0 / hip error. */
+int lf_device_name(char* buf, int buflen);
+
+/* ------------------------------------------------------------------------------------------
+ * 3-D resampling: out[n,z,y,x,:] = trilinear(vol[n or 0], g(n; x,y,z)), padding=border,
+ * align_corners=False, i.e. F.grid_sample as used by
+ *   ObjectToCameraTransform.forward   modules/geometry.py:669-690  (+ camera_coords :515-531)
+ *   CameraToObjectTransform.forward   modules/geometry.py:625-657
+ * The sampling grid is never materialised; it is evaluated per voxel from `coef`:
+ *   LF_MAP_O2C: g = c0 + c1*a + c2*b + c3*k + c4*a*k + c5*b*k, (a,b,k) = (x/(W-1), y/(H-1),
+ *               z/(D-1)), c_j = coef[n][3*j .. 3*j+2] (x,y,z components)        -> 18 floats
+ *   LF_MAP_C2O: l = (lx,ly,lz,1) with lx = -1 + 2x/(W-1) (lattice in [-1,1]),
+ *               gx = (A0.l)/(A3.l), gy = (A1.l)/(A3.l), gz = A2.l, A_r = coef[n][4*r..] -> 16 floats
+ * vol_n == 1 broadcasts one volume to all N samples (Photographer.decode, recon/models.py:489-494).
+ * Output spatial size == input spatial size (D,H,W), channels C.
+ */
+int lf_resample3d_fwd(const float* vol, int vol_n, const float* coef, int kind,
+                      float* out, int N, int D, int H, int W, int C, void* stream);
+
+/* d(loss)/d(coef) for LF_MAP_O2C given gout = d(loss)/d(out): gcoef[n][18] (fixed-order,
+ * deterministic two-stage reduction).  Replaces grid_sampler_3d_backward (grid part) plus the
+ * autograd chain grid -> camera of modules/geometry.py:469-531,669-686.
+ * scratch must hold lf_resample3d_bwd_coef_scratch_bytes(N,D,H,W) bytes. */
+size_t lf_resample3d_bwd_coef_scratch_bytes(int N, int D, int H, int W);
+int lf_resample3d_bwd_coef(const float* gout, const float* vol, int vol_n, const float* coef,
+                           float* gcoef, void* scratch, size_t scratch_bytes,
+                           int N, int D, int H, int W, int C, void* stream);
+
+/* d(loss)/d(vol) (trilinear splat, fp32 atomics; training / encoder backward only).
+ * gvol must be zero-initialised by the caller; with vol_n == 1 all samples accumulate into one
+ * volume. */
+int lf_resample3d_bwd_vol(const float* gout, const float* coef, int kind, float* gvol, int vol_n,
+                          int N, int D, int H, int W, int C, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * He-equalised 3x3(x3) convolution with fused epilogue, stride 1, zero padding 1:
+ *   y = conv(x, W) * he + bias ; [LeakyReLU(slope)] ; [PixelNorm over channels (eps)]
+ * = Equalized.forward + nn.LeakyReLU + PixelNorm of one half of Block.forward
+ *   modules/equalized.py:57-64, modules/blocks.py:152-158, modules/__init__.py:14-15.
+ * dims = 3: x [N][D][H][W][Cin];  dims = 2: D must be 1.
+ * wpack: weights re-laid-out by the host as [tap][CoutP][CinP], tap = (kz*3+ky)*3+kx (dims=2:
+ *        ky*3+kx), CinP = Cin rounded up to 16, CoutP = lf_conv3x3_cout_padded(Cout), zero padded.
+ * bias: [Cout] or NULL.  norm_out: [N*D*H*W] receives sqrt(mean_c(y^2)+eps) when
+ * LF_EPI_PIXELNORM is set (needed by the backward), may be NULL otherwise.
+ * LF_EPI_PIXELNORM requires Cout <= 64 here; wider layers use lf_pixelnorm_fwd afterwards.
+ */
+/* Padded cout count the host packer must use for wpack (multiple of the cout-tile group). */
+int lf_conv3x3_cout_padded(int Cout);
+int lf_conv1x1_cout_padded(int Cout);
+
+int lf_conv3x3_fwd(const float* x, const float* wpack, const float* bias, float* y, float* norm_out,
+                   int dims, int N, int D, int H, int W, int Cin, int Cout,
+                   float he, unsigned flags, float slope, float eps, void* stream);
+
+/* Pointwise (1x1 / 1x1x1) He-equalised convolution with the same epilogue, i.e. a GEMM over
+ * pixels.  Used for InputBlock/OutputBlock (modules/blocks.py:78-133), FactorProjection2d3d
+ * and FactorProjection3d2d (modules/geometry.py:711-749).
+ * Input addressing is generalised so that the depth axis of a channels-last volume can be
+ * folded into K without a copy: K = ksl * Cin; element (pixel p, k = s*Cin + c) is read from
+ * x[n*x_batch_stride + s*x_slice_stride + p*Cin + c].  wpack: [CoutP][Kp] (K ordered s-major,
+ * Kp = K rounded up to 16, CoutP = lf_conv1x1_cout_padded(Cout), zero padded).
+ * Output addressing is generalised the same way: channel co of pixel p of sample n is written to
+ *   y[n*y_batch_stride + (co / y_slice_channels)*y_slice_stride + p*y_row_stride + co % y_slice_channels]
+ * (y_slice_channels >= Cout: plain channels-last rows; y_slice_channels = C: the output is
+ * unfolded into Cout/C depth slices of a channels-last volume -- used by the projection backward).
+ * LF_EPI_PIXELNORM requires Cout <= 128 here. */
+int lf_conv1x1_fwd(const float* x, const float* wpack, const float* bias, float* y, float* norm_out,
+                   int N, int P, int Cin, int ksl, long x_batch_stride, long x_slice_stride,
+                   int Cout, long y_batch_stride, int y_row_stride, int y_slice_channels,
+                   long y_slice_stride,
+                   float he, unsigned flags, float slope, float eps, void* stream);
+
+/* Standalone PixelNorm over the last (channel) axis of [rows][C], in place allowed.
+ * norm_out[rows] receives sqrt(mean+eps).  modules/__init__.py:14-15. */
+int lf_pixelnorm_fwd(const float* x, float* y, float* norm_out, long rows, int C, float eps, void* stream);
+
+/* Backward of the fused epilogue: given gy = dL/dy, the saved output y and norm, produce
+ * dL/d(conv*he + bias) (the caller then runs the transposed convolution and applies he):
+ *   flags = LRELU|PIXELNORM: gp = lrelu'(y) * (gy - y * mean_c(gy*y)) / norm
+ *   flags = LRELU           : gp = lrelu'(y) * gy
+ *   flags = PIXELNORM       : gp = (gy - y*mean_c(gy*y)) / norm
+ * rows x C, channels-last; in place (gp == gy) allowed. */
+int lf_epilogue_bwd(const float* gy, const float* y, const float* norm, float* gp,
+                    long rows, int C, unsigned flags, float slope, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Layout helpers (the reference is NCDHW; kernels are channels-last). */
+int lf_nchw_to_nhwc(const float* src, float* dst, int N, int C, long P, void* stream);
+int lf_nhwc_to_nchw(const float* src, float* dst, int N, int C, long P, void* stream);
+/* FactorProjection2d3d.view (geometry.py:728): src [N][P][C0*S] with channel = c*S + d
+ * -> dst [N][S][P][C0], optionally scaling row (n,p) by 1/norm[n*P+p] (deferred PixelNorm). */
+int lf_lift_unfold(const float* src, const float* norm_or_null, float* dst,
+                   int N, long P, int C0, int S, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LF_HIP_H */

@@ -1,0 +1,82 @@
+"""ctypes binding of liblf_hip.so (the C ABI declared in include/lf_hip.h).
+
+The product path has NO fallback: if the shared object is missing or a symbol cannot be
+resolved, `lib()` raises.  (On a box with hipcc the library is built on first use.)
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_long, c_size_t, c_uint, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'liblf_hip.so')
+
+LF_EPI_LRELU = 1
+LF_EPI_PIXELNORM = 2
+LF_MAP_O2C = 0
+LF_MAP_C2O = 1
+LF_MAP_COEFS = 20
+
+P = c_void_p
+# name -> (restype, argtypes); mirrors include/lf_hip.h one to one
+SIGNATURES = {
+    'lf_abi_version': (c_int, []),
+    'lf_device_name': (c_int, [c_char_p, c_int]),
+    'lf_resample3d_fwd': (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
+    'lf_resample3d_bwd_coef_scratch_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
+    'lf_resample3d_bwd_coef': (c_int, [P, P, c_int, P, P, P, c_size_t, c_int, c_int, c_int, c_int, c_int, P]),
+    'lf_resample3d_bwd_vol': (c_int, [P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    'lf_conv3x3_cout_padded': (c_int, [c_int]),
+    'lf_conv1x1_cout_padded': (c_int, [c_int]),
+    'lf_conv3x3_fwd': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                               c_float, c_uint, c_float, c_float, P]),
+    'lf_conv1x1_fwd': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_long, c_long, c_int, c_long, c_int,
+                               c_int, c_long, c_float, c_uint, c_float, c_float, P]),
+    'lf_pixelnorm_fwd': (c_int, [P, P, P, c_long, c_int, c_float, P]),
+    'lf_epilogue_bwd': (c_int, [P, P, P, P, c_long, c_int, c_uint, c_float, P]),
+    'lf_nchw_to_nhwc': (c_int, [P, P, c_int, c_int, c_long, P]),
+    'lf_nhwc_to_nchw': (c_int, [P, P, c_int, c_int, c_long, P]),
+    'lf_lift_unfold': (c_int, [P, P, P, c_int, c_long, c_int, c_int, P]),
+}
+
+_lib = None
+
+
+class LFHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Returns the loaded library, building it first if absent and hipcc is available."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        try:
+            from .csrc import build as _build
+            _build.build(verbose=False)
+        except Exception as e:  # noqa: BLE001
+            raise LFHipError(f'liblf_hip.so is missing at {LIB_PATH} and could not be built: {e}') from e
+    try:
+        handle = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise LFHipError(f'cannot load {LIB_PATH}: {e}') from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(handle, name)
+        except AttributeError as e:
+            raise LFHipError(f'{LIB_PATH} does not export {name}') from e
+        fn.restype = res
+        fn.argtypes = args
+    if handle.lf_abi_version() != 1:
+        raise LFHipError('liblf_hip.so ABI version mismatch')
+    _lib = handle
+    return _lib
+
+
+_ERR = {-1: 'LF_EINVAL (bad size/flag combination)', -2: 'LF_EALIGN (alignment / channel count)',
+        -3: 'LF_ENOSPC (scratch too small)'}
+
+
+def check(rc, what):
+    if rc != 0:
+        raise LFHipError(f'{what} failed: {_ERR.get(rc, "hipError " + str(rc))}')

@@ -1,0 +1,213 @@
+// HBM-bound row kernels of the reconstruct-and-render path (gfx950):
+//   PixelNorm forward          latentfusion/modules/__init__.py:14-15
+//   fused-epilogue backward    LeakyReLU' * PixelNorm' (autograd of modules/blocks.py:152-158)
+//   layout changes             NCHW <-> NHWC, FactorProjection2d3d's view (modules/geometry.py:728)
+// Rows are channels-last records of C floats.  When C/4 is a power of two <= 64 a group of C/4
+// lanes owns one row (float4 per lane, xor-shuffle reduction inside the group); otherwise one
+// wavefront walks the row.
+#include "lf_common.h"
+
+namespace {
+
+__device__ __forceinline__ float group_sum(float v, int lanes) {
+  for (int o = lanes >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// MODE 0: pixelnorm fwd (a = x).  MODE 1: epilogue bwd (a = gy, b = y, nrm in).
+template <int MODE>
+__global__ void __launch_bounds__(256) rows_vec4_kernel(
+    const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ nrm_in,
+    float* __restrict__ out, float* __restrict__ nrm_out, long rows, int C, int lpr,
+    unsigned flags, float slope, float eps) {
+  const int rpb = 256 / lpr;                              // rows per block-iteration
+  const int q = threadIdx.x % lpr, slot = threadIdx.x / lpr;
+  const long iters = (rows + (long)gridDim.x * rpb - 1) / ((long)gridDim.x * rpb);
+  for (long it = 0; it < iters; ++it) {
+    const long row = (it * gridDim.x + blockIdx.x) * rpb + slot;
+    const bool live = row < rows;
+    f32x4 va = (f32x4){0.f, 0.f, 0.f, 0.f}, vb = va;
+    if (live) {
+      va = *(const f32x4*)(a + row * C + q * 4);
+      if (MODE == 1) vb = *(const f32x4*)(b + row * C + q * 4);
+    }
+    if (MODE == 0) {
+      float ss = va[0] * va[0] + va[1] * va[1] + va[2] * va[2] + va[3] * va[3];
+      ss = group_sum(ss, lpr);
+      const float r = sqrtf(ss / (float)C + eps);
+      if (live) {
+        f32x4 o = {va[0] / r, va[1] / r, va[2] / r, va[3] / r};
+        *(f32x4*)(out + row * C + q * 4) = o;
+        if (q == 0 && nrm_out) nrm_out[row] = r;
+      }
+    } else {
+      f32x4 g = va;
+      if (flags & LF_EPI_PIXELNORM) {
+        float dot = va[0] * vb[0] + va[1] * vb[1] + va[2] * vb[2] + va[3] * vb[3];
+        dot = group_sum(dot, lpr) / (float)C;
+        const float r = live ? nrm_in[row] : 1.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] = (va[e] - vb[e] * dot) / r;
+      }
+      if (flags & LF_EPI_LRELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] = vb[e] > 0.f ? g[e] : g[e] * slope;
+      }
+      if (live) *(f32x4*)(out + row * C + q * 4) = g;
+    }
+  }
+}
+
+// generic C: one wavefront per row
+template <int MODE>
+__global__ void __launch_bounds__(256) rows_wave_kernel(
+    const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ nrm_in,
+    float* __restrict__ out, float* __restrict__ nrm_out, long rows, int C,
+    unsigned flags, float slope, float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+    const float* pa = a + row * C;
+    const float* pb = (MODE == 1) ? b + row * C : nullptr;
+    float s = 0.f;
+    if (MODE == 0) {
+      for (int c = lane; c < C; c += 64) s += pa[c] * pa[c];
+      s = lf_wave_sum(s);
+      const float r = sqrtf(s / (float)C + eps);
+      for (int c = lane; c < C; c += 64) out[row * C + c] = pa[c] / r;
+      if (lane == 0 && nrm_out) nrm_out[row] = r;
+    } else {
+      float dot = 0.f, r = 1.f;
+      if (flags & LF_EPI_PIXELNORM) {
+        for (int c = lane; c < C; c += 64) s += pa[c] * pb[c];
+        dot = lf_wave_sum(s) / (float)C;
+        r = nrm_in[row];
+      }
+      for (int c = lane; c < C; c += 64) {
+        float g = pa[c];
+        const float yv = pb[c];
+        if (flags & LF_EPI_PIXELNORM) g = (g - yv * dot) / r;
+        if (flags & LF_EPI_LRELU) g = yv > 0.f ? g : g * slope;
+        out[row * C + c] = g;
+      }
+    }
+  }
+}
+
+// [N][C][P] -> [N][P][C] through a 32x32 LDS tile (coalesced on both sides)
+__global__ void __launch_bounds__(256) transpose_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                        int R, long Q) {
+  // src: [n][R][Q] -> dst: [n][Q][R]
+  __shared__ float t[32][33];
+  const int n = blockIdx.z;
+  const long q0 = (long)blockIdx.x * 32;
+  const int r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
+  const float* s = src + (long)n * R * Q;
+  float* d = dst + (long)n * R * Q;
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i;
+    const long q = q0 + tx;
+    t[i][tx] = (r < R && q < Q) ? s[(long)r * Q + q] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const long q = q0 + i;
+    const int r = r0 + tx;
+    if (r < R && q < Q) d[q * R + r] = t[tx][i];
+  }
+}
+
+// src [N][P][C0*S] (channel = c*S + d)  ->  dst [N][S][P][C0], optional per-row 1/norm scaling
+__global__ void __launch_bounds__(256) lift_unfold_kernel(const float* __restrict__ src,
+                                                          const float* __restrict__ nrm,
+                                                          float* __restrict__ dst, long P, int C0, int S) {
+  extern __shared__ float row[];                            // C0*S floats of one pixel
+  const int n = blockIdx.y;
+  const int CS = C0 * S;
+  for (long p = blockIdx.x; p < P; p += gridDim.x) {
+    const float* s = src + ((long)n * P + p) * CS;
+    const float inv = nrm ? 1.f / nrm[(long)n * P + p] : 1.f;
+    __syncthreads();
+    for (int i = threadIdx.x; i < CS; i += 256) row[i] = nrm ? s[i] / nrm[(long)n * P + p] : s[i];
+    (void)inv;
+    __syncthreads();
+    for (int i = threadIdx.x; i < CS; i += 256) {
+      const int c = i % C0, d = i / C0;                     // destination order: d-major, c fastest
+      dst[(((long)n * S + d) * P + p) * C0 + c] = row[c * S + d];
+    }
+  }
+}
+
+bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+template <int MODE>
+int launch_rows(const float* a, const float* b, const float* nrm_in, float* out, float* nrm_out,
+                long rows, int C, unsigned flags, float slope, float eps, hipStream_t s) {
+  if (rows <= 0 || C <= 0) return LF_EINVAL;
+  const bool vec = (C % 4 == 0) && pow2(C / 4) && (C / 4) <= 64 && lf_aligned16(a) && lf_aligned16(out) &&
+                   (MODE == 0 || lf_aligned16(b));
+  if (vec) {
+    const int lpr = C / 4, rpb = 256 / lpr;
+    const long blocks = (rows + rpb - 1) / rpb;
+    const unsigned grid = (unsigned)(blocks < 16384 ? blocks : 16384);
+    hipLaunchKernelGGL((rows_vec4_kernel<MODE>), dim3(grid), dim3(256), 0, s, a, b, nrm_in, out, nrm_out, rows, C, lpr,
+                       flags, slope, eps);
+  } else {
+    const long blocks = (rows + 3) / 4;
+    const unsigned grid = (unsigned)(blocks < 16384 ? blocks : 16384);
+    hipLaunchKernelGGL((rows_wave_kernel<MODE>), dim3(grid), dim3(256), 0, s, a, b, nrm_in, out, nrm_out, rows, C,
+                       flags, slope, eps);
+  }
+  return lf_launch_status();
+}
+
+}  // namespace
+
+extern "C" int lf_pixelnorm_fwd(const float* x, float* y, float* norm_out, long rows, int C, float eps, void* stream) {
+  return launch_rows<0>(x, nullptr, nullptr, y, norm_out, rows, C, LF_EPI_PIXELNORM, 0.f, eps, (hipStream_t)stream);
+}
+
+extern "C" int lf_epilogue_bwd(const float* gy, const float* y, const float* norm, float* gp,
+                               long rows, int C, unsigned flags, float slope, void* stream) {
+  if ((flags & LF_EPI_PIXELNORM) && norm == nullptr) return LF_EINVAL;
+  return launch_rows<1>(gy, y, norm, gp, nullptr, rows, C, flags, slope, 0.f, (hipStream_t)stream);
+}
+
+extern "C" int lf_nchw_to_nhwc(const float* src, float* dst, int N, int C, long P, void* stream) {
+  if (N <= 0 || C <= 0 || P <= 0) return LF_EINVAL;
+  dim3 grid((unsigned)((P + 31) / 32), (unsigned)((C + 31) / 32), N);
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, dst, C, P);
+  return lf_launch_status();
+}
+
+extern "C" int lf_nhwc_to_nchw(const float* src, float* dst, int N, int C, long P, void* stream) {
+  if (N <= 0 || C <= 0 || P <= 0) return LF_EINVAL;
+  if (P > 0x7fffffffL) return LF_EINVAL;
+  // src [n][P][C] -> dst [n][C][P]: the same transpose with R = P, Q = C
+  dim3 grid((unsigned)((C + 31) / 32), (unsigned)((P + 31) / 32), N);
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, dst, (int)P, (long)C);
+  return lf_launch_status();
+}
+
+extern "C" int lf_lift_unfold(const float* src, const float* norm_or_null, float* dst,
+                              int N, long P, int C0, int S, void* stream) {
+  if (N <= 0 || P <= 0 || C0 <= 0 || S <= 0) return LF_EINVAL;
+  const size_t shmem = (size_t)C0 * S * sizeof(float);
+  if (shmem > 64 * 1024) return LF_EINVAL;
+  const unsigned gx = (unsigned)(P < 8192 ? P : 8192);
+  hipLaunchKernelGGL(lift_unfold_kernel, dim3(gx, N), dim3(256), shmem, (hipStream_t)stream, src, norm_or_null, dst, P, C0, S);
+  return lf_launch_status();
+}
+
+extern "C" int lf_abi_version(void) { return LF_ABI_VERSION; }
+
+extern "C" int lf_device_name(char* buf, int buflen) {
+  hipDeviceProp_t prop;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  e = hipGetDeviceProperties(&prop, dev);
+  if (e != hipSuccess) return (int)e;
+  snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+  return 0;
+}

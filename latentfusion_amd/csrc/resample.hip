@@ -1,0 +1,325 @@
+// Camera <-> object voxel resampling for gfx950 (trilinear gather / coefficient-gradient
+// reduction / splat).  Replaces F.grid_sample(…, padding_mode='border', align_corners=False) of
+//   ObjectToCameraTransform.forward  latentfusion/modules/geometry.py:669-690
+//   CameraToObjectTransform.forward  latentfusion/modules/geometry.py:625-657
+// The sampling grid is evaluated per voxel from a per-sample coefficient block (see lf_hip.h);
+// volumes are channels-last so that every trilinear tap is one contiguous C-float record.
+#include "lf_common.h"
+
+namespace {
+
+struct Tap {
+  int x0, y0, z0, x1, y1, z1;   // clamped integer corners
+  float tx, ty, tz;             // fractional offsets
+  float mx, my, mz;             // d(ix)/d(gx) incl. border-clip mask (0 outside the volume)
+};
+
+template <int KIND>
+__device__ __forceinline__ void eval_grid(const float* __restrict__ cf, int x, int y, int z,
+                                          int W, int H, int D, float& gx, float& gy, float& gz,
+                                          float& a, float& b, float& k) {
+  // lattice coordinates in [0,1] (torch.linspace(0,1,S): geometry.py:476-480)
+  a = W > 1 ? (float)x / (float)(W - 1) : 0.f;
+  b = H > 1 ? (float)y / (float)(H - 1) : 0.f;
+  k = D > 1 ? (float)z / (float)(D - 1) : 0.f;
+  if (KIND == LF_MAP_O2C) {
+    const float ak = a * k, bk = b * k;
+    gx = cf[0] + cf[3] * a + cf[6] * b + cf[9] * k + cf[12] * ak + cf[15] * bk;
+    gy = cf[1] + cf[4] * a + cf[7] * b + cf[10] * k + cf[13] * ak + cf[16] * bk;
+    gz = cf[2] + cf[5] * a + cf[8] * b + cf[11] * k + cf[14] * ak + cf[17] * bk;
+  } else {
+    // lattice in [-1,1] (torch.linspace(-c/2,c/2,S) / (c/2): geometry.py:599-611)
+    const float lx = 2.f * a - 1.f, ly = 2.f * b - 1.f, lz = 2.f * k - 1.f;
+    const float n0 = cf[0] * lx + cf[1] * ly + cf[2] * lz + cf[3];
+    const float n1 = cf[4] * lx + cf[5] * ly + cf[6] * lz + cf[7];
+    const float n2 = cf[8] * lx + cf[9] * ly + cf[10] * lz + cf[11];
+    const float dn = cf[12] * lx + cf[13] * ly + cf[14] * lz + cf[15];
+    gx = n0 / dn;
+    gy = n1 / dn;
+    gz = n2;
+  }
+}
+
+__device__ __forceinline__ void unnormalize_clip(float g, int size, float& pos, float& mult) {
+  // grid_sampler_unnormalize (align_corners=False) + clip_coordinates_set_grad (border)
+  float p = ((g + 1.f) * (float)size - 1.f) * 0.5f;
+  const float hi = (float)(size - 1);
+  mult = (p > 0.f && p < hi) ? 0.5f * (float)size : 0.f;
+  p = fminf(fmaxf(p, 0.f), hi);
+  pos = p;
+}
+
+__device__ __forceinline__ Tap make_tap(float gx, float gy, float gz, int W, int H, int D) {
+  Tap t;
+  float px, py, pz;
+  unnormalize_clip(gx, W, px, t.mx);
+  unnormalize_clip(gy, H, py, t.my);
+  unnormalize_clip(gz, D, pz, t.mz);
+  // NaN coordinates (degenerate cameras) sample voxel 0, like ATen's clip of NaN
+  if (!(px == px)) px = 0.f;
+  if (!(py == py)) py = 0.f;
+  if (!(pz == pz)) pz = 0.f;
+  const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+  t.tx = px - fx; t.ty = py - fy; t.tz = pz - fz;
+  t.x0 = (int)fx; t.y0 = (int)fy; t.z0 = (int)fz;
+  t.x1 = min(t.x0 + 1, W - 1); t.y1 = min(t.y0 + 1, H - 1); t.z1 = min(t.z0 + 1, D - 1);
+  return t;
+}
+
+// VEC = 4: one thread per (voxel, 4-channel group), C % 4 == 0.  VEC = 1: one thread per (voxel, channel).
+template <int KIND, int VEC>
+__global__ void __launch_bounds__(256) resample_fwd_kernel(
+    const float* __restrict__ vol, long vol_bstride, const float* __restrict__ coef,
+    float* __restrict__ out, int N, int D, int H, int W, int C) {
+  const int lpv = C / VEC;
+  const long per_sample = (long)D * H * W * lpv;
+  const int n = blockIdx.y;
+  const float* cf = coef + (long)n * LF_MAP_COEFS;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < per_sample;
+       idx += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(idx % lpv);
+    long v = idx / lpv;
+    const int x = (int)(v % W); v /= W;
+    const int y = (int)(v % H);
+    const int z = (int)(v / H);
+    float gx, gy, gz, a, b, k;
+    eval_grid<KIND>(cf, x, y, z, W, H, D, gx, gy, gz, a, b, k);
+    const Tap t = make_tap(gx, gy, gz, W, H, D);
+    const float* base = vol + (long)n * vol_bstride + (long)q * VEC;
+    const long sW = C, sH = (long)W * C, sD = (long)H * W * C;
+    const float wx1 = t.tx, wx0 = 1.f - t.tx, wy1 = t.ty, wy0 = 1.f - t.ty, wz1 = t.tz, wz0 = 1.f - t.tz;
+    const long o00 = t.z0 * sD + t.y0 * sH, o01 = t.z0 * sD + t.y1 * sH;
+    const long o10 = t.z1 * sD + t.y0 * sH, o11 = t.z1 * sD + t.y1 * sH;
+    const long x0 = t.x0 * sW, x1 = t.x1 * sW;
+    const long oo = (((long)n * D + z) * H + y) * W + x;
+    if (VEC == 4) {
+      const f32x4 v000 = *(const f32x4*)(base + o00 + x0), v001 = *(const f32x4*)(base + o00 + x1);
+      const f32x4 v010 = *(const f32x4*)(base + o01 + x0), v011 = *(const f32x4*)(base + o01 + x1);
+      const f32x4 v100 = *(const f32x4*)(base + o10 + x0), v101 = *(const f32x4*)(base + o10 + x1);
+      const f32x4 v110 = *(const f32x4*)(base + o11 + x0), v111 = *(const f32x4*)(base + o11 + x1);
+      f32x4 r = v000 * (wx0 * wy0 * wz0) + v001 * (wx1 * wy0 * wz0) + v010 * (wx0 * wy1 * wz0) +
+                v011 * (wx1 * wy1 * wz0) + v100 * (wx0 * wy0 * wz1) + v101 * (wx1 * wy0 * wz1) +
+                v110 * (wx0 * wy1 * wz1) + v111 * (wx1 * wy1 * wz1);
+      *(f32x4*)(out + oo * C + (long)q * 4) = r;
+    } else {
+      float r = base[o00 + x0] * (wx0 * wy0 * wz0) + base[o00 + x1] * (wx1 * wy0 * wz0) +
+                base[o01 + x0] * (wx0 * wy1 * wz0) + base[o01 + x1] * (wx1 * wy1 * wz0) +
+                base[o10 + x0] * (wx0 * wy0 * wz1) + base[o10 + x1] * (wx1 * wy0 * wz1) +
+                base[o11 + x0] * (wx0 * wy1 * wz1) + base[o11 + x1] * (wx1 * wy1 * wz1);
+      out[oo * C + q] = r;
+    }
+  }
+}
+
+// ---- backward w.r.t. the O2C coefficient block ------------------------------------------------
+// stage 1: every block reduces a contiguous run of voxels of one sample to 18 partial sums.
+constexpr int BWD_VOX_PER_BLOCK = 4096;
+
+template <int VEC>
+__global__ void __launch_bounds__(256) resample_bwd_coef_kernel(
+    const float* __restrict__ gout, const float* __restrict__ vol, long vol_bstride,
+    const float* __restrict__ coef, float* __restrict__ partial, int nblk,
+    int N, int D, int H, int W, int C, int lpv) {
+  // lpv = lanes cooperating on one voxel: a power of two <= 64 with lpv * VEC >= C
+  const int n = blockIdx.y;
+  const float* cf = coef + (long)n * LF_MAP_COEFS;
+  const long nvox = (long)D * H * W;
+  const long v_begin = (long)blockIdx.x * BWD_VOX_PER_BLOCK;
+  const long v_end = min(v_begin + (long)BWD_VOX_PER_BLOCK, nvox);
+  const int q = threadIdx.x % lpv;
+  const int vslot = threadIdx.x / lpv;
+  const int vstep = blockDim.x / lpv;
+  float acc[18];
+#pragma unroll
+  for (int i = 0; i < 18; ++i) acc[i] = 0.f;
+  const long sW = C, sH = (long)W * C, sD = (long)H * W * C;
+  // all lanes of a wave iterate the same number of times so the shuffles below are convergent
+  const long iters = (v_end - v_begin + vstep - 1) / vstep;
+  for (long it = 0; it < iters; ++it) {
+    const long v = v_begin + it * vstep + vslot;
+    const bool live = v < v_end;
+    float hx = 0.f, hy = 0.f, hz = 0.f, a = 0.f, b = 0.f, k = 0.f;
+    if (live && q * VEC < C) {
+      long vv = v;
+      const int x = (int)(vv % W); vv /= W;
+      const int y = (int)(vv % H);
+      const int z = (int)(vv / H);
+      float gx, gy, gz;
+      eval_grid<LF_MAP_O2C>(cf, x, y, z, W, H, D, gx, gy, gz, a, b, k);
+      const Tap t = make_tap(gx, gy, gz, W, H, D);
+      const float* base = vol + (long)n * vol_bstride + (long)q * VEC;
+      const float* g = gout + (((long)n * nvox + v) * C) + (long)q * VEC;
+      const long o00 = t.z0 * sD + t.y0 * sH, o01 = t.z0 * sD + t.y1 * sH;
+      const long o10 = t.z1 * sD + t.y0 * sH, o11 = t.z1 * sD + t.y1 * sH;
+      const long x0 = t.x0 * sW, x1 = t.x1 * sW;
+      const float wx1 = t.tx, wx0 = 1.f - t.tx, wy1 = t.ty, wy0 = 1.f - t.ty, wz1 = t.tz, wz0 = 1.f - t.tz;
+      float dx = 0.f, dy = 0.f, dz = 0.f;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const float go = g[e];
+        const float v000 = base[o00 + x0 + e], v001 = base[o00 + x1 + e];
+        const float v010 = base[o01 + x0 + e], v011 = base[o01 + x1 + e];
+        const float v100 = base[o10 + x0 + e], v101 = base[o10 + x1 + e];
+        const float v110 = base[o11 + x0 + e], v111 = base[o11 + x1 + e];
+        dx += go * ((v001 - v000) * (wy0 * wz0) + (v011 - v010) * (wy1 * wz0) +
+                    (v101 - v100) * (wy0 * wz1) + (v111 - v110) * (wy1 * wz1));
+        dy += go * ((v010 - v000) * (wx0 * wz0) + (v011 - v001) * (wx1 * wz0) +
+                    (v110 - v100) * (wx0 * wz1) + (v111 - v101) * (wx1 * wz1));
+        dz += go * ((v100 - v000) * (wx0 * wy0) + (v101 - v001) * (wx1 * wy0) +
+                    (v110 - v010) * (wx0 * wy1) + (v111 - v011) * (wx1 * wy1));
+      }
+      hx = dx * t.mx; hy = dy * t.my; hz = dz * t.mz;
+    }
+    // sum the channel-group lanes of this voxel (xor butterfly stays inside the lpv-lane group)
+    for (int o = lpv >> 1; o > 0; o >>= 1) {
+      hx += __shfl_xor(hx, o, 64);
+      hy += __shfl_xor(hy, o, 64);
+      hz += __shfl_xor(hz, o, 64);
+    }
+    if (q == 0 && live) {
+      const float ak = a * k, bk = b * k;
+      acc[0] += hx;       acc[1] += hy;       acc[2] += hz;
+      acc[3] += hx * a;   acc[4] += hy * a;   acc[5] += hz * a;
+      acc[6] += hx * b;   acc[7] += hy * b;   acc[8] += hz * b;
+      acc[9] += hx * k;   acc[10] += hy * k;  acc[11] += hz * k;
+      acc[12] += hx * ak; acc[13] += hy * ak; acc[14] += hz * ak;
+      acc[15] += hx * bk; acc[16] += hy * bk; acc[17] += hz * bk;
+    }
+  }
+  __shared__ float red[4][18];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < 18; ++i) {
+    const float s = lf_wave_sum(acc[i]);
+    if (lane == 0) red[wave][i] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 18) {
+    const float s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    partial[((long)n * nblk + blockIdx.x) * 18 + threadIdx.x] = s;
+  }
+}
+
+// stage 2: fixed-order fp64 reduction of the per-block partials -> gcoef[n][18]
+__global__ void __launch_bounds__(256) resample_bwd_coef_reduce(const float* __restrict__ partial,
+                                                                int nblk, float* __restrict__ gcoef) {
+  const int n = blockIdx.x;
+  __shared__ double red[256];
+  const int comp = threadIdx.x % 18;        // threads 0..251 -> 14 strided groups of 18
+  const int grp = threadIdx.x / 18;
+  double s = 0.0;
+  if (grp < 14)
+    for (int b = grp; b < nblk; b += 14) s += (double)partial[((long)n * nblk + b) * 18 + comp];
+  red[threadIdx.x] = (grp < 14) ? s : 0.0;
+  __syncthreads();
+  if (threadIdx.x < 18) {
+    double tot = 0.0;
+    for (int g = 0; g < 14; ++g) tot += red[g * 18 + threadIdx.x];
+    gcoef[(long)n * 18 + threadIdx.x] = (float)tot;
+  }
+}
+
+// ---- backward w.r.t. the sampled volume (splat) -----------------------------------------------
+template <int KIND>
+__global__ void __launch_bounds__(256) resample_bwd_vol_kernel(
+    const float* __restrict__ gout, const float* __restrict__ coef, float* __restrict__ gvol,
+    long gvol_bstride, int N, int D, int H, int W, int C) {
+  const long per_sample = (long)D * H * W * C;
+  const int n = blockIdx.y;
+  const float* cf = coef + (long)n * LF_MAP_COEFS;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < per_sample;
+       idx += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % C);
+    long v = idx / C;
+    const int x = (int)(v % W); v /= W;
+    const int y = (int)(v % H);
+    const int z = (int)(v / H);
+    float gx, gy, gz, a, b, k;
+    eval_grid<KIND>(cf, x, y, z, W, H, D, gx, gy, gz, a, b, k);
+    const Tap t = make_tap(gx, gy, gz, W, H, D);
+    const float go = gout[(long)n * per_sample + idx];
+    float* base = gvol + (long)n * gvol_bstride + c;
+    const long sW = C, sH = (long)W * C, sD = (long)H * W * C;
+    const float wx1 = t.tx, wx0 = 1.f - t.tx, wy1 = t.ty, wy0 = 1.f - t.ty, wz1 = t.tz, wz0 = 1.f - t.tz;
+    atomicAdd(base + t.z0 * sD + t.y0 * sH + t.x0 * sW, go * (wx0 * wy0 * wz0));
+    atomicAdd(base + t.z0 * sD + t.y0 * sH + t.x1 * sW, go * (wx1 * wy0 * wz0));
+    atomicAdd(base + t.z0 * sD + t.y1 * sH + t.x0 * sW, go * (wx0 * wy1 * wz0));
+    atomicAdd(base + t.z0 * sD + t.y1 * sH + t.x1 * sW, go * (wx1 * wy1 * wz0));
+    atomicAdd(base + t.z1 * sD + t.y0 * sH + t.x0 * sW, go * (wx0 * wy0 * wz1));
+    atomicAdd(base + t.z1 * sD + t.y0 * sH + t.x1 * sW, go * (wx1 * wy0 * wz1));
+    atomicAdd(base + t.z1 * sD + t.y1 * sH + t.x0 * sW, go * (wx0 * wy1 * wz1));
+    atomicAdd(base + t.z1 * sD + t.y1 * sH + t.x1 * sW, go * (wx1 * wy1 * wz1));
+  }
+}
+
+bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+}  // namespace
+
+extern "C" int lf_resample3d_fwd(const float* vol, int vol_n, const float* coef, int kind, float* out,
+                                 int N, int D, int H, int W, int C, void* stream) {
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0) return LF_EINVAL;
+  if (vol_n != 1 && vol_n != N) return LF_EINVAL;
+  if (kind != LF_MAP_O2C && kind != LF_MAP_C2O) return LF_EINVAL;
+  const long bstride = vol_n == 1 ? 0 : (long)D * H * W * C;
+  const bool vec = (C % 4 == 0) && lf_aligned16(vol) && lf_aligned16(out);
+  const long items = (long)D * H * W * (vec ? C / 4 : C);
+  dim3 grid((unsigned)min((items + 255) / 256, (long)65535 * 16), N), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(K, V) hipLaunchKernelGGL((resample_fwd_kernel<K, V>), grid, block, 0, s, vol, bstride, coef, out, N, D, H, W, C)
+  if (kind == LF_MAP_O2C) { if (vec) LAUNCH(LF_MAP_O2C, 4); else LAUNCH(LF_MAP_O2C, 1); }
+  else                    { if (vec) LAUNCH(LF_MAP_C2O, 4); else LAUNCH(LF_MAP_C2O, 1); }
+#undef LAUNCH
+  return lf_launch_status();
+}
+
+extern "C" size_t lf_resample3d_bwd_coef_scratch_bytes(int N, int D, int H, int W) {
+  const long nvox = (long)D * H * W;
+  const long nblk = (nvox + BWD_VOX_PER_BLOCK - 1) / BWD_VOX_PER_BLOCK;
+  return (size_t)N * nblk * 18 * sizeof(float);
+}
+
+extern "C" int lf_resample3d_bwd_coef(const float* gout, const float* vol, int vol_n, const float* coef,
+                                      float* gcoef, void* scratch, size_t scratch_bytes,
+                                      int N, int D, int H, int W, int C, void* stream) {
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0) return LF_EINVAL;
+  if (vol_n != 1 && vol_n != N) return LF_EINVAL;
+  if (scratch_bytes < lf_resample3d_bwd_coef_scratch_bytes(N, D, H, W)) return LF_ENOSPC;
+  const long nvox = (long)D * H * W;
+  const int nblk = (int)((nvox + BWD_VOX_PER_BLOCK - 1) / BWD_VOX_PER_BLOCK);
+  const long bstride = vol_n == 1 ? 0 : nvox * C;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(nblk, N), block(256);
+  float* partial = (float*)scratch;
+  // lanes per voxel: next power of two covering the channel groups (idle lanes contribute 0)
+  const bool vec = (C % 4 == 0) && lf_aligned16(gout) && lf_aligned16(vol);
+  const int groups = vec ? C / 4 : C;
+  int lpv = 1;
+  while (lpv < groups) lpv <<= 1;
+  if (lpv > 64) return LF_EINVAL;                       // C > 256 (vec) / C > 64 (scalar)
+  if (vec)
+    hipLaunchKernelGGL((resample_bwd_coef_kernel<4>), grid, block, 0, s, gout, vol, bstride, coef, partial, nblk, N, D, H, W, C, lpv);
+  else
+    hipLaunchKernelGGL((resample_bwd_coef_kernel<1>), grid, block, 0, s, gout, vol, bstride, coef, partial, nblk, N, D, H, W, C, lpv);
+  int st = lf_launch_status();
+  if (st) return st;
+  hipLaunchKernelGGL(resample_bwd_coef_reduce, dim3(N), dim3(256), 0, s, partial, nblk, gcoef);
+  return lf_launch_status();
+}
+
+extern "C" int lf_resample3d_bwd_vol(const float* gout, const float* coef, int kind, float* gvol, int vol_n,
+                                     int N, int D, int H, int W, int C, void* stream) {
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0) return LF_EINVAL;
+  if (vol_n != 1 && vol_n != N) return LF_EINVAL;
+  const long bstride = vol_n == 1 ? 0 : (long)D * H * W * C;
+  const long items = (long)D * H * W * C;
+  dim3 grid((unsigned)min((items + 255) / 256, (long)65535 * 16), N), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (kind == LF_MAP_O2C)
+    hipLaunchKernelGGL((resample_bwd_vol_kernel<LF_MAP_O2C>), grid, block, 0, s, gout, coef, gvol, bstride, N, D, H, W, C);
+  else if (kind == LF_MAP_C2O)
+    hipLaunchKernelGGL((resample_bwd_vol_kernel<LF_MAP_C2O>), grid, block, 0, s, gout, coef, gvol, bstride, N, D, H, W, C);
+  else
+    return LF_EINVAL;
+  return lf_launch_status();
+}

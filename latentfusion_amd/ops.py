@@ -1,0 +1,398 @@
+"""Device operators of the hot path: thin autograd wrappers over the C ABI (include/lf_hip.h).
+
+Tensors keep the reference's LOGICAL shapes (N,C,D,H,W) / (N,C,H,W) but live in channels-last
+memory (torch.channels_last_3d / torch.channels_last), which is exactly the [N][D][H][W][C]
+layout the kernels use -- so the modules built on these ops are shape-compatible drop-ins for
+the reference's nn.Modules without any transposes between layers.
+
+There is no CPU or ATen fallback in this file: every op calls into liblf_hip.so.
+"""
+import math
+
+import torch
+
+from . import _lib
+from ._lib import LF_EPI_LRELU, LF_EPI_PIXELNORM, LF_MAP_C2O, LF_MAP_COEFS, LF_MAP_O2C, check
+
+SLOPE = 0.2
+PN_EPS = 1e-8
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _req(t, name):
+    if not t.is_cuda:
+        raise _lib.LFHipError(f'{name} must be a device tensor: the HIP path has no CPU fallback')
+    if t.dtype != torch.float32:
+        raise TypeError(f'{name} must be float32')
+    return t
+
+
+def cl(t):
+    """channels-last physical layout for a logical NC[D]HW tensor (no copy if already so)."""
+    if t.dim() == 5:
+        return t.contiguous(memory_format=torch.channels_last_3d)
+    if t.dim() == 4:
+        return t.contiguous(memory_format=torch.channels_last)
+    raise ValueError('expected a 4-D or 5-D tensor')
+
+
+def empty_cl(shape, device):
+    fmt = torch.channels_last_3d if len(shape) == 5 else torch.channels_last
+    return torch.empty(shape, device=device, dtype=torch.float32, memory_format=fmt)
+
+
+def _ptr(t):
+    return t.data_ptr()
+
+
+# ---------------------------------------------------------------------------------------------
+# weight packing (host side, cached per parameter version)
+# ---------------------------------------------------------------------------------------------
+def _cached(key_tensor, tag, fn):
+    """Memoises a packed layout ON the parameter object (so it dies with it and can never be
+    confused with another tensor that later reuses the same device address); re-packs when the
+    parameter is modified in place (version counter) or moved."""
+    store = key_tensor.__dict__.setdefault('_lf_pack', {})
+    stamp = (key_tensor._version, key_tensor.data_ptr())
+    hit = store.get(tag)
+    if hit is None or hit[0] != stamp:
+        hit = (stamp, fn())
+        store[tag] = hit
+    return hit[1]
+
+
+def _pad16(v):
+    return (v + 15) // 16 * 16
+
+
+def pack_conv3x3(weight, transpose=False):
+    """[Cout,Cin,k..] -> [tap][CoutP][CinP] (lf_conv3x3_fwd layout).  transpose=True builds the
+    data-gradient operator: taps flipped, in/out channels swapped."""
+    L = _lib.lib()
+    w = weight.detach()
+    if transpose:
+        w = w.transpose(0, 1).flip(dims=tuple(range(2, w.dim())))
+    cout, cin = w.shape[0], w.shape[1]
+    taps = w[0, 0].numel()
+    coutp, cinp = L.lf_conv3x3_cout_padded(cout), _pad16(cin)
+    out = torch.zeros(taps, coutp, cinp, device=w.device, dtype=torch.float32)
+    out[:, :cout, :cin] = w.reshape(cout, cin, taps).permute(2, 0, 1)
+    return out.contiguous()
+
+
+def pack_conv1x1(weight2d):
+    """[Cout,K] -> [CoutP][Kp] (lf_conv1x1_fwd layout)."""
+    L = _lib.lib()
+    cout, k = weight2d.shape
+    out = torch.zeros(L.lf_conv1x1_cout_padded(cout), _pad16(k), device=weight2d.device, dtype=torch.float32)
+    out[:cout, :k] = weight2d.detach()
+    return out.contiguous()
+
+
+def he_constant(weight):
+    """sqrt(2 / fan_in)  (modules/equalized.py:66-74)."""
+    return math.sqrt(2.0 / weight[0].numel())
+
+
+# ---------------------------------------------------------------------------------------------
+# 3-D resampling
+# ---------------------------------------------------------------------------------------------
+def _resample_fwd(vol, coef, kind):
+    L = _lib.lib()
+    n = coef.shape[0]
+    vol_n = 1 if (vol.shape[0] == 1 or vol.stride(0) == 0) else vol.shape[0]
+    if vol_n not in (1, n):
+        raise ValueError('batch dimension of the volume and the cameras must match')
+    v = cl(vol[:1] if vol_n == 1 else vol)
+    _, C, D, H, W = v.shape
+    out = empty_cl((n, C, D, H, W), v.device)
+    cf = torch.zeros(n, LF_MAP_COEFS, device=v.device, dtype=torch.float32)
+    cf[:, :coef.shape[1]] = coef
+    check(L.lf_resample3d_fwd(_ptr(v), vol_n, _ptr(cf), kind, _ptr(out), n, D, H, W, C, _stream()),
+          'lf_resample3d_fwd')
+    return out, v, cf, vol_n
+
+
+class _Resample(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, vol, coef, kind):
+        _req(vol, 'vol'), _req(coef, 'coef')
+        out, v, cf, vol_n = _resample_fwd(vol, coef.detach().float(), kind)
+        ctx.save_for_backward(v, cf)
+        ctx.kind, ctx.vol_n, ctx.vol_shape, ctx.ncoef = kind, vol_n, vol.shape, coef.shape[1]
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        L = _lib.lib()
+        v, cf = ctx.saved_tensors
+        g = cl(gout)
+        n, C, D, H, W = g.shape
+        gvol = gcoef = None
+        if ctx.needs_input_grad[1]:
+            if ctx.kind != LF_MAP_O2C:
+                raise NotImplementedError('the reference C2O transform is not differentiable w.r.t. the camera '
+                                          '(in-place division, modules/geometry.py:636)')
+            gcoef = torch.empty(n, 18, device=g.device, dtype=torch.float32)
+            nbytes = L.lf_resample3d_bwd_coef_scratch_bytes(n, D, H, W)
+            scratch = torch.empty(max(nbytes, 4) // 4 + 1, device=g.device, dtype=torch.float32)
+            check(L.lf_resample3d_bwd_coef(_ptr(g), _ptr(v), ctx.vol_n, _ptr(cf), _ptr(gcoef), _ptr(scratch),
+                                           scratch.numel() * 4, n, D, H, W, C, _stream()), 'lf_resample3d_bwd_coef')
+        if ctx.needs_input_grad[0]:
+            gv = empty_cl((ctx.vol_n, C, D, H, W), g.device).zero_()
+            check(L.lf_resample3d_bwd_vol(_ptr(g), _ptr(cf), ctx.kind, _ptr(gv), ctx.vol_n, n, D, H, W, C, _stream()),
+                  'lf_resample3d_bwd_vol')
+            if gv.shape[0] == ctx.vol_shape[0]:
+                gvol = gv
+            else:
+                # expanded (stride-0) input: autograd sums over the expanded batch itself, so hand
+                # back the accumulated volume once and zeros elsewhere
+                gvol = torch.zeros(ctx.vol_shape, device=g.device, dtype=torch.float32)
+                gvol[0] = gv[0]
+        return gvol, gcoef, None
+
+
+def resample_o2c(vol, coef):
+    """ObjectToCameraTransform as an op: vol (1|N,C,S,S,S), coef (N,18) -> (N,C,S,S,S)."""
+    return _Resample.apply(vol, coef, LF_MAP_O2C)
+
+
+def resample_c2o(vol, coef):
+    """CameraToObjectTransform as an op: vol (N,C,S,S,S), coef (N,16) -> (N,C,S,S,S)."""
+    return _Resample.apply(vol, coef, LF_MAP_C2O)
+
+
+# ---------------------------------------------------------------------------------------------
+# convolutions with fused epilogue
+# ---------------------------------------------------------------------------------------------
+def _conv3x3_raw(x, wpack, bias, cout, he, flags, want_norm):
+    L = _lib.lib()
+    dims = x.dim() - 2
+    if dims == 3:
+        N, cin, D, H, W = x.shape
+    else:
+        N, cin, H, W = x.shape
+        D = 1
+    fuse_pn = bool(flags & LF_EPI_PIXELNORM) and cout <= 64
+    kflags = flags if fuse_pn else (flags & ~LF_EPI_PIXELNORM)
+    y = empty_cl((N, cout) + tuple(x.shape[2:]), x.device)
+    norm = torch.empty(N * D * H * W, device=x.device, dtype=torch.float32) if (flags & LF_EPI_PIXELNORM) else None
+    check(L.lf_conv3x3_fwd(_ptr(x), _ptr(wpack), _ptr(bias) if bias is not None else None, _ptr(y),
+                           _ptr(norm) if (norm is not None and fuse_pn) else None,
+                           dims, N, D, H, W, cin, cout, he, kflags, SLOPE, PN_EPS, _stream()), 'lf_conv3x3_fwd')
+    if (flags & LF_EPI_PIXELNORM) and not fuse_pn:
+        check(L.lf_pixelnorm_fwd(_ptr(y), _ptr(y), _ptr(norm), N * D * H * W, cout, PN_EPS, _stream()), 'lf_pixelnorm_fwd')
+    return y, norm
+
+
+def _epilogue_bwd(gy, y, norm, flags):
+    L = _lib.lib()
+    if flags == 0:
+        return gy
+    rows = gy.numel() // gy.shape[1]
+    gp = torch.empty_like(gy, memory_format=torch.preserve_format)
+    check(L.lf_epilogue_bwd(_ptr(gy), _ptr(y), _ptr(norm) if norm is not None else None, _ptr(gp), rows,
+                            gy.shape[1], flags, SLOPE, _stream()), 'lf_epilogue_bwd')
+    return gp
+
+
+class _Conv3x3(torch.autograd.Function):
+    """x -> epilogue(conv3x3(x, W) * he + b).  Data gradient only: the hot loop never needs
+    weight gradients; asking for them raises."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, flags):
+        _req(x, 'x'), _req(weight, 'weight')
+        x = cl(x)
+        he = he_constant(weight)
+        wpack = _cached(weight, 'c3f', lambda: pack_conv3x3(weight))
+        y, norm = _conv3x3_raw(x, wpack, bias.detach() if bias is not None else None, weight.shape[0], he, flags, True)
+        ctx.flags, ctx.he = flags, he
+        ctx.weight = weight
+        ctx.save_for_backward(y, norm) if norm is not None else ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            raise NotImplementedError('weight gradients are outside the inference hot path (training step: SURVEY 8f)')
+        saved = ctx.saved_tensors
+        y = saved[0]
+        norm = saved[1] if len(saved) > 1 else None
+        gp = _epilogue_bwd(cl(gy), y, norm, ctx.flags)
+        w = ctx.weight
+        wpack_t = _cached(w, 'c3b', lambda: pack_conv3x3(w, transpose=True))
+        gx, _ = _conv3x3_raw(gp, wpack_t, None, w.shape[1], ctx.he, 0, False)
+        return gx, None, None, None
+
+
+def conv3x3(x, weight, bias, lrelu=True, pixelnorm=True):
+    flags = (LF_EPI_LRELU if lrelu else 0) | (LF_EPI_PIXELNORM if pixelnorm else 0)
+    return _Conv3x3.apply(x, weight, bias, flags)
+
+
+def _conv1x1_raw(x_ptr_tensor, wpack, bias, N, P, cin, ksl, xbs, xss, cout, y2d, he, flags, yaddr=None):
+    """y2d: output buffer; yaddr = (batch_stride, row_stride, slice_channels, slice_stride) or None
+    for plain [N*P][cout] rows.  Returns norm or None."""
+    L = _lib.lib()
+    ybs, yrs, ysc, yss = yaddr if yaddr is not None else (P * cout, cout, 1 << 30, 0)
+    fuse_pn = bool(flags & LF_EPI_PIXELNORM) and cout <= 128
+    kflags = flags if fuse_pn else (flags & ~LF_EPI_PIXELNORM)
+    norm = torch.empty(N * P, device=y2d.device, dtype=torch.float32) if (flags & LF_EPI_PIXELNORM) else None
+    check(L.lf_conv1x1_fwd(_ptr(x_ptr_tensor), _ptr(wpack), _ptr(bias) if bias is not None else None, _ptr(y2d),
+                           _ptr(norm) if (norm is not None and fuse_pn) else None,
+                           N, P, cin, ksl, xbs, xss, cout, ybs, yrs, ysc, yss, he, kflags, SLOPE, PN_EPS, _stream()),
+          'lf_conv1x1_fwd')
+    if (flags & LF_EPI_PIXELNORM) and not fuse_pn:
+        check(L.lf_pixelnorm_fwd(_ptr(y2d), _ptr(y2d), _ptr(norm), N * P, cout, PN_EPS, _stream()), 'lf_pixelnorm_fwd')
+    return norm
+
+
+class _Conv1x1(torch.autograd.Function):
+    """Pointwise conv on NC[D]HW (channels-last) tensors; weight [Cout,Cin,1,1[,1]]."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, flags):
+        _req(x, 'x'), _req(weight, 'weight')
+        x = cl(x)
+        N, cin = x.shape[0], x.shape[1]
+        P = x[0, 0].numel()
+        cout = weight.shape[0]
+        he = he_constant(weight)
+        wpack = _cached(weight, 'c1f', lambda: pack_conv1x1(weight.reshape(cout, cin)))
+        y = empty_cl((N, cout) + tuple(x.shape[2:]), x.device)
+        norm = _conv1x1_raw(x, wpack, bias.detach() if bias is not None else None, N, P, cin, 1, P * cin, 0, cout, y, he, flags)
+        ctx.flags, ctx.he, ctx.weight = flags, he, weight
+        ctx.save_for_backward(y, norm) if norm is not None else ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            raise NotImplementedError('weight gradients are outside the inference hot path (training step: SURVEY 8f)')
+        saved = ctx.saved_tensors
+        y = saved[0]
+        norm = saved[1] if len(saved) > 1 else None
+        gp = _epilogue_bwd(cl(gy), y, norm, ctx.flags)
+        w = ctx.weight
+        cout, cin = w.shape[0], w.shape[1]
+        wpack_t = _cached(w, 'c1b', lambda: pack_conv1x1(w.reshape(cout, cin).t()))
+        N = gp.shape[0]
+        P = gp[0, 0].numel()
+        gx = empty_cl((N, cin) + tuple(gp.shape[2:]), gp.device)
+        _conv1x1_raw(gp, wpack_t, None, N, P, cout, 1, P * cout, 0, cin, gx, ctx.he, 0)
+        return gx, None, None, None
+
+
+def conv1x1(x, weight, bias, lrelu=False, pixelnorm=False):
+    flags = (LF_EPI_LRELU if lrelu else 0) | (LF_EPI_PIXELNORM if pixelnorm else 0)
+    return _Conv1x1.apply(x, weight, bias, flags)
+
+
+class _FactorProject(torch.autograd.Function):
+    """FactorProjection3d2d (modules/geometry.py:731-749): folds the depth axis of a
+    channels-last volume into the contraction dimension without copying it."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _req(x, 'x'), _req(weight, 'weight')
+        x = cl(x)
+        N, C, D, H, W = x.shape
+        cout = weight.shape[0]
+        he = he_constant(weight)                      # fan_in = C*D
+        # reference K index = c*D + d; kernel K index = d*C + c
+        w2 = weight.reshape(cout, C, D)
+        wpack = _cached(weight, 'fpf', lambda: pack_conv1x1(w2.permute(0, 2, 1).reshape(cout, D * C)))
+        y = empty_cl((N, cout, H, W), x.device)
+        flags = LF_EPI_LRELU | LF_EPI_PIXELNORM
+        if C % 4:
+            raise NotImplementedError('factor projection needs C % 4 == 0 on the HIP path')
+        norm = _conv1x1_raw(x, wpack, bias.detach() if bias is not None else None, N, H * W, C, D,
+                            D * H * W * C, H * W * C, cout, y, he, flags)
+        ctx.flags, ctx.he, ctx.weight, ctx.xshape = flags, he, weight, x.shape
+        ctx.save_for_backward(y, norm)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            raise NotImplementedError('weight gradients are outside the inference hot path (training step: SURVEY 8f)')
+        y, norm = ctx.saved_tensors
+        gp = _epilogue_bwd(cl(gy), y, norm, ctx.flags)
+        N, C, D, H, W = ctx.xshape
+        w = ctx.weight
+        cout = w.shape[0]
+        # gx[n,d,p,c] = he * sum_co gp[n,p,co] * W[co, c*D+d]  == pointwise conv with Cout' = D*C
+        wt = _cached(w, 'fpb', lambda: pack_conv1x1(w.reshape(cout, C, D).permute(2, 1, 0).reshape(D * C, cout)))
+        # output channel d*C + c of pixel p goes straight to gx[n][d][p][c] (channels-last volume)
+        gx = empty_cl((N, C, D, H, W), gp.device)
+        _conv1x1_raw(gp, wt, None, N, H * W, cout, 1, H * W * cout, 0, D * C, gx, ctx.he, 0,
+                     yaddr=(D * H * W * C, C, C, H * W * C))
+        return gx, None, None
+
+
+def factor_project(x, weight, bias):
+    return _FactorProject.apply(x, weight, bias)
+
+
+def lift(x, weight, bias, out_size):
+    """FactorProjection2d3d (modules/geometry.py:711-728): 1x1 conv to C0*S channels, LeakyReLU,
+    PixelNorm over ALL C0*S channels, viewed as (V,C0,S,H,W).  Inference-only (no autograd)."""
+    L = _lib.lib()
+    _req(x, 'x')
+    x = cl(x)
+    V, cin, H, W = x.shape
+    cs = weight.shape[0]
+    c0 = cs // out_size
+    he = he_constant(weight)
+    wpack = _cached(weight, 'c1f', lambda: pack_conv1x1(weight.reshape(cs, cin)))
+    P = H * W
+    tmp = torch.empty(V * P, cs, device=x.device, dtype=torch.float32)
+    norm = _conv1x1_raw(x, wpack, bias.detach() if bias is not None else None, V, P, cin, 1, P * cin, 0, cs, tmp, he,
+                        LF_EPI_LRELU | (LF_EPI_PIXELNORM if cs <= 128 else 0))
+    if cs > 128:
+        norm = torch.empty(V * P, device=x.device, dtype=torch.float32)
+        # norm only: normalisation itself is folded into the unfold pass below
+        tmp2 = torch.empty_like(tmp)
+        check(L.lf_pixelnorm_fwd(_ptr(tmp), _ptr(tmp2), _ptr(norm), V * P, cs, PN_EPS, _stream()), 'lf_pixelnorm_fwd')
+        tmp = tmp2
+    out = empty_cl((V, c0, out_size, H, W), x.device)
+    check(L.lf_lift_unfold(_ptr(tmp), None, _ptr(out), V, P, c0, out_size, _stream()), 'lf_lift_unfold')
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# standalone PixelNorm / rescale
+# ---------------------------------------------------------------------------------------------
+class _PixelNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        L = _lib.lib()
+        _req(x, 'x')
+        x = cl(x)
+        rows = x.numel() // x.shape[1]
+        y = torch.empty_like(x, memory_format=torch.preserve_format)
+        norm = torch.empty(rows, device=x.device, dtype=torch.float32)
+        check(L.lf_pixelnorm_fwd(_ptr(x), _ptr(y), _ptr(norm), rows, x.shape[1], PN_EPS, _stream()), 'lf_pixelnorm_fwd')
+        ctx.save_for_backward(y, norm)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        y, norm = ctx.saved_tensors
+        return _epilogue_bwd(cl(gy), y, norm, LF_EPI_PIXELNORM)
+
+
+def pixelnorm(x):
+    return _PixelNorm.apply(x)
+
+
+def interpolate(x, scale_factor, mode):
+    """Block-end rescale (modules/__init__.py:18-36).  Only the released 2-D decoder/encoder
+    use it (SYN configs have no U/D tokens); currently served by ATen's upsample kernels on the
+    device -- a fused HIP version is listed in DESIGN.md as open work."""
+    ac = False if mode in ('bilinear', 'trilinear') else None
+    return torch.nn.functional.interpolate(x, scale_factor=scale_factor, mode=mode, align_corners=ac)

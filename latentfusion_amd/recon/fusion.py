@@ -1,0 +1,188 @@
+"""Multi-view fusers (API mirror of latentfusion/recon/fusion.py:17-246).
+
+z_obj is (B, V, C, S, S, S).  Pool fusers are reductions over the view axis (shardable over
+GPUs with one all-reduce of the fused volume, see latentfusion_amd.parallel); GRU/LSTM fusers
+are order-dependent recurrences whose gate convolutions run on the fused conv kernel."""
+import abc
+
+import torch
+from torch import nn
+
+from ..modules import EqualizedConv2d, EqualizedConv3d, unet
+from ..modules.geometry import CameraToObjectTransform
+from ..three.batchview import b2bv, bv2b
+from . import utils
+
+
+def get_fuser(fuser_type, in_channels, cube_size, block_config=None, conv_module=EqualizedConv3d):
+    if fuser_type.startswith('pool:'):
+        return PoolFuser(fuser_type.split(':')[1])
+    if fuser_type == 'concat':
+        return ConcatFuser()
+    if fuser_type == 'blend':
+        return BlendFuser(block_config, in_channels=in_channels, cube_size=cube_size, conv_module=conv_module)
+    if fuser_type == 'gru':
+        return GRUFuser(in_channels=in_channels, cube_size=cube_size, conv_module=conv_module)
+    if fuser_type == 'lstm':
+        return LSTMFuser(in_channels=in_channels, cube_size=cube_size, conv_module=conv_module)
+    raise ValueError(f'Unknown fuser type {fuser_type!r}')
+
+
+def from_checkpoint(checkpoint):
+    return globals()[checkpoint['type']].from_checkpoint(checkpoint)
+
+
+def absolute_max_pool(tensor, dim):
+    """Signed value of largest magnitude along `dim` (reference functional.py:47-49)."""
+    idx = tensor.abs().max(dim=dim, keepdim=True)[1]
+    return torch.gather(tensor, dim, idx)
+
+
+def pool_tensor(tensor, pool_type, dim=0):
+    if pool_type == 'max':
+        return tensor.max(dim=dim, keepdim=True)[0]
+    if pool_type == 'abs_max':
+        return absolute_max_pool(tensor, dim=dim)
+    if pool_type == 'mean':
+        return tensor.mean(dim=dim, keepdim=True)
+    if pool_type == 'median':
+        return tensor.median(dim=dim, keepdim=True)[0]        # lower median for even V
+    raise ValueError(f'Unknown pool_type value {pool_type}')
+
+
+class Fuser(nn.Module, abc.ABC):
+    @classmethod
+    def from_checkpoint(cls, checkpoint):
+        if 'args' in checkpoint:
+            model = cls(**checkpoint['args'])
+            model.load_state_dict(checkpoint['state_dict'])
+            return model
+        return cls(**({'pool_type': checkpoint['pool_type']} if 'pool_type' in checkpoint else {}))
+
+    def create_checkpoint(self):
+        return {'type': self.__class__.__qualname__}
+
+
+class PoolFuser(Fuser):
+    def __init__(self, pool_type='mean'):
+        super().__init__()
+        self.pool_type = pool_type
+
+    def create_checkpoint(self):
+        # the reference drops pool_type on save (fusion.py:66-69); keep it as an extra key
+        return {'type': 'PoolFuser', 'pool_type': self.pool_type}
+
+    def forward(self, z_obj, z_cam_mid, z_obj_mid, camera):
+        return pool_tensor(z_obj, self.pool_type, dim=1), {}
+
+
+class ConcatFuser(Fuser):
+    def forward(self, z_obj, z_cam_mid, z_obj_mid, camera):
+        N, V, C, D, H, W = z_obj.shape
+        return z_obj.reshape(N, 1, V * C, D, H, W), {}
+
+
+class _ArgsFuser(Fuser):
+    def create_checkpoint(self):
+        return {'type': self.__class__.__qualname__, 'args': self._args(),
+                'state_dict': {k: v.cpu() for k, v in self.state_dict().items()}}
+
+
+class BlendFuser(_ArgsFuser):
+    """Per-view blend logits from a 3-D U-Net, softmax over views (reference :95-149)."""
+
+    def __init__(self, block_config, in_channels, cube_size=1.0, conv_module=EqualizedConv3d):
+        super().__init__()
+        self.block_config, self.in_channels, self.cube_size = block_config, in_channels, cube_size
+        self.unet = unet.BaseUNet(in_channels + 1, 1, block_config, conv_module=conv_module)
+        self.transform_block = CameraToObjectTransform(cube_size)
+
+    def _args(self):
+        return {'block_config': self.block_config, 'in_channels': self.in_channels, 'cube_size': self.cube_size}
+
+    def compute_blend_weights(self, z_cam, camera):
+        V = z_cam.shape[1]
+        z_cam = bv2b(z_cam)
+        w = self.unet(torch.cat((z_cam, utils.get_normalized_voxel_depth(z_cam)), dim=1))
+        w = b2bv(self.transform_block(w, camera), V)
+        return torch.softmax(w, dim=1)
+
+    def forward(self, z_obj, z_cam_mid, z_obj_mid, camera):
+        w = self.compute_blend_weights(z_cam_mid[-1], camera)
+        return torch.sum(z_obj * w, dim=1, keepdim=True), {'blend_weights': w.squeeze(2)}
+
+
+class ConvGRUCell(nn.Module):
+    """u = s(conv_u[x,h]); r = s(conv_r[x,h]); c = conv_o[x, h*r] (NO tanh);
+    h' = h(1-u) + c u   (reference modules/gru.py:7-43)."""
+
+    def __init__(self, in_channels, hidden_channels, kernel_size, bias=True, conv_module=EqualizedConv3d):
+        super().__init__()
+        self.input_dim, self.hidden_dim = in_channels, hidden_channels
+        pad = kernel_size // 2
+        self.update_gate = conv_module(in_channels + hidden_channels, hidden_channels, kernel_size, padding=pad, bias=bias)
+        self.reset_gate = conv_module(in_channels + hidden_channels, hidden_channels, kernel_size, padding=pad, bias=bias)
+        self.out_gate = conv_module(in_channels + hidden_channels, hidden_channels, kernel_size, padding=pad, bias=bias)
+
+    def forward(self, x, h_cur):
+        x_in = torch.cat([x, h_cur], dim=1)
+        update = torch.sigmoid(self.update_gate(x_in))
+        reset = torch.sigmoid(self.reset_gate(x_in))
+        x_out = self.out_gate(torch.cat([x, h_cur * reset], dim=1))
+        return h_cur * (1 - update) + x_out * update
+
+
+class ConvLSTMCell(nn.Module):
+    """reference modules/lstm.py:7-56."""
+
+    def __init__(self, in_channels, hidden_channels, kernel_size, bias=True, conv_module=EqualizedConv3d):
+        super().__init__()
+        self.in_channels, self.hidden_channels = in_channels, hidden_channels
+        self.conv = conv_module(in_channels + hidden_channels, 4 * hidden_channels, kernel_size,
+                                padding=kernel_size // 2, bias=bias)
+
+    def forward(self, input_tensor, cur_state):
+        h_cur, c_cur = cur_state
+        cc = self.conv(torch.cat([input_tensor, h_cur], dim=1))
+        i, f, o, g = torch.split(cc, self.hidden_channels, dim=1)
+        c_next = torch.sigmoid(f) * c_cur + torch.sigmoid(i) * torch.tanh(g)
+        return torch.sigmoid(o) * torch.tanh(c_next), c_next
+
+
+class GRUFuser(_ArgsFuser):
+    """h0 = view 0; for each further view x = cat(z_i, voxel coords (z,y,x)) (reference :152-201)."""
+
+    def __init__(self, in_channels, cube_size=1.0, conv_module=EqualizedConv3d):
+        super().__init__()
+        self.in_channels, self.cube_size, self.conv_module = in_channels, cube_size, conv_module
+        n_coord = 2 if conv_module == EqualizedConv2d else 3
+        self.gru = ConvGRUCell(in_channels + n_coord, in_channels, kernel_size=3, bias=True, conv_module=conv_module)
+
+    def _args(self):
+        return {'in_channels': self.in_channels, 'cube_size': self.cube_size}
+
+    def forward(self, z_obj, z_cam_mid, z_obj_mid, camera):
+        h = z_obj[:, 0]
+        coords = (utils.get_normalized_pixel_coords(h) if self.conv_module == EqualizedConv2d
+                  else utils.get_normalized_voxel_coords(h))
+        for i in range(1, z_obj.shape[1]):
+            h = self.gru(torch.cat((z_obj[:, i], coords), dim=1), h)
+        return h.unsqueeze(1), {}
+
+
+class LSTMFuser(_ArgsFuser):
+    def __init__(self, in_channels, cube_size=1.0, conv_module=EqualizedConv3d):
+        super().__init__()
+        self.in_channels, self.cube_size = in_channels, cube_size
+        self.lstm = ConvLSTMCell(in_channels + 3, in_channels, kernel_size=3, bias=True, conv_module=conv_module)
+
+    def _args(self):
+        return {'in_channels': self.in_channels, 'cube_size': self.cube_size}
+
+    def forward(self, z_obj, z_cam_mid, z_obj_mid, camera):
+        h = z_obj[:, 0]
+        c = torch.zeros_like(h)
+        coords = utils.get_normalized_voxel_coords(h)
+        for i in range(1, z_obj.shape[1]):
+            h, c = self.lstm(torch.cat((z_obj[:, i], coords), dim=1), (h, c))
+        return h.unsqueeze(1), {}

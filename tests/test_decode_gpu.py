@@ -1,0 +1,76 @@
+"""End-to-end GPU parity of the renderer (Photographer.decode) and the encoder (Sculptor.encode
++ fusers) on the HIP path against golden vectors produced by the real reference.
+
+North-star tolerance: rendered depth / mask within 1e-3 relative of the reference."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def close(a, b, atol=1e-4, rtol=1e-3):
+    torch.testing.assert_close(a.detach().cpu().contiguous(), b.detach().cpu().contiguous(), atol=atol, rtol=rtol)
+
+
+def prod_camera(d, device=DEV):
+    from latentfusion_amd.modules.geometry import Camera
+    return Camera(d['K'].to(device), None, d['z_span'], d['viewport'].to(device), width=d['width'],
+                  height=d['height'], log_quaternion=d['log_q'].to(device), translation=d['t'].to(device))
+
+
+@pytest.mark.parametrize('variant', ['factor', 'sum', 'occlusion'])
+def test_g5_decode(golden, variant):
+    from latentfusion_amd.recon.models import Photographer
+    r = golden('g5_decode')[variant]
+    ph = Photographer.from_checkpoint(r['ck']).to(DEV)
+    cam = prod_camera(r['cam'])
+    for p in (cam.log_quaternion, cam.translation, cam.viewport):
+        p.requires_grad_(True)
+    y, lat, zd = ph.decode(r['z_obj'].to(DEV), cam, return_latent=True, apply_mask=True)
+    for k in ('depth_logits', 'mask_logits', 'depth', 'mask'):
+        close(y[k], r['y'][k], atol=1e-4, rtol=1e-3)
+    close(lat, r['latent'], atol=1e-4, rtol=1e-3)
+    if r['z_depth'] is not None:
+        close(zd, r['z_depth'], atol=1e-4)
+    ((y['depth_logits'] * r['wd'].to(DEV)).sum() + (y['mask_logits'] * r['wm'].to(DEV)).sum()).backward()
+    # Camera gradients: relative L2 error of the 10-vector per sample.  The network is piecewise
+    # linear in places (LeakyReLU): when a pre-activation of the reference run is within fp32
+    # noise of 0 (|pre| ~ 2e-5 exists in the 'occlusion' fixture) the two runs may take different
+    # slopes for that one activation, which moves the summed gradient by ~1e-2 relative.  That is
+    # a property of the test point, not of the kernels (layerwise forward agreement is ~2e-6).
+    got = torch.cat((cam.log_quaternion.grad, cam.translation.grad, cam.viewport.grad), dim=1).cpu()
+    want = torch.cat((r['g_log_q'], r['g_t'], r['g_viewport']), dim=1)
+    rel = ((got - want).norm(dim=1) / want.norm(dim=1)).max().item()
+    assert rel < (3e-2 if variant == "occlusion" else 1e-2), rel
+
+
+@pytest.mark.parametrize('tag', ['gru', 'pool_mean'])
+def test_g10_encode(golden, tag):
+    from latentfusion_amd.recon.models import Sculptor
+    from latentfusion_amd.recon import fusion
+    g = golden('g10_encode_' + tag)
+    sc = Sculptor.from_checkpoint(g['sculptor']).to(DEV)
+    fu = fusion.from_checkpoint(g['fuser']).to(DEV)
+    o = g['obs_pre']
+    cam = prod_camera(o['cam'])
+    with torch.no_grad():
+        z, _ = sc.encode(fu, cam, o['color'].unsqueeze(0).to(DEV), o['depth'].unsqueeze(0).to(DEV),
+                         o['mask'].unsqueeze(0).to(DEV))
+    close(z, g['z_obj'], atol=1e-4, rtol=1e-3)
+
+
+def test_g4_fusers(golden):
+    from latentfusion_amd.recon import fusion
+    g = golden('g4_fusers')
+    z = g['z'].to(DEV)
+    cam = prod_camera(g['cam'])
+    for pool in ('mean', 'max', 'abs_max', 'median'):
+        out, _ = fusion.PoolFuser(pool)(z, None, None, cam)
+        close(out, g['pool_' + pool], atol=1e-6)
+    for kind in ('gru', 'lstm', 'blend'):
+        f = fusion.from_checkpoint(g[kind]['ck']).to(DEV)
+        with torch.no_grad():
+            mids = [g['blend']['z_cam_mid'].to(DEV)] if kind == 'blend' else None
+            out, _ = f(z, mids, None, cam)
+        close(out, g[kind]['out'], atol=1e-4, rtol=1e-3)
