@@ -1,0 +1,180 @@
+#!/usr/bin/env python
+"""Benchmark of the reconstruct-and-render hot loop (BASELINE.json metric):
+
+    pose-optim iters/sec (reconstruct + render + backward), 16 views, 128^3 voxels
+
+One "step" = one pose-optimisation iteration of GradientPoseEstimator on the adam_quick preset:
+render N=8 pose samples of the fused latent volume (O2C resample, 2 fused conv3d blocks, factor
+projection, 2-D decoder), pose loss against the target frame, backward to the 10 camera
+parameters of every sample, batched Adam + plateau step, ranking.  Workload: SYN(128,16)
+(SURVEY 8d), V=16 reference views, fp32, synthetic data, random-init weights.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Multi-GPU (weak scaling): every rank owns one object (its own latent volume, target and pose
+samples; BASELINE cfg 4) -- the pose loop has no data-path collective; value = total
+iterations/s over all ranks, timed between barriers with the max over ranks.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--size', type=int, default=128, help='latent volume side S of SYN(S,C)')
+    ap.add_argument('--channels', type=int, default=16)
+    ap.add_argument('--views', type=int, default=16)
+    ap.add_argument('--samples', type=int, default=8)
+    ap.add_argument('--fuser', default='gru')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-iters', type=int, default=1)
+    return ap.parse_args()
+
+
+def cpu_baseline(cks, z_obj_cpu, target_data, init, cfg, iters):
+    """The oracle (CPU restatement of the reference, pinned by tests/golden) on the SAME workload:
+    `iters` timed iterations of the same loop after one warm-up iteration."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import lf_oracle as O
+    from lf_oracle import pose as opose
+    sck, fck, pck, dist = cks
+    # the oracle's ATen CPU ops peak at ~32 threads on the GPU box's host (measured: 16/32/64/128
+    # threads -> 1.52/1.33/1.57/2.80 s per SYN(64,16) iteration); more threads only oversubscribe
+    torch.set_num_threads(min(32, os.cpu_count()))
+    model = opose.Model(sck, fck, pck, dist)
+    target = opose.Obs(None, target_data['depth'], target_data['mask'],
+                       O.Cam.from_extrinsic(target_data['intrinsic'], target_data['extrinsic']))
+    cam0 = O.Cam(init['K'], init['log_q'], init['t'])
+    c = dict(cfg)
+    c['args'] = dict(cfg['args'])
+    c['args']['num_iters'] = 1
+    c['args']['converge_patience'] = 10 ** 6
+    opose.gradient_estimate(model, z_obj_cpu, target, cam0, c)              # warm-up (page-in, thread pools)
+    c['args']['num_iters'] = iters
+    t0 = time.perf_counter()
+    opose.gradient_estimate(model, z_obj_cpu, target, cam0, c)
+    dt = time.perf_counter() - t0
+    return iters / dt, torch.get_num_threads()
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    torch.cuda.set_device(local)
+    dev = f'cuda:{local}'
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl')
+
+    from latentfusion_amd import ops, synth
+    from latentfusion_amd.modules.geometry import Camera
+    from latentfusion_amd.pose import estimation, utils as pu
+
+    S, C, V, N = a.size, a.channels, a.views, a.samples
+    # every rank owns its own object: different weights seed -> different volume, same shapes
+    model, cks = synth.build_model(S, C, a.fuser, seed=rank, device=dev)
+    ref_obs = synth.make_observation(V, seed=100 + rank, device=dev)
+    tdata = synth.make_observation_data(1, seed=200 + rank)
+    from latentfusion_amd.observation import Observation
+    target = Observation(tdata['color'], tdata['depth'], tdata['mask'],
+                         Camera(tdata['intrinsic'], tdata['extrinsic'])).to(dev)
+
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    z_obj = model.build_latent_object(ref_obs)
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t0
+    del ref_obs
+    torch.cuda.empty_cache()
+
+    cfg = estimation._load_toml(os.path.join(ROOT, 'configs', 'adam_quick.toml'))
+    cfg['args']['num_samples'] = N
+    cfg['args']['ranking_size'] = N
+    est = estimation.load_from_config(cfg, model, converge_patience=10 ** 6)
+    torch.manual_seed(300 + rank)
+    init = pu.sample_cameras_with_estimate(N, target.camera.to('cpu'))
+    init_rec = {'K': init.intrinsic.clone(), 'log_q': init.log_quaternion.clone(), 't': init.translation.clone()}
+    st = est.start(z_obj, target, init.zoom(None, model.input_size, model.camera_dist).to(dev))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        est.iterate(st)
+    barrier()
+    ops.KERNEL_TIMER = []
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        est.iterate(st)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timer, ops.KERNEL_TIMER = ops.KERNEL_TIMER, None
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+
+    # roofline of the dominant kernel: conv3x3_kernel<3,1> (fused conv3d C->C block; 2 fwd + 2
+    # data-grad launches per iteration), HIP events recorded on the launch stream in the timed region
+    name = f'conv3x3_3d_{C}x{C}'
+    durs = [e0.elapsed_time(e1) for n_, e0, e1 in timer if n_ == name]
+    conv_ms = sum(durs) / max(len(durs), 1)
+    flops = 2.0 * 27 * C * C * (S ** 3) * N                        # algorithmic flops per launch
+    achieved = flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, 'profiles', 'r01_conv3d_hbm_bytes.json')
+    if os.path.exists(tpath) and S == 128 and C == 16 and N == 8:
+        try:
+            traffic = json.load(open(tpath)).get('bytes_per_launch')
+        except Exception:                                           # noqa: BLE001
+            traffic = None
+
+    if rank != 0:
+        return
+    value = world * a.steps / elapsed
+    out = {
+        'metric': 'pose-optim iters/sec (reconstruct+render+backward), 16 views, 128^3 voxels',
+        'value': value, 'unit': 'iters/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+        'ms_per_step': elapsed / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic (SYN(S,C) random-init weights, synthetic observations)',
+        'config': {'workload': f'SYN({S},{C}) latent volume, {V} reference views, adam_quick pose loop, '
+                               f'{N} pose samples per iteration, one object per GPU',
+                   'fuser': a.fuser, 'pose_samples': N, 'ref_views': V, 'volume': S, 'channels': C,
+                   'parallelism': f'objects x{world} (no data-path collective in the loop)'},
+        't_build_s': t_build,
+        'roofline': {'bound': 'mfma', 'kernel': 'conv3x3_kernel<3,1> (fused conv3d+He+bias+LeakyReLU+PixelNorm)',
+                     'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': traffic,
+                     'avg_launch_ms': conv_ms, 'launches_timed': len(durs), 'flops_per_launch': flops},
+    }
+    if world == 1 and not a.no_cpu_baseline:
+        v, cores = cpu_baseline(cks[:3] + (cks[3],), z_obj.cpu(), tdata, init_rec, cfg, a.cpu_iters)
+        out['cpu_baseline'] = {'value': v, 'unit': 'iters/s', 'cores': cores, 'kind': 'port',
+                               'sample': f'{a.cpu_iters} timed iteration(s) of the same SYN({S},{C}) N={N} pose loop '
+                                         f'(oracle, after 1 warm-up iteration; latent volume taken from the GPU build)'}
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

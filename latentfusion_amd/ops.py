@@ -17,6 +17,28 @@ from ._lib import LF_EPI_LRELU, LF_EPI_PIXELNORM, LF_MAP_C2O, LF_MAP_COEFS, LF_M
 SLOPE = 0.2
 PN_EPS = 1e-8
 
+# Optional per-kernel timing with HIP events on the launch stream (used by bench.py for the
+# roofline of the dominant kernel).  Set to a list to collect (name, start_event, end_event).
+KERNEL_TIMER = None
+
+
+class _timed:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if KERNEL_TIMER is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()                    # current stream == the stream the kernel is launched on
+        return self
+
+    def __exit__(self, *exc):
+        if KERNEL_TIMER is not None:
+            self.e1.record()
+            KERNEL_TIMER.append((self.name, self.e0, self.e1))
+        return False
+
 
 def _stream():
     return torch.cuda.current_stream().cuda_stream
@@ -180,9 +202,10 @@ def _conv3x3_raw(x, wpack, bias, cout, he, flags, want_norm):
     kflags = flags if fuse_pn else (flags & ~LF_EPI_PIXELNORM)
     y = empty_cl((N, cout) + tuple(x.shape[2:]), x.device)
     norm = torch.empty(N * D * H * W, device=x.device, dtype=torch.float32) if (flags & LF_EPI_PIXELNORM) else None
-    check(L.lf_conv3x3_fwd(_ptr(x), _ptr(wpack), _ptr(bias) if bias is not None else None, _ptr(y),
-                           _ptr(norm) if (norm is not None and fuse_pn) else None,
-                           dims, N, D, H, W, cin, cout, he, kflags, SLOPE, PN_EPS, _stream()), 'lf_conv3x3_fwd')
+    with _timed(f'conv3x3_{dims}d_{cin}x{cout}'):
+        check(L.lf_conv3x3_fwd(_ptr(x), _ptr(wpack), _ptr(bias) if bias is not None else None, _ptr(y),
+                               _ptr(norm) if (norm is not None and fuse_pn) else None,
+                               dims, N, D, H, W, cin, cout, he, kflags, SLOPE, PN_EPS, _stream()), 'lf_conv3x3_fwd')
     if (flags & LF_EPI_PIXELNORM) and not fuse_pn:
         check(L.lf_pixelnorm_fwd(_ptr(y), _ptr(y), _ptr(norm), N * D * H * W, cout, PN_EPS, _stream()), 'lf_pixelnorm_fwd')
     return y, norm

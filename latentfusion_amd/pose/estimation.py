@@ -1,0 +1,432 @@
+"""Pose estimators driving the render loop (API mirror of latentfusion/pose/estimation.py):
+`load_from_config(toml|dict, model, **overrides)` -> estimator with `.estimate(z_obj, target_obs,
+camera=|cameras=)`, the TOML formats of configs/*.toml, `default_pose_loss`, track_stats /
+return_camera_history outputs.
+
+MI355X design notes (vs. the reference loop, pose/estimation.py:579-679):
+  * the N pose samples live in THREE batched leaf tensors (N,3)/(N,3)/(N,4) instead of 3N tiny
+    nn.Parameters; the optimiser is one batched update that reproduces torch.optim.{Adam,AdamW,
+    SGD,Adagrad} element for element (a per-sample learning-rate vector carries the
+    ReduceLROnPlateau state), so N independent optimisers cost one launch chain, not N;
+  * exactly one device->host read-back per iteration (the N rank losses), used for the
+    plateau schedulers, the ranking and the convergence test -- all host-side scalar logic;
+  * weight gradients of the renderer are never formed.
+"""
+import copy
+import math
+from collections import defaultdict
+from pathlib import Path
+
+import torch
+
+from .. import three
+from ..modules.geometry import Camera
+from ..utils import ExponentialScheduler, LinearScheduler
+from . import utils as pu
+from .loss import default_pose_loss, weigh_losses  # noqa: F401  (re-exported like the reference)
+
+DEFAULT_TRANSLATION_STD = 0.01
+DEFAULT_QUATERION_STD = 10.0 / 180.0 * math.pi
+
+
+def _load_toml(path):
+    import tomli
+    with open(path, 'rb') as f:
+        return tomli.load(f)
+
+
+def load_from_config(config, model, **kwargs):
+    if isinstance(config, (Path, str)):
+        config = _load_toml(config)
+    params = dict(config['args'])
+    params.update(kwargs)
+    kind = config['type']
+    if kind == 'metropolis':
+        return MetropolisPoseEstimator(model=model, **params, loss_weights=config['loss_weights'])
+    if kind == 'cross_entropy':
+        return CrossEntropyPoseEstimator(model=model, **params, loss_weights=config['loss_weights'])
+    if kind == 'gradient':
+        schedules = {k: load_schedules_from_config(v) for k, v in config.get('loss_schedules', {}).items()}
+        return GradientPoseEstimator(model=model, **params, loss_weights=config['loss_weights'],
+                                     loss_schedules=schedules)
+    raise ValueError(f"Unknown estimator type {kind}")
+
+
+def load_schedules_from_config(config):
+    config = dict(config)
+    kind = config.pop('type')
+    if kind == 'exponential':
+        return ExponentialScheduler(**config)
+    if kind == 'linear':
+        return LinearScheduler(**config)
+    raise ValueError(f'Unknown schedule type {kind}')
+
+
+class PoseEstimator:
+    def __init__(self, *, model, ranking_size, loss_weights, loss_func=None, return_camera_history=False,
+                 verbose=False):
+        self.model = model
+        self.ranking_size = ranking_size
+        self.loss_func = default_pose_loss if loss_func is None else loss_func
+        self.loss_weights = defaultdict(float)
+        self.loss_weights.update(loss_weights)
+        self.return_camera_history = return_camera_history
+        self.verbose = verbose
+
+    @property
+    def device(self):
+        return self.model.device
+
+    @classmethod
+    def initial_pose(cls, target_obs):
+        raise NotImplementedError('translation initialisation from depth (pose/initialization.py) is outside the '
+                                  'hot path: pass camera= / cameras= to estimate()')
+
+    def estimate(self, z_obj, target_obs, **kwargs):
+        if len(target_obs) > 1:
+            raise ValueError('The pose can only be estiamted for one observation at a time.')
+        return self._estimate(z_obj, target_obs, **kwargs)
+
+    def _track_best_items(self, ranking, step, items, loss):
+        """Merge this step's (camera, loss) pairs into the top-`ranking_size` list; returns the
+        improvement of the best loss (reference :187-205).  `loss` is a host sequence."""
+        prev_best = ranking[0][1] if ranking else float('inf')
+        ranking.extend((c, float(e), step) for c, e in zip(items, loss))
+        ranking.sort(key=lambda r: r[1])
+        del ranking[self.ranking_size:]
+        best = ranking[0][1]
+        return prev_best - best if best < prev_best else 0.0
+
+    def _render_observation(self, z_obj, camera, **kwargs):
+        """Zoom, render without grad, denormalise, multiply by the mask (reference :207-216)."""
+        z_camera = camera.zoom(None, self.model.input_size, self.model.camera_dist)
+        with torch.set_grad_enabled(kwargs.get('grad_enabled', False)):
+            pred, z_latent = self.model.render_latent_object(z_obj, z_camera.to(self.device), return_latent=True)
+            z_mask = pred['mask'].squeeze(0)
+            z_depth = camera.denormalize_depth(pred['depth'].squeeze(0)) * z_mask
+        return z_depth, pred['mask_logits'].squeeze(0), z_latent, z_camera
+
+
+# ---------------------------------------------------------------------------------------------
+class MetropolisPoseEstimator(PoseEstimator):
+    """Metropolis-Hastings with simulated annealing (reference :219-295)."""
+
+    def __init__(self, *, num_samples, num_iters, translation_std=DEFAULT_TRANSLATION_STD,
+                 quaternion_std=DEFAULT_QUATERION_STD, **kwargs):
+        super().__init__(**kwargs)
+        self.num_samples, self.num_iters = num_samples, num_iters
+        self.translation_std, self.quaternion_std = translation_std, quaternion_std
+
+    def _estimate(self, z_obj, target_obs, **kwargs):
+        camera_init = kwargs['camera'] if 'camera' in kwargs else self.initial_pose(target_obs)
+        camera = pu.sample_cameras_with_estimate(self.num_samples, camera_init).to(self.device)
+        error = torch.full((self.num_samples,), 100.0, device=self.device)
+        temp_weight = 1.0 / camera_init.translation[:, -1].mean().item()
+        sched = ExponentialScheduler(temp_weight * 0.1, temp_weight * 0.005, num_steps=self.num_iters)
+        target_obs = target_obs.to(self.device)
+        ranking, history = [], []
+        for step in range(self.num_iters):
+            camera, error, _ = self._refine_pose(z_obj, camera.clone(), error.clone(), target_obs, sched.get(step))
+            if self._track_best_items(ranking, step, list(camera), error.tolist()) > 0:
+                history.append((error, camera.clone().to('cpu')))
+        cameras = Camera.cat([c for c, _, _ in ranking])
+        return (cameras, history) if self.return_camera_history else cameras
+
+    def _refine_pose(self, z_obj, prev_camera, prev_error, target_obs, temperature=1.0):
+        camera = pu.perturb_camera(prev_camera, self.translation_std, self.quaternion_std)
+        with torch.no_grad():
+            z_target_latent = self.model.compute_latent_code(target_obs, camera)
+            zd, zl, z_lat, z_camera = self._render_observation(z_obj, camera)
+            ld = self.loss_func(target_obs, zd, zl, z_camera, z_pred_latent=z_lat, z_target_latent=z_target_latent)
+            loss = sum(weigh_losses(ld, self.loss_weights).values())
+        accept = torch.exp((prev_error - loss) / temperature) > torch.rand_like(loss)
+        camera[~accept] = prev_camera[~accept]
+        loss[~accept] = prev_error[~accept]
+        return camera, loss, int(accept.sum().item())
+
+
+# ---------------------------------------------------------------------------------------------
+class CrossEntropyPoseEstimator(PoseEstimator):
+    """Cross-entropy method over a diagonal GMM on (t, log_q) (reference :298-497).  Rendering and
+    loss evaluation are the device work; GMM fit/sampling is scikit-learn on the host as in the
+    reference."""
+
+    def __init__(self, *, num_samples, num_elites, num_iters, num_gmm_components, learning_rate,
+                 sample_flipped=False, init_hemisphere=False, init_upright=False,
+                 translation_std=DEFAULT_TRANSLATION_STD, quaternion_std=DEFAULT_QUATERION_STD, **kwargs):
+        super().__init__(**kwargs)
+        self.num_samples, self.num_elites, self.num_iters = num_samples, num_elites, num_iters
+        self.num_gmm_components, self.learning_rate = num_gmm_components, learning_rate
+        self.sample_flipped, self.init_upright, self.init_hemisphere = sample_flipped, init_upright, init_hemisphere
+        self.translation_std, self.quaternion_std = translation_std, quaternion_std
+        self.elite_sched = ExponentialScheduler(num_samples, num_elites, num_iters)
+
+    def _estimate(self, z_obj, target_obs, **kwargs):
+        if kwargs.get('cameras', None):
+            cameras, camera_init = kwargs['cameras'], kwargs['cameras'][0]
+        else:
+            camera_init = kwargs['camera'] if 'camera' in kwargs else self.initial_pose(target_obs)
+            cameras = pu.sample_cameras_with_estimate(n=self.num_gmm_components * self.num_samples,
+                                                      camera_est=camera_init, upright=self.init_upright,
+                                                      hemisphere=self.init_hemisphere)
+        gmm = self._create_gmm(self._camera_to_params(cameras).cpu())
+        target_obs = target_obs.to(self.device)
+        prev_gmm, ranking, history = None, [], []
+        for step in range(self.num_iters):
+            n_elite = int(self.elite_sched.get(step))
+            cameras, losses = self._refine_pose(z_obj, target_obs, prev_gmm, gmm, n_elite, camera_init)
+            prev_gmm = gmm
+            gmm = self._create_gmm(self._camera_to_params(cameras).cpu())
+            if self._track_best_items(ranking, step, list(cameras), losses.tolist()) > 0:
+                history.append((losses, Camera.cat([c for c, _, _ in ranking])))
+        out = Camera.cat([c for c, _, _ in ranking])
+        return (out, history) if self.return_camera_history else out
+
+    def evaluate_samples(self, z_obj, target_obs, cameras):
+        """Flip-augment, render without grad, weighted loss per sample (reference :383-401)."""
+        if self.sample_flipped:
+            cameras = Camera.cat([cameras, pu.flip_camera(cameras, axis=(0.0, 0.0, 1.0)),
+                                  pu.flip_camera(cameras, axis=(0.0, 1.0, 0.0)),
+                                  pu.flip_camera(cameras, axis=(1.0, 0.0, 0.0))])
+        z_target_latent = None
+        if self.loss_weights.get('latent', 0.0) > 0.0:
+            with torch.no_grad():
+                z_target_latent = self.model.compute_latent_code(target_obs, cameras[0])
+        with torch.no_grad():
+            zd, zl, z_lat, z_camera = self._render_observation(z_obj, cameras)
+            ld = self.loss_func(target_obs, zd, zl, z_camera, z_pred_latent=z_lat, z_target_latent=z_target_latent)
+            loss = sum(weigh_losses(ld, self.loss_weights).values())
+        return cameras, loss
+
+    def _refine_pose(self, z_obj, target_obs, prev_gmm, gmm, num_elites, camera_init):
+        sample_gmm = self._combined_gmm(prev_gmm, gmm, self.learning_rate) if prev_gmm is not None else gmm
+        n = self.num_samples // 4 if self.sample_flipped else self.num_samples
+        cameras = self._params_to_camera(self._sample_poses(sample_gmm, n), camera_init, device=self.device)
+        cameras, loss = self.evaluate_samples(z_obj, target_obs, cameras)
+        elite = torch.argsort(loss)[:num_elites]
+        return cameras[elite], loss[elite]
+
+    def _sample_poses(self, gmm, n):
+        params, _ = gmm.sample(n)
+        params = torch.tensor(params, dtype=torch.float32, device=self.device)
+        params[:, :3] += torch.randn_like(params[:, :3]) * self.translation_std
+        params[:, 3:] += torch.randn_like(params[:, 3:]) * self.quaternion_std
+        return params
+
+    def _create_gmm(self, params=None):
+        import sklearn.mixture
+        gmm = sklearn.mixture.GaussianMixture(covariance_type='diag', n_components=self.num_gmm_components,
+                                              reg_covar=1e-5)
+        if params is not None:
+            gmm.fit(params.numpy() if torch.is_tensor(params) else params)
+        return gmm
+
+    def _combined_gmm(self, old_gmm, new_gmm, alpha):
+        import numpy as np
+        if alpha > 1.0 or alpha < 0.0:
+            raise ValueError('alpha must be between 0.0 and 1.0')
+        out = self._create_gmm()
+        out.weights_ = np.concatenate([(1.0 - alpha) * old_gmm.weights_, alpha * new_gmm.weights_], axis=0)
+        out.means_ = np.concatenate([old_gmm.means_, new_gmm.means_], axis=0)
+        out.covariances_ = np.concatenate([old_gmm.covariances_, new_gmm.covariances_], axis=0)
+        out.precisions_cholesky_ = np.concatenate([old_gmm.precisions_cholesky_, new_gmm.precisions_cholesky_], axis=0)
+        return out
+
+    @classmethod
+    def _camera_to_params(cls, camera):
+        return torch.cat([camera.translation, camera.log_quaternion], dim=-1).detach()
+
+    @classmethod
+    def _params_to_camera(cls, params, camera_init, device='cpu'):
+        if params.dim() == 1:
+            params = params.unsqueeze(0)
+        return Camera(intrinsic=camera_init.intrinsic.expand(params.shape[0], -1, -1).to(device), extrinsic=None,
+                      translation=params[:, :3].to(device), log_quaternion=params[:, 3:].to(device),
+                      width=camera_init.width, height=camera_init.height, z_span=camera_init.z_span)
+
+
+# ---------------------------------------------------------------------------------------------
+class _PlateauLR:
+    """N independent torch.optim.lr_scheduler.ReduceLROnPlateau(mode='min', threshold_mode='rel')
+    instances as host-side vectors."""
+
+    def __init__(self, n, lr, patience, threshold, factor, min_lr=0.0, eps=1e-8):
+        self.lr = [lr] * n
+        self.best = [float('inf')] * n
+        self.bad = [0] * n
+        self.patience, self.threshold, self.factor, self.min_lr, self.eps = patience, threshold, factor, min_lr, eps
+
+    def step(self, metrics):
+        for i, cur in enumerate(metrics):
+            if cur < self.best[i] * (1.0 - self.threshold):
+                self.best[i], self.bad[i] = cur, 0
+            else:
+                self.bad[i] += 1
+            if self.bad[i] > self.patience:
+                new_lr = max(self.lr[i] * self.factor, self.min_lr)
+                if self.lr[i] - new_lr > self.eps:
+                    self.lr[i] = new_lr
+                self.bad[i] = 0
+
+
+class BatchedOptimizer:
+    """One update for N independent per-sample optimisers over rows of batched parameters.
+    Reproduces the update rules of torch.optim.{Adam, AdamW, SGD, Adagrad} (defaults) exactly;
+    `lr` is a per-row vector."""
+
+    def __init__(self, name, params):
+        if name not in ('adam', 'adamw', 'sgd', 'adagrad'):
+            raise ValueError(f'Unknow optimizer {name!r}')
+        self.name, self.params, self.t = name, params, 0
+        self.m = [torch.zeros_like(p) for p in params]
+        self.v = [torch.zeros_like(p) for p in params]
+
+    def step(self, lr_rows):
+        self.t += 1
+        dev = self.params[0].device
+        lr = torch.tensor(lr_rows, dtype=torch.float32, device=dev).unsqueeze(1)
+        with torch.no_grad():
+            for p, m, v in zip(self.params, self.m, self.v):
+                g = p.grad
+                if g is None:
+                    continue
+                if self.name in ('adam', 'adamw'):
+                    b1, b2, eps = 0.9, 0.999, 1e-8
+                    if self.name == 'adamw':
+                        p.mul_(1 - lr * 1e-2)
+                    m.lerp_(g, 1 - b1)
+                    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+                    bc1, bc2 = 1 - b1 ** self.t, 1 - b2 ** self.t
+                    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+                    # step size formed in double on the host like torch.optim (lr / bias_correction1)
+                    step_size = torch.tensor([l / bc1 for l in lr_rows], dtype=torch.float32, device=dev).unsqueeze(1)
+                    p.sub_(step_size * (m / denom))
+                elif self.name == 'sgd':
+                    p.sub_(lr * g)
+                else:                                            # adagrad: lr_decay 0, eps 1e-10
+                    v.addcmul_(g, g, value=1.0)
+                    p.sub_(lr * (g / v.sqrt().add_(1e-10)))
+
+
+class GradientPoseEstimator(PoseEstimator):
+    """Gradient descent on (log_quaternion, translation, viewport) of the ZOOMED camera of every
+    pose sample (reference :500-713)."""
+
+    def __init__(self, *, learning_rate, num_samples, num_iters, converge_threshold, converge_patience,
+                 lr_reduce_patience=25, lr_reduce_threshold=1e-5, lr_reduce_factor=0.5, track_stats=False,
+                 loss_schedules=None, optimizer='adamw', **kwargs):
+        super().__init__(**kwargs)
+        self.learning_rate, self.num_samples, self.num_iters = learning_rate, num_samples, num_iters
+        self.optimizer = optimizer
+        self.lr_reduce_patience, self.lr_reduce_threshold = lr_reduce_patience, lr_reduce_threshold
+        self.lr_reduce_factor = lr_reduce_factor
+        self.converge_threshold, self.converge_patience = converge_threshold, converge_patience
+        self.loss_schedules = dict(loss_schedules) if loss_schedules else {}
+        self.track_stats = track_stats
+
+    def _estimate(self, z_obj, target_obs, **kwargs):
+        if 'camera' in kwargs:
+            camera = kwargs['camera']
+        else:
+            camera = pu.sample_cameras_with_estimate(n=self.num_samples, camera_est=self.initial_pose(target_obs))
+        target_obs = target_obs.to(self.device)
+        camera = camera.zoom(None, self.model.input_size, self.model.camera_dist).to(self.device)
+        ranking = []
+        stats, history = self._optimize_camera(z_obj, target_obs, camera, iters=self.num_iters, ranking=ranking)
+        best = Camera.cat([c for c, _, _ in ranking])
+        if self.track_stats and self.return_camera_history:
+            return best, stats, history
+        if self.track_stats:
+            return best, stats
+        if self.return_camera_history:
+            return best, history
+        return best
+
+    # one iteration = render N samples + loss + backward to the camera parameters
+    def loss_and_grad(self, z_obj, target_obs, cameras, step=0, z_target_latent=None):
+        z_depth, z_mask_logits, z_pred_latent = self._render_observation(z_obj, cameras)
+        optim_weights = copy.copy(self.loss_weights)
+        optim_weights.update({k: v.get(step) for k, v in self.loss_schedules.items()})
+        loss_dict = self.loss_func(target_obs, z_depth, z_mask_logits, cameras, z_pred_latent=z_pred_latent,
+                                   z_target_latent=z_target_latent)
+        optim_loss = sum(weigh_losses(loss_dict, optim_weights).values())
+        optim_loss.mean().backward()
+        rank_loss = sum(weigh_losses(loss_dict, self.loss_weights).values()).detach()
+        return loss_dict, optim_loss.detach(), rank_loss, optim_weights
+
+    def start(self, z_obj, target_obs, cameras, ranking=None):
+        """Creates the per-run loop state (parameters, optimiser, schedulers); `cameras` must
+        already be zoomed and on the device.  Exposed so that bench.py can time `iterate`."""
+        cam = pu.parameterize_camera(cameras, optimize_viewport=True)     # batched leaves (N,3),(N,3),(N,4)
+        params = [cam.log_quaternion, cam.translation, cam.viewport]
+        return {
+            'z_obj': z_obj, 'target': target_obs, 'cam': cam, 'params': params,
+            'opt': BatchedOptimizer(self.optimizer, params),
+            'sched': _PlateauLR(len(cameras), self.learning_rate, self.lr_reduce_patience, self.lr_reduce_threshold,
+                                self.lr_reduce_factor),
+            'ranking': [] if ranking is None else ranking, 'step': 0, 'converge_count': 0,
+            'stat_history': {}, 'camera_history': [], 'target_q': target_obs.camera.quaternion,
+        }
+
+    def iterate(self, st):
+        """One pose-optimisation iteration: render the N samples, loss, backward to the camera
+        parameters, rank, optimiser + scheduler step.  Returns True when converged."""
+        cam, params, target_obs, step = st['cam'], st['params'], st['target'], st['step']
+        for p in params:
+            p.grad = None
+        z_target_latent = None
+        if self.loss_weights.get('latent', 0.0) > 0.0:
+            with torch.no_grad():
+                z_target_latent = self.model.compute_latent_code(target_obs, cam)
+        loss_dict, optim_loss, rank_loss, optim_weights = self.loss_and_grad(st['z_obj'], target_obs, cam, step,
+                                                                           z_target_latent)
+        rank_host = rank_loss.tolist()                                # the one D2H sync per iteration
+        detached = cam.uncrop().detach().clone()
+        if self.return_camera_history:
+            st['camera_history'].append((rank_loss.cpu(), detached.to('cpu')))
+        delta = self._track_best_items(st['ranking'], step, list(detached.to('cpu')), rank_host)
+        if self.track_stats:
+            angle = three.quaternion.angular_distance(detached.quaternion, st['target_q']).squeeze()
+            trans = torch.norm(detached.translation - target_obs.camera.translation, dim=1).squeeze()
+            self._record_stat_dict(st['stat_history'], {
+                **{f'{k}_loss': v.detach().cpu() for k, v in loss_dict.items()},
+                **{f'{k}_weight': v for k, v in optim_weights.items()},
+                'delta': delta, 'converge_count': st['converge_count'], 'angle_dist': angle.cpu(),
+                'trans_dist': trans.cpu(), 'optim_loss': optim_loss.cpu(), 'rank_loss': rank_loss.cpu()})
+        st['opt'].step(st['sched'].lr)
+        st['sched'].step(rank_host)
+        if delta < self.converge_threshold:
+            st['converge_count'] += 1
+        elif delta > self.converge_threshold:
+            st['converge_count'] = 0
+        st['step'] += 1
+        return st['converge_count'] >= self.converge_patience
+
+    def _optimize_camera(self, z_obj, target_obs, cameras, iters, ranking):
+        st = self.start(z_obj, target_obs, cameras, ranking)
+        for _ in range(iters):
+            if self.iterate(st):
+                break
+        return st['stat_history'], st['camera_history']
+
+    @classmethod
+    def _record_stat(cls, history, key, value):
+        value = value.detach().cpu() if torch.is_tensor(value) else torch.tensor(value)
+        value = value.squeeze().unsqueeze(0)
+        if value.dim() > 2:
+            for i in range(value.shape[-1]):
+                cls._record_stat(history, f'{key}[{i}]', value[..., i])
+        else:
+            history[key] = torch.cat((history[key], value), dim=0) if key in history else value
+
+    @classmethod
+    def _record_stat_dict(cls, history, d):
+        for k, v in d.items():
+            cls._record_stat(history, k, v)
+
+    def _render_observation(self, z_obj, camera, **kwargs):
+        """The optimised camera IS the zoomed one; the un-thresholded depth goes to the loss
+        (reference :703-713)."""
+        pred, z_latent = self.model.render_latent_object(z_obj, camera.to(self.model.device), return_latent=True)
+        z_depth = camera.denormalize_depth(pred['depth'].squeeze(0))
+        return z_depth, pred['mask_logits'].squeeze(0), z_latent

@@ -1,0 +1,303 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every declared symbol, the
+host-side mirror of the reference interface (Camera, Observation, block grammar, estimators'
+control logic) is pinned to the reference's golden vectors.  No kernel is launched here."""
+import copy
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import lf_oracle as O
+from lf_oracle import nets, pose as opose
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def close(a, b, atol=1e-5, rtol=1e-4):
+    torch.testing.assert_close(a, b, atol=atol, rtol=rtol)
+
+
+def prod_camera(d):
+    from latentfusion_amd.modules.geometry import Camera
+    return Camera(d['K'].clone(), None, d['z_span'], d['viewport'].clone(), width=d['width'], height=d['height'],
+                  log_quaternion=d['log_q'].clone(), translation=d['t'].clone())
+
+
+# ---------------------------------------------------------------------------------------------
+def test_cabi_exports_every_declared_symbol():
+    from latentfusion_amd import _lib
+    header = open(os.path.join(ROOT, 'include', 'lf_hip.h')).read()
+    declared = set(re.findall(r'\b(lf_[a-z0-9_]+)\s*\(', header))
+    assert declared, 'no declarations parsed'
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    L = _lib.lib()                               # loads (and resolves) without a GPU
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.lf_abi_version() == 1
+    assert L.lf_conv3x3_cout_padded(7) == 16 and L.lf_conv3x3_cout_padded(48) == 64
+    assert L.lf_conv1x1_cout_padded(200) == 256
+    assert L.lf_resample3d_bwd_coef_scratch_bytes(8, 128, 128, 128) == 8 * 512 * 18 * 4
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'latentfusion_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                assert 'lf_oracle' not in src and 'import oracle' not in src, os.path.join(dirpath, f)
+
+
+def test_hip_ops_fail_loudly_without_a_device():
+    from latentfusion_amd import ops, _lib
+    with pytest.raises(_lib.LFHipError):
+        ops.conv3x3(torch.zeros(1, 16, 4, 4, 4), torch.zeros(16, 16, 3, 3, 3), None)
+    with pytest.raises(_lib.LFHipError):
+        ops.resample_o2c(torch.zeros(1, 4, 4, 4, 4), torch.zeros(1, 18))
+
+
+# ---------------------------------------------------------------------------------------------
+def test_camera_algebra_golden(golden):
+    g = golden('g1_camera')
+    cam = prod_camera(g['cam'])
+    close(cam.quaternion, g['quaternion'])
+    close(cam.rotation_matrix, g['R'])
+    close(cam.obj_to_cam, g['obj_to_cam'])
+    close(cam.cam_to_obj, g['cam_to_obj'])
+    close(cam.znear, g['znear'])
+    close(cam.position, g['position'])
+    close(cam.zoom(None, 32, 2.5).viewport, g['zoom_viewport'], atol=1e-3)
+    close(cam.normalize_depth(g['depth']), g['depth_norm'])
+    close(cam.denormalize_depth(g['depth'] * 2 - 1), g['depth_denorm'])
+    from latentfusion_amd.three import quaternion as Q
+    close(Q.qmul(g['qa'], g['qb']), g['qmul'])
+    close(Q.quat_to_mat(g['qa']), g['qa_mat'])
+    close(Q.mat_to_quat(g['qa_mat']), g['mat_to_quat'])
+    close(Q.qlog(g['qa']), g['qlog'])
+    close(Q.angular_distance(g['qa'], g['qb']), g['angdist'], atol=1e-4)
+    from latentfusion_amd import three
+    torch.manual_seed(g['edq_seed'])
+    close(three.orientation.evenly_distributed_quats(8), g['edq8'])
+    torch.manual_seed(g['edq_seed'])
+    close(three.orientation.evenly_distributed_quats(6, hemisphere=True, upright=True), g['edq6_hemi_upright'])
+
+
+def test_camera_container_semantics(golden):
+    from latentfusion_amd.modules.geometry import Camera
+    cam = prod_camera(golden('g1_camera')['cam'])
+    assert len(cam) == 5 and len(cam[1:3]) == 2 and len(cam[2]) == 1
+    parts = cam.split(2)
+    assert [len(p) for p in parts] == [2, 2, 1]
+    close(Camera.cat(parts).translation, cam.translation)
+    close(cam.repeat(2).viewport[5:], cam.viewport)
+    rebuilt = Camera(cam.intrinsic[:, :, :3], cam.extrinsic, viewport=cam.viewport)
+    close(rebuilt.rotation_matrix, cam.rotation_matrix, atol=1e-5)
+    close(rebuilt.translation, cam.translation)
+    with pytest.raises(ValueError):
+        Camera(cam.intrinsic, None)
+
+
+def test_coefficient_blocks_reproduce_reference_grids(golden):
+    """The (N,18)/(N,16) coefficient blocks handed to the HIP resampler generate the same sampling
+    grids as the reference's transforms."""
+    from latentfusion_amd.modules.geometry import o2c_coefficients, c2o_coefficients
+    d = golden('g2_resample')['cam']
+    cam, ocam, S = prod_camera(d), O.cam_from_dict(d), 8
+    lin = torch.linspace(0, 1, S, dtype=torch.float64)
+    k, b, a = torch.meshgrid(lin, lin, lin, indexing='ij')
+    c = o2c_coefficients(cam, 1.0).double().view(-1, 6, 3)
+    basis = torch.stack((torch.ones_like(a), a, b, k, a * k, b * k), dim=-1)
+    grid = torch.einsum('zyxj,njc->nzyxc', basis, c)
+    close(grid.float(), nets.o2c_grid(ocam, S), atol=2e-6)
+    A = c2o_coefficients(cam, 1.0).double().view(-1, 4, 4)
+    l = torch.stack((2 * a - 1, 2 * b - 1, 2 * k - 1, torch.ones_like(a)), -1)
+    num = torch.einsum('nrc,zyxc->nzyxr', A, l)
+    g2 = torch.stack((num[..., 0] / num[..., 3], num[..., 1] / num[..., 3], num[..., 2]), -1)
+    close(g2.float(), nets.c2o_grid(ocam, S), atol=2e-5)
+
+
+def test_observation_preprocessing_golden(golden):
+    from latentfusion_amd.observation import Observation
+    g = golden('g0_preprocess')
+    o = g['obs']
+    obs = Observation(o['color'], o['depth'], o['mask'], prod_camera(o['cam']))
+    z = obs.zoom(g['target_dist'], g['target_size'])
+    assert z.meta['is_zoomed'] and not z.meta['is_prepared']
+    close(z.color, g['zoom']['color'])
+    close(z.depth, g['zoom']['depth'])
+    close(z.mask, g['zoom']['mask'])
+    n = z.prepare().normalize()
+    assert n.meta['is_prepared'] and n.meta['is_normalized']
+    close(n.color, g['normalize']['color'])
+    close(n.depth, g['normalize']['depth'])
+    assert len(obs) == 2 and len(obs[0]) == 1 and len(Observation.collate(obs.to_list())) == 2
+
+
+def test_block_grammar_and_config_parser():
+    from latentfusion_amd.utils import parse_block_config, ExponentialScheduler
+    from latentfusion_amd.modules.blocks import create_blocks
+    from latentfusion_amd.modules import EqualizedConv2d
+    assert parse_block_config('64,D,128:128,U,64') == [[64, 'D', 128], [128, 'U', 64]]
+    assert parse_block_config('none') == [] and parse_block_config('8,8') == [8, 8]
+    cfg = [64, 'D', 128, 196, 'U', 32, 'I', 16]
+    blocks = create_blocks(cfg, EqualizedConv2d, 0.5)
+    plan = nets.plan_blocks(cfg, 0.5)
+    assert len(blocks) == len(plan) == 4
+    for blk, (cin, cout, scale) in zip(blocks, plan):
+        assert blk.conv1.module.weight.shape[:2] == (cout, cin)
+        assert (blk.interpolate.scale_factor if blk.interpolate else 1.0) == scale
+    s = ExponentialScheduler(128, 48, 10)
+    assert int(s.get(0)) == 128 and abs(s.get(9) - 48) < 1e-9 and s.get(50) == 48
+    with pytest.raises(ValueError):
+        create_blocks([8, 'X', 8], EqualizedConv2d, 0.5)
+
+
+def test_checkpoint_roundtrip_keeps_reference_keys(golden):
+    from latentfusion_amd.recon.models import Photographer, Sculptor
+    r = golden('g5_decode')['factor']
+    ph = Photographer.from_checkpoint(r['ck'])
+    assert set(ph.state_dict()) == set(r['ck']['state_dict'])
+    ck2 = ph.create_checkpoint()
+    for k, v in r['ck']['state_dict'].items():
+        assert torch.equal(ck2['state_dict'][k], v)
+    g = golden('g10_encode_gru')
+    sc = Sculptor.from_checkpoint(g['sculptor'])
+    assert set(sc.state_dict()) == set(g['sculptor']['state_dict'])
+    assert sc.out_size == 16 and sc.out_channels == 8
+    with pytest.raises(ValueError):
+        ph(torch.zeros(2, 8, 16, 16, 16), prod_camera(r['cam']))       # 2 volumes vs 3 cameras
+
+
+def test_presets_and_loader():
+    from latentfusion_amd.pose import estimation
+    est = estimation.load_from_config(os.path.join(ROOT, 'configs', 'adam_quick.toml'), model=None, num_iters=5)
+    assert isinstance(est, estimation.GradientPoseEstimator) and est.num_iters == 5 and est.optimizer == 'adam'
+    assert est.loss_weights['ov_depth'] == 0.3 and est.loss_weights['missing'] == 0.0
+    est = estimation.load_from_config(os.path.join(ROOT, 'configs', 'cross_entropy_linemod.toml'), model=None)
+    assert isinstance(est, estimation.CrossEntropyPoseEstimator) and est.sample_flipped and est.num_samples == 128
+    with pytest.raises(ValueError):
+        estimation.load_from_config({'type': 'nope', 'args': {}, 'loss_weights': {}}, model=None)
+
+
+@pytest.mark.parametrize('name', ['adam', 'adamw', 'sgd', 'adagrad'])
+def test_batched_optimizer_matches_torch_optim(name):
+    """N independent torch optimisers + ReduceLROnPlateau == one batched update + lr vector."""
+    from latentfusion_amd.pose.estimation import BatchedOptimizer, _PlateauLR
+    g = torch.Generator().manual_seed(0)
+    n = 5
+    init = [torch.randn(n, 3, generator=g), torch.randn(n, 4, generator=g)]
+    ref = [[p[i:i + 1].clone().requires_grad_(True) for p in init] for i in range(n)]
+    cls = {'adam': torch.optim.Adam, 'adamw': torch.optim.AdamW, 'sgd': torch.optim.SGD, 'adagrad': torch.optim.Adagrad}[name]
+    opts = [cls(ps, lr=0.01) for ps in ref]
+    scheds = [torch.optim.lr_scheduler.ReduceLROnPlateau(o, patience=2, threshold=1e-4, factor=0.5) for o in opts]
+    mine = [p.clone().requires_grad_(True) for p in init]
+    bo = BatchedOptimizer(name, mine)
+    pl = _PlateauLR(n, 0.01, 2, 1e-4, 0.5)
+    for step in range(25):
+        grads = [torch.randn(n, 3, generator=g), torch.randn(n, 4, generator=g)]
+        metric = (torch.rand(n, generator=g) + 1.0 / (step + 1)).tolist()
+        for i in range(n):
+            for p, gr in zip(ref[i], grads):
+                p.grad = gr[i:i + 1].clone()
+            opts[i].step()
+            scheds[i].step(metric[i])
+        for p, gr in zip(mine, grads):
+            p.grad = gr.clone()
+        bo.step(pl.lr)
+        pl.step(metric)
+        assert pl.lr == [o.param_groups[0]['lr'] for o in opts]
+    for j, p in enumerate(mine):
+        close(p.detach(), torch.cat([ref[i][j] for i in range(n)]).detach(), atol=1e-6, rtol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------
+class OracleBackedModel:
+    """LatentFusionModel stand-in whose renderer is the CPU oracle: lets the estimator CONTROL
+    LOGIC (optimiser, schedulers, ranking, convergence, loss) run without a GPU."""
+
+    def __init__(self, g):
+        self.device = 'cpu'
+        self.pck = g['photographer']
+        self.camera_dist = g['camera_dist']
+        self.input_size = g['sculptor']['args']['in_size']
+
+    def render_latent_object(self, z_obj, camera, return_latent=True, apply_mask=True):
+        ocam = O.Cam(camera.intrinsic, camera.log_quaternion, camera.translation, viewport=camera.viewport,
+                     z_span=camera.z_span, width=camera.width, height=camera.height)
+        y, lat, _ = nets.decode(self.pck, z_obj, ocam, apply_mask=apply_mask)
+        return y, lat.squeeze(0)
+
+
+def _target(g):
+    from latentfusion_amd.observation import Observation
+    tg = g['target']
+    return Observation(None, tg['depth'], tg['mask'].float(), prod_camera(tg['cam']))
+
+
+def test_gradient_estimator_follows_reference_trace(golden):
+    """G7: the product's pose loop (batched optimiser, plateau vector, ranking) driven by an
+    oracle-backed renderer reproduces the reference's per-iteration losses, argmin indices and
+    camera trajectory."""
+    from latentfusion_amd.pose import estimation
+    g = golden('g7_adam_trace')
+    est = estimation.load_from_config(copy.deepcopy(g['cfg']), OracleBackedModel(g), track_stats=True,
+                                      return_camera_history=True)
+    best, stats, hist = est.estimate(g['z_obj'], _target(g), camera=prod_camera(g['init']))
+    close(stats['rank_loss'], g['rank_loss'], atol=5e-5, rtol=1e-3)
+    for k in ('depth_loss', 'ov_depth_loss', 'iou_loss', 'mask_loss'):
+        close(stats[k], g[k], atol=1e-4, rtol=1e-3)
+    assert torch.argmin(stats['rank_loss'], dim=1).tolist() == g['argmin'].tolist()
+    close(torch.stack([c.log_quaternion for _, c in hist]), g['hist_log_q'], atol=2e-3, rtol=1e-2)
+    close(torch.stack([c.translation for _, c in hist]), g['hist_t'], atol=2e-3, rtol=1e-2)
+    close(best.log_quaternion, g['best']['log_q'], atol=2e-3, rtol=1e-2)
+    close(best.translation, g['best']['t'], atol=2e-3, rtol=1e-2)
+    assert len(best) == g['cfg']['args']['ranking_size']
+
+
+def test_cross_entropy_step_matches_reference(golden):
+    from latentfusion_amd.pose import estimation
+    g, t7 = golden('g8_ce_step'), golden('g7_adam_trace')
+    est = estimation.CrossEntropyPoseEstimator(model=OracleBackedModel(t7), num_samples=24, num_elites=5, num_iters=3,
+                                               num_gmm_components=2, learning_rate=0.9, sample_flipped=True,
+                                               ranking_size=4, loss_weights=g['weights'])
+    cams, loss = est.evaluate_samples(t7['z_obj'], _target(t7), prod_camera(g['cams']))
+    close(cams.log_quaternion, g['all_cams']['log_q'], atol=1e-5)
+    close(loss, g['loss'], atol=5e-5, rtol=1e-3)
+    assert torch.argsort(loss).tolist() == g['order'].tolist()
+
+
+def test_pose_loss_golden(golden):
+    from latentfusion_amd.pose.loss import default_pose_loss, weigh_losses
+    from latentfusion_amd.observation import Observation
+    g = golden('g6_loss')
+    tg = g['target']
+    target = Observation(None, tg['depth'], tg['mask'].float(), prod_camera(tg['cam']))
+    cam = prod_camera(g['cam'])
+    cam.viewport.requires_grad_(True)
+    cam.translation.requires_grad_(True)
+    dn = g['depth_n'].clone().requires_grad_(True)
+    lg = g['logits'].clone().requires_grad_(True)
+    ld = default_pose_loss(target, cam.denormalize_depth(dn), lg, cam)
+    for k, v in g['loss'].items():
+        close(ld[k], v)
+    sum(weigh_losses(ld, g['weights']).values()).mean().backward()
+    close(dn.grad, g['g_depth_n'], atol=1e-7, rtol=1e-3)
+    close(cam.viewport.grad, g['g_viewport'], atol=1e-6, rtol=1e-3)
+    close(cam.translation.grad, g['g_t'], atol=1e-6, rtol=1e-3)
+
+
+def test_synthetic_workload_is_consumable_by_the_oracle():
+    """bench.py feeds the same generated checkpoints to the HIP path and to the CPU oracle."""
+    from latentfusion_amd import synth
+    sck, fck, pck, dist = synth.make_syn_checkpoints(8, 4, 'pool:mean', seed=1, bias_std=0.1)
+    from latentfusion_amd.recon.models import Photographer, Sculptor
+    assert set(Sculptor.from_checkpoint(sck).state_dict()) == set(sck['state_dict'])
+    assert set(Photographer.from_checkpoint(pck).state_dict()) == set(pck['state_dict'])
+    d = synth.make_observation_data(2, seed=3, height=60, width=80)
+    cam = O.Cam.from_extrinsic(d['intrinsic'], d['extrinsic'], width=80, height=60)
+    obs = opose.Obs(d['color'], d['depth'], d['mask'], cam)
+    model = opose.Model(sck, fck, pck, dist)
+    z = model.build_latent_object(obs)
+    assert z.shape == (1, 1, 4, 8, 8, 8) and torch.isfinite(z).all()
