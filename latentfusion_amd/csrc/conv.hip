@@ -68,11 +68,12 @@ __device__ __forceinline__ void epilogue_store(f32x4 (&acc)[NT][NR], const long 
         acc[t][j][e] = v;
         ss += v * v;
       }
-    float r = 1.f;
+    float r = 1.f, rinv = 1.f;
     if (flags & LF_EPI_PIXELNORM) {
       ss += __shfl_xor(ss, 16, 64);
       ss += __shfl_xor(ss, 32, 64);
       r = sqrtf(ss / (float)Cout + eps);
+      rinv = 1.0f / r;          // one IEEE division per voxel; y = v * (1/r) is within 1 ulp of v / r
     }
     if (rowoff[j] >= 0) {
       float* dst = y + rowoff[j];
@@ -80,7 +81,7 @@ __device__ __forceinline__ void epilogue_store(f32x4 (&acc)[NT][NR], const long 
       for (int t = 0; t < NT; ++t) {
         const int co = co_base + t * 16 + cq * 4;
         f32x4 v = acc[t][j];
-        if (flags & LF_EPI_PIXELNORM) { v[0] /= r; v[1] /= r; v[2] /= r; v[3] /= r; }
+        if (flags & LF_EPI_PIXELNORM) { v[0] *= rinv; v[1] *= rinv; v[2] *= rinv; v[3] *= rinv; }
         if (vec_out) {
           if (co < Cout) *(f32x4*)(dst + (long)(co / ysc) * yss + (co % ysc)) = v;
         } else {
@@ -91,6 +92,50 @@ __device__ __forceinline__ void epilogue_store(f32x4 (&acc)[NT][NR], const long 
       }
       if ((flags & LF_EPI_PIXELNORM) && norm_out != nullptr && cq == 0) norm_out[rowidx[j]] = r;
     }
+  }
+}
+
+// Stages the zero-padded halo tile of 16 input channels [c_first, c_first+16) into LDS.  All
+// global loads of a thread (NST = ceil(HALO*4/256) float4s) are issued back to back into registers
+// before the first LDS write, so one memory latency is paid per tile instead of one per load.
+template <int DIMS>
+__device__ __forceinline__ void stage_halo(float* __restrict__ tile, const float* __restrict__ x,
+                                           int n, int x0, int y0, int z0, int D, int H, int W, int Cin,
+                                           int c_first, bool vec_in) {
+  using G = TileGeom<DIMS>;
+  constexpr int HX = TX + 2;
+  constexpr int HALO = G::HZ * G::HY * HX;
+  constexpr int NST = (HALO * 4 + 255) / 256;
+  const int tid = threadIdx.x;
+  f32x4 st[NST];
+#pragma unroll
+  for (int it = 0; it < NST; ++it) {
+    const int i = tid + it * 256;
+    const int q = i & 3;
+    int v = i >> 2;
+    const int lx = v % HX; v /= HX;
+    const int ly = v % G::HY;
+    const int lz = v / G::HY;
+    const int gx = x0 + lx - 1, gy = y0 + ly - 1;
+    const int gz = (DIMS == 3) ? (z0 + lz - 1) : 0;
+    f32x4 val = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int c0 = c_first + q * 4;
+    if (i < HALO * 4 && gx >= 0 && gx < W && gy >= 0 && gy < H && gz >= 0 && gz < D && c0 < Cin) {
+      const float* src = x + ((((long)n * D + gz) * H + gy) * W + gx) * Cin + c0;
+      if (vec_in) {
+        val = *(const f32x4*)src;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (c0 + e < Cin) val[e] = src[e];
+      }
+    }
+    st[it] = val;
+  }
+#pragma unroll
+  for (int it = 0; it < NST; ++it) {
+    const int i = tid + it * 256;
+    if (i < HALO * 4) *(f32x4*)(tile + i * 4) = st[it];
   }
 }
 
@@ -138,28 +183,7 @@ __global__ void __launch_bounds__(256) conv3x3_kernel(
   for (int ch = 0; ch < nchunks; ++ch) {
     if (ch) __syncthreads();
     // ---- stage the zero-padded halo tile of channels [16*ch, 16*ch+16) ----
-    for (int i = tid; i < HALO * 4; i += 256) {
-      const int q = i & 3;
-      int v = i >> 2;
-      const int lx = v % HX; v /= HX;
-      const int ly = v % G::HY;
-      const int lz = v / G::HY;
-      const int gx = x0 + lx - 1, gy = y0 + ly - 1;
-      const int gz = (DIMS == 3) ? (z0 + lz - 1) : 0;
-      f32x4 val = (f32x4){0.f, 0.f, 0.f, 0.f};
-      const int c0 = ch * 16 + q * 4;
-      if (gx >= 0 && gx < W && gy >= 0 && gy < H && gz >= 0 && gz < D && c0 < Cin) {
-        const float* src = x + ((((long)n * D + gz) * H + gy) * W + gx) * Cin + c0;
-        if (vec_in) {
-          val = *(const f32x4*)src;
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (c0 + e < Cin) val[e] = src[e];
-        }
-      }
-      *(f32x4*)(tile + (i >> 2) * 16 + q * 4) = val;
-    }
+    stage_halo<DIMS>(tile, x, n, x0, y0, z0, D, H, W, Cin, ch * 16, vec_in);
     __syncthreads();
     // ---- 27 (9) taps x NT cout tiles x 4 rows ----
     const float* wch = wpack + (long)(co_base + li) * CinP + ch * 16 + cq * 4;
@@ -196,6 +220,283 @@ __global__ void __launch_bounds__(256) conv3x3_kernel(
   }
   epilogue_store<NT, 4>(acc, rowoff, rowidx, bias, y, norm_out, Cout, co_base, 1 << 30, 0, (Cout & 3) == 0,
                         he, flags, slope, eps);
+}
+
+// ---- C = 16 specialisation of the 3x3(x3) kernel (the SYN(S,16) hot path) ---------------------
+// One Cin chunk, one Cout tile: all 27 (9) weight fragments live in registers (108 / 36 VGPRs), the
+// tap loop is fully unrolled (constant LDS offsets) and the B fragments of tap t+1 are read from LDS
+// before the 16 MFMAs of tap t are issued, so the matrix pipe never waits on LDS or VMEM.
+template <int DIMS>
+__global__ void __launch_bounds__(256, 2) conv3x3_c16_kernel(
+    const float* __restrict__ x, const float* __restrict__ wpack, const float* __restrict__ bias,
+    float* __restrict__ y, float* __restrict__ norm_out,
+    int N, int D, int H, int W, int Cin, int Cout,
+    int tiles_x, int tiles_y, int tiles_z,
+    float he, unsigned flags, float slope, float eps) {
+  using G = TileGeom<DIMS>;
+  constexpr int HX = TX + 2;
+  constexpr int HALO = G::HZ * G::HY * HX;
+  __shared__ __attribute__((aligned(16))) float tile[HALO * 16];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, cq = lane >> 4;
+
+  int b = blockIdx.x;
+  const int bx = b % tiles_x; b /= tiles_x;
+  const int by = b % tiles_y; b /= tiles_y;
+  const int bz = b % tiles_z; b /= tiles_z;
+  const int n = b;
+  const int x0 = bx * TX, y0 = by * G::TY, z0 = bz * G::TZ;
+
+  // ---- weights -> registers (L2-resident 27 KB, read once per wave) ----
+  f32x4 wreg[G::TAPS];
+  {
+    const float* wl = wpack + li * 16 + cq * 4;                 // [tap][16 cout][16 cin]
+#pragma unroll
+    for (int tap = 0; tap < G::TAPS; ++tap) wreg[tap] = *(const f32x4*)(wl + tap * 256);
+  }
+
+  // ---- stage the zero-padded halo tile ----
+  stage_halo<DIMS>(tile, x, n, x0, y0, z0, D, H, W, Cin, 0, (Cin & 3) == 0);
+  __syncthreads();
+
+  const float* rowp[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = wave * 4 + j;
+    const int ry = (DIMS == 3) ? (r & 3) : r;
+    const int rz = (DIMS == 3) ? (r >> 2) : 0;
+    rowp[j] = tile + ((rz * G::HY + ry) * HX + li) * 16 + cq * 4;
+  }
+
+  f32x4 acc[1][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[0][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  f32x4 bcur[4], bnext[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bcur[j] = *(const f32x4*)(rowp[j]);      // tap 0: offset 0
+#pragma unroll
+  for (int tap = 0; tap < G::TAPS; ++tap) {
+    if (tap + 1 < G::TAPS) {
+      constexpr int dummy = 0; (void)dummy;
+      const int t1 = tap + 1;
+      const int kx = t1 % 3, ky = (t1 / 3) % 3, kz = (DIMS == 3) ? t1 / 9 : 0;
+      const int toff = ((kz * G::HY + ky) * HX + kx) * 16;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bnext[j] = *(const f32x4*)(rowp[j] + toff);
+    }
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[tap][st], bcur[j][st], acc[0][j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bcur[j] = bnext[j];
+  }
+
+  long rowoff[4], rowidx[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = wave * 4 + j;
+    const int gy = y0 + ((DIMS == 3) ? (r & 3) : r);
+    const int gz = (DIMS == 3) ? z0 + (r >> 2) : 0;
+    const int gx = x0 + li;
+    rowidx[j] = (gx < W && gy < H && gz < D) ? ((((long)n * D + gz) * H + gy) * W + gx) : -1;
+    rowoff[j] = rowidx[j] < 0 ? -1 : rowidx[j] * Cout;
+  }
+  epilogue_store<1, 4>(acc, rowoff, rowidx, bias, y, norm_out, Cout, 0, 1 << 30, 0, (Cout & 3) == 0,
+                       he, flags, slope, eps);
+}
+
+// ---- persistent, double-buffered C = 16 conv3d kernel (the dominant kernel of the pose loop) ---
+// One 512-thread workgroup per CU walks a contiguous run of 4x8x16 output tiles.
+//  * weights stay in registers for the whole run (108 VGPRs, no per-tile L2 weight traffic);
+//  * the zero-padded halo of tile t+1 (6x10x18 voxels x 16 ch = 67.5 KB) is DMA'd straight into
+//    the other LDS buffer with `buffer_load_dwordx4 ... lds` while tile t is multiplied: no
+//    staging registers, no ds_write, and out-of-volume voxels are zero-filled by the buffer
+//    descriptor's range check (offset forced out of range) instead of by branches;
+//  * 8 waves = 2 per SIMD, each wave owns four 16-voxel rows: 16 independent MFMAs per tap,
+//    taps fully unrolled, B fragments of tap t+1 read from LDS before tap t's MFMAs issue.
+namespace p3 {
+constexpr int TZ = 4, TY = 8, HZ = 6, HY = 10, HX = TX + 2;
+constexpr int HALO = HZ * HY * HX;                         // 1080 voxels
+constexpr int NTHREADS = 512;
+constexpr int NSLOT = (HALO * 4 + 63) / 64;                // 68 wave-wide 1 KiB DMA pieces per tile
+constexpr int NIT = (NSLOT + 7) / 8;                       // 9 pieces per wave
+constexpr int BUF_FLOATS = NSLOT * 256;                    // 69,632 B per buffer
+}  // namespace p3
+
+__global__ void __launch_bounds__(512, 2) conv3d_c16_persistent_kernel(
+    const float* __restrict__ x, const float* __restrict__ wpack, const float* __restrict__ bias,
+    float* __restrict__ y, float* __restrict__ norm_out,
+    int N, int D, int H, int W, int tiles_x, int tiles_y, int tiles_z, int ntiles,
+    float he, unsigned flags, float slope, float eps) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * p3::BUF_FLOATS];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, cq = lane >> 4;
+
+  const int per = (ntiles + gridDim.x - 1) / gridDim.x;
+  const int t_begin = blockIdx.x * per;
+  const int t_end = min(t_begin + per, ntiles);
+  if (t_begin >= t_end) return;
+
+  const long nvox = (long)D * H * W;
+  const unsigned sample_bytes = (unsigned)(nvox * 64);
+
+  // ---- per-lane constants of the DMA pieces this wave issues: piece s = wave + 8*it ----
+  int rel[p3::NIT];        // byte offset of the lane's 16 B relative to the halo origin voxel
+  int lxyz[p3::NIT];       // packed halo coordinates lx | ly << 8 | lz << 16 (0xffffff: beyond the halo)
+#pragma unroll
+  for (int it = 0; it < p3::NIT; ++it) {
+    const int e = (wave + 8 * it) * 64 + lane;               // float4 index inside the halo buffer
+    int v = e >> 2;
+    const int q = e & 3;
+    const int lx = v % p3::HX; v /= p3::HX;
+    const int ly = v % p3::HY;
+    const int lz = v / p3::HY;
+    const bool inside = e < p3::HALO * 4;
+    rel[it] = ((lz * H + ly) * W + lx) * 64 + q * 16;
+    lxyz[it] = inside ? (lx | (ly << 8) | (lz << 16)) : 0x7f7f7f;
+  }
+
+  f32x4 wreg[27];
+  {
+    const float* wl = wpack + li * 16 + cq * 4;                 // [tap][16 cout][16 cin]
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) wreg[tap] = *(const f32x4*)(wl + tap * 256);
+  }
+  f32x4 bv4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (bias != nullptr) bv4 = *(const f32x4*)(bias + cq * 4);
+
+  int rowoffs[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = wave * 4 + j;                                  // rz = r / 8, ry = r % 8
+    rowoffs[j] = (((r >> 3) * p3::HY + (r & 7)) * p3::HX + li) * 16 + cq * 4;
+  }
+
+  auto issue_dma = [&](int t, int buf) {
+    int tt = t;
+    const int bx = tt % tiles_x; tt /= tiles_x;
+    const int by = tt % tiles_y; tt /= tiles_y;
+    const int bz = tt % tiles_z; tt /= tiles_z;
+    const int n = tt;
+    const int ox = bx * TX - 1, oy = by * p3::TY - 1, oz = bz * p3::TZ - 1;      // halo origin (may be -1)
+    const int tile_off = ((oz * H + oy) * W + ox) * 64;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long)n * nvox * 16), 0,
+                                                                  sample_bytes, 0x00020000);
+#pragma unroll
+    for (int it = 0; it < p3::NIT; ++it) {
+      const int s = wave + 8 * it;
+      if (s < p3::NSLOT) {                                         // wave-uniform
+        const int gx = ox + (lxyz[it] & 0xff), gy = oy + ((lxyz[it] >> 8) & 0xff), gz = oz + (lxyz[it] >> 16);
+        const bool ok = (unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H && (unsigned)gz < (unsigned)D;
+        const int voff = ok ? (rel[it] + tile_off) : 0x7fffffff;   // out of range -> the DMA writes zeros
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            rs, (__attribute__((address_space(3))) void*)(lds + buf * p3::BUF_FLOATS + s * 256), 16, voff, 0, 0, 0);
+      }
+    }
+  };
+
+  issue_dma(t_begin, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  f32x4 acc[4];
+
+  auto compute = [&](int buf) {
+    const float* base = lds + buf * p3::BUF_FLOATS;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 bcur[4], bnext[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bcur[j] = *(const f32x4*)(base + rowoffs[j]);
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+      if (tap + 1 < 27) {
+        const int t1 = tap + 1;
+        const int kx = t1 % 3, ky = (t1 / 3) % 3, kz = t1 / 9;
+        const int toff = ((kz * p3::HY + ky) * p3::HX + kx) * 16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bnext[j] = *(const f32x4*)(base + rowoffs[j] + toff);
+      }
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[tap][s4], bcur[j][s4], acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bcur[j] = bnext[j];
+    }
+  };
+
+  // fused epilogue of tile t: He scale + bias, LeakyReLU, PixelNorm over the 16 channels, float4 store
+  auto epilogue = [&](int t) {
+    int tt = t;
+    const int bx = tt % tiles_x; tt /= tiles_x;
+    const int by = tt % tiles_y; tt /= tiles_y;
+    const int bz = tt % tiles_z; tt /= tiles_z;
+    const int n = tt;
+    float* ybase = y + (long)n * nvox * 16;
+    float* nbase = norm_out ? norm_out + (long)n * nvox : nullptr;
+    const int gx = bx * TX + li;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = wave * 4 + j;
+      const int gz = bz * p3::TZ + (r >> 3), gy = by * p3::TY + (r & 7);
+      f32x4 v;
+      float ss = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float u = acc[j][e] * he + bv4[e];
+        if (flags & LF_EPI_LRELU) u = fmaxf(u, u * slope);        // slope in (0,1): max(u, slope*u) == lrelu
+        v[e] = u;
+        ss += u * u;
+      }
+      float r_ = 1.f;
+      if (flags & LF_EPI_PIXELNORM) {
+        ss += __shfl_xor(ss, 16, 64);
+        ss += __shfl_xor(ss, 32, 64);
+        r_ = sqrtf(ss / 16.f + eps);
+        const float rinv = 1.0f / r_;
+        v[0] *= rinv; v[1] *= rinv; v[2] *= rinv; v[3] *= rinv;
+      }
+      if (gx < W && gy < H && gz < D) {
+        const int vox = (gz * H + gy) * W + gx;
+        *(f32x4*)(ybase + vox * 16 + cq * 4) = v;
+        if ((flags & LF_EPI_PIXELNORM) && nbase != nullptr && cq == 0) nbase[vox] = r_;
+      }
+    }
+  };
+
+  // The two waves that share a SIMD (w and w+4) run their VALU-heavy epilogue at opposite ends of
+  // the inter-barrier interval, so one wave's epilogue always overlaps its partner's MFMAs:
+  //   waves 0-3:  [MFMA tile t][epilogue t]       | barrier
+  //   waves 4-7:  [epilogue t-1][MFMA tile t]     | barrier
+  int cur = 0;
+  if (wave < 4) {
+    for (int t = t_begin; t < t_end; ++t) {
+      if (t + 1 < t_end) issue_dma(t + 1, cur ^ 1);               // lands during the MFMAs below
+      compute(cur);
+      epilogue(t);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // next tile's DMA has landed
+      __syncthreads();
+      cur ^= 1;
+    }
+  } else {
+    for (int t = t_begin; t < t_end; ++t) {
+      if (t + 1 < t_end) issue_dma(t + 1, cur ^ 1);
+      if (t > t_begin) epilogue(t - 1);
+      compute(cur);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      cur ^= 1;
+    }
+    epilogue(t_end - 1);
+  }
 }
 
 // ---- pointwise convolution: GEMM over pixels, depth axis optionally folded into K ------------
@@ -284,6 +585,29 @@ extern "C" int lf_conv3x3_fwd(const float* x, const float* wpack, const float* b
   if (nblk > 0x7fffffffL) return LF_EINVAL;
   dim3 grid((unsigned)nblk, groups), block(256);
   hipStream_t s = (hipStream_t)stream;
+  if (Cin == 16 && Cout == 16 && dims == 3 && (long)D * H * W >= 4096 && (long)D * H * W * 64 < 0x7fffffffL &&
+      slope > 0.f && slope < 1.f && (bias == nullptr || lf_aligned16(bias))) {
+    // persistent double-buffered kernel: one 512-thread workgroup per CU
+    const int ptx = (W + TX - 1) / TX, pty = (H + p3::TY - 1) / p3::TY, ptz = (D + p3::TZ - 1) / p3::TZ;
+    const long pt = (long)ptx * pty * ptz * N;
+    if (pt <= 0x7fffffffL) {
+      int dev = 0, cus = 256;
+      if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      const unsigned pgrid = (unsigned)(pt < cus ? pt : cus);
+      hipLaunchKernelGGL(conv3d_c16_persistent_kernel, dim3(pgrid), dim3(p3::NTHREADS), 0, s, x, wpack, bias, y, norm_out,
+                         N, D, H, W, ptx, pty, ptz, (int)pt, he, flags, slope, eps);
+      return lf_launch_status();
+    }
+  }
+  if (CinP == 16 && CoutP == 16) {          // register-resident weights, unrolled + pipelined taps
+    if (dims == 3)
+      hipLaunchKernelGGL((conv3x3_c16_kernel<3>), grid, block, 0, s, x, wpack, bias, y, norm_out, N, D, H, W, Cin, Cout,
+                         tiles_x, tiles_y, tiles_z, he, flags, slope, eps);
+    else
+      hipLaunchKernelGGL((conv3x3_c16_kernel<2>), grid, block, 0, s, x, wpack, bias, y, norm_out, N, D, H, W, Cin, Cout,
+                         tiles_x, tiles_y, tiles_z, he, flags, slope, eps);
+    return lf_launch_status();
+  }
 #define LAUNCH(DM, T) hipLaunchKernelGGL((conv3x3_kernel<DM, T>), grid, block, 0, s, x, wpack, bias, y, norm_out, \
                                          N, D, H, W, Cin, Cout, CinP, CoutP, tiles_x, tiles_y, tiles_z, he, flags, slope, eps)
   if (dims == 3) { if (NT == 4) LAUNCH(3, 4); else if (NT == 2) LAUNCH(3, 2); else LAUNCH(3, 1); }
