@@ -129,6 +129,51 @@ int lf_epilogue_bwd(const float* gy, const float* y, const float* norm, float* g
                     long rows, int C, unsigned flags, float slope, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Camera -> coefficient blocks, with Jacobian (fp64 forward-mode duals inside).
+ * Replaces the chain of tiny ops log_quaternion -> qexp -> normalize -> quat_to_mat -> cam_to_obj ->
+ * camera_coords (three/quaternion.py:39-93,287-311; modules/geometry.py:106-153,207-213,469-531)
+ * plus the viewport / depth-range algebra of Camera.uncrop and denormalize_depth (:261-285,555-558).
+ *   params     [N][10] = (log_quaternion 3, translation 3, viewport xmin,ymin,xmax,ymax)
+ *   intrinsics [N][4]  = (fu, fv, u0, v0)
+ *   coefs      [N][24] : [0..17] LF_MAP_O2C block; [18..21] (ax,bx,ay,by): crop sample position of
+ *                         frame pixel (x,y) is (ax*x+bx, ay*y+by); [22..23] (a,b): depth = d*a + b
+ *   jac        [N][24][10] = d coefs / d params
+ * lf_camera_coefs_bwd: gparams[N][10] = sum_j gcoefs[N][j] * jac[N][j][:]. */
+#define LF_CAM_PARAMS 10
+#define LF_CAM_COEFS  24
+int lf_camera_coefs(const float* params, const float* intrinsics, float cube_size, float z_span,
+                    int crop_h, int crop_w, float* coefs, float* jac, int N, void* stream);
+int lf_camera_coefs_bwd(const float* gcoefs, const float* jac, float* gparams, int N, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused pose loss = default_pose_loss (pose/estimation.py:70-118, pose/utils.py:81-117) over
+ * Photographer.interpret_logits(apply_mask=True) (recon/models.py:455-484), Camera.uncrop
+ * (nearest for depth, bilinear for mask logits, border padding) and denormalize_depth.
+ *   logits  [N][h*w][2]  head outputs (depth_logit, mask_logit), channels-last
+ *   coefs   [N][24]      from lf_camera_coefs (entries 18..23 are used)
+ *   target_depth/mask [H*W] of the (single) target frame; weights[4] = (depth, ov_depth, iou, mask)
+ *   sums    [N][8]  S0..S6 (sum l1, sum l1*sig*mt, sum sig*mt, sum sig, intersection, sum mt*valid, sum bce)
+ *   losses  [N][8]  (depth, ov_depth, iou, mask, weighted total, 0,0,0)
+ *   gsums   [N][8]  d(mean_n total)/d(sums), consumed by lf_pose_loss_bwd
+ * lf_pose_loss_bwd writes glogits [N][h*w][2] and gcoefs[N][24] entries 18..23 (0..17 untouched).
+ * All reductions are fixed-order (no float atomics).  scratch: lf_pose_loss_scratch_bytes. */
+size_t lf_pose_loss_scratch_bytes(int N, int h, int w, int H, int W);
+int lf_pose_loss_fwd(const float* logits, const float* coefs, const float* target_depth,
+                     const float* target_mask, const float* weights, float* sums, float* losses,
+                     float* gsums, void* scratch, size_t scratch_bytes,
+                     int N, int h, int w, int H, int W, void* stream);
+int lf_pose_loss_bwd(const float* logits, const float* coefs, const float* target_depth,
+                     const float* target_mask, const float* gsums, float* glogits, float* gcoefs,
+                     void* scratch, size_t scratch_bytes, int N, int h, int w, int H, int W, void* stream);
+
+/* Batched Adam / AdamW step over N independent rows of P parameters (pose/estimation.py:579-594,
+ * 664-666).  step_size[n] = lr[n] / (1 - beta1^t) and bias_correction2_sqrt = sqrt(1 - beta2^t)
+ * are formed on the host in double like torch.optim does. */
+int lf_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                 const float* step_size, const float* lr, float bias_correction2_sqrt,
+                 float beta1, float beta2, float eps, float weight_decay, int N, int P, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Layout helpers (the reference is NCDHW; kernels are channels-last). */
 int lf_nchw_to_nhwc(const float* src, float* dst, int N, int C, long P, void* stream);
 int lf_nhwc_to_nchw(const float* src, float* dst, int N, int C, long P, void* stream);

@@ -33,6 +33,12 @@ SIGNATURES = {
                                c_int, c_long, c_float, c_uint, c_float, c_float, P]),
     'lf_pixelnorm_fwd': (c_int, [P, P, P, c_long, c_int, c_float, P]),
     'lf_epilogue_bwd': (c_int, [P, P, P, P, c_long, c_int, c_uint, c_float, P]),
+    'lf_camera_coefs': (c_int, [P, P, c_float, c_float, c_int, c_int, P, P, c_int, P]),
+    'lf_camera_coefs_bwd': (c_int, [P, P, P, c_int, P]),
+    'lf_pose_loss_scratch_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    'lf_pose_loss_fwd': (c_int, [P, P, P, P, P, P, P, P, P, c_size_t, c_int, c_int, c_int, c_int, c_int, P]),
+    'lf_pose_loss_bwd': (c_int, [P, P, P, P, P, P, P, P, c_size_t, c_int, c_int, c_int, c_int, c_int, P]),
+    'lf_adam_step': (c_int, [P, P, P, P, P, P, c_float, c_float, c_float, c_float, c_float, c_int, c_int, P]),
     'lf_nchw_to_nhwc': (c_int, [P, P, c_int, c_int, c_long, P]),
     'lf_nhwc_to_nchw': (c_int, [P, P, c_int, c_int, c_long, P]),
     'lf_lift_unfold': (c_int, [P, P, P, c_int, c_long, c_int, c_int, P]),

@@ -1,0 +1,217 @@
+"""Fused render-and-score engine of the gradient pose loop.
+
+One call = the forward AND backward of
+    camera params -> coefficient blocks -> O2C resample -> camera conv3d blocks -> factor projection
+                  -> 2-D decoder + heads -> interpret_logits -> uncrop -> pose loss
+for N pose hypotheses of one latent object, returning the per-sample losses and
+d(mean weighted loss)/d(log_quaternion, translation, viewport).
+
+Compared with driving the same kernels through the generic autograd modules this removes the
+~600 tiny ATen launches per iteration of the camera algebra and of the loss (they become
+lf_camera_coefs, lf_pose_loss_fwd/bwd and lf_camera_coefs_bwd), keeps the 3-D activations in
+preallocated buffers and sequences the heavy kernels explicitly.  The 2-D decoder (a generic
+U-Net in the released model) still runs through the autograd ops on its (N,C,h,w) maps.
+
+Numerically it is the same computation as Photographer.decode + default_pose_loss
+(reference recon/models.py:397-505, pose/estimation.py:70-118); tests/test_engine_gpu.py checks it
+against the module path and against the reference's golden loop trace.
+"""
+import torch
+
+from . import _lib, ops
+from ._lib import LF_EPI_LRELU, LF_EPI_PIXELNORM, LF_MAP_O2C, check
+
+NCOEF = 24
+NPAR = 10
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class _CameraCoefs(torch.autograd.Function):
+    """(N,10) camera parameters -> (N,24) coefficient blocks (lf_camera_coefs)."""
+
+    @staticmethod
+    def forward(ctx, params, intr, cube, z_span, h, w):
+        L = _lib.lib()
+        n = params.shape[0]
+        coefs = torch.empty(n, NCOEF, device=params.device, dtype=torch.float32)
+        jac = torch.empty(n, NCOEF, NPAR, device=params.device, dtype=torch.float32)
+        check(L.lf_camera_coefs(params.contiguous().data_ptr(), intr.contiguous().data_ptr(), cube, z_span, h, w,
+                                coefs.data_ptr(), jac.data_ptr(), n, _s()), 'lf_camera_coefs')
+        ctx.save_for_backward(jac)
+        return coefs
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        jac, = ctx.saved_tensors
+        n = jac.shape[0]
+        gp = torch.empty(n, NPAR, device=jac.device, dtype=torch.float32)
+        check(L.lf_camera_coefs_bwd(g.contiguous().data_ptr(), jac.data_ptr(), gp.data_ptr(), n, _s()), 'lf_camera_coefs_bwd')
+        return gp, None, None, None, None, None
+
+
+def camera_params(camera):
+    return torch.cat((camera.log_quaternion, camera.translation, camera.viewport), dim=1)
+
+
+def camera_intrinsics(camera):
+    K = camera.intrinsic
+    return torch.stack((K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2]), dim=1).contiguous()
+
+
+def camera_coefs(camera, cube_size, crop_h, crop_w):
+    """Differentiable (w.r.t. log_quaternion / translation / viewport) coefficient blocks."""
+    return _CameraCoefs.apply(camera_params(camera), camera_intrinsics(camera), float(cube_size), float(camera.z_span),
+                              int(crop_h), int(crop_w))
+
+
+class _PoseLoss(torch.autograd.Function):
+    """Fused default_pose_loss over head logits.  Returns (total (N,), components (N,4))."""
+
+    @staticmethod
+    def forward(ctx, logits, coefs, tdepth, tmask, weights, H, W):
+        L = _lib.lib()
+        lg = ops.cl(logits)                                   # (N,2,h,w) channels-last == [N][h*w][2]
+        n, _, h, w = lg.shape
+        nbytes = L.lf_pose_loss_scratch_bytes(n, h, w, H, W)
+        scratch = torch.empty(nbytes // 4 + 1, device=lg.device, dtype=torch.float32)
+        sums = torch.empty(n, 8, device=lg.device, dtype=torch.float32)
+        losses = torch.empty(n, 8, device=lg.device, dtype=torch.float32)
+        gsums = torch.empty(n, 8, device=lg.device, dtype=torch.float32)
+        cf = coefs.detach().contiguous()
+        check(L.lf_pose_loss_fwd(lg.data_ptr(), cf.data_ptr(), tdepth.data_ptr(), tmask.data_ptr(), weights.data_ptr(),
+                                 sums.data_ptr(), losses.data_ptr(), gsums.data_ptr(), scratch.data_ptr(),
+                                 scratch.numel() * 4, n, h, w, H, W, _s()), 'lf_pose_loss_fwd')
+        ctx.save_for_backward(lg, cf, tdepth, tmask, gsums, scratch)
+        ctx.dims = (n, h, w, H, W)
+        ctx.mark_non_differentiable(losses)
+        return losses[:, 4].clone(), losses
+
+    @staticmethod
+    def backward(ctx, g_total, _g_losses):
+        L = _lib.lib()
+        lg, cf, tdepth, tmask, gsums, scratch = ctx.saved_tensors
+        n, h, w, H, W = ctx.dims
+        # gsums were formed for d(mean_n total); rescale to the incoming per-sample gradient
+        gs = (gsums * (g_total * n).unsqueeze(1)).contiguous()
+        glogits = torch.empty_like(lg)
+        gcoefs = torch.zeros(n, NCOEF, device=lg.device, dtype=torch.float32)
+        check(L.lf_pose_loss_bwd(lg.data_ptr(), cf.data_ptr(), tdepth.data_ptr(), tmask.data_ptr(), gs.data_ptr(),
+                                 glogits.data_ptr(), gcoefs.data_ptr(), scratch.data_ptr(), scratch.numel() * 4,
+                                 n, h, w, H, W, _s()), 'lf_pose_loss_bwd')
+        return glogits, gcoefs, None, None, None, None, None
+
+
+def pose_loss(logits, coefs, tdepth, tmask, weights, H, W):
+    return _PoseLoss.apply(logits, coefs, tdepth, tmask, weights, H, W)
+
+
+class RenderLoopEngine:
+    """Explicit forward+backward of N pose hypotheses through a Photographer (factor projection,
+    no occlusion / skip connections) and the fused pose loss."""
+
+    LOSS_KEYS = ('depth', 'ov_depth', 'iou', 'mask')
+
+    @staticmethod
+    def supports(photographer, loss_weights):
+        return (photographer.projection_type == 'factor' and photographer.occlusion_module is None
+                and not photographer.skip_connections and len(photographer.object_blocks) == 0
+                and all(b.interpolate is None for b in photographer.camera_blocks)
+                and photographer.predict_depth and photographer.predict_mask and not photographer.predict_color
+                and loss_weights.get('latent', 0.0) == 0.0
+                and photographer.camera_config[-1] % 4 == 0)
+
+    def __init__(self, photographer, z_obj, target_obs, loss_weights):
+        self.ph = photographer
+        self.cube = photographer.cube_size
+        dev = z_obj.device
+        self.z = ops.cl(z_obj.reshape(1, *z_obj.shape[-4:]))              # (1,C,S,S,S) channels-last, resident
+        self.S = self.z.shape[-1]
+        self.C = self.z.shape[1]
+        self.crop = photographer.out_size
+        self.tdepth = target_obs.depth.reshape(-1).float().contiguous()
+        self.tmask = target_obs.mask.reshape(-1).float().contiguous()
+        self.H, self.W = target_obs.depth.shape[-2:]
+        self.set_weights(loss_weights)
+        self.convs = []
+        for blk in photographer.camera_blocks:
+            for conv in (blk.conv1, blk.conv2):
+                w = conv.module.weight
+                self.convs.append((w, conv.bias, ops.he_constant(w), ops.pack_conv3x3(w), ops.pack_conv3x3(w, transpose=True)))
+        pw = photographer.projection_block.conv.module.weight
+        cout, C, D = pw.shape[0], self.convs[-1][0].shape[0] if self.convs else self.C, self.S
+        self.proj = (pw, photographer.projection_block.conv.bias, ops.he_constant(pw),
+                     ops.pack_conv1x1(pw.reshape(cout, C, D).permute(0, 2, 1).reshape(cout, D * C)),
+                     ops.pack_conv1x1(pw.reshape(cout, C, D).permute(2, 1, 0).reshape(D * C, cout)))
+        self.dev = dev
+
+    def set_weights(self, loss_weights):
+        self.weights = torch.tensor([loss_weights.get(k, 0.0) for k in self.LOSS_KEYS], dtype=torch.float32,
+                                    device=self.z.device)
+
+    # -----------------------------------------------------------------------------------------
+    def forward_backward(self, camera, need_grad=True):
+        """Returns (losses (N,8): depth, ov_depth, iou, mask, weighted total ..., gparams (N,10) or None)."""
+        L = _lib.lib()
+        dev, S, s = self.dev, self.S, _s()
+        params = camera_params(camera).detach().contiguous()
+        n = params.shape[0]
+        intr = camera_intrinsics(camera)
+        coefs = torch.empty(n, NCOEF, device=dev, dtype=torch.float32)
+        jac = torch.empty(n, NCOEF, NPAR, device=dev, dtype=torch.float32)
+        check(L.lf_camera_coefs(params.data_ptr(), intr.data_ptr(), float(self.cube), float(camera.z_span), self.crop,
+                                self.crop, coefs.data_ptr(), jac.data_ptr(), n, s), 'lf_camera_coefs')
+        # O2C coefficient block padded to the resampler's stride (LF_MAP_COEFS = 20)
+        cf20 = torch.zeros(n, 20, device=dev, dtype=torch.float32)
+        cf20[:, :18] = coefs[:, :18]
+
+        # ---- 3-D forward ----
+        x0 = ops.empty_cl((n, self.C, S, S, S), dev)
+        check(L.lf_resample3d_fwd(self.z.data_ptr(), 1, cf20.data_ptr(), LF_MAP_O2C, x0.data_ptr(), n, S, S, S, self.C, s),
+              'lf_resample3d_fwd')
+        acts, norms = [x0], []
+        flags = LF_EPI_LRELU | LF_EPI_PIXELNORM
+        for (w, b, he, wp, _wt) in self.convs:
+            y, nrm = ops._conv3x3_raw(acts[-1], wp, b, w.shape[0], he, flags, True)
+            acts.append(y)
+            norms.append(nrm)
+        pw, pb, phe, ppack, ppack_t = self.proj
+        cout = pw.shape[0]
+        Cl = acts[-1].shape[1]
+        zp = ops.empty_cl((n, cout, S, S), dev)
+        pnorm = ops._conv1x1_raw(acts[-1], ppack, pb, n, S * S, Cl, S, S * S * S * Cl, S * S * Cl, cout, zp, phe, flags)
+
+        # ---- 2-D decoder + heads + fused loss (autograd over small maps) ----
+        zp_leaf = zp.detach().requires_grad_(need_grad)
+        cf_leaf = coefs.detach().requires_grad_(need_grad)
+        with torch.set_grad_enabled(need_grad):
+            yimg = self.ph.image_decoder(zp_leaf)
+            logits = torch.cat([ob(yimg) for ob in self.ph.output_blocks], dim=1)
+            total, losses = pose_loss(logits, cf_leaf, self.tdepth, self.tmask, self.weights, self.H, self.W)
+            objective = total.mean()                     # the optimised quantity (estimation.py:616-617)
+        if not need_grad:
+            return losses, None
+        g_zp, g_cf = torch.autograd.grad(objective, [zp_leaf, cf_leaf])
+
+        # ---- 3-D backward (data gradients only) ----
+        gp = ops._epilogue_bwd(ops.cl(g_zp), zp, pnorm, flags)
+        g = ops.empty_cl((n, Cl, S, S, S), dev)
+        ops._conv1x1_raw(gp, ppack_t, None, n, S * S, cout, 1, S * S * cout, 0, S * Cl, g, phe, 0,
+                         yaddr=(S * S * S * Cl, Cl, Cl, S * S * Cl))
+        for i in range(len(self.convs) - 1, -1, -1):
+            w, b, he, _wp, wt = self.convs[i]
+            gpre = ops._epilogue_bwd(g, acts[i + 1], norms[i], flags)
+            g, _ = ops._conv3x3_raw(gpre, wt, None, w.shape[1], he, 0, False)
+        gcoef18 = torch.empty(n, 18, device=dev, dtype=torch.float32)
+        nbytes = L.lf_resample3d_bwd_coef_scratch_bytes(n, S, S, S)
+        scratch = torch.empty(nbytes // 4 + 1, device=dev, dtype=torch.float32)
+        check(L.lf_resample3d_bwd_coef(g.data_ptr(), self.z.data_ptr(), 1, cf20.data_ptr(), gcoef18.data_ptr(),
+                                       scratch.data_ptr(), scratch.numel() * 4, n, S, S, S, self.C, s), 'lf_resample3d_bwd_coef')
+        gcoefs = g_cf.contiguous()
+        gcoefs[:, :18] = gcoef18
+        gparams = torch.empty(n, NPAR, device=dev, dtype=torch.float32)
+        check(L.lf_camera_coefs_bwd(gcoefs.data_ptr(), jac.data_ptr(), gparams.data_ptr(), n, s), 'lf_camera_coefs_bwd')
+        return losses, gparams

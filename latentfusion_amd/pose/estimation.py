@@ -281,8 +281,29 @@ class BatchedOptimizer:
         self.m = [torch.zeros_like(p) for p in params]
         self.v = [torch.zeros_like(p) for p in params]
 
+    def _step_hip_adam(self, lr_rows):
+        """lf_adam_step: one launch per parameter tensor (same arithmetic as the torch branch below)."""
+        from .. import _lib
+        L = _lib.lib()
+        b1, b2, eps = 0.9, 0.999, 1e-8
+        bc1, bc2 = 1 - b1 ** self.t, 1 - b2 ** self.t
+        dev = self.params[0].device
+        host = torch.tensor([[l / bc1 for l in lr_rows], list(lr_rows)], dtype=torch.float32)
+        both = host.to(dev, non_blocking=True)
+        wd = 1e-2 if self.name == 'adamw' else 0.0
+        stream = torch.cuda.current_stream().cuda_stream
+        for p, m, v in zip(self.params, self.m, self.v):
+            if p.grad is None:
+                continue
+            g = p.grad.contiguous()
+            _lib.check(L.lf_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), both[0].data_ptr(),
+                                      both[1].data_ptr(), math.sqrt(bc2), b1, b2, eps, wd, p.shape[0], p.shape[1], stream),
+                       'lf_adam_step')
+
     def step(self, lr_rows):
         self.t += 1
+        if self.name in ('adam', 'adamw') and all(p.is_cuda and p.is_contiguous() and p.dim() == 2 for p in self.params):
+            return self._step_hip_adam(lr_rows)
         dev = self.params[0].device
         lr = torch.tensor(lr_rows, dtype=torch.float32, device=dev).unsqueeze(1)
         with torch.no_grad():
@@ -314,8 +335,9 @@ class GradientPoseEstimator(PoseEstimator):
 
     def __init__(self, *, learning_rate, num_samples, num_iters, converge_threshold, converge_patience,
                  lr_reduce_patience=25, lr_reduce_threshold=1e-5, lr_reduce_factor=0.5, track_stats=False,
-                 loss_schedules=None, optimizer='adamw', **kwargs):
+                 loss_schedules=None, optimizer='adamw', use_engine=True, **kwargs):
         super().__init__(**kwargs)
+        self.use_engine = use_engine
         self.learning_rate, self.num_samples, self.num_iters = learning_rate, num_samples, num_iters
         self.optimizer = optimizer
         self.lr_reduce_patience, self.lr_reduce_threshold = lr_reduce_patience, lr_reduce_threshold
@@ -354,9 +376,35 @@ class GradientPoseEstimator(PoseEstimator):
         rank_loss = sum(weigh_losses(loss_dict, self.loss_weights).values()).detach()
         return loss_dict, optim_loss.detach(), rank_loss, optim_weights
 
+    def _engine_for(self, z_obj, target_obs):
+        """The fused HIP engine when the configuration allows it (default loss, factor-projection
+        renderer, no latent term); None selects the generic autograd-module path."""
+        if not self.use_engine or self.loss_func is not default_pose_loss or not z_obj.is_cuda:
+            return None
+        from ..engine import RenderLoopEngine
+        ph = getattr(self.model, 'photographer', None)
+        if ph is None or not RenderLoopEngine.supports(ph, self.loss_weights):
+            return None
+        return RenderLoopEngine(ph, z_obj, target_obs, self.loss_weights)
+
     def start(self, z_obj, target_obs, cameras, ranking=None):
         """Creates the per-run loop state (parameters, optimiser, schedulers); `cameras` must
         already be zoomed and on the device.  Exposed so that bench.py can time `iterate`."""
+        engine = self._engine_for(z_obj, target_obs)
+        if engine is not None:
+            from ..engine import camera_params
+            P = camera_params(cameras).detach().clone().contiguous()          # (N,10) master copy on the device
+            P.requires_grad_(True)
+            cam = cameras._like(log_quaternion=P[:, 0:3], translation=P[:, 3:6], viewport=P[:, 6:10])   # views of P
+            return {
+                'engine': engine, 'P': P, 'z_obj': z_obj, 'target': target_obs, 'cam': cam, 'params': [P],
+                'opt': BatchedOptimizer(self.optimizer, [P]),
+                'sched': _PlateauLR(len(cameras), self.learning_rate, self.lr_reduce_patience,
+                                    self.lr_reduce_threshold, self.lr_reduce_factor),
+                'ranking': [] if ranking is None else ranking, 'step': 0, 'converge_count': 0,
+                'stat_history': {}, 'camera_history': [], 'target_q': target_obs.camera.quaternion,
+                'template_cpu': cameras.to('cpu'),
+            }
         cam = pu.parameterize_camera(cameras, optimize_viewport=True)     # batched leaves (N,3),(N,3),(N,4)
         params = [cam.log_quaternion, cam.translation, cam.viewport]
         return {
@@ -371,6 +419,8 @@ class GradientPoseEstimator(PoseEstimator):
     def iterate(self, st):
         """One pose-optimisation iteration: render the N samples, loss, backward to the camera
         parameters, rank, optimiser + scheduler step.  Returns True when converged."""
+        if 'engine' in st:
+            return self._iterate_engine(st)
         cam, params, target_obs, step = st['cam'], st['params'], st['target'], st['step']
         for p in params:
             p.grad = None
@@ -393,6 +443,41 @@ class GradientPoseEstimator(PoseEstimator):
                 **{f'{k}_weight': v for k, v in optim_weights.items()},
                 'delta': delta, 'converge_count': st['converge_count'], 'angle_dist': angle.cpu(),
                 'trans_dist': trans.cpu(), 'optim_loss': optim_loss.cpu(), 'rank_loss': rank_loss.cpu()})
+        st['opt'].step(st['sched'].lr)
+        st['sched'].step(rank_host)
+        if delta < self.converge_threshold:
+            st['converge_count'] += 1
+        elif delta > self.converge_threshold:
+            st['converge_count'] = 0
+        st['step'] += 1
+        return st['converge_count'] >= self.converge_patience
+
+    def _iterate_engine(self, st):
+        """Same iteration on the fused engine: ONE device->host transfer (losses + parameters)."""
+        eng, P, step, target_obs = st['engine'], st['P'], st['step'], st['target']
+        optim_weights = copy.copy(self.loss_weights)
+        if self.loss_schedules:
+            optim_weights.update({k: v.get(step) for k, v in self.loss_schedules.items()})
+            eng.set_weights(optim_weights)
+        with torch.no_grad():
+            losses, gparams = eng.forward_backward(st['cam'], need_grad=True)
+            host = torch.cat((losses[:, :5], P.detach()), dim=1).cpu()            # the one D2H sync per iteration
+        comp = {k: host[:, i] for i, k in enumerate(eng.LOSS_KEYS)}
+        rank = sum(self.loss_weights.get(k, 0.0) * comp[k] for k in eng.LOSS_KEYS)
+        rank_host = rank.tolist()
+        tpl = st['template_cpu']
+        detached = tpl._like(log_quaternion=host[:, 5:8].clone(), translation=host[:, 8:11].clone(), viewport=None)
+        if self.return_camera_history:
+            st['camera_history'].append((rank.clone(), detached))
+        delta = self._track_best_items(st['ranking'], step, list(detached), rank_host)
+        if self.track_stats:
+            angle = three.quaternion.angular_distance(detached.quaternion, st['target_q'].cpu()).squeeze()
+            trans = torch.norm(detached.translation - target_obs.camera.translation.cpu(), dim=1).squeeze()
+            self._record_stat_dict(st['stat_history'], {
+                **{f'{k}_loss': v for k, v in comp.items()}, **{f'{k}_weight': v for k, v in optim_weights.items()},
+                'delta': delta, 'converge_count': st['converge_count'], 'angle_dist': angle, 'trans_dist': trans,
+                'optim_loss': host[:, 4].clone(), 'rank_loss': rank.clone()})
+        P.grad = gparams
         st['opt'].step(st['sched'].lr)
         st['sched'].step(rank_host)
         if delta < self.converge_threshold:
