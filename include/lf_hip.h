@@ -115,6 +115,20 @@ int lf_conv1x1_fwd(const float* x, const float* wpack, const float* bias, float*
                    long y_slice_stride,
                    float he, unsigned flags, float slope, float eps, void* stream);
 
+/* Data gradients of the two convolutions: gx = conv^T(gy) * he with the host-packed transposed
+ * weights (taps flipped / in-out swapped).  When prev_y != NULL the epilogue backward of the layer
+ * that PRODUCED this convolution's input (whose saved output is prev_y, norm prev_norm, epilogue
+ * prev_flags) is folded into the store, i.e. the result is already dL/d(pre-activation) of that
+ * layer and no separate lf_epilogue_bwd pass over the volume is needed.  Requires 16-channel
+ * records (Cout == 16 for 3x3; y_slice_channels == y_row_stride == 16 for 1x1). */
+int lf_conv3x3_bwd_data(const float* gy, const float* wpack_t, float* gx, int dims, int N, int D, int H, int W,
+                        int Cin, int Cout, float he, const float* prev_y, const float* prev_norm,
+                        unsigned prev_flags, float slope, void* stream);
+int lf_conv1x1_bwd_data(const float* gy, const float* wpack_t, float* gx, int N, int P, int Cin, int Cout,
+                        long y_batch_stride, int y_row_stride, int y_slice_channels, long y_slice_stride,
+                        float he, const float* prev_y, const float* prev_norm, unsigned prev_flags,
+                        float slope, void* stream);
+
 /* Standalone PixelNorm over the last (channel) axis of [rows][C], in place allowed.
  * norm_out[rows] receives sqrt(mean+eps).  modules/__init__.py:14-15. */
 int lf_pixelnorm_fwd(const float* x, float* y, float* norm_out, long rows, int C, float eps, void* stream);

@@ -31,6 +31,10 @@ SIGNATURES = {
                                c_float, c_uint, c_float, c_float, P]),
     'lf_conv1x1_fwd': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_long, c_long, c_int, c_long, c_int,
                                c_int, c_long, c_float, c_uint, c_float, c_float, P]),
+    'lf_conv3x3_bwd_data': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, P, P, c_uint,
+                                    c_float, P]),
+    'lf_conv1x1_bwd_data': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_long, c_int, c_int, c_long, c_float, P, P,
+                                    c_uint, c_float, P]),
     'lf_pixelnorm_fwd': (c_int, [P, P, P, c_long, c_int, c_float, P]),
     'lf_epilogue_bwd': (c_int, [P, P, P, P, c_long, c_int, c_uint, c_float, P]),
     'lf_camera_coefs': (c_int, [P, P, c_float, c_float, c_int, c_int, P, P, c_int, P]),

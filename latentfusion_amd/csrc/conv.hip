@@ -43,7 +43,9 @@ __device__ __forceinline__ void epilogue_store(f32x4 (&acc)[NT][NR], const long 
                                                const float* __restrict__ bias, float* __restrict__ y,
                                                float* __restrict__ norm_out, int Cout, int co_base,
                                                int ysc, long yss, bool vec_out,
-                                               float he, unsigned flags, float slope, float eps) {
+                                               float he, unsigned flags, float slope, float eps,
+                                               const float* __restrict__ prev_y = nullptr,
+                                               const float* __restrict__ prev_norm = nullptr, unsigned prev_flags = 0) {
   const int lane = threadIdx.x & 63;
   const int cq = lane >> 4;
   float bv[NT][4];
@@ -74,6 +76,34 @@ __device__ __forceinline__ void epilogue_store(f32x4 (&acc)[NT][NR], const long 
       ss += __shfl_xor(ss, 32, 64);
       r = sqrtf(ss / (float)Cout + eps);
       rinv = 1.0f / r;          // one IEEE division per voxel; y = v * (1/r) is within 1 ulp of v / r
+    }
+    if (prev_y != nullptr) {
+      // Data-gradient use: acc holds dL/d(output of the previous layer's epilogue) for 16-channel
+      // records; fold that layer's LeakyReLU' * PixelNorm' in here (saves one HBM round trip):
+      //   g <- lrelu'(y_prev) * (g - y_prev * mean_c(g * y_prev)) / norm_prev      (C == 16 per tile)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int co = co_base + t * 16 + cq * 4;
+        const bool ok = rowoff[j] >= 0 && co < Cout;
+        const long off = ok ? rowoff[j] + (long)(co / ysc) * yss + (co % ysc) : 0;
+        f32x4 yp = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (ok) yp = *(const f32x4*)(prev_y + off);
+        f32x4 g = acc[t][j];
+        if (prev_flags & LF_EPI_PIXELNORM) {
+          float dot = g[0] * yp[0] + g[1] * yp[1] + g[2] * yp[2] + g[3] * yp[3];
+          dot += __shfl_xor(dot, 16, 64);
+          dot += __shfl_xor(dot, 32, 64);
+          dot *= (1.f / 16.f);
+          const float nr = ok ? prev_norm[off >> 4] : 1.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) g[e] = (g[e] - yp[e] * dot) / nr;
+        }
+        if (prev_flags & LF_EPI_LRELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) g[e] = yp[e] > 0.f ? g[e] : g[e] * slope;
+        }
+        acc[t][j] = g;
+      }
     }
     if (rowoff[j] >= 0) {
       float* dst = y + rowoff[j];
@@ -145,7 +175,8 @@ __global__ void __launch_bounds__(256) conv3x3_kernel(
     float* __restrict__ y, float* __restrict__ norm_out,
     int N, int D, int H, int W, int Cin, int Cout, int CinP, int CoutP,
     int tiles_x, int tiles_y, int tiles_z,
-    float he, unsigned flags, float slope, float eps) {
+    float he, unsigned flags, float slope, float eps,
+    const float* __restrict__ prev_y, const float* __restrict__ prev_norm, unsigned prev_flags) {
   using G = TileGeom<DIMS>;
   constexpr int HX = TX + 2;
   constexpr int HALO = G::HZ * G::HY * HX;
@@ -219,7 +250,7 @@ __global__ void __launch_bounds__(256) conv3x3_kernel(
     rowoff[j] = rowidx[j] < 0 ? -1 : rowidx[j] * Cout;
   }
   epilogue_store<NT, 4>(acc, rowoff, rowidx, bias, y, norm_out, Cout, co_base, 1 << 30, 0, (Cout & 3) == 0,
-                        he, flags, slope, eps);
+                        he, flags, slope, eps, prev_y, prev_norm, prev_flags);
 }
 
 // ---- C = 16 specialisation of the 3x3(x3) kernel (the SYN(S,16) hot path) ---------------------
@@ -232,7 +263,8 @@ __global__ void __launch_bounds__(256, 2) conv3x3_c16_kernel(
     float* __restrict__ y, float* __restrict__ norm_out,
     int N, int D, int H, int W, int Cin, int Cout,
     int tiles_x, int tiles_y, int tiles_z,
-    float he, unsigned flags, float slope, float eps) {
+    float he, unsigned flags, float slope, float eps,
+    const float* __restrict__ prev_y, const float* __restrict__ prev_norm, unsigned prev_flags) {
   using G = TileGeom<DIMS>;
   constexpr int HX = TX + 2;
   constexpr int HALO = G::HZ * G::HY * HX;
@@ -306,7 +338,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_c16_kernel(
     rowoff[j] = rowidx[j] < 0 ? -1 : rowidx[j] * Cout;
   }
   epilogue_store<1, 4>(acc, rowoff, rowidx, bias, y, norm_out, Cout, 0, 1 << 30, 0, (Cout & 3) == 0,
-                       he, flags, slope, eps);
+                       he, flags, slope, eps, prev_y, prev_norm, prev_flags);
 }
 
 // ---- persistent, double-buffered C = 16 conv3d kernel (the dominant kernel of the pose loop) ---
@@ -331,7 +363,8 @@ __global__ void __launch_bounds__(512, 2) conv3d_c16_persistent_kernel(
     const float* __restrict__ x, const float* __restrict__ wpack, const float* __restrict__ bias,
     float* __restrict__ y, float* __restrict__ norm_out,
     int N, int D, int H, int W, int tiles_x, int tiles_y, int tiles_z, int ntiles,
-    float he, unsigned flags, float slope, float eps) {
+    float he, unsigned flags, float slope, float eps,
+    const float* __restrict__ prev_y, const float* __restrict__ prev_norm, unsigned prev_flags) {
   __shared__ __attribute__((aligned(16))) float lds[2 * p3::BUF_FLOATS];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -407,6 +440,30 @@ __global__ void __launch_bounds__(512, 2) conv3d_c16_persistent_kernel(
 
   f32x4 acc[4];
 
+  // data-gradient launches: the previous layer's saved output / norm of the tile's 4 rows, fetched
+  // BEFORE the tile's MFMAs so the global latency is hidden behind them
+  f32x4 pyv[4];
+  float pnv[4];
+  auto prefetch_prev = [&](int t) {
+    if (prev_y == nullptr) return;
+    int tt = t;
+    const int bx = tt % tiles_x; tt /= tiles_x;
+    const int by = tt % tiles_y; tt /= tiles_y;
+    const int bz = tt % tiles_z; tt /= tiles_z;
+    const float* pybase = prev_y + (long)tt * nvox * 16;
+    const float* pnbase = prev_norm ? prev_norm + (long)tt * nvox : nullptr;
+    const int gx = bx * TX + li;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = wave * 4 + j;
+      const int gz = bz * p3::TZ + (r >> 3), gy = by * p3::TY + (r & 7);
+      const bool ok = gx < W && gy < H && gz < D;
+      const int vox = ok ? (gz * H + gy) * W + gx : 0;
+      pyv[j] = ok ? *(const f32x4*)(pybase + vox * 16 + cq * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      pnv[j] = (ok && pnbase) ? pnbase[vox] : 1.f;
+    }
+  };
+
   auto compute = [&](int buf) {
     const float* base = lds + buf * p3::BUF_FLOATS;
 #pragma unroll
@@ -447,6 +504,28 @@ __global__ void __launch_bounds__(512, 2) conv3d_c16_persistent_kernel(
     for (int j = 0; j < 4; ++j) {
       const int r = wave * 4 + j;
       const int gz = bz * p3::TZ + (r >> 3), gy = by * p3::TY + (r & 7);
+      if (prev_y != nullptr) {
+        // data-gradient launch: fold the previous layer's LeakyReLU' * PixelNorm' into the store
+        const bool ok = gx < W && gy < H && gz < D;
+        const int vox = ok ? (gz * H + gy) * W + gx : 0;
+        const f32x4 yp = pyv[j];
+        f32x4 g = acc[j] * he;
+        if (prev_flags & LF_EPI_PIXELNORM) {
+          float dot = g[0] * yp[0] + g[1] * yp[1] + g[2] * yp[2] + g[3] * yp[3];
+          dot += __shfl_xor(dot, 16, 64);
+          dot += __shfl_xor(dot, 32, 64);
+          dot *= (1.f / 16.f);
+          const float rinv = 1.0f / pnv[j];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) g[e] = (g[e] - yp[e] * dot) * rinv;
+        }
+        if (prev_flags & LF_EPI_LRELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) g[e] = yp[e] > 0.f ? g[e] : g[e] * slope;
+        }
+        if (ok) *(f32x4*)(ybase + vox * 16 + cq * 4) = g;
+        continue;
+      }
       f32x4 v;
       float ss = 0.f;
 #pragma unroll
@@ -480,6 +559,7 @@ __global__ void __launch_bounds__(512, 2) conv3d_c16_persistent_kernel(
   if (wave < 4) {
     for (int t = t_begin; t < t_end; ++t) {
       if (t + 1 < t_end) issue_dma(t + 1, cur ^ 1);               // lands during the MFMAs below
+      prefetch_prev(t);
       compute(cur);
       epilogue(t);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // next tile's DMA has landed
@@ -490,6 +570,7 @@ __global__ void __launch_bounds__(512, 2) conv3d_c16_persistent_kernel(
     for (int t = t_begin; t < t_end; ++t) {
       if (t + 1 < t_end) issue_dma(t + 1, cur ^ 1);
       if (t > t_begin) epilogue(t - 1);
+      prefetch_prev(t);
       compute(cur);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -506,7 +587,8 @@ __global__ void __launch_bounds__(256) conv1x1_kernel(
     float* __restrict__ y, float* __restrict__ norm_out,
     int P, int Cin, int ksl, long x_batch_stride, long x_slice_stride, int Cout, int Kp,
     long y_batch_stride, int y_row_stride, int y_slice_channels, long y_slice_stride,
-    float he, unsigned flags, float slope, float eps) {
+    float he, unsigned flags, float slope, float eps,
+    const float* __restrict__ prev_y, const float* __restrict__ prev_norm, unsigned prev_flags) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, cq = lane >> 4;
   const int n = blockIdx.z;
@@ -547,7 +629,7 @@ __global__ void __launch_bounds__(256) conv1x1_kernel(
   long rowoff[1] = {live ? ((long)n * y_batch_stride + p * y_row_stride) : -1};
   const bool vec_out = ((y_row_stride | y_slice_channels) & 3) == 0 && ((y_batch_stride | y_slice_stride) & 3) == 0;
   epilogue_store<NT, 1>(acc, rowoff, rowidx, bias, y, norm_out, Cout, co_base, y_slice_channels, y_slice_stride,
-                        vec_out, he, flags, slope, eps);
+                        vec_out, he, flags, slope, eps, prev_y, prev_norm, prev_flags);
 }
 
 }  // namespace
@@ -567,10 +649,16 @@ extern "C" int lf_conv1x1_cout_padded(int Cout) {
   return (c16 + 127) & ~127;
 }
 
-extern "C" int lf_conv3x3_fwd(const float* x, const float* wpack, const float* bias, float* y, float* norm_out,
-                              int dims, int N, int D, int H, int W, int Cin, int Cout,
-                              float he, unsigned flags, float slope, float eps, void* stream) {
+static int conv3x3_launch(const float* x, const float* wpack, const float* bias, float* y, float* norm_out,
+                          int dims, int N, int D, int H, int W, int Cin, int Cout,
+                          float he, unsigned flags, float slope, float eps, void* stream,
+                          const float* prev_y, const float* prev_norm, unsigned prev_flags) {
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return LF_EINVAL;
+  if (prev_y != nullptr) {
+    // fused previous-layer epilogue backward: plain data-gradient launch onto 16-channel records
+    if (flags != 0 || bias != nullptr || Cout != 16 || !lf_aligned16(prev_y)) return LF_EINVAL;
+    if ((prev_flags & LF_EPI_PIXELNORM) && prev_norm == nullptr) return LF_EINVAL;
+  }
   if (dims != 2 && dims != 3) return LF_EINVAL;
   if (dims == 2 && D != 1) return LF_EINVAL;
   if ((flags & LF_EPI_PIXELNORM) && Cout > 64) return LF_EINVAL;
@@ -595,33 +683,55 @@ extern "C" int lf_conv3x3_fwd(const float* x, const float* wpack, const float* b
       if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
       const unsigned pgrid = (unsigned)(pt < cus ? pt : cus);
       hipLaunchKernelGGL(conv3d_c16_persistent_kernel, dim3(pgrid), dim3(p3::NTHREADS), 0, s, x, wpack, bias, y, norm_out,
-                         N, D, H, W, ptx, pty, ptz, (int)pt, he, flags, slope, eps);
+                         N, D, H, W, ptx, pty, ptz, (int)pt, he, flags, slope, eps, prev_y, prev_norm, prev_flags);
       return lf_launch_status();
     }
   }
   if (CinP == 16 && CoutP == 16) {          // register-resident weights, unrolled + pipelined taps
     if (dims == 3)
       hipLaunchKernelGGL((conv3x3_c16_kernel<3>), grid, block, 0, s, x, wpack, bias, y, norm_out, N, D, H, W, Cin, Cout,
-                         tiles_x, tiles_y, tiles_z, he, flags, slope, eps);
+                         tiles_x, tiles_y, tiles_z, he, flags, slope, eps, prev_y, prev_norm, prev_flags);
     else
       hipLaunchKernelGGL((conv3x3_c16_kernel<2>), grid, block, 0, s, x, wpack, bias, y, norm_out, N, D, H, W, Cin, Cout,
-                         tiles_x, tiles_y, tiles_z, he, flags, slope, eps);
+                         tiles_x, tiles_y, tiles_z, he, flags, slope, eps, prev_y, prev_norm, prev_flags);
     return lf_launch_status();
   }
 #define LAUNCH(DM, T) hipLaunchKernelGGL((conv3x3_kernel<DM, T>), grid, block, 0, s, x, wpack, bias, y, norm_out, \
-                                         N, D, H, W, Cin, Cout, CinP, CoutP, tiles_x, tiles_y, tiles_z, he, flags, slope, eps)
+                                         N, D, H, W, Cin, Cout, CinP, CoutP, tiles_x, tiles_y, tiles_z, he, flags, slope, eps, \
+                                         prev_y, prev_norm, prev_flags)
   if (dims == 3) { if (NT == 4) LAUNCH(3, 4); else if (NT == 2) LAUNCH(3, 2); else LAUNCH(3, 1); }
   else           { if (NT == 4) LAUNCH(2, 4); else if (NT == 2) LAUNCH(2, 2); else LAUNCH(2, 1); }
 #undef LAUNCH
   return lf_launch_status();
 }
 
-extern "C" int lf_conv1x1_fwd(const float* x, const float* wpack, const float* bias, float* y, float* norm_out,
-                              int N, int P, int Cin, int ksl, long x_batch_stride, long x_slice_stride,
-                              int Cout, long y_batch_stride, int y_row_stride, int y_slice_channels,
-                              long y_slice_stride,
+extern "C" int lf_conv3x3_fwd(const float* x, const float* wpack, const float* bias, float* y, float* norm_out,
+                              int dims, int N, int D, int H, int W, int Cin, int Cout,
                               float he, unsigned flags, float slope, float eps, void* stream) {
+  return conv3x3_launch(x, wpack, bias, y, norm_out, dims, N, D, H, W, Cin, Cout, he, flags, slope, eps, stream,
+                        nullptr, nullptr, 0);
+}
+
+extern "C" int lf_conv3x3_bwd_data(const float* gy, const float* wpack_t, float* gx, int dims, int N, int D, int H, int W,
+                                   int Cin, int Cout, float he, const float* prev_y, const float* prev_norm,
+                                   unsigned prev_flags, float slope, void* stream) {
+  return conv3x3_launch(gy, wpack_t, nullptr, gx, nullptr, dims, N, D, H, W, Cin, Cout, he, 0, slope, 0.f, stream,
+                        prev_y, prev_norm, prev_flags);
+}
+
+static int conv1x1_launch(const float* x, const float* wpack, const float* bias, float* y, float* norm_out,
+                          int N, int P, int Cin, int ksl, long x_batch_stride, long x_slice_stride,
+                          int Cout, long y_batch_stride, int y_row_stride, int y_slice_channels,
+                          long y_slice_stride,
+                          float he, unsigned flags, float slope, float eps, void* stream,
+                          const float* prev_y, const float* prev_norm, unsigned prev_flags) {
   if (N <= 0 || P <= 0 || Cin <= 0 || ksl <= 0 || Cout <= 0 || y_slice_channels <= 0) return LF_EINVAL;
+  if (prev_y != nullptr) {
+    if (flags != 0 || bias != nullptr || y_slice_channels != 16 || y_row_stride != 16 || (Cout & 15) ||
+        !lf_aligned16(prev_y) || ((y_batch_stride | y_slice_stride) & 15))
+      return LF_EINVAL;
+    if ((prev_flags & LF_EPI_PIXELNORM) && prev_norm == nullptr) return LF_EINVAL;
+  }
   if (y_row_stride < (y_slice_channels < Cout ? y_slice_channels : Cout)) return LF_EINVAL;
   if (ksl > 1 && (Cin & 3)) return LF_EALIGN;     // a lane's 4-channel group must not straddle slices
   if ((flags & LF_EPI_PIXELNORM) && Cout > 128) return LF_EINVAL;
@@ -636,7 +746,7 @@ extern "C" int lf_conv1x1_fwd(const float* x, const float* wpack, const float* b
   hipStream_t s = (hipStream_t)stream;
 #define LAUNCH(T) hipLaunchKernelGGL((conv1x1_kernel<T>), grid, block, 0, s, x, wpack, bias, y, norm_out, \
                                      P, Cin, ksl, x_batch_stride, x_slice_stride, Cout, Kp, y_batch_stride, y_row_stride, \
-                                     y_slice_channels, y_slice_stride, he, flags, slope, eps)
+                                     y_slice_channels, y_slice_stride, he, flags, slope, eps, prev_y, prev_norm, prev_flags)
   switch (NT) {
     case 1: LAUNCH(1); break;
     case 2: LAUNCH(2); break;
@@ -646,4 +756,23 @@ extern "C" int lf_conv1x1_fwd(const float* x, const float* wpack, const float* b
   }
 #undef LAUNCH
   return lf_launch_status();
+}
+
+extern "C" int lf_conv1x1_fwd(const float* x, const float* wpack, const float* bias, float* y, float* norm_out,
+                              int N, int P, int Cin, int ksl, long x_batch_stride, long x_slice_stride,
+                              int Cout, long y_batch_stride, int y_row_stride, int y_slice_channels,
+                              long y_slice_stride,
+                              float he, unsigned flags, float slope, float eps, void* stream) {
+  return conv1x1_launch(x, wpack, bias, y, norm_out, N, P, Cin, ksl, x_batch_stride, x_slice_stride, Cout,
+                        y_batch_stride, y_row_stride, y_slice_channels, y_slice_stride, he, flags, slope, eps, stream,
+                        nullptr, nullptr, 0);
+}
+
+extern "C" int lf_conv1x1_bwd_data(const float* gy, const float* wpack_t, float* gx, int N, int P, int Cin, int Cout,
+                                   long y_batch_stride, int y_row_stride, int y_slice_channels, long y_slice_stride,
+                                   float he, const float* prev_y, const float* prev_norm, unsigned prev_flags,
+                                   float slope, void* stream) {
+  return conv1x1_launch(gy, wpack_t, nullptr, gx, nullptr, N, P, Cin, 1, (long)P * Cin, 0, Cout, y_batch_stride,
+                        y_row_stride, y_slice_channels, y_slice_stride, he, 0, slope, 0.f, stream, prev_y, prev_norm,
+                        prev_flags);
 }

@@ -199,12 +199,25 @@ class RenderLoopEngine:
         # ---- 3-D backward (data gradients only) ----
         gp = ops._epilogue_bwd(ops.cl(g_zp), zp, pnorm, flags)
         g = ops.empty_cl((n, Cl, S, S, S), dev)
-        ops._conv1x1_raw(gp, ppack_t, None, n, S * S, cout, 1, S * S * cout, 0, S * Cl, g, phe, 0,
-                         yaddr=(S * S * S * Cl, Cl, Cl, S * S * Cl))
-        for i in range(len(self.convs) - 1, -1, -1):
-            w, b, he, _wp, wt = self.convs[i]
-            gpre = ops._epilogue_bwd(g, acts[i + 1], norms[i], flags)
-            g, _ = ops._conv3x3_raw(gpre, wt, None, w.shape[1], he, 0, False)
+        fuse = (Cl == 16 and self.C == 16 and all(w.shape[0] == 16 and w.shape[1] == 16 for w, *_ in self.convs))
+        nconv = len(self.convs)
+        if fuse and nconv:
+            # every data-gradient kernel also applies the LeakyReLU'/PixelNorm' of the layer feeding it,
+            # so no separate epilogue-backward pass touches the (N,16,S,S,S) volumes
+            check(L.lf_conv1x1_bwd_data(gp.data_ptr(), ppack_t.data_ptr(), g.data_ptr(), n, S * S, cout, S * Cl,
+                                        S * S * S * Cl, Cl, Cl, S * S * Cl, phe, acts[nconv].data_ptr(),
+                                        norms[nconv - 1].data_ptr(), flags, ops.SLOPE, s), 'lf_conv1x1_bwd_data')
+            for i in range(nconv - 1, -1, -1):
+                w, b, he, _wp, wt = self.convs[i]
+                prev = (acts[i], norms[i - 1], flags) if i > 0 else None
+                g = ops.conv3x3_bwd_data(g, wt, w.shape[1], he, prev)
+        else:
+            ops._conv1x1_raw(gp, ppack_t, None, n, S * S, cout, 1, S * S * cout, 0, S * Cl, g, phe, 0,
+                             yaddr=(S * S * S * Cl, Cl, Cl, S * S * Cl))
+            for i in range(nconv - 1, -1, -1):
+                w, b, he, _wp, wt = self.convs[i]
+                gpre = ops._epilogue_bwd(g, acts[i + 1], norms[i], flags)
+                g, _ = ops._conv3x3_raw(gpre, wt, None, w.shape[1], he, 0, False)
         gcoef18 = torch.empty(n, 18, device=dev, dtype=torch.float32)
         nbytes = L.lf_resample3d_bwd_coef_scratch_bytes(n, S, S, S)
         scratch = torch.empty(nbytes // 4 + 1, device=dev, dtype=torch.float32)

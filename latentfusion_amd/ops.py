@@ -211,6 +211,22 @@ def _conv3x3_raw(x, wpack, bias, cout, he, flags, want_norm):
     return y, norm
 
 
+def conv3x3_bwd_data(gy, wpack_t, cin, he, prev=None):
+    """gx = conv^T(gy) * he; prev = (y_prev, norm_prev, flags_prev) folds the producing layer's
+    epilogue backward into the store (16-channel records only)."""
+    L = _lib.lib()
+    dims = gy.dim() - 2
+    N, cout = gy.shape[0], gy.shape[1]
+    D, H, W = (gy.shape[2:] if dims == 3 else (1,) + tuple(gy.shape[2:]))
+    gx = empty_cl((N, cin) + tuple(gy.shape[2:]), gy.device)
+    py, pn, pf = (prev[0], prev[1], prev[2]) if prev is not None else (None, None, 0)
+    with _timed(f'conv3x3_{dims}d_{cout}x{cin}'):
+        check(L.lf_conv3x3_bwd_data(_ptr(gy), _ptr(wpack_t), _ptr(gx), dims, N, D, H, W, cout, cin, he,
+                                    _ptr(py) if py is not None else None, _ptr(pn) if pn is not None else None, pf,
+                                    SLOPE, _stream()), 'lf_conv3x3_bwd_data')
+    return gx
+
+
 def _epilogue_bwd(gy, y, norm, flags):
     L = _lib.lib()
     if flags == 0:
