@@ -135,8 +135,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
 
-    # roofline of the dominant kernel: conv3x3_kernel<3,1> (fused conv3d C->C block; 2 fwd + 2
-    # data-grad launches per iteration), HIP events recorded on the launch stream in the timed region
+    # roofline of the dominant kernel: conv3d_c16_persistent_kernel (fused conv3d C->C block; 2 forward +
+    # 2 data-gradient launches per iteration), HIP events recorded on the launch stream in the timed region
     name = f'conv3x3_3d_{C}x{C}'
     durs = [e0.elapsed_time(e1) for n_, e0, e1 in timer if n_ == name]
     conv_ms = sum(durs) / max(len(durs), 1)
@@ -163,7 +163,7 @@ def main():
                    'fuser': a.fuser, 'pose_samples': N, 'ref_views': V, 'volume': S, 'channels': C,
                    'parallelism': f'objects x{world} (no data-path collective in the loop)'},
         't_build_s': t_build,
-        'roofline': {'bound': 'mfma', 'kernel': 'conv3x3_kernel<3,1> (fused conv3d+He+bias+LeakyReLU+PixelNorm)',
+        'roofline': {'bound': 'mfma', 'kernel': 'conv3d_c16_persistent_kernel (fused conv3d 16->16 + He + bias + LeakyReLU + PixelNorm; fwd and data-grad)',
                      'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': traffic,
                      'avg_launch_ms': conv_ms, 'launches_timed': len(durs), 'flops_per_launch': flops},

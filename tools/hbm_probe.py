@@ -1,0 +1,21 @@
+#!/usr/bin/env python
+"""Workload for the HBM-traffic PMC passes: a calibration copy of known size (1 GiB read + 1 GiB
+written by ATen's copy kernel) followed by the dominant conv3d kernel on the bench shape."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from latentfusion_amd import ops  # noqa: E402
+
+g = torch.Generator().manual_seed(0)
+x = ops.cl(torch.randn(8, 16, 128, 128, 128, generator=g).cuda())
+w = torch.randn(16, 16, 3, 3, 3, generator=g).cuda()
+b = torch.zeros(16).cuda()
+for _ in range(3):
+    y = x.clone()            # calibration: 1 GiB in, 1 GiB out
+torch.cuda.synchronize()
+for _ in range(3):
+    y = ops.conv3x3(x, w, b)
+torch.cuda.synchronize()
