@@ -381,6 +381,50 @@ def g0_preprocess(lf):
                            'zoom': obs_dict(z), 'prepare': obs_dict(p), 'normalize': obs_dict(n)})
 
 
+def g11_released_like(lf):
+    """A scaled-down copy of the RELEASED architecture's structure (tools/train/train.sh:28-66):
+    U-Nets with D/U tokens, bilinear rescaling and skip connections, channel counts that are not
+    multiples of 16, camera blocks that change width, tanh-free heads.  Pins the generic paths."""
+    from latentfusion.recon.models import Sculptor, Photographer
+    from latentfusion.recon import fusion
+    from latentfusion.recon.inference import LatentFusionModel
+    torch.manual_seed(50)
+    S_in = 16
+    sc = Sculptor(in_size=S_in, image_config=[[8, 'D', 24, 'D', 24], [24, 'U', 24, 'U', 12]],
+                  camera_config=[4, 8, 20], object_config=[20, 20], projection_type='factor',
+                  input_color=True, input_depth=False, input_mask=True, scale_mode='nearest').eval()
+    S = sc.out_size
+    ph = Photographer(in_size=S, image_config=[[12, 'D', 24, 'D', 24], [24, 'U', 24, 'U', 12, 'U', 8]],
+                      camera_config=[20, 20], object_config=[], projection_type='factor',
+                      predict_depth=True, predict_mask=True, scale_mode='nearest').eval()
+    fu = fusion.get_fuser('gru', 20, 1.0).eval()
+    for m in (sc, ph, fu):
+        for k, p in m.named_parameters():
+            if k.endswith('bias'):
+                p.data.normal_(0, 0.1)
+    dist = lf.recon.utils.optimal_camera_dist(615.4991, S_in, 0.5, slack=0.5)
+    model = LatentFusionModel(sc, fu, ph, dist, 'cpu')
+    ref_obs = synth_obs(lf, 3 + 1, seed=51)
+    pre = model.preprocess_observation(ref_obs)
+    z_obj = model.build_latent_object(ref_obs)
+    cam = rand_cameras(lf, 2, zoomed_size=S_in, dist=dist, seed=52)
+    cam.log_quaternion = cam.log_quaternion.detach().requires_grad_(True)
+    cam.translation = cam.translation.detach().requires_grad_(True)
+    cam.viewport = cam.viewport.detach().requires_grad_(True)
+    y, lat, _ = ph.decode(z_obj, cam, return_latent=True, apply_mask=True)
+    g = torch.Generator().manual_seed(53)
+    wd = torch.randn(y['depth_logits'].shape, generator=g)
+    wm = torch.randn(y['mask_logits'].shape, generator=g)
+    ((y['depth_logits'] * wd).sum() + (y['mask_logits'] * wm).sum()).backward()
+    save('g11_released_like', {
+        'sculptor': ck(sc), 'fuser': ck(fu), 'photographer': ck(ph), 'camera_dist': dist,
+        'obs_pre': {'color': pre.color.clone(), 'depth': pre.depth.clone(), 'mask': pre.mask.clone(), 'cam': cam_dict(pre.camera)},
+        'z_obj': z_obj.clone(), 'cam': cam_dict(cam), 'wd': wd, 'wm': wm,
+        'y': {k: v.detach().clone() for k, v in y.items()}, 'latent': lat.detach().clone(),
+        'g_log_q': cam.log_quaternion.grad.clone(), 'g_t': cam.translation.grad.clone(),
+        'g_viewport': cam.viewport.grad.clone(), 'sizes': {'sculptor_out': S, 'photographer_out': ph.out_size}})
+
+
 def main():
     lf = refharness.load_reference()
     import latentfusion.recon.utils  # noqa
@@ -394,6 +438,7 @@ def main():
     g6_loss(lf)
     g7_g10_loop(lf)
     g9_ibr(lf)
+    g11_released_like(lf)
 
 
 if __name__ == '__main__':

@@ -74,3 +74,52 @@ def test_g4_fusers(golden):
             mids = [g['blend']['z_cam_mid'].to(DEV)] if kind == 'blend' else None
             out, _ = f(z, mids, None, cam)
         close(out, g[kind]['out'], atol=1e-4, rtol=1e-3)
+
+
+def test_g11_released_like_structure(golden):
+    """The generic kernel paths behind the released architecture's structure: U-Nets with D/U
+    rescaling and skip concatenations, channel counts 12/20/24/48 (multi-chunk, non-multiple-of-16),
+    camera blocks that change width, 32x32 output from a 16^3 volume -- encode, decode, camera grads."""
+    from latentfusion_amd.recon import fusion
+    from latentfusion_amd.recon.models import Photographer, Sculptor
+    g = golden('g11_released_like')
+    sc = Sculptor.from_checkpoint(g['sculptor']).to(DEV)
+    fu = fusion.from_checkpoint(g['fuser']).to(DEV)
+    ph = Photographer.from_checkpoint(g['photographer']).to(DEV)
+    o = g['obs_pre']
+    with torch.no_grad():
+        z, _ = sc.encode(fu, prod_camera(o['cam']), o['color'].unsqueeze(0).to(DEV), o['depth'].unsqueeze(0).to(DEV),
+                         o['mask'].unsqueeze(0).to(DEV))
+    close(z, g['z_obj'], atol=2e-4, rtol=2e-3)
+    cam = prod_camera(g['cam'])
+    for p in (cam.log_quaternion, cam.translation, cam.viewport):
+        p.requires_grad_(True)
+    y, lat, _ = ph.decode(g['z_obj'].to(DEV), cam, return_latent=True, apply_mask=True)
+    for k in ('depth_logits', 'mask_logits', 'depth', 'mask'):
+        close(y[k], g['y'][k], atol=2e-4, rtol=2e-3)
+    ((y['depth_logits'] * g['wd'].to(DEV)).sum() + (y['mask_logits'] * g['wm'].to(DEV)).sum()).backward()
+    got = torch.cat((cam.log_quaternion.grad, cam.translation.grad, cam.viewport.grad), dim=1).cpu()
+    want = torch.cat((g['g_log_q'], g['g_t'], g['g_viewport']), dim=1)
+    rel = ((got - want).norm(dim=1) / want.norm(dim=1)).max().item()
+    assert rel < 2e-2, rel
+
+
+def test_g8_cross_entropy_step_on_hip(golden):
+    """CrossEntropyPoseEstimator.evaluate_samples (flip augmentation, zoom, render without grad,
+    loss) on the HIP path: per-sample losses and their ORDER equal the reference's."""
+    from latentfusion_amd.observation import Observation
+    from latentfusion_amd.pose import estimation
+    from latentfusion_amd.recon import fusion
+    from latentfusion_amd.recon.inference import LatentFusionModel
+    from latentfusion_amd.recon.models import Photographer, Sculptor
+    g, t7 = golden('g8_ce_step'), golden('g7_adam_trace')
+    model = LatentFusionModel(Sculptor.from_checkpoint(t7['sculptor']), fusion.from_checkpoint(t7['fuser']),
+                              Photographer.from_checkpoint(t7['photographer']), t7['camera_dist'], DEV)
+    est = estimation.CrossEntropyPoseEstimator(model=model, num_samples=24, num_elites=5, num_iters=3,
+                                               num_gmm_components=2, learning_rate=0.9, sample_flipped=True,
+                                               ranking_size=4, loss_weights=g['weights'])
+    tg = t7['target']
+    target = Observation(None, tg['depth'], tg['mask'].float(), prod_camera(tg['cam'], 'cpu')).to(DEV)
+    cams, loss = est.evaluate_samples(t7['z_obj'].to(DEV), target, prod_camera(g['cams']))
+    close(loss, g['loss'], atol=1e-4, rtol=1e-3)
+    assert torch.argsort(loss).cpu().tolist() == g['order'].tolist()
