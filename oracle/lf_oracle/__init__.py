@@ -7,7 +7,7 @@ Parity status: PINNED.  Every function here is checked by tests/test_oracle_gold
 golden vectors produced by the real reference (oracle/make_golden.py, which imports
 /root/reference in the build container; fixtures G0-G10 under tests/golden/).
 """
-from . import camera, nets, pose, quat  # noqa: F401
+from . import camera, ibr, nets, pose, quat  # noqa: F401
 from .camera import Cam  # noqa: F401
 
 

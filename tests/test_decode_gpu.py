@@ -123,3 +123,21 @@ def test_g8_cross_entropy_step_on_hip(golden):
     cams, loss = est.evaluate_samples(t7['z_obj'].to(DEV), target, prod_camera(g['cams']))
     close(loss, g['loss'], atol=1e-4, rtol=1e-3)
     assert torch.argsort(loss).cpu().tolist() == g['order'].tolist()
+
+
+def test_g9_ibr_on_hip(golden):
+    """render_ibr_basic-style colour rendering: depths from the HIP renderer, reprojection + blend."""
+    from latentfusion_amd import ibr
+    from latentfusion_amd.recon.models import Photographer
+    g = golden('g9_ibr')
+    ph = Photographer.from_checkpoint(g['ck']).to(DEV)
+    cam_in, cam_out = prod_camera(g['cam_in']), prod_camera(g['cam_out'])
+    y, z = ibr.render_latent_ibr2(ph, g['z_obj'].to(DEV), cam_in, cam_out, g['image_in'].to(DEV), p=0.5,
+                                  weight_type='cam_dist', apply_mask=True)
+    close(y['depth'], g['depth'], atol=2e-4, rtol=2e-3)
+    close(y['color'], g['color'], atol=2e-3, rtol=1e-2)
+    with torch.no_grad():
+        y_in, _, _ = ph.decode(g['z_obj'].to(DEV), cam_in, apply_mask=True)
+        y_out, _, _ = ph.decode(g['z_obj'].to(DEV), cam_out, apply_mask=True)
+        img_re, dep_re = ibr.reproject_views(g['image_in'][0].to(DEV), y_in['depth'][0], y_out['depth'][0], cam_in, cam_out)
+    close(img_re, g['image_reproj'], atol=2e-3, rtol=1e-2)
