@@ -142,6 +142,15 @@ int lf_pixelnorm_fwd(const float* x, float* y, float* norm_out, long rows, int C
 int lf_epilogue_bwd(const float* gy, const float* y, const float* norm, float* gp,
                     long rows, int C, unsigned flags, float slope, void* stream);
 
+/* Block-end rescale by exactly x2 (up = 1) or x0.5 (up = 0): nearest (linear = 0) or bi-/tri-linear
+ * with align_corners=False (linear = 1) = Interpolate / F.interpolate(scale_factor=...) of
+ * modules/__init__.py:18-36, blocks.py:160-162.  x: [N][D][H][W][C] (D = 1 for dims = 2); the output
+ * extent is 2*in or floor(in/2) per spatial axis.  lf_resize_bwd is the exact adjoint (gather form). */
+int lf_resize_fwd(const float* x, float* y, int dims, int N, int D, int H, int W, int C, int linear, int up,
+                  void* stream);
+int lf_resize_bwd(const float* gy, float* gx, int dims, int N, int D, int H, int W, int C, int linear, int up,
+                  void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Camera -> coefficient blocks, with Jacobian (fp64 forward-mode duals inside).
  * Replaces the chain of tiny ops log_quaternion -> qexp -> normalize -> quat_to_mat -> cam_to_obj ->

@@ -37,6 +37,8 @@ SIGNATURES = {
                                     c_uint, c_float, P]),
     'lf_pixelnorm_fwd': (c_int, [P, P, P, c_long, c_int, c_float, P]),
     'lf_epilogue_bwd': (c_int, [P, P, P, P, c_long, c_int, c_uint, c_float, P]),
+    'lf_resize_fwd': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    'lf_resize_bwd': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     'lf_camera_coefs': (c_int, [P, P, c_float, c_float, c_int, c_int, P, P, c_int, P]),
     'lf_camera_coefs_bwd': (c_int, [P, P, P, c_int, P]),
     'lf_pose_loss_scratch_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),

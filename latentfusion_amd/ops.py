@@ -429,9 +429,34 @@ def pixelnorm(x):
     return _PixelNorm.apply(x)
 
 
+class _Resize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, linear, up):
+        L = _lib.lib()
+        _req(x, 'x')
+        x = cl(x)
+        dims = x.dim() - 2
+        N, C = x.shape[0], x.shape[1]
+        D, H, W = (x.shape[2:] if dims == 3 else (1,) + tuple(x.shape[2:]))
+        out_sp = tuple((s * 2 if up else s // 2) for s in x.shape[2:])
+        y = empty_cl((N, C) + out_sp, x.device)
+        check(L.lf_resize_fwd(_ptr(x), _ptr(y), dims, N, D, H, W, C, linear, up, _stream()), 'lf_resize_fwd')
+        ctx.meta = (dims, N, C, D, H, W, linear, up, tuple(x.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        L = _lib.lib()
+        dims, N, C, D, H, W, linear, up, xshape = ctx.meta
+        g = cl(gy)
+        gx = empty_cl(xshape, g.device)
+        check(L.lf_resize_bwd(_ptr(g), _ptr(gx), dims, N, D, H, W, C, linear, up, _stream()), 'lf_resize_bwd')
+        return gx, None, None
+
+
 def interpolate(x, scale_factor, mode):
-    """Block-end rescale (modules/__init__.py:18-36).  Only the released 2-D decoder/encoder
-    use it (SYN configs have no U/D tokens); currently served by ATen's upsample kernels on the
-    device -- a fused HIP version is listed in DESIGN.md as open work."""
-    ac = False if mode in ('bilinear', 'trilinear') else None
-    return torch.nn.functional.interpolate(x, scale_factor=scale_factor, mode=mode, align_corners=ac)
+    """Block-end rescale (modules/__init__.py:18-36): x2 / x0.5, nearest or (bi|tri)linear with
+    align_corners=False -- the only combinations the block grammar (I/U/D tokens) can produce."""
+    if scale_factor not in (2.0, 0.5) or mode not in ('nearest', 'bilinear', 'trilinear'):
+        raise NotImplementedError(f'rescale {scale_factor} / {mode} is not produced by the block grammar')
+    return _Resize.apply(x, 0 if mode == 'nearest' else 1, 1 if scale_factor == 2.0 else 0)

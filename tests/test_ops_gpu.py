@@ -222,3 +222,23 @@ def test_ops_refuse_cpu_tensors():
     from latentfusion_amd import ops, _lib
     with pytest.raises(_lib.LFHipError):
         ops.conv3x3(torch.zeros(1, 16, 4, 4, 4), torch.zeros(16, 16, 3, 3, 3), None)
+
+
+@pytest.mark.parametrize('dims', [2, 3])
+@pytest.mark.parametrize('mode', ['nearest', 'linear'])
+@pytest.mark.parametrize('factor', [2.0, 0.5])
+@pytest.mark.parametrize('S,C', [(8, 7), (9, 16), (6, 4)])
+def test_resize_vs_torch(dims, mode, factor, S, C):
+    """Block-end Interpolate: forward and the exact adjoint against F.interpolate (odd sizes incl.)."""
+    from latentfusion_amd import ops
+    g = torch.Generator().manual_seed(dims * 100 + S)
+    x = torch.randn((2, C) + (S,) * dims, generator=g, requires_grad=True)
+    tmode = 'nearest' if mode == 'nearest' else ('bilinear' if dims == 2 else 'trilinear')
+    want = torch.nn.functional.interpolate(x, scale_factor=factor, mode=tmode, align_corners=None if mode == 'nearest' else False)
+    gw = torch.randn(want.shape, generator=g)
+    (want * gw).sum().backward()
+    xd = x.detach().to(DEV).requires_grad_(True)
+    got = ops.interpolate(xd, factor, tmode)
+    close(got, want, atol=1e-6)
+    (got * gw.to(DEV)).sum().backward()
+    close(xd.grad, x.grad, atol=1e-5)
