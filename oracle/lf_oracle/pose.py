@@ -67,6 +67,18 @@ class Model:
         with torch.no_grad():
             return nets.encode(self.sck, self.fck, obs.cam, obs.color, obs.depth, obs.mask)
 
+    def compute_latent_code(self, obs, cam):
+        """Encode the (single) target crop under every candidate camera, decode, return the 2-D
+        latent (inference.py:86-99 -> autoencode models.py:73-81)."""
+        obs = self.preprocess(obs)
+        n = len(cam)
+        outs = []
+        for i in range(n):                                  # one (object = 1 view) per candidate camera
+            z_obj = nets.encode(self.sck, self.fck, cam[i], obs.color, obs.depth, obs.mask)
+            _, lat, _ = nets.decode(self.pck, z_obj, cam[i])
+            outs.append(lat[:, 0])
+        return torch.cat(outs, dim=0)
+
     def render_latent_object(self, z_obj, cam, apply_mask=True):
         y, lat, _ = nets.decode(self.pck, z_obj, cam, apply_mask=apply_mask)
         return y, lat.squeeze(0)
@@ -95,6 +107,13 @@ def pose_loss(target, pred_depth_crop, pred_mask_logits_crop, cam):
     out['mask'] = F.binary_cross_entropy_with_logits(pred_logits, tmask.expand_as(pred_mask),
                                                      reduction='none').mean(dim=(1, 2, 3))
     return out
+
+
+def latent_loss(z_pred, z_target):
+    """1 - cosine similarity of the flattened 2-D latents (estimation.py:111-116, distances.py:5-9)."""
+    a = z_pred.reshape(z_pred.shape[0], -1)
+    b = z_target.reshape(z_target.shape[0], -1).expand_as(a)
+    return 1.0 - torch.cosine_similarity(a, b, 1, 1e-8)
 
 
 def weigh(loss_dict, weights):

@@ -425,6 +425,32 @@ def g11_released_like(lf):
         'g_viewport': cam.viewport.grad.clone(), 'sizes': {'sculptor_out': S, 'photographer_out': ph.out_size}})
 
 
+def g12_latent_code(lf):
+    """compute_latent_code (inference.py:86-99 -> autoencode, models.py:73-81) and the latent term of
+    default_pose_loss (estimation.py:111-116): the path behind adam_latent / cross_entropy_latent."""
+    from latentfusion.pose.estimation import default_pose_loss
+    model, cks, dist = _model(lf, 16, 8, 'gru', seed=60)
+    ref_obs = synth_obs(lf, 4, seed=61)
+    target = synth_obs(lf, 1, seed=62)
+    target.color = torch.round(target.color * 255.0) / 255.0          # 8-bit colours: stored as uint8 below
+    z_obj = model.build_latent_object(ref_obs)
+    cams = rand_cameras(lf, 3, seed=63)
+    zcams = cams.zoom(None, model.input_size, model.camera_dist)
+    with torch.no_grad():
+        z_target = model.compute_latent_code(target, zcams)
+        pred, z_pred = model.render_latent_object(z_obj, zcams, return_latent=True)
+        zd = zcams.denormalize_depth(pred['depth'].squeeze(0))
+        ld = default_pose_loss(target, zd, pred['mask_logits'].squeeze(0), zcams, z_pred_latent=z_pred,
+                               z_target_latent=z_target)
+    save('g12_latent_code', {'sculptor': cks[0], 'fuser': cks[1], 'photographer': cks[2], 'camera_dist': dist,
+                             'z_obj': z_obj.clone(),
+                             'target': {'color_u8': torch.round(target.color * 255.0).to(torch.uint8), 'depth': target.depth.clone(),
+                                        'mask': target.mask.bool(), 'cam': cam_dict(target.camera)},
+                             'cams': cam_dict(zcams),
+                             'z_target_latent': z_target.clone(), 'z_pred_latent': z_pred.clone(),
+                             'latent_loss': ld['latent'].clone()})
+
+
 def main():
     lf = refharness.load_reference()
     import latentfusion.recon.utils  # noqa
@@ -439,6 +465,7 @@ def main():
     g7_g10_loop(lf)
     g9_ibr(lf)
     g11_released_like(lf)
+    g12_latent_code(lf)
 
 
 if __name__ == '__main__':

@@ -141,3 +141,27 @@ def test_g9_ibr_on_hip(golden):
         y_out, _, _ = ph.decode(g['z_obj'].to(DEV), cam_out, apply_mask=True)
         img_re, dep_re = ibr.reproject_views(g['image_in'][0].to(DEV), y_in['depth'][0], y_out['depth'][0], cam_in, cam_out)
     close(img_re, g['image_reproj'], atol=2e-3, rtol=1e-2)
+
+
+def test_g12_latent_code_on_hip(golden):
+    """compute_latent_code (encode the target crop under each candidate camera + decode) and the
+    latent term of the pose loss -- the path used by adam_latent / cross_entropy_latent."""
+    from latentfusion_amd.observation import Observation
+    from latentfusion_amd.pose.loss import default_pose_loss
+    from latentfusion_amd.recon import fusion
+    from latentfusion_amd.recon.inference import LatentFusionModel
+    from latentfusion_amd.recon.models import Photographer, Sculptor
+    g = golden('g12_latent_code')
+    model = LatentFusionModel(Sculptor.from_checkpoint(g['sculptor']), fusion.from_checkpoint(g['fuser']),
+                              Photographer.from_checkpoint(g['photographer']), g['camera_dist'], DEV)
+    tg = g['target']
+    target = Observation(tg['color_u8'].float() / 255.0, tg['depth'], tg['mask'].float(), prod_camera(tg['cam'], 'cpu')).to(DEV)
+    cams = prod_camera(g['cams'])
+    with torch.no_grad():
+        zt = model.compute_latent_code(target, cams)
+        pred, zp = model.render_latent_object(g['z_obj'].to(DEV), cams, return_latent=True)
+        ld = default_pose_loss(target, cams.denormalize_depth(pred['depth'].squeeze(0)), pred['mask_logits'].squeeze(0),
+                               cams, z_pred_latent=zp, z_target_latent=zt)
+    close(zt, g['z_target_latent'], atol=3e-4, rtol=3e-3)
+    close(zp, g['z_pred_latent'], atol=3e-4, rtol=3e-3)
+    close(ld['latent'], g['latent_loss'], atol=1e-4, rtol=1e-3)
