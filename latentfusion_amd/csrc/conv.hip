@@ -81,22 +81,29 @@ __device__ __forceinline__ void epilogue_store(f32x4 (&acc)[NT][NR], const long 
       // Data-gradient use: acc holds dL/d(output of the previous layer's epilogue) for 16-channel
       // records; fold that layer's LeakyReLU' * PixelNorm' in here (saves one HBM round trip):
       //   g <- lrelu'(y_prev) * (g - y_prev * mean_c(g * y_prev)) / norm_prev      (C == 16 per tile)
+      // All NT loads are issued before the first use so they overlap each other.
+      f32x4 ypv[NT];
+      float nrv[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int co = co_base + t * 16 + cq * 4;
         const bool ok = rowoff[j] >= 0 && co < Cout;
         const long off = ok ? rowoff[j] + (long)(co / ysc) * yss + (co % ysc) : 0;
-        f32x4 yp = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (ok) yp = *(const f32x4*)(prev_y + off);
+        ypv[t] = ok ? *(const f32x4*)(prev_y + off) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        nrv[t] = (ok && (prev_flags & LF_EPI_PIXELNORM)) ? prev_norm[off >> 4] : 1.f;
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const f32x4 yp = ypv[t];
         f32x4 g = acc[t][j];
         if (prev_flags & LF_EPI_PIXELNORM) {
           float dot = g[0] * yp[0] + g[1] * yp[1] + g[2] * yp[2] + g[3] * yp[3];
           dot += __shfl_xor(dot, 16, 64);
           dot += __shfl_xor(dot, 32, 64);
           dot *= (1.f / 16.f);
-          const float nr = ok ? prev_norm[off >> 4] : 1.f;
+          const float rinv = 1.0f / nrv[t];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) g[e] = (g[e] - yp[e] * dot) / nr;
+          for (int e = 0; e < 4; ++e) g[e] = (g[e] - yp[e] * dot) * rinv;
         }
         if (prev_flags & LF_EPI_LRELU) {
 #pragma unroll
