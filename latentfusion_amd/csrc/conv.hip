@@ -25,14 +25,6 @@ template <int DIMS> struct TileGeom;
 template <> struct TileGeom<3> { static constexpr int TY = 4, TZ = 4, HY = 6, HZ = 6, TAPS = 27; };
 template <> struct TileGeom<2> { static constexpr int TY = 16, TZ = 1, HY = 18, HZ = 1, TAPS = 9; };
 
-__device__ __forceinline__ f32x4 mfma4(const f32x4 a, const f32x4 b, f32x4 c) {
-  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], c, 0, 0, 0);
-  return c;
-}
-
 // Shared epilogue: acc[t][j] = raw conv sums of cout tile t for voxel-row j.
 // rowoff[j] = float offset of the row's output record in y (< 0: lane/row outside the tensor),
 // rowidx[j] = flat voxel index (for norm_out).  Output channel co lands at
@@ -629,7 +621,9 @@ __global__ void __launch_bounds__(256) conv1x1_kernel(
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const f32x4 afrag = *(const f32x4*)(wrow + (long)t * 16 * Kp + kc * 16);
-      acc[t][0] = mfma4(afrag, bfrag, acc[t][0]);
+#pragma unroll
+      for (int st = 0; st < 4; ++st)
+        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[st], bfrag[st], acc[t][0], 0, 0, 0);
     }
   }
   long rowidx[1] = {live ? ((long)n * P + p) : -1};

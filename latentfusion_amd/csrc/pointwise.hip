@@ -126,10 +126,8 @@ __global__ void __launch_bounds__(256) lift_unfold_kernel(const float* __restric
   const int CS = C0 * S;
   for (long p = blockIdx.x; p < P; p += gridDim.x) {
     const float* s = src + ((long)n * P + p) * CS;
-    const float inv = nrm ? 1.f / nrm[(long)n * P + p] : 1.f;
     __syncthreads();
     for (int i = threadIdx.x; i < CS; i += 256) row[i] = nrm ? s[i] / nrm[(long)n * P + p] : s[i];
-    (void)inv;
     __syncthreads();
     for (int i = threadIdx.x; i < CS; i += 256) {
       const int c = i % C0, d = i / C0;                     // destination order: d-major, c fastest

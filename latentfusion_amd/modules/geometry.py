@@ -106,6 +106,25 @@ class Camera:
                         log_quaternion=torch.cat([c.log_quaternion for c in cameras], dim=0),
                         translation=torch.cat([c.translation for c in cameras], dim=0))
 
+    @classmethod
+    def vcat(cls, cameras, batch_size=-1):
+        """Concatenate along the VIEW axis of (batch, view)-flattened cameras (reference :407-429)."""
+        def bv(t):
+            return t.reshape(batch_size, -1, *t.shape[1:])
+
+        def join(name):
+            return torch.cat([bv(getattr(c, name)) for c in cameras], dim=1).flatten(0, 1)
+        return cameras[0]._like(intrinsic=join('intrinsic'), viewport=join('viewport'),
+                                log_quaternion=join('log_quaternion'), translation=join('translation'))
+
+    def translate(self, offset):
+        """Moves the camera centre by `offset` in object space (reference :239-247)."""
+        if offset.dim() == 1:
+            offset = offset.unsqueeze(0)
+        pos = self.position + offset.expand_as(self.position)
+        self.translation = -(self.rotation_matrix[:, :3, :3] @ pos.unsqueeze(-1)).squeeze(-1)
+        return self
+
     def to_kwargs(self):
         return {'intrinsic': self.intrinsic, 'extrinsic': self.extrinsic, 'z_span': self.z_span,
                 'viewport': self.viewport, 'height': self.height, 'width': self.width}

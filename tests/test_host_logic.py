@@ -301,3 +301,39 @@ def test_synthetic_workload_is_consumable_by_the_oracle():
     model = opose.Model(sck, fck, pck, dist)
     z = model.build_latent_object(obs)
     assert z.shape == (1, 1, 4, 8, 8, 8) and torch.isfinite(z).all()
+
+
+def test_camera_vcat_and_translate(golden):
+    from latentfusion_amd.modules.geometry import Camera
+    cam = prod_camera(golden('g1_camera')['cam'])
+    a, b = cam[0:2], cam[2:4]                      # two "objects" x one view each, twice
+    v = Camera.vcat([a, b], batch_size=2)          # -> (object0: a0,b0), (object1: a1,b1)
+    close(v.translation, torch.stack((cam.translation[0], cam.translation[2], cam.translation[1], cam.translation[3])))
+    moved = cam.clone().translate(torch.tensor([0.01, -0.02, 0.03]))
+    close(moved.position, cam.position + torch.tensor([0.01, -0.02, 0.03]), atol=1e-6)
+    close(moved.rotation_matrix, cam.rotation_matrix)
+
+
+def test_from_checkpoint_training_format(golden, tmp_path):
+    """LatentFusionModel.from_checkpoint on the trainer's nested format (trainutils.py:274-285):
+    {'args','epoch','name','modules':{'sculptor','fuser','photographer',...}} incl. legacy keys."""
+    from latentfusion_amd.recon.inference import LatentFusionModel
+    g = golden('g7_adam_trace')
+    sck = copy.deepcopy(g['sculptor'])
+    pck = copy.deepcopy(g['photographer'])
+    for k in ('input_color', 'input_depth', 'input_mask'):
+        sck['args'].pop(k)                          # legacy checkpoint: flags live in the global args
+    for k in ('predict_color', 'predict_depth', 'predict_mask'):
+        pck['args'].pop(k)
+    ck = {'args': {'camera_dist': g['camera_dist'], 'generator_input_depth': False, 'generator_input_mask': True,
+                   'predict_color': False, 'predict_depth': True, 'predict_mask': True, 'no_discriminator': True},
+          'epoch': 12, 'name': 'unit-test', 'meter_hists': {},
+          'modules': {'sculptor': sck, 'fuser': copy.deepcopy(g['fuser']), 'photographer': pck}}
+    path = tmp_path / 'ck.pth'
+    torch.save(ck, path)
+    model = LatentFusionModel.from_checkpoint(str(path), device='cpu')
+    assert model.input_size == 16 and abs(model.camera_dist - g['camera_dist']) < 1e-12
+    assert model.sculptor.input_mask and not model.sculptor.input_depth and model.photographer.predict_mask
+    for k, v in g['photographer']['state_dict'].items():
+        assert torch.equal(model.photographer.state_dict()[k], v)
+    assert type(model.fuser).__name__ == 'GRUFuser'
