@@ -680,8 +680,15 @@ static int conv3x3_launch(const float* x, const float* wpack, const float* bias,
     const int ptx = (W + TX - 1) / TX, pty = (H + p3::TY - 1) / p3::TY, ptz = (D + p3::TZ - 1) / p3::TZ;
     const long pt = (long)ptx * pty * ptz * N;
     if (pt <= 0x7fffffffL) {
-      int dev = 0, cus = 256;
-      if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      static int cus = 0;                                         // CU count of the current device (cached)
+      if (cus == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+          cus = v;
+        else
+          cus = 256;
+      }
       const unsigned pgrid = (unsigned)(pt < cus ? pt : cus);
       hipLaunchKernelGGL(conv3d_c16_persistent_kernel, dim3(pgrid), dim3(p3::NTHREADS), 0, s, x, wpack, bias, y, norm_out,
                          N, D, H, W, ptx, pty, ptz, (int)pt, he, flags, slope, eps, prev_y, prev_norm, prev_flags);
