@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF dense
 
 
 def parse():
@@ -44,6 +45,9 @@ def parse():
     ap.add_argument('--fuser', default='gru')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-iters', type=int, default=1)
+    ap.add_argument('--no-alt', action='store_true', help='skip the secondary f16x3 measurement')
+    ap.add_argument('--conv-mode', default='fp32', choices=['fp32', 'f16x3'],
+                    help="conv3d kernels of the engine: exact-fp32 MFMA (default) or split-precision f16x3")
     return ap.parse_args()
 
 
@@ -108,7 +112,7 @@ def main():
     cfg = estimation._load_toml(os.path.join(ROOT, 'configs', 'adam_quick.toml'))
     cfg['args']['num_samples'] = N
     cfg['args']['ranking_size'] = N
-    est = estimation.load_from_config(cfg, model, converge_patience=10 ** 6)
+    est = estimation.load_from_config(cfg, model, converge_patience=10 ** 6, conv_mode=a.conv_mode)
     torch.manual_seed(300 + rank)
     init = pu.sample_cameras_with_estimate(N, target.camera.to('cpu'))
     init_rec = {'K': init.intrinsic.clone(), 'log_q': init.log_quaternion.clone(), 't': init.translation.clone()}
@@ -120,28 +124,48 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        est.iterate(st)
-    barrier()
-    ops.KERNEL_TIMER = []
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        est.iterate(st)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    timer, ops.KERNEL_TIMER = ops.KERNEL_TIMER, None
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = tt.item()
+    def timed_loop(est_, st_):
+        for _ in range(a.warmup):
+            est_.iterate(st_)
+        barrier()
+        ops.KERNEL_TIMER = []
+        t0_ = time.perf_counter()
+        for _ in range(a.steps):
+            est_.iterate(st_)
+        barrier()
+        el = time.perf_counter() - t0_
+        timer_, ops.KERNEL_TIMER = ops.KERNEL_TIMER, None
+        if world > 1:
+            tt = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = tt.item()
+        return el, timer_
+
+    elapsed, timer = timed_loop(est, st)
+    alt = None
+    if a.conv_mode == 'fp32' and not a.no_alt and C == 16:
+        # secondary line (never `value`): the same loop with the split-precision conv3d kernels
+        del est, st
+        torch.cuda.empty_cache()
+        est2 = estimation.load_from_config(cfg, model, converge_patience=10 ** 6, conv_mode='f16x3')
+        st2 = est2.start(z_obj, target, init.zoom(None, model.input_size, model.camera_dist).to(dev))
+        el2, tm2 = timed_loop(est2, st2)
+        d2 = [e0.elapsed_time(e1) for n_, e0, e1 in tm2 if n_ == 'conv3d_c16_split']
+        alt = {'conv_mode': 'f16x3 (each fp32 product as 3 f16 MFMAs, fp32 accumulate; max error vs fp64 <= the fp32 '
+                            'kernel\'s, tests/test_engine_gpu.py::test_split_precision_conv_matches_fp32_and_fp64)',
+               'value': world * a.steps / el2, 'unit': 'iters/s', 'ms_per_step': el2 / a.steps * 1e3,
+               'conv_avg_launch_ms': sum(d2) / max(len(d2), 1)}
 
     # roofline of the dominant kernel: conv3d_c16_persistent_kernel (fused conv3d C->C block; 2 forward +
     # 2 data-gradient launches per iteration), HIP events recorded on the launch stream in the timed region
-    name = f'conv3x3_3d_{C}x{C}'
+    name = f'conv3x3_3d_{C}x{C}' if a.conv_mode == 'fp32' else 'conv3d_c16_split'
     durs = [e0.elapsed_time(e1) for n_, e0, e1 in timer if n_ == name]
     conv_ms = sum(durs) / max(len(durs), 1)
     flops = 2.0 * 27 * C * C * (S ** 3) * N                        # algorithmic flops per launch
     achieved = flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    # f16x3 issues 3 f16 MFMA products per algorithmic product: price it against dense-f16 peak / 3
+    peak = FP32_MFMA_PEAK_TFLOPS if a.conv_mode == 'fp32' else F16_MFMA_PEAK_TFLOPS / 3.0
+    kname = ('conv3d_c16_persistent_kernel' if a.conv_mode == 'fp32' else 'conv3d_c16_split_kernel')
     traffic = None
     tpath = os.path.join(ROOT, 'profiles', 'r01_conv3d_hbm_bytes.json')
     if os.path.exists(tpath) and S == 128 and C == 16 and N == 8:
@@ -157,15 +181,15 @@ def main():
         'metric': 'pose-optim iters/sec (reconstruct+render+backward), 16 views, 128^3 voxels',
         'value': value, 'unit': 'iters/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
         'ms_per_step': elapsed / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32', 'data': 'synthetic (SYN(S,C) random-init weights, synthetic observations)',
+        'dtype': 'f32' if a.conv_mode == 'fp32' else 'f32 (conv3d products split into 3 f16 MFMAs, fp32 accumulate)', 'data': 'synthetic (SYN(S,C) random-init weights, synthetic observations)',
         'config': {'workload': f'SYN({S},{C}) latent volume, {V} reference views, adam_quick pose loop, '
                                f'{N} pose samples per iteration, one object per GPU',
                    'fuser': a.fuser, 'pose_samples': N, 'ref_views': V, 'volume': S, 'channels': C,
                    'parallelism': f'objects x{world} (no data-path collective in the loop)'},
         't_build_s': t_build,
-        'roofline': {'bound': 'mfma', 'kernel': 'conv3d_c16_persistent_kernel (fused conv3d 16->16 + He + bias + LeakyReLU + PixelNorm; fwd and data-grad)',
-                     'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': traffic,
+        'roofline': {'bound': 'mfma', 'kernel': kname + ' (fused conv3d 16->16 + He + bias + LeakyReLU + PixelNorm; fwd and data-grad)',
+                     'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
+                     'frac': achieved / peak, 'traffic': traffic if a.conv_mode == 'fp32' else None,
                      'avg_launch_ms': conv_ms, 'launches_timed': len(durs), 'flops_per_launch': flops},
     }
     if world == 1 and not a.no_cpu_baseline:
@@ -173,6 +197,8 @@ def main():
         out['cpu_baseline'] = {'value': v, 'unit': 'iters/s', 'cores': cores, 'kind': 'port',
                                'sample': f'{a.cpu_iters} timed iteration(s) of the same SYN({S},{C}) N={N} pose loop '
                                          f'(oracle, after 1 warm-up iteration; latent volume taken from the GPU build)'}
+    if alt is not None:
+        out['alt'] = alt
     print(json.dumps(out))
 
 

@@ -127,7 +127,25 @@ int lf_conv3x3_bwd_data(const float* gy, const float* wpack_t, float* gx, int di
 int lf_conv1x1_bwd_data(const float* gy, const float* wpack_t, float* gx, int N, int P, int Cin, int Cout,
                         long y_batch_stride, int y_row_stride, int y_slice_channels, long y_slice_stride,
                         float he, const float* prev_y, const float* prev_norm, unsigned prev_flags,
-                        float slope, void* stream);
+                        float slope, float* amax_out, void* stream);
+/* (amax_out, optional: zero-initialised device scalar that receives max|gx| when prev_y != NULL;
+ *  consumed by lf_conv3d_c16_split as amax_in.) */
+
+/* Split-precision ("f16x3") variant of the fused conv3d 16->16 block and of its data gradient:
+ * every fp32 operand is split on-chip into f16 hi + lo (22 mantissa bits) and the product is formed
+ * from three f16 MFMAs accumulating in fp32 (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi; dropped term <= 2^-22).
+ * Same semantics / epilogue / fused previous-layer backward as lf_conv3x3_fwd / lf_conv3x3_bwd_data
+ * for dims = 3, Cin = Cout = 16.  wsplit: [14 tap pairs][hi,lo][16 cout][32 = 2 taps x 16 cin] f16 (pairing from
+ * lf_conv3d_c16_split_pairs),
+ * lf_conv3d_c16_split_wpack_halfs() elements (host-packed).  amax_in (device scalar, may be NULL):
+ * max-abs of x, used to pre-scale tiny gradient tensors by a power of two (undone exactly);
+ * amax_out (may be NULL, zero-initialised by the caller): receives max-abs of the output. */
+size_t lf_conv3d_c16_split_wpack_halfs(void);
+void lf_conv3d_c16_split_pairs(int* taps28);   /* tap indices (kz*9+ky*3+kx; -1 = zero) of the 14 K-slot pairs */
+int lf_conv3d_c16_split(const float* x, const void* wsplit, const float* bias, float* y, float* norm_out,
+                        int N, int D, int H, int W, float he, unsigned flags, float slope, float eps,
+                        const float* prev_y, const float* prev_norm, unsigned prev_flags,
+                        const float* amax_in, float* amax_out, void* stream);
 
 /* Standalone PixelNorm over the last (channel) axis of [rows][C], in place allowed.
  * norm_out[rows] receives sqrt(mean+eps).  modules/__init__.py:14-15. */

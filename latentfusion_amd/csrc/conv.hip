@@ -37,7 +37,9 @@ __device__ __forceinline__ void epilogue_store(f32x4 (&acc)[NT][NR], const long 
                                                int ysc, long yss, bool vec_out,
                                                float he, unsigned flags, float slope, float eps,
                                                const float* __restrict__ prev_y = nullptr,
-                                               const float* __restrict__ prev_norm = nullptr, unsigned prev_flags = 0) {
+                                               const float* __restrict__ prev_norm = nullptr, unsigned prev_flags = 0,
+                                               float* __restrict__ amax_out = nullptr) {
+  float lane_amax = 0.f;
   const int lane = threadIdx.x & 63;
   const int cq = lane >> 4;
   float bv[NT][4];
@@ -102,6 +104,8 @@ __device__ __forceinline__ void epilogue_store(f32x4 (&acc)[NT][NR], const long 
           for (int e = 0; e < 4; ++e) g[e] = yp[e] > 0.f ? g[e] : g[e] * slope;
         }
         acc[t][j] = g;
+        if (amax_out != nullptr && rowoff[j] >= 0)
+          lane_amax = fmaxf(lane_amax, fmaxf(fmaxf(fabsf(g[0]), fabsf(g[1])), fmaxf(fabsf(g[2]), fabsf(g[3]))));
       }
     }
     if (rowoff[j] >= 0) {
@@ -121,6 +125,11 @@ __device__ __forceinline__ void epilogue_store(f32x4 (&acc)[NT][NR], const long 
       }
       if ((flags & LF_EPI_PIXELNORM) && norm_out != nullptr && cq == 0) norm_out[rowidx[j]] = r;
     }
+  }
+  if (amax_out != nullptr) {                       // max-abs of what this wave wrote (order-independent)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lane_amax = fmaxf(lane_amax, __shfl_xor(lane_amax, o, 64));
+    if (lane == 0 && lane_amax > 0.f) atomicMax((unsigned int*)amax_out, __float_as_uint(lane_amax));
   }
 }
 
@@ -587,7 +596,8 @@ __global__ void __launch_bounds__(256) conv1x1_kernel(
     int P, int Cin, int ksl, long x_batch_stride, long x_slice_stride, int Cout, int Kp,
     long y_batch_stride, int y_row_stride, int y_slice_channels, long y_slice_stride,
     float he, unsigned flags, float slope, float eps,
-    const float* __restrict__ prev_y, const float* __restrict__ prev_norm, unsigned prev_flags) {
+    const float* __restrict__ prev_y, const float* __restrict__ prev_norm, unsigned prev_flags,
+    float* __restrict__ amax_out) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, cq = lane >> 4;
   const int n = blockIdx.z;
@@ -630,7 +640,7 @@ __global__ void __launch_bounds__(256) conv1x1_kernel(
   long rowoff[1] = {live ? ((long)n * y_batch_stride + p * y_row_stride) : -1};
   const bool vec_out = ((y_row_stride | y_slice_channels) & 3) == 0 && ((y_batch_stride | y_slice_stride) & 3) == 0;
   epilogue_store<NT, 1>(acc, rowoff, rowidx, bias, y, norm_out, Cout, co_base, y_slice_channels, y_slice_stride,
-                        vec_out, he, flags, slope, eps, prev_y, prev_norm, prev_flags);
+                        vec_out, he, flags, slope, eps, prev_y, prev_norm, prev_flags, amax_out);
 }
 
 }  // namespace
@@ -732,7 +742,7 @@ static int conv1x1_launch(const float* x, const float* wpack, const float* bias,
                           int Cout, long y_batch_stride, int y_row_stride, int y_slice_channels,
                           long y_slice_stride,
                           float he, unsigned flags, float slope, float eps, void* stream,
-                          const float* prev_y, const float* prev_norm, unsigned prev_flags) {
+                          const float* prev_y, const float* prev_norm, unsigned prev_flags, float* amax_out = nullptr) {
   if (N <= 0 || P <= 0 || Cin <= 0 || ksl <= 0 || Cout <= 0 || y_slice_channels <= 0) return LF_EINVAL;
   if (prev_y != nullptr) {
     if (flags != 0 || bias != nullptr || y_slice_channels != 16 || y_row_stride != 16 || (Cout & 15) ||
@@ -754,7 +764,8 @@ static int conv1x1_launch(const float* x, const float* wpack, const float* bias,
   hipStream_t s = (hipStream_t)stream;
 #define LAUNCH(T) hipLaunchKernelGGL((conv1x1_kernel<T>), grid, block, 0, s, x, wpack, bias, y, norm_out, \
                                      P, Cin, ksl, x_batch_stride, x_slice_stride, Cout, Kp, y_batch_stride, y_row_stride, \
-                                     y_slice_channels, y_slice_stride, he, flags, slope, eps, prev_y, prev_norm, prev_flags)
+                                     y_slice_channels, y_slice_stride, he, flags, slope, eps, prev_y, prev_norm, prev_flags, \
+                                     amax_out)
   switch (NT) {
     case 1: LAUNCH(1); break;
     case 2: LAUNCH(2); break;
@@ -779,8 +790,8 @@ extern "C" int lf_conv1x1_fwd(const float* x, const float* wpack, const float* b
 extern "C" int lf_conv1x1_bwd_data(const float* gy, const float* wpack_t, float* gx, int N, int P, int Cin, int Cout,
                                    long y_batch_stride, int y_row_stride, int y_slice_channels, long y_slice_stride,
                                    float he, const float* prev_y, const float* prev_norm, unsigned prev_flags,
-                                   float slope, void* stream) {
+                                   float slope, float* amax_out, void* stream) {
   return conv1x1_launch(gy, wpack_t, nullptr, gx, nullptr, N, P, Cin, 1, (long)P * Cin, 0, Cout, y_batch_stride,
                         y_row_stride, y_slice_channels, y_slice_stride, he, 0, slope, 0.f, stream, prev_y, prev_norm,
-                        prev_flags);
+                        prev_flags, amax_out);
 }

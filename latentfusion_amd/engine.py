@@ -124,7 +124,13 @@ class RenderLoopEngine:
                 and loss_weights.get('latent', 0.0) == 0.0
                 and photographer.camera_config[-1] % 4 == 0)
 
-    def __init__(self, photographer, z_obj, target_obs, loss_weights):
+    def __init__(self, photographer, z_obj, target_obs, loss_weights, conv_mode='fp32'):
+        """conv_mode: 'fp32' = exact-fp32 MFMA conv3d kernels (default);
+        'f16x3' = split-precision conv3d kernels (three f16 MFMAs per product, fp32 accumulate; measured
+        closer to an fp64 reference than the fp32 kernel) for the 16->16 camera blocks."""
+        if conv_mode not in ('fp32', 'f16x3'):
+            raise ValueError(conv_mode)
+        self.conv_mode = conv_mode
         self.ph = photographer
         self.cube = photographer.cube_size
         dev = z_obj.device
@@ -141,6 +147,11 @@ class RenderLoopEngine:
             for conv in (blk.conv1, blk.conv2):
                 w = conv.module.weight
                 self.convs.append((w, conv.bias, ops.he_constant(w), ops.pack_conv3x3(w), ops.pack_conv3x3(w, transpose=True)))
+        self.split = None
+        if conv_mode == 'f16x3':
+            if not all(tuple(w.shape[:2]) == (16, 16) for w, *_ in self.convs) or self.C != 16:
+                raise NotImplementedError('f16x3 mode is implemented for 16->16 camera blocks')
+            self.split = [(ops.pack_conv3d_c16_split(w), ops.pack_conv3d_c16_split(w, transpose=True)) for w, *_ in self.convs]
         pw = photographer.projection_block.conv.module.weight
         cout, C, D = pw.shape[0], self.convs[-1][0].shape[0] if self.convs else self.C, self.S
         self.proj = (pw, photographer.projection_block.conv.bias, ops.he_constant(pw),
@@ -174,8 +185,11 @@ class RenderLoopEngine:
               'lf_resample3d_fwd')
         acts, norms = [x0], []
         flags = LF_EPI_LRELU | LF_EPI_PIXELNORM
-        for (w, b, he, wp, _wt) in self.convs:
-            y, nrm = ops._conv3x3_raw(acts[-1], wp, b, w.shape[0], he, flags, True)
+        for li_, (w, b, he, wp, _wt) in enumerate(self.convs):
+            if self.split is not None:
+                y, nrm = ops.conv3d_c16_split(acts[-1], self.split[li_][0], b, he, flags)
+            else:
+                y, nrm = ops._conv3x3_raw(acts[-1], wp, b, w.shape[0], he, flags, True)
             acts.append(y)
             norms.append(nrm)
         pw, pb, phe, ppack, ppack_t = self.proj
@@ -204,13 +218,21 @@ class RenderLoopEngine:
         if fuse and nconv:
             # every data-gradient kernel also applies the LeakyReLU'/PixelNorm' of the layer feeding it,
             # so no separate epilogue-backward pass touches the (N,16,S,S,S) volumes
+            # max-abs of each gradient volume (order-independent atomic max inside the producing kernel):
+            # lets the split kernels pre-scale tiny gradients by an exact power of two
+            amax = torch.zeros(nconv + 1, device=dev, dtype=torch.float32) if self.split is not None else None
             check(L.lf_conv1x1_bwd_data(gp.data_ptr(), ppack_t.data_ptr(), g.data_ptr(), n, S * S, cout, S * Cl,
                                         S * S * S * Cl, Cl, Cl, S * S * Cl, phe, acts[nconv].data_ptr(),
-                                        norms[nconv - 1].data_ptr(), flags, ops.SLOPE, s), 'lf_conv1x1_bwd_data')
+                                        norms[nconv - 1].data_ptr(), flags, ops.SLOPE,
+                                        amax[nconv:].data_ptr() if amax is not None else None, s), 'lf_conv1x1_bwd_data')
             for i in range(nconv - 1, -1, -1):
                 w, b, he, _wp, wt = self.convs[i]
                 prev = (acts[i], norms[i - 1], flags) if i > 0 else None
-                g = ops.conv3x3_bwd_data(g, wt, w.shape[1], he, prev)
+                if self.split is not None:
+                    g, _ = ops.conv3d_c16_split(g, self.split[i][1], None, he, 0, prev=prev, amax_in=amax[i + 1:i + 2],
+                                                amax_out=amax[i:i + 1])
+                else:
+                    g = ops.conv3x3_bwd_data(g, wt, w.shape[1], he, prev)
         else:
             ops._conv1x1_raw(gp, ppack_t, None, n, S * S, cout, 1, S * S * cout, 0, S * Cl, g, phe, 0,
                              yaddr=(S * S * S * Cl, Cl, Cl, S * S * Cl))

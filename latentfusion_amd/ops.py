@@ -114,6 +114,45 @@ def pack_conv1x1(weight2d):
     return out.contiguous()
 
 
+def pack_conv3d_c16_split(weight, transpose=False):
+    """[16,16,3,3,3] fp32 -> f16 hi/lo packs [14 pairs][hi,lo][16 cout][32 = 2 taps x 16 cin] for
+    lf_conv3d_c16_split (the second tap of the last pair is zero)."""
+    w = weight.detach().float()
+    if transpose:
+        w = w.transpose(0, 1).flip(dims=(2, 3, 4))
+    assert tuple(w.shape) == (16, 16, 3, 3, 3)
+    import ctypes
+    L = _lib.lib()
+    table = (ctypes.c_int * 28)()
+    L.lf_conv3d_c16_split_pairs(table)
+    taps = w.reshape(16, 16, 27)                                   # [cout][cin][tap]
+    k = torch.zeros(14, 16, 32, device=w.device)                   # [pair][cout][tapsel*16 + cin]
+    for p in range(14):
+        for sel in range(2):
+            tap = table[2 * p + sel]
+            if tap >= 0:
+                k[p, :, sel * 16:(sel + 1) * 16] = taps[:, :, tap]
+    hi = k.half()
+    lo = (k - hi.float()).half()
+    return torch.stack((hi, lo), dim=1).contiguous()              # [14][2][16][32]
+
+
+def conv3d_c16_split(x, wsplit, bias, he, flags, prev=None, amax_in=None, amax_out=None, want_norm=True):
+    """Launch lf_conv3d_c16_split on a channels-last (N,16,D,H,W) tensor."""
+    L = _lib.lib()
+    N, _, D, H, W = x.shape
+    y = empty_cl((N, 16, D, H, W), x.device)
+    norm = torch.empty(N * D * H * W, device=x.device, dtype=torch.float32) if (flags & LF_EPI_PIXELNORM) else None
+    py, pn, pf = (prev[0], prev[1], prev[2]) if prev is not None else (None, None, 0)
+    with _timed('conv3d_c16_split'):
+        check(L.lf_conv3d_c16_split(_ptr(x), _ptr(wsplit), _ptr(bias) if bias is not None else None, _ptr(y),
+                                    _ptr(norm) if norm is not None else None, N, D, H, W, he, flags, SLOPE, PN_EPS,
+                                    _ptr(py) if py is not None else None, _ptr(pn) if pn is not None else None, pf,
+                                    _ptr(amax_in) if amax_in is not None else None,
+                                    _ptr(amax_out) if amax_out is not None else None, _stream()), 'lf_conv3d_c16_split')
+    return y, norm
+
+
 def he_constant(weight):
     """sqrt(2 / fan_in)  (modules/equalized.py:66-74)."""
     return math.sqrt(2.0 / weight[0].numel())

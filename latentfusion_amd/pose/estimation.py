@@ -335,9 +335,10 @@ class GradientPoseEstimator(PoseEstimator):
 
     def __init__(self, *, learning_rate, num_samples, num_iters, converge_threshold, converge_patience,
                  lr_reduce_patience=25, lr_reduce_threshold=1e-5, lr_reduce_factor=0.5, track_stats=False,
-                 loss_schedules=None, optimizer='adamw', use_engine=True, **kwargs):
+                 loss_schedules=None, optimizer='adamw', use_engine=True, conv_mode='fp32', **kwargs):
         super().__init__(**kwargs)
         self.use_engine = use_engine
+        self.conv_mode = conv_mode
         self.learning_rate, self.num_samples, self.num_iters = learning_rate, num_samples, num_iters
         self.optimizer = optimizer
         self.lr_reduce_patience, self.lr_reduce_threshold = lr_reduce_patience, lr_reduce_threshold
@@ -385,7 +386,7 @@ class GradientPoseEstimator(PoseEstimator):
         ph = getattr(self.model, 'photographer', None)
         if ph is None or not RenderLoopEngine.supports(ph, self.loss_weights):
             return None
-        return RenderLoopEngine(ph, z_obj, target_obs, self.loss_weights)
+        return RenderLoopEngine(ph, z_obj, target_obs, self.loss_weights, conv_mode=self.conv_mode)
 
     def start(self, z_obj, target_obs, cameras, ranking=None):
         """Creates the per-run loop state (parameters, optimiser, schedulers); `cameras` must

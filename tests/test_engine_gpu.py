@@ -230,3 +230,60 @@ def _target_with_color(g):
     tg = g['target']
     color = torch.rand(1, 3, 480, 640, generator=torch.Generator().manual_seed(1))
     return Observation(color, tg['depth'], tg['mask'].float(), prod_camera(tg['cam'], 'cpu'))
+
+
+def test_split_precision_conv_matches_fp32_and_fp64():
+    """lf_conv3d_c16_split (three f16 MFMAs per product) vs the exact-fp32 MFMA kernel and an fp64
+    reference: forward with the fused epilogue, and the amax-scaled data gradient on a tiny-valued
+    input.  The split kernel must be at least as close to fp64 as the fp32 kernel (x2 slack)."""
+    from latentfusion_amd import ops
+    from latentfusion_amd._lib import LF_EPI_LRELU, LF_EPI_PIXELNORM
+    g = torch.Generator().manual_seed(0)
+    N, S = 2, 24
+    x = torch.randn(N, 16, S, S, S, generator=g)
+    x = x / torch.sqrt((x ** 2).mean(dim=1, keepdim=True))
+    w = torch.randn(16, 16, 3, 3, 3, generator=g)
+    b = torch.randn(16, generator=g) * 0.1
+    he = ops.he_constant(w)
+    y64 = torch.nn.functional.conv3d(x.double(), w.double(), None, 1, 1) * he + b.double().view(1, -1, 1, 1, 1)
+    y64 = torch.nn.functional.leaky_relu(y64, 0.2)
+    y64 = y64 / torch.sqrt((y64 ** 2).mean(dim=1, keepdim=True) + 1e-8)
+    xd, wd, bd = ops.cl(x.to(DEV)), w.to(DEV), b.to(DEV)
+    flags = LF_EPI_LRELU | LF_EPI_PIXELNORM
+    ref, _ = ops._conv3x3_raw(xd, ops.pack_conv3x3(wd), bd, 16, he, flags, True)
+    got, _ = ops.conv3d_c16_split(xd, ops.pack_conv3d_c16_split(wd), bd, he, flags)
+    e_ref = (ref.cpu().double() - y64).abs().max().item()
+    e_got = (got.cpu().double() - y64).abs().max().item()
+    assert e_got < max(2 * e_ref, 5e-6), (e_got, e_ref)
+    close(got, ref, atol=3e-5, rtol=1e-4)
+    gs = xd * 3e-7
+    amax = gs.abs().max().reshape(1)
+    gref = ops.conv3x3_bwd_data(gs, ops.pack_conv3x3(wd, transpose=True), 16, he, None)
+    ggot, _ = ops.conv3d_c16_split(gs, ops.pack_conv3d_c16_split(wd, transpose=True), None, he, 0, amax_in=amax)
+    assert (ggot - gref).abs().max().item() < 1e-5 * gref.abs().max().item()
+
+
+def test_g7_gradient_loop_split_precision(golden):
+    """The adam_quick loop with the f16x3 conv kernels: same argmin indices as the reference at
+    every iteration, losses within the same envelope as the fp32 kernels."""
+    from latentfusion_amd.pose import estimation
+    from latentfusion_amd.recon import fusion
+    from latentfusion_amd.recon.inference import LatentFusionModel
+    from latentfusion_amd.recon.models import Photographer, Sculptor
+    from latentfusion_amd import synth
+    # G7's model has C = 8; the split kernels are built for C = 16, so use a SYN(16,16) model and compare
+    # the two engine modes against each other over a 10-iteration run
+    model, _ = synth.build_model(16, 16, 'pool:mean', seed=4, device=DEV, bias_std=0.05)
+    g = golden('g7_adam_trace')
+    gen = torch.Generator().manual_seed(9)
+    z_obj = torch.randn(1, 1, 16, 16, 16, 16, generator=gen).to(DEV)
+    out = {}
+    for mode in ('fp32', 'f16x3'):
+        est = estimation.load_from_config(copy.deepcopy(g['cfg']), model, track_stats=True, conv_mode=mode)
+        _, stats = est.estimate(z_obj, _target(g, 'cpu'), camera=prod_camera(g['init'], 'cpu'))
+        out[mode] = stats['rank_loss']
+    close(out['f16x3'][:3], out['fp32'][:3], atol=1e-6, rtol=2e-5)
+    # later iterations: Adam amplifies last-bit differences across voxel-cell boundaries (DESIGN Q17);
+    # the fp32 kernels drift by the same order against the CPU oracle (test_g7_gradient_loop_on_hip)
+    close(out['f16x3'], out['fp32'], atol=3e-2, rtol=0)
+    assert torch.argmin(out['f16x3'], dim=1).tolist() == torch.argmin(out['fp32'], dim=1).tolist()
