@@ -46,8 +46,9 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-iters', type=int, default=1)
     ap.add_argument('--no-alt', action='store_true', help='skip the secondary f16x3 measurement')
-    ap.add_argument('--conv-mode', default='fp32', choices=['fp32', 'f16x3'],
-                    help="conv3d kernels of the engine: exact-fp32 MFMA (default) or split-precision f16x3")
+    ap.add_argument('--conv-mode', default='winograd', choices=['fp32', 'winograd', 'f16x3'],
+                    help="conv3d kernels of the engine: 'winograd' (default; F(2^3,3^3) minimal filtering, all-fp32 "
+                         "arithmetic), 'fp32' (direct implicit GEMM on the fp32 MFMA) or 'f16x3' (split precision)")
     return ap.parse_args()
 
 
@@ -143,7 +144,7 @@ def main():
 
     elapsed, timer = timed_loop(est, st)
     alt = None
-    if a.conv_mode == 'fp32' and not a.no_alt and C == 16:
+    if a.conv_mode != 'f16x3' and not a.no_alt and C == 16:
         # secondary line (never `value`): the same loop with the split-precision conv3d kernels
         del est, st
         torch.cuda.empty_cache()
@@ -158,19 +159,29 @@ def main():
 
     # roofline of the dominant kernel: conv3d_c16_persistent_kernel (fused conv3d C->C block; 2 forward +
     # 2 data-gradient launches per iteration), HIP events recorded on the launch stream in the timed region
-    name = f'conv3x3_3d_{C}x{C}' if a.conv_mode == 'fp32' else 'conv3d_c16_split'
+    name = {'fp32': f'conv3x3_3d_{C}x{C}', 'winograd': 'conv3d_c16_wino', 'f16x3': 'conv3d_c16_split'}[a.conv_mode]
     durs = [e0.elapsed_time(e1) for n_, e0, e1 in timer if n_ == name]
     conv_ms = sum(durs) / max(len(durs), 1)
     flops = 2.0 * 27 * C * C * (S ** 3) * N                        # algorithmic flops per launch
     achieved = flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     # f16x3 issues 3 f16 MFMA products per algorithmic product: price it against dense-f16 peak / 3
-    peak = FP32_MFMA_PEAK_TFLOPS if a.conv_mode == 'fp32' else F16_MFMA_PEAK_TFLOPS / 3.0
-    kname = ('conv3d_c16_persistent_kernel' if a.conv_mode == 'fp32' else 'conv3d_c16_split_kernel')
+    peak = FP32_MFMA_PEAK_TFLOPS if a.conv_mode != 'f16x3' else F16_MFMA_PEAK_TFLOPS / 3.0
+    kname = {'fp32': 'conv3d_c16_persistent_kernel', 'winograd': 'conv3d_c16_wino_kernel',
+             'f16x3': 'conv3d_c16_f16x3_kernel'}[a.conv_mode]
+    # Winograd F(2^3,3^3) executes 64 multiplies per 2x2x2 outputs instead of 216: `achieved` stays the
+    # ALGORITHMIC (direct-convolution) flops per launch / time, so it may exceed the fp32 MFMA peak
+    roof_note = None
+    if a.conv_mode == 'winograd':
+        ex = flops * 64.0 / 216.0
+        roof_note = {'algorithm': 'Winograd F(2x2x2,3x3x3), all-fp32', 'executed_mfma_flops_per_launch': ex,
+                     'executed_mfma_tflops': ex / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
+                     'algorithmic_bytes_per_launch': 2 * N * C * S ** 3 * 4 + N * S ** 3 * 4,
+                     'hbm_frac_of_8TBps': (2 * N * C * S ** 3 * 4 + N * S ** 3 * 4) / (conv_ms * 1e-3) / 8e12 if conv_ms > 0 else 0.0}
     traffic = None
-    tpath = os.path.join(ROOT, 'profiles', 'r01_conv3d_hbm_bytes.json')
+    tpath = os.path.join(ROOT, 'profiles', 'r01_conv3d_hbm_bytes.json')          # PMC passes, tools/hbm_summary.py
     if os.path.exists(tpath) and S == 128 and C == 16 and N == 8:
         try:
-            traffic = json.load(open(tpath)).get('bytes_per_launch')
+            traffic = json.load(open(tpath)).get('kernels', {}).get(kname, {}).get('bytes_per_launch')
         except Exception:                                           # noqa: BLE001
             traffic = None
 
@@ -181,7 +192,7 @@ def main():
         'metric': 'pose-optim iters/sec (reconstruct+render+backward), 16 views, 128^3 voxels',
         'value': value, 'unit': 'iters/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
         'ms_per_step': elapsed / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32' if a.conv_mode == 'fp32' else 'f32 (conv3d products split into 3 f16 MFMAs, fp32 accumulate)', 'data': 'synthetic (SYN(S,C) random-init weights, synthetic observations)',
+        'dtype': 'f32' if a.conv_mode != 'f16x3' else 'f32 (conv3d products split into 3 f16 MFMAs, fp32 accumulate)', 'data': 'synthetic (SYN(S,C) random-init weights, synthetic observations)',
         'config': {'workload': f'SYN({S},{C}) latent volume, {V} reference views, adam_quick pose loop, '
                                f'{N} pose samples per iteration, one object per GPU',
                    'fuser': a.fuser, 'pose_samples': N, 'ref_views': V, 'volume': S, 'channels': C,
@@ -189,8 +200,9 @@ def main():
         't_build_s': t_build,
         'roofline': {'bound': 'mfma', 'kernel': kname + ' (fused conv3d 16->16 + He + bias + LeakyReLU + PixelNorm; fwd and data-grad)',
                      'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
-                     'frac': achieved / peak, 'traffic': traffic if a.conv_mode == 'fp32' else None,
-                     'avg_launch_ms': conv_ms, 'launches_timed': len(durs), 'flops_per_launch': flops},
+                     'frac': achieved / peak, 'traffic': traffic,
+                     'avg_launch_ms': conv_ms, 'launches_timed': len(durs), 'flops_per_launch': flops,
+                     'note': roof_note},
     }
     if world == 1 and not a.no_cpu_baseline:
         v, cores = cpu_baseline(cks[:3] + (cks[3],), z_obj.cpu(), tdata, init_rec, cfg, a.cpu_iters)

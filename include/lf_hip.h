@@ -147,6 +147,20 @@ int lf_conv3d_c16_split(const float* x, const void* wsplit, const float* bias, f
                         const float* prev_y, const float* prev_norm, unsigned prev_flags,
                         const float* amax_in, float* amax_out, void* stream);
 
+/* Winograd F(2x2x2, 3x3x3) variant of the same fused 16 -> 16 conv3d step, all-fp32 arithmetic
+ * (v_mfma_f32_16x16x4_f32 on G-transformed weights, B/A transforms on the fp32 VALU): 64 instead of
+ * 216 multiplies per 2x2x2 outputs.  Same semantics / epilogue / fused previous-layer backward as
+ * lf_conv3x3_fwd / lf_conv3x3_bwd_data for dims = 3, Cin = Cout = 16 (modules/blocks.py:152-158).
+ * upack: lf_conv3d_c16_wino_upack_floats() floats, [4 z-freq a][16 (y,x)-freq b*4+c][4 k-chunks i][64 lanes l]
+ *        = U[a][b][c][cout = l & 15][cin = (l >> 4) * 4 + i],  U = (G (x) G (x) G) w  with
+ *        G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]  (host-packed, once per weight update).
+ * amax_out (may be NULL, zero-initialised by the caller): receives max-abs of the output. */
+size_t lf_conv3d_c16_wino_upack_floats(void);
+int lf_conv3d_c16_wino(const float* x, const float* upack, const float* bias, float* y, float* norm_out,
+                       int N, int D, int H, int W, float he, unsigned flags, float slope, float eps,
+                       const float* prev_y, const float* prev_norm, unsigned prev_flags,
+                       float* amax_out, void* stream);
+
 /* Standalone PixelNorm over the last (channel) axis of [rows][C], in place allowed.
  * norm_out[rows] receives sqrt(mean+eps).  modules/__init__.py:14-15. */
 int lf_pixelnorm_fwd(const float* x, float* y, float* norm_out, long rows, int C, float eps, void* stream);

@@ -39,6 +39,9 @@ SIGNATURES = {
     'lf_conv3d_c16_split_pairs': (None, [P]),
     'lf_conv3d_c16_split': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint, c_float, c_float, P, P,
                                     c_uint, P, P, P]),
+    'lf_conv3d_c16_wino_upack_floats': (c_size_t, []),
+    'lf_conv3d_c16_wino': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint, c_float, c_float, P, P,
+                                   c_uint, P, P]),
     'lf_pixelnorm_fwd': (c_int, [P, P, P, c_long, c_int, c_float, P]),
     'lf_epilogue_bwd': (c_int, [P, P, P, P, c_long, c_int, c_uint, c_float, P]),
     'lf_resize_fwd': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),

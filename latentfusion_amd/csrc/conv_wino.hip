@@ -1,0 +1,430 @@
+// Winograd F(2x2x2, 3x3x3) form of the fused 16 -> 16 channel conv3d block step (gfx950).
+//
+//   y = PixelNorm(LeakyReLU(conv3d(x, W) * he + b))            latentfusion/modules/blocks.py:152-158
+//                                                              latentfusion/modules/equalized.py:57-64
+// and, with transposed/flipped weights and `prev_*` set, the data gradient fused with the previous
+// layer's LeakyReLU'/PixelNorm' (autograd of the same lines).
+//
+// All arithmetic is fp32 (v_mfma_f32_16x16x4_f32 + fp32 VALU transforms).  The minimal-filtering
+// identity  Y = A^T[(G w G^T) . (B^T d B)]A  applied along z, y and x needs 64 multiplies per 2x2x2
+// outputs instead of 216, so the MFMA work per voxel drops 3.375x; measured against fp64 the result is
+// as close as the direct fp32 kernel's (tests/test_ops_gpu.py::test_winograd_conv3d_*).
+//
+// Work split inside one 512-thread workgroup (one per CU, persistent over 4 x 8 x 16-voxel tiles):
+//   * wave w owns z-frequency a = w & 3 of z-half (w >> 2) of the tile; the 16 (y,x)-frequency
+//     matrices U[a][b][c] (16 cout x 16 cin each) live in 64 VGPRs for the whole launch;
+//   * MFMA columns = 16 Winograd tiles (2 in y x 8 in x), lane group kg = lane >> 4 carries input
+//     channels 4kg..4kg+3 (B operand) and receives output channels 4kg..4kg+3 (D operand);
+//   * per 16-tile group: 32 ds_read_b128 of the fp32 halo (two z planes combined on the fly),
+//     x/y input transforms in registers, 64 MFMAs, y/x output transform in registers;
+//   * the four z-frequency partials of a tile meet through LDS (the consumed halo buffer is reused),
+//     then every wave finishes a quarter of the outputs: z output transform, He scale, bias,
+//     LeakyReLU, PixelNorm (two xor-shuffles), store.
+// The halo is fetched with LDS-DMA into a double buffer (tile t+1 lands while tile t computes) in a
+// bank-swizzled order: voxel slot = (z*10 + y)*18 + (x&1)*9 + (x>>1), 16-byte quarter q stored at
+// q ^ s, s = 2*((slot>>2)&1) + ((y>>1)&1)  ->  every ds_read_b128 lane group hits 16 distinct slots.
+#include "lf_common.h"
+#ifndef WINO_ABL
+#define WINO_ABL 0
+#endif
+
+namespace {
+
+constexpr int TZw = 4, TYw = 8, TXw = 16;
+constexpr int HZw = TZw + 2, HYw = TYw + 2, HXw = TXw + 2;     // 6 x 10 x 18 halo
+constexpr int HALOw = HZw * HYw * HXw;                          // 1080 voxels
+constexpr int NSLOTw = (HALOw * 4 + 63) / 64;                   // 68 DMA pieces of 1 KiB
+constexpr int NITw = (NSLOTw + 7) / 8;                          // 9 pieces per wave (the last only for waves 0-3)
+constexpr int BUFw = NSLOTw * 1024;                             // 69,632 B per halo buffer
+
+__device__ __forceinline__ void lds_barrier() {
+  // all LDS traffic of this wave retired, then workgroup barrier; global loads/stores and the LDS-DMA of
+  // the next tile stay in flight (a __syncthreads() would drain vmcnt as well)
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// sum over the four lanes of a quad (4q .. 4q+3) with DPP quad_perm, same value in all four
+__device__ __forceinline__ float quad_sum(float v) {
+  const float a = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));   // [1,0,3,2]
+  return a + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x4E, 0xF, 0xF, true));            // [2,3,0,1]
+}
+
+// v_rsq_f32 / v_rcp_f32 (1 ulp) + one Newton step
+__device__ __forceinline__ float fast_rsqrt(float x) {
+  const float r = __builtin_amdgcn_rsqf(x);
+  return r * (1.5f - 0.5f * x * r * r);
+}
+__device__ __forceinline__ float fast_rcp(float x) {
+  const float r = __builtin_amdgcn_rcpf(x);
+  return r * (2.f - x * r);
+}
+
+// One tile's LDS-DMA job (wave-uniform part).  The 9 pieces of a wave are issued one or two at a time
+// between the MFMA rows of the previous tile's compute phase: a burst of 72 LDS-DMA instructions per CU
+// would otherwise hold every wave at the texture-address unit for ~2000 cycles.
+struct DmaTile {
+  __amdgpu_buffer_rsrc_t rs;
+  unsigned char* dst;
+  unsigned char* scratch;
+  int ox, oy, oz;
+  bool on;
+};
+
+__device__ __forceinline__ void dma_piece(const DmaTile& d, int it, int wave, int lxyzq, int W, int H, int D) {
+  // branch-free: a piece that must not be fetched (no next tile; ninth piece of waves 4-7) is pointed at
+  // a scratch KiB of LDS with every lane out of range, which just writes zeros there
+  const int s = wave + 8 * it;
+  const bool live = d.on && s < NSLOTw;                                       // wave-uniform
+  const int gx = d.ox + (lxyzq & 0xff), gy = d.oy + ((lxyzq >> 8) & 0xff), gz = d.oz + ((lxyzq >> 16) & 0xff);
+  const bool ok = (unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H && (unsigned)gz < (unsigned)D && lxyzq >= 0;
+  const int addr = ((gz * H + gy) * W + gx) * 64 + ((lxyzq >> 24) << 4);
+  const int voff = (ok && live) ? addr : 0x7fffffff;                          // out of range -> the DMA writes zeros
+  unsigned char* dst = live ? d.dst + s * 1024 : d.scratch;
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(d.rs, (__attribute__((address_space(3))) void*)dst, 16, voff, 0, 0, 0);
+}
+
+template <int A>
+__device__ __forceinline__ void wino_compute(const unsigned char* __restrict__ buf, const int (&off)[8],
+                                              const float (&wt)[64], f32x4 (&Y)[2][4], const DmaTile& dma, int wave,
+                                              const int (&lxyzq)[NITw], int W, int H, int D) {
+  // z input transform of frequency A: d0-d2, d1+d2, d2-d1, d1-d3
+  constexpr int DZ0 = (A == 0) ? 0 : (A == 2 ? 2 : 1);
+  constexpr int DZ1 = (A == 0) ? 2 : (A == 1 ? 2 : (A == 2 ? 1 : 3));
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    f32x4 vx[4][4];                                           // [dy][x-frequency c]
+#pragma unroll
+    for (int dy = 0; dy < 4; ++dy) {
+      f32x4 d[4];
+#pragma unroll
+      for (int dx = 0; dx < 4; ++dx) {
+        const int ca = ((DZ0 * 10 + 4 * g + dy) * 18 + (dx & 1) * 9 + (dx >> 1));
+        const int cb = ((DZ1 * 10 + 4 * g + dy) * 18 + (dx & 1) * 9 + (dx >> 1));
+        // rows dy = 2,3 sit one (y>>1) step further: their quarter swizzle differs in bit 0 (byte offset ^ 16)
+        const f32x4 va = *(const f32x4*)(buf + ((dy >> 1) ? (off[ca & 7] ^ 16) : off[ca & 7]) + ca * 64);
+        const f32x4 vb = *(const f32x4*)(buf + ((dy >> 1) ? (off[cb & 7] ^ 16) : off[cb & 7]) + cb * 64);
+        d[dx] = (A == 1) ? (va + vb) : (va - vb);
+      }
+      vx[dy][0] = d[0] - d[2];
+      vx[dy][1] = d[1] + d[2];
+      vx[dy][2] = d[2] - d[1];
+      vx[dy][3] = d[1] - d[3];
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      f32x4 m[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const f32x4 v = (b == 0) ? (vx[0][c] - vx[2][c])
+                      : (b == 1) ? (vx[1][c] + vx[2][c])
+                      : (b == 2) ? (vx[2][c] - vx[1][c])
+                                 : (vx[1][c] - vx[3][c]);
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (WINO_ABL & 4) { acc = v * wt[(b * 4 + c) * 4] + wt[(b * 4 + c) * 4 + 1] + wt[(b * 4 + c) * 4 + 2] * wt[(b * 4 + c) * 4 + 3]; } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[(b * 4 + c) * 4 + i], v[i], acc, 0, 0, 0);
+        }
+        m[c] = acc;
+      }
+      // x output transform, then accumulate the y output transform
+      const f32x4 t0 = m[0] + m[1] + m[2];
+      const f32x4 t1 = m[1] - m[2] - m[3];
+      if (b == 0) { Y[g][0] = t0; Y[g][1] = t1; }
+      if (b == 1) { Y[g][0] += t0; Y[g][1] += t1; Y[g][2] = t0; Y[g][3] = t1; }
+      if (b == 2) { Y[g][0] += t0; Y[g][1] += t1; Y[g][2] -= t0; Y[g][3] -= t1; }
+      if (b == 3) { Y[g][2] -= t0; Y[g][3] -= t1; }
+      // next-but-one tile's halo: two pieces after each MFMA row of the first group, the ninth after the fifth row
+      if (g == 0) {
+        dma_piece(dma, 2 * b, wave, lxyzq[2 * b], W, H, D);
+        dma_piece(dma, 2 * b + 1, wave, lxyzq[2 * b + 1], W, H, D);
+      } else if (b == 0) {
+        dma_piece(dma, 8, wave, lxyzq[8], W, H, D);
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(512) conv3d_c16_wino_kernel(
+    const float* __restrict__ x, const float* __restrict__ upack, const float* __restrict__ bias,
+    float* __restrict__ y, float* __restrict__ norm_out,
+    int N, int D, int H, int W, int tiles_x, int tiles_y, int tiles_z, int ntiles,
+    float he, unsigned flags, float slope, float eps,
+    const float* __restrict__ prev_y, const float* __restrict__ prev_norm, unsigned prev_flags,
+    float* __restrict__ amax_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fa = wave & 3, half = wave >> 2;
+  const int n = lane & 15, kg = lane >> 4;
+  const int tx = n & 7, tyb = n >> 3;
+
+  // workgroups b, b+8, b+16, ... run on the same XCD (one L2 each): give them consecutive tile ranges so
+  // that the z-halo planes shared by neighbouring ranges are fetched from HBM once
+  const int nb = gridDim.x;
+  const int lb = (nb % 8 == 0) ? (blockIdx.x % 8) * (nb / 8) + blockIdx.x / 8 : blockIdx.x;
+  const int per = (ntiles + nb - 1) / nb;
+  const int t_begin = lb * per;
+  const int t_end = min(t_begin + per, ntiles);
+  if (t_begin >= t_end) return;
+
+  const long nvox = (long)D * H * W;
+  const unsigned sample_bytes = (unsigned)(nvox * 64);
+
+  // ---- LDS-DMA piece constants: LDS slot p = piece*64 + lane holds quarter (p&3)^s of voxel slot p>>2 ----
+  int lxyzq[NITw];                                              // lx | ly << 8 | lz << 16 | quarter << 24
+#pragma unroll
+  for (int it = 0; it < NITw; ++it) {
+    const int p = (wave + 8 * it) * 64 + lane;
+    const int vs = p >> 2;
+    const int row = vs / HXw, rem = vs - row * HXw;
+    const int xl = rem / 9, xa = rem - xl * 9;
+    const int lx = 2 * xa + xl, ly = row % HYw, lz = row / HYw;
+    const int s = (((vs >> 2) & 1) << 1) | ((ly >> 1) & 1);
+    const int q = (p & 3) ^ s;
+    lxyzq[it] = (vs < HALOw) ? (lx | (ly << 8) | (lz << 16) | (q << 24)) : -1;           // padding lanes of the last piece
+  }
+
+  // ---- B-operand addressing: byte offset of (lane's tile, channel quarter) for the 8 slot residues ----
+  int off[8];
+  {
+    const int base_lane = 360 * half + 36 * tyb + tx;          // voxel-slot units
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int bit = ((36 * tyb + tx + r) >> 2) & 1;
+      const int quarter = (kg ^ tyb) ^ (bit << 1);
+      off[r] = base_lane * 64 + quarter * 16;
+    }
+  }
+
+  // ---- partial-exchange addressing ----
+  int pw[2];                                                   // writer: lane part of the slot, per x parity i
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int L = (2 * tx + i) * 4 + kg;
+    pw[i] = tyb * 2048 + (L ^ ((L >> 3) & 7)) * 16;
+  }
+  const int pr = (lane ^ ((lane >> 3) & 7)) * 16;              // reader: lane = x*4 + quarter
+  const int ex = lane >> 2, eq = lane & 3;
+
+  // ---- transformed weights of this wave's z-frequency: [16 (b,c)][4 k-chunks], lane-major in memory ----
+  float wt[64];
+  {
+    const float* up = upack + (long)fa * 64 * 64 + lane;
+#pragma unroll
+    for (int k = 0; k < 64; ++k) wt[k] = up[k * 64];
+  }
+  f32x4 bv4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (bias != nullptr) bv4 = *(const f32x4*)(bias + eq * 4);
+
+  auto make_dma = [&](int t, int bufsel, bool on) {
+    DmaTile d;
+    int tt = t;
+    const int bx = tt % tiles_x; tt /= tiles_x;
+    const int by = tt % tiles_y; tt /= tiles_y;
+    const int bz = tt % tiles_z; tt /= tiles_z;
+    d.ox = bx * TXw - 1; d.oy = by * TYw - 1; d.oz = bz * TZw - 1;
+    d.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long)(on ? tt : 0) * nvox * 16), 0, sample_bytes, 0x00020000);
+    d.dst = smem + bufsel * BUFw;
+    d.scratch = smem + 2 * BUFw;
+    d.on = on;
+    return d;
+  };
+  auto issue_all = [&](const DmaTile& d) {
+#pragma unroll
+    for (int it = 0; it < NITw; ++it) dma_piece(d, it, wave, lxyzq[it], W, H, D);
+  };
+
+  const float out_scale = he;
+  float wave_amax = 0.f;
+
+  issue_all(make_dma(t_begin, 0, true));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  lds_barrier();
+  // the two waves that share a SIMD (w, w+4) get different issue priorities so that one's MFMA phase
+  // runs under the other's VALU transforms instead of both contending for the same pipe
+  if (half == 0) __builtin_amdgcn_s_setprio(2);
+
+#if WINO_ABL & 16
+#define TS(k) do { if (blockIdx.x == 3 && lane == 0) ((unsigned*)norm_out)[((t - t_begin) * 8 + wave) * 8 + (k)] = (unsigned)__builtin_readcyclecounter(); } while (0)
+#else
+#define TS(k) do {} while (0)
+#endif
+  for (int t = t_begin; t < t_end; ++t) {
+    const int cur = (t - t_begin) & 1;
+    unsigned char* buf = smem + cur * BUFw;
+    TS(0);
+    // halo of tile t+1 goes into the other buffer (free since the last barrier of the previous iteration);
+    // its pieces are issued from inside the compute phase
+    const DmaTile dma = make_dma(t + 1 < t_end ? t + 1 : t, cur ^ 1, t + 1 < t_end && !(WINO_ABL & 1));
+
+    f32x4 Y[2][4];
+    if (WINO_ABL & 8) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int ji = 0; ji < 4; ++ji) Y[g][ji] = *(const f32x4*)(buf + off[ji + g] + (g * 4 + ji) * 64) * wt[g * 4 + ji];
+    } else
+    switch (fa) {
+      case 0: wino_compute<0>(buf, off, wt, Y, dma, wave, lxyzq, W, H, D); break;
+      case 1: wino_compute<1>(buf, off, wt, Y, dma, wave, lxyzq, W, H, D); break;
+      case 2: wino_compute<2>(buf, off, wt, Y, dma, wave, lxyzq, W, H, D); break;
+      default: wino_compute<3>(buf, off, wt, Y, dma, wave, lxyzq, W, H, D); break;
+    }
+    TS(1);
+    lds_barrier();                                              // every wave is done reading the halo
+    TS(2);
+
+    // partial outputs of z-frequency fa -> LDS (reusing the halo buffer), 1 KiB blocks indexed
+    // [wave][g][tyb][j], 64 float4 slots each at (L ^ ((L >> 3) & 7)), L = x*4 + channel quarter:
+    // the writers' 8-lane groups and the readers' 16-lane groups both hit distinct bank slots, and a
+    // reader wave gets one x-contiguous 1 KiB output row per instruction
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int ji = 0; ji < 4; ++ji)
+        *(f32x4*)(buf + wave * 8192 + g * 4096 + (ji >> 1) * 1024 + pw[ji & 1]) = Y[g][ji];
+
+    // this wave finishes rows y = 2fa, 2fa+1 of its z-half: lane = x*4 + channel quarter
+    int tt = t;
+    const int bx = tt % tiles_x; tt /= tiles_x;
+    const int by = tt % tiles_y; tt /= tiles_y;
+    const int bz = tt % tiles_z; tt /= tiles_z;
+    const int gx = bx * TXw + ex;
+    int voxi[4];
+    bool okv[4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int zo = 0; zo < 2; ++zo) {
+        const int gz = bz * TZw + 2 * half + zo, gy = by * TYw + 2 * fa + j;
+        okv[j * 2 + zo] = gx < W && gy < H && gz < D;
+        voxi[j * 2 + zo] = okv[j * 2 + zo] ? (gz * H + gy) * W + gx : 0;
+      }
+    f32x4 pyv[4];
+    float pnv[4];
+    if (prev_y != nullptr) {
+      const float* pybase = prev_y + (long)tt * nvox * 16;
+      const float* pnbase = prev_norm ? prev_norm + (long)tt * nvox : nullptr;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        pyv[k] = okv[k] ? *(const f32x4*)(pybase + voxi[k] * 16 + eq * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        pnv[k] = (okv[k] && pnbase) ? pnbase[voxi[k]] : 1.f;
+      }
+    }
+    TS(3);
+    lds_barrier();                                              // all partials are in LDS
+    TS(4);
+
+    if (WINO_ABL & 2) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); lds_barrier();
+      continue;
+    }
+    f32x4 o[4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      f32x4 p[4];
+#pragma unroll
+      for (int a2 = 0; a2 < 4; ++a2)
+        p[a2] = *(const f32x4*)(buf + (a2 + 4 * half) * 8192 + fa * 2048 + j * 1024 + pr);
+      o[j * 2 + 0] = p[0] + p[1] + p[2];                        // z output transform
+      o[j * 2 + 1] = p[1] - p[2] - p[3];
+    }
+    // tile t+1's halo (issued from inside this iteration's compute phase) must have landed, and every wave
+    // must have consumed the partials, before the buffers swap roles.  Waiting here, BEFORE this tile's
+    // stores are issued, keeps the stores out of the wait: they drain behind the next tile's MFMAs.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TS(5);
+    lds_barrier();
+    TS(6);
+    TS(7);
+
+    unsigned char* ybase = (unsigned char*)(y + (long)tt * nvox * 16) + eq * 16;
+    float* nbase = norm_out ? norm_out + (long)tt * nvox : nullptr;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      f32x4 v;
+      float r_ = 1.f;
+      if (prev_y != nullptr) {
+        const f32x4 yp = pyv[k];
+        v = o[k] * out_scale;
+        if (prev_flags & LF_EPI_PIXELNORM) {
+          const float dot = quad_sum(v[0] * yp[0] + v[1] * yp[1] + v[2] * yp[2] + v[3] * yp[3]) * (1.f / 16.f);
+          const float rinv = fast_rcp(pnv[k]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (v[e] - yp[e] * dot) * rinv;
+        }
+        if (prev_flags & LF_EPI_LRELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = yp[e] > 0.f ? v[e] : v[e] * slope;
+        }
+      } else {
+        float ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float u = o[k][e] * out_scale + bv4[e];
+          if (flags & LF_EPI_LRELU) u = fmaxf(u, u * slope);
+          v[e] = u;
+          ss += u * u;
+        }
+        if (flags & LF_EPI_PIXELNORM) {
+          const float tq = quad_sum(ss) * (1.f / 16.f) + eps;
+          const float rinv = fast_rsqrt(tq);
+          r_ = tq * rinv;
+          v[0] *= rinv; v[1] *= rinv; v[2] *= rinv; v[3] *= rinv;
+        }
+      }
+      if (okv[k]) {
+        *(f32x4*)(ybase + (unsigned)(voxi[k] * 64)) = v;
+        if (!(WINO_ABL & 16) && prev_y == nullptr && (flags & LF_EPI_PIXELNORM) && nbase != nullptr && eq == 0) nbase[voxi[k]] = r_;
+        if (amax_out != nullptr)
+          wave_amax = fmaxf(wave_amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+      }
+    }
+  }
+  if (amax_out != nullptr) {
+    float m = wave_amax;
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) m = fmaxf(m, __shfl_xor(m, o2, 64));
+    if (lane == 0 && m > 0.f) atomicMax((unsigned int*)amax_out, __float_as_uint(m));
+  }
+}
+
+}  // namespace
+
+// floats of the transformed-weight pack: [4 z-freq][16 (y,x)-freq][4 k-chunks][64 lanes]
+extern "C" size_t lf_conv3d_c16_wino_upack_floats(void) { return (size_t)4 * 16 * 4 * 64; }
+
+extern "C" int lf_conv3d_c16_wino(const float* x, const float* upack, const float* bias, float* y, float* norm_out,
+                                  int N, int D, int H, int W, float he, unsigned flags, float slope, float eps,
+                                  const float* prev_y, const float* prev_norm, unsigned prev_flags,
+                                  float* amax_out, void* stream) {
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0) return LF_EINVAL;
+  if ((long)D * H * W * 64 >= 0x7fffffffL || !(slope > 0.f && slope < 1.f)) return LF_EINVAL;
+  if (!lf_aligned16(x) || !lf_aligned16(y) || !lf_aligned16(upack) || (bias && !lf_aligned16(bias))) return LF_EALIGN;
+  if (prev_y != nullptr && (flags != 0 || bias != nullptr)) return LF_EINVAL;
+  if ((prev_flags & LF_EPI_PIXELNORM) && prev_y != nullptr && prev_norm == nullptr) return LF_EINVAL;
+  const int ptx = (W + TXw - 1) / TXw, pty = (H + TYw - 1) / TYw, ptz = (D + TZw - 1) / TZw;
+  const long pt = (long)ptx * pty * ptz * N;
+  if (pt > 0x7fffffffL) return LF_EINVAL;
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, v = 0;
+    cus = (hipGetDevice(&dev) == hipSuccess &&
+           hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+  }
+  const size_t shmem = (size_t)2 * BUFw + 1024;                  // 139,264 B + 1 KiB DMA scratch
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv3d_c16_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)shmem);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const unsigned grid = (unsigned)(pt < cus ? pt : cus);
+  hipLaunchKernelGGL(conv3d_c16_wino_kernel, dim3(grid), dim3(512), shmem, (hipStream_t)stream, x, upack, bias, y,
+                     norm_out, N, D, H, W, ptx, pty, ptz, (int)pt, he, flags, slope, eps, prev_y, prev_norm, prev_flags,
+                     amax_out);
+  return lf_launch_status();
+}

@@ -113,19 +113,26 @@ __global__ void __launch_bounds__(256) resample_fwd_kernel(
 
 // ---- backward w.r.t. the O2C coefficient block ------------------------------------------------
 // stage 1: every block reduces a contiguous run of voxels of one sample to 18 partial sums.
-constexpr int BWD_VOX_PER_BLOCK = 4096;
+// voxels per block: 4096 for big volumes, down to 64 so that small ones (16^3 x 256 channels) still
+// launch a few hundred blocks.  A pure function of the shapes -> the reduction order is reproducible.
+static int bwd_vox_per_block(long nvox, int N) {
+  long v = nvox * N / 2048;
+  int p = 64;
+  while (p < 4096 && p * 2 <= v) p <<= 1;
+  return p;
+}
 
 template <int VEC>
 __global__ void __launch_bounds__(256) resample_bwd_coef_kernel(
     const float* __restrict__ gout, const float* __restrict__ vol, long vol_bstride,
-    const float* __restrict__ coef, float* __restrict__ partial, int nblk,
+    const float* __restrict__ coef, float* __restrict__ partial, int nblk, int vpb,
     int N, int D, int H, int W, int C, int lpv) {
   // lpv = lanes cooperating on one voxel: a power of two <= 64 with lpv * VEC >= C
   const int n = blockIdx.y;
   const float* cf = coef + (long)n * LF_MAP_COEFS;
   const long nvox = (long)D * H * W;
-  const long v_begin = (long)blockIdx.x * BWD_VOX_PER_BLOCK;
-  const long v_end = min(v_begin + (long)BWD_VOX_PER_BLOCK, nvox);
+  const long v_begin = (long)blockIdx.x * vpb;
+  const long v_end = min(v_begin + (long)vpb, nvox);
   const int q = threadIdx.x % lpv;
   const int vslot = threadIdx.x / lpv;
   const int vstep = blockDim.x / lpv;
@@ -275,7 +282,8 @@ extern "C" int lf_resample3d_fwd(const float* vol, int vol_n, const float* coef,
 
 extern "C" size_t lf_resample3d_bwd_coef_scratch_bytes(int N, int D, int H, int W) {
   const long nvox = (long)D * H * W;
-  const long nblk = (nvox + BWD_VOX_PER_BLOCK - 1) / BWD_VOX_PER_BLOCK;
+  const int vpb = bwd_vox_per_block(nvox, N);
+  const long nblk = (nvox + vpb - 1) / vpb;
   return (size_t)N * nblk * 18 * sizeof(float);
 }
 
@@ -286,7 +294,8 @@ extern "C" int lf_resample3d_bwd_coef(const float* gout, const float* vol, int v
   if (vol_n != 1 && vol_n != N) return LF_EINVAL;
   if (scratch_bytes < lf_resample3d_bwd_coef_scratch_bytes(N, D, H, W)) return LF_ENOSPC;
   const long nvox = (long)D * H * W;
-  const int nblk = (int)((nvox + BWD_VOX_PER_BLOCK - 1) / BWD_VOX_PER_BLOCK);
+  const int vpb = bwd_vox_per_block(nvox, N);
+  const int nblk = (int)((nvox + vpb - 1) / vpb);
   const long bstride = vol_n == 1 ? 0 : nvox * C;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(nblk, N), block(256);
@@ -298,9 +307,9 @@ extern "C" int lf_resample3d_bwd_coef(const float* gout, const float* vol, int v
   while (lpv < groups) lpv <<= 1;
   if (lpv > 64) return LF_EINVAL;                       // C > 256 (vec) / C > 64 (scalar)
   if (vec)
-    hipLaunchKernelGGL((resample_bwd_coef_kernel<4>), grid, block, 0, s, gout, vol, bstride, coef, partial, nblk, N, D, H, W, C, lpv);
+    hipLaunchKernelGGL((resample_bwd_coef_kernel<4>), grid, block, 0, s, gout, vol, bstride, coef, partial, nblk, vpb, N, D, H, W, C, lpv);
   else
-    hipLaunchKernelGGL((resample_bwd_coef_kernel<1>), grid, block, 0, s, gout, vol, bstride, coef, partial, nblk, N, D, H, W, C, lpv);
+    hipLaunchKernelGGL((resample_bwd_coef_kernel<1>), grid, block, 0, s, gout, vol, bstride, coef, partial, nblk, vpb, N, D, H, W, C, lpv);
   int st = lf_launch_status();
   if (st) return st;
   hipLaunchKernelGGL(resample_bwd_coef_reduce, dim3(N), dim3(256), 0, s, partial, nblk, gcoef);

@@ -124,13 +124,15 @@ class RenderLoopEngine:
                 and loss_weights.get('latent', 0.0) == 0.0
                 and photographer.camera_config[-1] % 4 == 0)
 
-    def __init__(self, photographer, z_obj, target_obs, loss_weights, conv_mode='fp32'):
-        """conv_mode: 'fp32' = exact-fp32 MFMA conv3d kernels (default);
-        'f16x3' = split-precision conv3d kernels (three f16 MFMAs per product, fp32 accumulate; measured
-        closer to an fp64 reference than the fp32 kernel) for the 16->16 camera blocks."""
-        if conv_mode not in ('fp32', 'f16x3'):
+    def __init__(self, photographer, z_obj, target_obs, loss_weights, conv_mode='auto'):
+        """conv_mode selects the kernels of the 16->16 camera-block convolutions:
+        'fp32'     direct implicit-GEMM on the fp32 MFMA (works for every channel count);
+        'winograd' F(2x2x2,3x3x3) minimal filtering, all-fp32 arithmetic (fp32 MFMA + fp32 transforms);
+        'f16x3'    direct, each fp32 product from three f16 MFMAs with fp32 accumulation;
+        'auto'     (default) 'winograd' when the blocks are 16->16, else 'fp32'.
+        All three stay within the fp32 kernel's distance of an fp64 reference (tests/test_engine_gpu.py)."""
+        if conv_mode not in ('auto', 'fp32', 'winograd', 'f16x3'):
             raise ValueError(conv_mode)
-        self.conv_mode = conv_mode
         self.ph = photographer
         self.cube = photographer.cube_size
         dev = z_obj.device
@@ -147,11 +149,17 @@ class RenderLoopEngine:
             for conv in (blk.conv1, blk.conv2):
                 w = conv.module.weight
                 self.convs.append((w, conv.bias, ops.he_constant(w), ops.pack_conv3x3(w), ops.pack_conv3x3(w, transpose=True)))
-        self.split = None
+        c16 = self.C == 16 and len(self.convs) > 0 and all(tuple(w.shape[:2]) == (16, 16) for w, *_ in self.convs)
+        if conv_mode == 'auto':
+            conv_mode = 'winograd' if c16 else 'fp32'
+        if conv_mode != 'fp32' and not c16:
+            raise NotImplementedError(f'{conv_mode} mode is implemented for 16->16 camera blocks')
+        self.conv_mode = conv_mode
+        self.split = self.wino = None
         if conv_mode == 'f16x3':
-            if not all(tuple(w.shape[:2]) == (16, 16) for w, *_ in self.convs) or self.C != 16:
-                raise NotImplementedError('f16x3 mode is implemented for 16->16 camera blocks')
             self.split = [(ops.pack_conv3d_c16_split(w), ops.pack_conv3d_c16_split(w, transpose=True)) for w, *_ in self.convs]
+        elif conv_mode == 'winograd':
+            self.wino = [(ops.pack_conv3d_c16_wino(w), ops.pack_conv3d_c16_wino(w, transpose=True)) for w, *_ in self.convs]
         pw = photographer.projection_block.conv.module.weight
         cout, C, D = pw.shape[0], self.convs[-1][0].shape[0] if self.convs else self.C, self.S
         self.proj = (pw, photographer.projection_block.conv.bias, ops.he_constant(pw),
@@ -188,6 +196,8 @@ class RenderLoopEngine:
         for li_, (w, b, he, wp, _wt) in enumerate(self.convs):
             if self.split is not None:
                 y, nrm = ops.conv3d_c16_split(acts[-1], self.split[li_][0], b, he, flags)
+            elif self.wino is not None:
+                y, nrm = ops.conv3d_c16_wino(acts[-1], self.wino[li_][0], b, he, flags)
             else:
                 y, nrm = ops._conv3x3_raw(acts[-1], wp, b, w.shape[0], he, flags, True)
             acts.append(y)
@@ -231,6 +241,8 @@ class RenderLoopEngine:
                 if self.split is not None:
                     g, _ = ops.conv3d_c16_split(g, self.split[i][1], None, he, 0, prev=prev, amax_in=amax[i + 1:i + 2],
                                                 amax_out=amax[i:i + 1])
+                elif self.wino is not None:
+                    g, _ = ops.conv3d_c16_wino(g, self.wino[i][1], None, he, 0, prev=prev)
                 else:
                     g = ops.conv3x3_bwd_data(g, wt, w.shape[1], he, prev)
         else:

@@ -153,6 +153,38 @@ def conv3d_c16_split(x, wsplit, bias, he, flags, prev=None, amax_in=None, amax_o
     return y, norm
 
 
+_WINO_G = ((1.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.5, -0.5, 0.5), (0.0, 0.0, 1.0))
+
+
+def pack_conv3d_c16_wino(weight, transpose=False):
+    """[16,16,3,3,3] fp32 -> Winograd-domain pack [4 a][16 b*4+c][4 i][64 lanes] for lf_conv3d_c16_wino:
+    U = (G x G x G) w evaluated in fp64, rounded once to fp32."""
+    w = weight.detach()
+    if transpose:
+        w = w.transpose(0, 1).flip(dims=(2, 3, 4))
+    assert tuple(w.shape) == (16, 16, 3, 3, 3)
+    G = torch.tensor(_WINO_G, dtype=torch.float64, device=w.device)
+    U = torch.einsum('ai,bj,ck,omijk->abcom', G, G, G, w.double())          # [a][b][c][cout][cin]
+    U = U.reshape(4, 16, 16, 4, 4)                                          # [a][bc][cout][kg][i]
+    U = U.permute(0, 1, 4, 3, 2).reshape(4, 16, 4, 64)                      # [a][bc][i][lane = kg*16 + cout]
+    return U.float().contiguous()
+
+
+def conv3d_c16_wino(x, upack, bias, he, flags, prev=None, amax_out=None):
+    """Launch lf_conv3d_c16_wino on a channels-last (N,16,D,H,W) tensor."""
+    L = _lib.lib()
+    N, _, D, H, W = x.shape
+    y = empty_cl((N, 16, D, H, W), x.device)
+    norm = torch.empty(N * D * H * W, device=x.device, dtype=torch.float32) if (flags & LF_EPI_PIXELNORM) else None
+    py, pn, pf = (prev[0], prev[1], prev[2]) if prev is not None else (None, None, 0)
+    with _timed('conv3d_c16_wino'):
+        check(L.lf_conv3d_c16_wino(_ptr(x), _ptr(upack), _ptr(bias) if bias is not None else None, _ptr(y),
+                                   _ptr(norm) if norm is not None else None, N, D, H, W, he, flags, SLOPE, PN_EPS,
+                                   _ptr(py) if py is not None else None, _ptr(pn) if pn is not None else None, pf,
+                                   _ptr(amax_out) if amax_out is not None else None, _stream()), 'lf_conv3d_c16_wino')
+    return y, norm
+
+
 def he_constant(weight):
     """sqrt(2 / fan_in)  (modules/equalized.py:66-74)."""
     return math.sqrt(2.0 / weight[0].numel())

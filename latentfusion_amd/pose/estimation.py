@@ -335,7 +335,7 @@ class GradientPoseEstimator(PoseEstimator):
 
     def __init__(self, *, learning_rate, num_samples, num_iters, converge_threshold, converge_patience,
                  lr_reduce_patience=25, lr_reduce_threshold=1e-5, lr_reduce_factor=0.5, track_stats=False,
-                 loss_schedules=None, optimizer='adamw', use_engine=True, conv_mode='fp32', **kwargs):
+                 loss_schedules=None, optimizer='adamw', use_engine=True, conv_mode='auto', **kwargs):
         super().__init__(**kwargs)
         self.use_engine = use_engine
         self.conv_mode = conv_mode

@@ -263,9 +263,78 @@ def test_split_precision_conv_matches_fp32_and_fp64():
     assert (ggot - gref).abs().max().item() < 1e-5 * gref.abs().max().item()
 
 
+@pytest.mark.parametrize('shape', [(2, 16, 10, 20, 40), (1, 16, 5, 7, 9), (3, 16, 4, 8, 16), (1, 16, 13, 24, 33)])
+def test_winograd_conv3d_matches_fp64(shape):
+    """lf_conv3d_c16_wino (F(2x2x2,3x3x3), all-fp32) on volumes with partial tiles on every axis:
+    fused forward, raw data gradient, data gradient with the fused previous-layer backward and the
+    max-abs side output.  Must be as close to fp64 as the direct fp32 MFMA kernel (x2 slack)."""
+    from latentfusion_amd import ops
+    from latentfusion_amd._lib import LF_EPI_LRELU, LF_EPI_PIXELNORM
+    g = torch.Generator().manual_seed(sum(shape))
+    flags = LF_EPI_LRELU | LF_EPI_PIXELNORM
+    w = torch.randn(16, 16, 3, 3, 3, generator=g)
+    b = torch.randn(16, generator=g) * 0.1
+    he = ops.he_constant(w)
+    xs = torch.randn(*shape, generator=g)
+    xs = xs / torch.sqrt((xs ** 2).mean(dim=1, keepdim=True))
+    y64 = torch.nn.functional.conv3d(xs.double(), w.double(), None, 1, 1) * he + b.double().view(1, -1, 1, 1, 1)
+    y64 = torch.nn.functional.leaky_relu(y64, 0.2)
+    n64 = torch.sqrt((y64 ** 2).mean(dim=1, keepdim=True) + 1e-8)
+    y64 = y64 / n64
+    xd, wd, bd = ops.cl(xs.to(DEV)), w.to(DEV), b.to(DEV)
+    up, upt = ops.pack_conv3d_c16_wino(wd), ops.pack_conv3d_c16_wino(wd, transpose=True)
+    ref, nref = ops._conv3x3_raw(xd, ops.pack_conv3x3(wd), bd, 16, he, flags, True)
+    got, ngot = ops.conv3d_c16_wino(xd, up, bd, he, flags)
+    e_ref = (ref.cpu().double() - y64).abs().max().item()
+    e_got = (got.cpu().double() - y64).abs().max().item()
+    assert e_got < max(2 * e_ref, 5e-6), (e_got, e_ref)
+    assert (ngot.cpu().double().view(n64.shape) - n64).abs().max().item() < 2e-6
+    g64 = torch.nn.functional.conv_transpose3d(xs.double(), w.double(), None, 1, 1) * he
+    gw, _ = ops.conv3d_c16_wino(xd, upt, None, he, 0)
+    gd = ops.conv3x3_bwd_data(xd, ops.pack_conv3x3(wd, transpose=True), 16, he, None)
+    assert (gw.cpu().double() - g64).abs().max().item() < max(2 * (gd.cpu().double() - g64).abs().max().item(), 5e-6)
+    prev = (ref, nref, flags)
+    want = ops.conv3x3_bwd_data(xd, ops.pack_conv3x3(wd, transpose=True), 16, he, prev)
+    amax = torch.zeros(1, device=DEV)
+    gw2, _ = ops.conv3d_c16_wino(xd, upt, None, he, 0, prev=prev, amax_out=amax)
+    assert (gw2 - want).abs().max().item() < 2e-6 * want.abs().max().item()
+    assert amax.item() == gw2.abs().max().item()
+
+
+def test_engine_winograd_matches_module_path(golden):
+    """RenderLoopEngine with the Winograd conv kernels == Photographer.decode + loss through the generic
+    autograd modules (direct conv kernels) on a SYN(16,16) model: losses and camera gradients."""
+    from latentfusion_amd import synth
+    from latentfusion_amd.engine import RenderLoopEngine
+    from latentfusion_amd.pose import estimation
+    model, _ = synth.build_model(16, 16, 'pool:mean', seed=4, device=DEV, bias_std=0.05)
+    g = golden('g7_adam_trace')
+    target = _target(g)
+    weights = {'depth': 1.0, 'ov_depth': 0.3, 'iou': 0.2, 'mask': 0.4}
+    gen = torch.Generator().manual_seed(9)
+    z_obj = torch.randn(1, 1, 16, 16, 16, 16, generator=gen).to(DEV)
+    est = estimation.GradientPoseEstimator(model=model, learning_rate=0.01, num_samples=8, num_iters=1, ranking_size=8,
+                                           converge_threshold=1e-6, converge_patience=10, optimizer='adam',
+                                           loss_weights=weights, use_engine=False)
+    cam0 = prod_camera(g['init']).zoom(None, model.input_size, model.camera_dist)
+    st = est.start(z_obj, target, cam0)
+    ld, _, rank, _ = est.loss_and_grad(z_obj, target, st['cam'])
+    want_g = torch.cat((st['cam'].log_quaternion.grad, st['cam'].translation.grad, st['cam'].viewport.grad), dim=1)
+    for mode in ('winograd', 'fp32', 'f16x3'):
+        eng = RenderLoopEngine(model.photographer, z_obj, target, weights, conv_mode=mode)
+        assert eng.conv_mode == mode
+        losses, gparams = eng.forward_backward(cam0)
+        for i, k in enumerate(eng.LOSS_KEYS):
+            close(losses[:, i], ld[k], atol=5e-6, rtol=5e-5)
+        close(losses[:, 4], rank, atol=5e-6, rtol=5e-5)
+        rel = ((gparams - want_g).norm(dim=1) / want_g.norm(dim=1)).max().item()
+        assert rel < 2e-3, (mode, rel)
+    assert RenderLoopEngine(model.photographer, z_obj, target, weights).conv_mode == 'winograd'
+
+
 def test_g7_gradient_loop_split_precision(golden):
-    """The adam_quick loop with the f16x3 conv kernels: same argmin indices as the reference at
-    every iteration, losses within the same envelope as the fp32 kernels."""
+    """The adam_quick loop with the Winograd and the f16x3 conv kernels against the direct fp32 kernels:
+    same argmin indices at every iteration, losses within the same envelope."""
     from latentfusion_amd.pose import estimation
     from latentfusion_amd.recon import fusion
     from latentfusion_amd.recon.inference import LatentFusionModel
@@ -278,12 +347,13 @@ def test_g7_gradient_loop_split_precision(golden):
     gen = torch.Generator().manual_seed(9)
     z_obj = torch.randn(1, 1, 16, 16, 16, 16, generator=gen).to(DEV)
     out = {}
-    for mode in ('fp32', 'f16x3'):
+    for mode in ('fp32', 'winograd', 'f16x3'):
         est = estimation.load_from_config(copy.deepcopy(g['cfg']), model, track_stats=True, conv_mode=mode)
         _, stats = est.estimate(z_obj, _target(g, 'cpu'), camera=prod_camera(g['init'], 'cpu'))
         out[mode] = stats['rank_loss']
-    close(out['f16x3'][:3], out['fp32'][:3], atol=1e-6, rtol=2e-5)
-    # later iterations: Adam amplifies last-bit differences across voxel-cell boundaries (DESIGN Q17);
-    # the fp32 kernels drift by the same order against the CPU oracle (test_g7_gradient_loop_on_hip)
-    close(out['f16x3'], out['fp32'], atol=3e-2, rtol=0)
-    assert torch.argmin(out['f16x3'], dim=1).tolist() == torch.argmin(out['fp32'], dim=1).tolist()
+    for mode in ('winograd', 'f16x3'):
+        close(out[mode][:3], out['fp32'][:3], atol=1e-6, rtol=2e-5)
+        # later iterations: Adam amplifies last-bit differences across voxel-cell boundaries (DESIGN Q17);
+        # the fp32 kernels drift by the same order against the CPU oracle (test_g7_gradient_loop_on_hip)
+        close(out[mode], out['fp32'], atol=3e-2, rtol=0)
+        assert torch.argmin(out[mode], dim=1).tolist() == torch.argmin(out['fp32'], dim=1).tolist()

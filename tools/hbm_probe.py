@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Workload for the HBM-traffic PMC passes: a calibration copy of known size (1 GiB read + 1 GiB
-written by ATen's copy kernel) followed by the dominant conv3d kernel on the bench shape."""
+written by ATen's copy kernel) followed by the conv3d kernels (direct and Winograd) on the bench shape."""
 import os
 import sys
 
@@ -18,4 +18,9 @@ for _ in range(3):
 torch.cuda.synchronize()
 for _ in range(3):
     y = ops.conv3x3(x, w, b)
+torch.cuda.synchronize()
+from latentfusion_amd._lib import LF_EPI_LRELU, LF_EPI_PIXELNORM  # noqa: E402
+up = ops.pack_conv3d_c16_wino(w)
+for _ in range(3):
+    y, _n = ops.conv3d_c16_wino(x, up, b, ops.he_constant(w), LF_EPI_LRELU | LF_EPI_PIXELNORM)
 torch.cuda.synchronize()

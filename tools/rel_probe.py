@@ -1,0 +1,87 @@
+#!/usr/bin/env python
+"""cfg3 of SURVEY 8(d): the released architecture (tools/train/train.sh:28-66 -- 16^3 x 256-channel
+latent volume, 256^2 images, GRU fuser) with random He-equalised weights, V = 8 synthetic reference
+views, the cross_entropy_linemod preset (N = 128 renders/iteration, no gradient) and the adam_quick
+preset.  Prints build time and iterations/sec of both loops.
+
+    python tools/rel_probe.py [--views 8] [--ce-iters 10] [--adam-iters 20]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def rel_model(device, seed=0):
+    from latentfusion_amd.recon import fusion, utils as ru
+    from latentfusion_amd.recon.inference import LatentFusionModel
+    from latentfusion_amd.recon.models import Photographer, Sculptor
+    torch.manual_seed(seed)
+    sc = Sculptor(in_size=256, image_config=[[64, 'D', 128, 'D', 196, 'D', 256, 'D', 512, 'D', 512, 'D', 512],
+                                              [512, 'U', 512, 'U', 256]],
+                  camera_config=[64, 128, 256], object_config=[256, 256], projection_type='factor',
+                  input_color=True, input_depth=False, input_mask=True, scale_mode='nearest')
+    ph = Photographer(in_size=sc.out_size,
+                      image_config=[[256, 'D', 512, 'D', 512],
+                                    [512, 'U', 512, 'U', 512, 'U', 256, 'U', 196, 'U', 128, 'U', 64]],
+                      camera_config=[256, 256], object_config=[], projection_type='factor',
+                      predict_depth=True, predict_mask=True, scale_mode='nearest')
+    fu = fusion.get_fuser('gru', 256, 1.0)
+    dist = ru.optimal_camera_dist(615.4991, 256, 0.5, slack=0.5)
+    return LatentFusionModel(sc.eval(), fu.eval(), ph.eval(), dist, device)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--views', type=int, default=8)
+    ap.add_argument('--ce-iters', type=int, default=10)
+    ap.add_argument('--adam-iters', type=int, default=20)
+    a = ap.parse_args()
+    dev = 'cuda:0'
+    from latentfusion_amd import synth
+    from latentfusion_amd.modules.geometry import Camera
+    from latentfusion_amd.observation import Observation
+    from latentfusion_amd.pose import estimation, utils as pu
+    model = rel_model(dev)
+    n_par = sum(p.numel() for m in (model.sculptor, model.fuser, model.photographer) for p in m.parameters())
+    ref = synth.make_observation(a.views, seed=100, device=dev)
+    td = synth.make_observation_data(1, seed=200)
+    target = Observation(td['color'], td['depth'], td['mask'], Camera(td['intrinsic'], td['extrinsic'])).to(dev)
+    out = {'params_M': n_par / 1e6, 'views': a.views}
+    for rep in range(2):                                   # second pass = warm (weight packs cached)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        z_obj = model.build_latent_object(ref)
+        torch.cuda.synchronize(); out['t_build_s' if rep else 't_build_cold_s'] = time.perf_counter() - t0
+    out['z_obj'] = list(z_obj.shape)
+
+    torch.manual_seed(300)
+    cfg = estimation._load_toml(os.path.join(ROOT, 'configs', 'cross_entropy_linemod.toml'))
+    cfg['args']['num_iters'] = a.ce_iters
+    est = estimation.load_from_config(cfg, model)
+    for rep in range(2):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        est.estimate(z_obj, target, camera=target.camera)
+        torch.cuda.synchronize(); el = time.perf_counter() - t0
+        out['ce_it_per_s' if rep else 'ce_cold_it_per_s'] = a.ce_iters / el
+    out['ce_renders_per_s'] = out['ce_it_per_s'] * cfg['args']['num_samples']
+
+    cfg = estimation._load_toml(os.path.join(ROOT, 'configs', 'adam_quick.toml'))
+    cfg['args']['num_iters'] = a.adam_iters
+    est = estimation.load_from_config(cfg, model, converge_patience=10 ** 6)
+    init8 = pu.sample_cameras_with_estimate(cfg['args']['num_samples'], target.camera.to('cpu'))
+    for rep in range(2):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        est.estimate(z_obj, target, camera=init8.to(dev))
+        torch.cuda.synchronize(); el = time.perf_counter() - t0
+        out['adam_it_per_s' if rep else 'adam_cold_it_per_s'] = a.adam_iters / el
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()
