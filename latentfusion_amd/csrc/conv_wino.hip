@@ -10,19 +10,24 @@
 // outputs instead of 216, so the MFMA work per voxel drops 3.375x; measured against fp64 the result is
 // as close as the direct fp32 kernel's (tests/test_ops_gpu.py::test_winograd_conv3d_*).
 //
-// Work split inside one 512-thread workgroup (one per CU, persistent over 4 x 8 x 16-voxel tiles):
-//   * wave w owns z-frequency a = w & 3 of z-half (w >> 2) of the tile; the 16 (y,x)-frequency
-//     matrices U[a][b][c] (16 cout x 16 cin each) live in 64 VGPRs for the whole launch;
+// Work split: 256-thread workgroups, TWO per CU (2 x 79,872 B of LDS), each persistent over its own range
+// of 2 x 8 x 16-voxel tiles.  The two workgroups of a CU are not synchronised with each other, so one's
+// exchange / epilogue / DMA-wait phases run under the other's MFMA phase (on gfx950 the fp32 MFMA and the
+// fp32 VALU share the SIMD's issue pipe -- measured: they do not overlap -- so everything that is not an
+// MFMA has to be either few instructions or hidden this way).
+//   * wave w owns z-frequency a = w of the tile; the 16 (y,x)-frequency matrices U[a][b][c]
+//     (16 cout x 16 cin each) live in 64 VGPRs for the whole launch;
 //   * MFMA columns = 16 Winograd tiles (2 in y x 8 in x), lane group kg = lane >> 4 carries input
 //     channels 4kg..4kg+3 (B operand) and receives output channels 4kg..4kg+3 (D operand);
 //   * per 16-tile group: 32 ds_read_b128 of the fp32 halo (two z planes combined on the fly),
 //     x/y input transforms in registers, 64 MFMAs, y/x output transform in registers;
-//   * the four z-frequency partials of a tile meet through LDS (the consumed halo buffer is reused),
-//     then every wave finishes a quarter of the outputs: z output transform, He scale, bias,
-//     LeakyReLU, PixelNorm (two xor-shuffles), store.
-// The halo is fetched with LDS-DMA into a double buffer (tile t+1 lands while tile t computes) in a
+//   * the four z-frequency partials of a tile meet through LDS, then every wave finishes a quarter of the
+//     outputs: z output transform, He scale, bias, LeakyReLU, PixelNorm (DPP quad reduction), and one
+//     x-contiguous 1 KiB row per store instruction.
+// The halo is fetched with LDS-DMA (issued as soon as the previous tile's halo has been consumed) in a
 // bank-swizzled order: voxel slot = (z*10 + y)*18 + (x&1)*9 + (x>>1), 16-byte quarter q stored at
-// q ^ s, s = 2*((slot>>2)&1) + ((y>>1)&1)  ->  every ds_read_b128 lane group hits 16 distinct slots.
+// q ^ s, s = 2*((slot>>2)&1) + ((y>>1)&1)  ->  every ds_read_b128 lane group hits 16 distinct slots
+// (SQ_LDS_BANK_CONFLICT = 0).
 #include "lf_common.h"
 #ifndef WINO_ABL
 #define WINO_ABL 0
@@ -30,12 +35,14 @@
 
 namespace {
 
-constexpr int TZw = 4, TYw = 8, TXw = 16;
-constexpr int HZw = TZw + 2, HYw = TYw + 2, HXw = TXw + 2;     // 6 x 10 x 18 halo
-constexpr int HALOw = HZw * HYw * HXw;                          // 1080 voxels
-constexpr int NSLOTw = (HALOw * 4 + 63) / 64;                   // 68 DMA pieces of 1 KiB
-constexpr int NITw = (NSLOTw + 7) / 8;                          // 9 pieces per wave (the last only for waves 0-3)
-constexpr int BUFw = NSLOTw * 1024;                             // 69,632 B per halo buffer
+constexpr int TZw = 2, TYw = 8, TXw = 16;
+constexpr int HZw = TZw + 2, HYw = TYw + 2, HXw = TXw + 2;     // 4 x 10 x 18 halo
+constexpr int HALOw = HZw * HYw * HXw;                          // 720 voxels
+constexpr int NSLOTw = (HALOw * 4 + 63) / 64;                   // 45 DMA pieces of 1 KiB
+constexpr int NITw = (NSLOTw + 3) / 4;                          // 12 pieces per wave (the last only for wave 0)
+constexpr int BUFw = NSLOTw * 1024;                             // 46,080 B halo buffer
+constexpr int PXw = 4 * 8192;                                   // 32,768 B partial-exchange region
+constexpr int LDSw = BUFw + PXw + 1024;                         // + 1 KiB DMA scratch = 79,872 B (two workgroups per CU)
 
 __device__ __forceinline__ void lds_barrier() {
   // all LDS traffic of this wave retired, then workgroup barrier; global loads/stores and the LDS-DMA of
@@ -59,9 +66,21 @@ __device__ __forceinline__ float fast_rcp(float x) {
   return r * (2.f - x * r);
 }
 
-// One tile's LDS-DMA job (wave-uniform part).  The 9 pieces of a wave are issued one or two at a time
-// between the MFMA rows of the previous tile's compute phase: a burst of 72 LDS-DMA instructions per CU
-// would otherwise hold every wave at the texture-address unit for ~2000 cycles.
+// a - b as two v_pk_add_f32 with negated second source.  (LLVM packs <4 x float> fadd into v_pk_add_f32 but
+// scalarises fsub; on this kernel every VALU instruction competes with the fp32 MFMAs for the issue pipe.)
+// Only used where neither operand is an MFMA result and the result does not feed an MFMA directly: the
+// MFMA <-> VALU wait states are inserted by the compiler, which does not look inside asm (feeding the
+// B operand of an MFMA straight from this asm gave wrong results on gfx950).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 pk_sub(f32x4 a, f32x4 b) {
+  f32x2 lo, hi;
+  const f32x2 alo = {a[0], a[1]}, ahi = {a[2], a[3]}, blo = {b[0], b[1]}, bhi = {b[2], b[3]};
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(lo) : "v"(alo), "v"(blo));
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(hi) : "v"(ahi), "v"(bhi));
+  return (f32x4){lo[0], lo[1], hi[0], hi[1]};
+}
+
+// One tile's LDS-DMA job (wave-uniform part).
 struct DmaTile {
   __amdgpu_buffer_rsrc_t rs;
   unsigned char* dst;
@@ -71,9 +90,9 @@ struct DmaTile {
 };
 
 __device__ __forceinline__ void dma_piece(const DmaTile& d, int it, int wave, int lxyzq, int W, int H, int D) {
-  // branch-free: a piece that must not be fetched (no next tile; ninth piece of waves 4-7) is pointed at
+  // branch-free: a piece that must not be fetched (no next tile; twelfth piece of waves 1-3) is pointed at
   // a scratch KiB of LDS with every lane out of range, which just writes zeros there
-  const int s = wave + 8 * it;
+  const int s = wave + 4 * it;
   const bool live = d.on && s < NSLOTw;                                       // wave-uniform
   const int gx = d.ox + (lxyzq & 0xff), gy = d.oy + ((lxyzq >> 8) & 0xff), gz = d.oz + ((lxyzq >> 16) & 0xff);
   const bool ok = (unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H && (unsigned)gz < (unsigned)D && lxyzq >= 0;
@@ -84,9 +103,8 @@ __device__ __forceinline__ void dma_piece(const DmaTile& d, int it, int wave, in
 }
 
 template <int A>
-__device__ __forceinline__ void wino_compute(const unsigned char* __restrict__ buf, const int (&off)[8],
-                                              const float (&wt)[64], f32x4 (&Y)[2][4], const DmaTile& dma, int wave,
-                                              const int (&lxyzq)[NITw], int W, int H, int D) {
+__device__ __forceinline__ void wino_compute(const unsigned char* __restrict__ buf, const int (&off)[8][2],
+                                              const float (&wt)[64], f32x4 (&Y)[2][4]) {
   // z input transform of frequency A: d0-d2, d1+d2, d2-d1, d1-d3
   constexpr int DZ0 = (A == 0) ? 0 : (A == 2 ? 2 : 1);
   constexpr int DZ1 = (A == 0) ? 2 : (A == 1 ? 2 : (A == 2 ? 1 : 3));
@@ -100,15 +118,14 @@ __device__ __forceinline__ void wino_compute(const unsigned char* __restrict__ b
       for (int dx = 0; dx < 4; ++dx) {
         const int ca = ((DZ0 * 10 + 4 * g + dy) * 18 + (dx & 1) * 9 + (dx >> 1));
         const int cb = ((DZ1 * 10 + 4 * g + dy) * 18 + (dx & 1) * 9 + (dx >> 1));
-        // rows dy = 2,3 sit one (y>>1) step further: their quarter swizzle differs in bit 0 (byte offset ^ 16)
-        const f32x4 va = *(const f32x4*)(buf + ((dy >> 1) ? (off[ca & 7] ^ 16) : off[ca & 7]) + ca * 64);
-        const f32x4 vb = *(const f32x4*)(buf + ((dy >> 1) ? (off[cb & 7] ^ 16) : off[cb & 7]) + cb * 64);
-        d[dx] = (A == 1) ? (va + vb) : (va - vb);
+        const f32x4 va = *(const f32x4*)(buf + off[ca & 7][dy >> 1] + ca * 64);
+        const f32x4 vb = *(const f32x4*)(buf + off[cb & 7][dy >> 1] + cb * 64);
+        d[dx] = (A == 1) ? (va + vb) : pk_sub(va, vb);
       }
-      vx[dy][0] = d[0] - d[2];
+      vx[dy][0] = pk_sub(d[0], d[2]);
       vx[dy][1] = d[1] + d[2];
-      vx[dy][2] = d[2] - d[1];
-      vx[dy][3] = d[1] - d[3];
+      vx[dy][2] = pk_sub(d[2], d[1]);
+      vx[dy][3] = pk_sub(d[1], d[3]);
     }
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
@@ -120,11 +137,9 @@ __device__ __forceinline__ void wino_compute(const unsigned char* __restrict__ b
                       : (b == 2) ? (vx[2][c] - vx[1][c])
                                  : (vx[1][c] - vx[3][c]);
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (WINO_ABL & 4) { acc = v * wt[(b * 4 + c) * 4] + wt[(b * 4 + c) * 4 + 1] + wt[(b * 4 + c) * 4 + 2] * wt[(b * 4 + c) * 4 + 3]; } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
           acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[(b * 4 + c) * 4 + i], v[i], acc, 0, 0, 0);
-        }
         m[c] = acc;
       }
       // x output transform, then accumulate the y output transform
@@ -132,20 +147,13 @@ __device__ __forceinline__ void wino_compute(const unsigned char* __restrict__ b
       const f32x4 t1 = m[1] - m[2] - m[3];
       if (b == 0) { Y[g][0] = t0; Y[g][1] = t1; }
       if (b == 1) { Y[g][0] += t0; Y[g][1] += t1; Y[g][2] = t0; Y[g][3] = t1; }
-      if (b == 2) { Y[g][0] += t0; Y[g][1] += t1; Y[g][2] -= t0; Y[g][3] -= t1; }
-      if (b == 3) { Y[g][2] -= t0; Y[g][3] -= t1; }
-      // next-but-one tile's halo: two pieces after each MFMA row of the first group, the ninth after the fifth row
-      if (g == 0) {
-        dma_piece(dma, 2 * b, wave, lxyzq[2 * b], W, H, D);
-        dma_piece(dma, 2 * b + 1, wave, lxyzq[2 * b + 1], W, H, D);
-      } else if (b == 0) {
-        dma_piece(dma, 8, wave, lxyzq[8], W, H, D);
-      }
+      if (b == 2) { Y[g][0] += t0; Y[g][1] += t1; Y[g][2] = pk_sub(Y[g][2], t0); Y[g][3] = pk_sub(Y[g][3], t1); }
+      if (b == 3) { Y[g][2] = pk_sub(Y[g][2], t0); Y[g][3] = pk_sub(Y[g][3], t1); }
     }
   }
 }
 
-__global__ void __launch_bounds__(512) conv3d_c16_wino_kernel(
+__global__ void __launch_bounds__(256, 2) conv3d_c16_wino_kernel(
     const float* __restrict__ x, const float* __restrict__ upack, const float* __restrict__ bias,
     float* __restrict__ y, float* __restrict__ norm_out,
     int N, int D, int H, int W, int tiles_x, int tiles_y, int tiles_z, int ntiles,
@@ -153,10 +161,11 @@ __global__ void __launch_bounds__(512) conv3d_c16_wino_kernel(
     const float* __restrict__ prev_y, const float* __restrict__ prev_norm, unsigned prev_flags,
     float* __restrict__ amax_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const buf = smem;                              // halo
+  unsigned char* const px = smem + BUFw;                        // partial exchange
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int fa = wave & 3, half = wave >> 2;
+  const int fa = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave = z-frequency
   const int n = lane & 15, kg = lane >> 4;
   const int tx = n & 7, tyb = n >> 3;
 
@@ -176,27 +185,27 @@ __global__ void __launch_bounds__(512) conv3d_c16_wino_kernel(
   int lxyzq[NITw];                                              // lx | ly << 8 | lz << 16 | quarter << 24
 #pragma unroll
   for (int it = 0; it < NITw; ++it) {
-    const int p = (wave + 8 * it) * 64 + lane;
+    const int p = (fa + 4 * it) * 64 + lane;
     const int vs = p >> 2;
     const int row = vs / HXw, rem = vs - row * HXw;
     const int xl = rem / 9, xa = rem - xl * 9;
     const int lx = 2 * xa + xl, ly = row % HYw, lz = row / HYw;
     const int s = (((vs >> 2) & 1) << 1) | ((ly >> 1) & 1);
     const int q = (p & 3) ^ s;
-    lxyzq[it] = (vs < HALOw) ? (lx | (ly << 8) | (lz << 16) | (q << 24)) : -1;           // padding lanes of the last piece
+    lxyzq[it] = (vs < HALOw) ? (lx | (ly << 8) | (lz << 16) | (q << 24)) : -1;           // padding lanes / pieces
   }
 
   // ---- B-operand addressing: byte offset of (lane's tile, channel quarter) for the 8 slot residues ----
-  int off[8];
-  {
-    const int base_lane = 360 * half + 36 * tyb + tx;          // voxel-slot units
+  // (rows dy = 2,3 sit one (y>>1) step further: their quarter swizzle differs in bit 0)
+  int off[8][2];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
+  for (int r = 0; r < 8; ++r)
+#pragma unroll
+    for (int dyb = 0; dyb < 2; ++dyb) {
       const int bit = ((36 * tyb + tx + r) >> 2) & 1;
-      const int quarter = (kg ^ tyb) ^ (bit << 1);
-      off[r] = base_lane * 64 + quarter * 16;
+      const int quarter = (kg ^ tyb ^ dyb) ^ (bit << 1);
+      off[r][dyb] = (36 * tyb + tx) * 64 + quarter * 16;
     }
-  }
 
   // ---- partial-exchange addressing ----
   int pw[2];                                                   // writer: lane part of the slot, per x parity i
@@ -218,89 +227,84 @@ __global__ void __launch_bounds__(512) conv3d_c16_wino_kernel(
   f32x4 bv4 = (f32x4){0.f, 0.f, 0.f, 0.f};
   if (bias != nullptr) bv4 = *(const f32x4*)(bias + eq * 4);
 
-  auto make_dma = [&](int t, int bufsel, bool on) {
+  // tile coordinates are stepped, not divided: (cx, cy, cz, cn) = tile t, (nx, ny, nz, nn) = tile t + 1
+  int cx, cy, cz, cn;
+  {
+    int tt = t_begin;
+    cx = tt % tiles_x; tt /= tiles_x;
+    cy = tt % tiles_y; tt /= tiles_y;
+    cz = tt % tiles_z; cn = tt / tiles_z;
+  }
+  auto issue_dma = [&](int bx, int by, int bz, int bn, bool on) {
     DmaTile d;
-    int tt = t;
-    const int bx = tt % tiles_x; tt /= tiles_x;
-    const int by = tt % tiles_y; tt /= tiles_y;
-    const int bz = tt % tiles_z; tt /= tiles_z;
     d.ox = bx * TXw - 1; d.oy = by * TYw - 1; d.oz = bz * TZw - 1;
-    d.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long)(on ? tt : 0) * nvox * 16), 0, sample_bytes, 0x00020000);
-    d.dst = smem + bufsel * BUFw;
-    d.scratch = smem + 2 * BUFw;
+    d.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long)(on ? bn : 0) * nvox * 16), 0, sample_bytes, 0x00020000);
+    d.dst = buf;
+    d.scratch = smem + BUFw + PXw;
     d.on = on;
-    return d;
-  };
-  auto issue_all = [&](const DmaTile& d) {
 #pragma unroll
-    for (int it = 0; it < NITw; ++it) dma_piece(d, it, wave, lxyzq[it], W, H, D);
+    for (int it = 0; it < NITw; ++it) dma_piece(d, it, fa, lxyzq[it], W, H, D);
   };
 
   const float out_scale = he;
   float wave_amax = 0.f;
 
-  issue_all(make_dma(t_begin, 0, true));
+  issue_dma(cx, cy, cz, cn, true);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   lds_barrier();
-  // the two waves that share a SIMD (w, w+4) get different issue priorities so that one's MFMA phase
-  // runs under the other's VALU transforms instead of both contending for the same pipe
-  if (half == 0) __builtin_amdgcn_s_setprio(2);
 
 #if WINO_ABL & 16
-#define TS(k) do { if (blockIdx.x == 3 && lane == 0) ((unsigned*)norm_out)[((t - t_begin) * 8 + wave) * 8 + (k)] = (unsigned)__builtin_readcyclecounter(); } while (0)
+#define TS(k) do { if (blockIdx.x == 11 && lane == 0) ((unsigned*)norm_out)[((t - t_begin) * 4 + fa) * 16 + (k)] = (unsigned)__builtin_readcyclecounter(); } while (0)
 #else
 #define TS(k) do {} while (0)
 #endif
   for (int t = t_begin; t < t_end; ++t) {
-    const int cur = (t - t_begin) & 1;
-    unsigned char* buf = smem + cur * BUFw;
     TS(0);
-    // halo of tile t+1 goes into the other buffer (free since the last barrier of the previous iteration);
-    // its pieces are issued from inside the compute phase
-    const DmaTile dma = make_dma(t + 1 < t_end ? t + 1 : t, cur ^ 1, t + 1 < t_end && !(WINO_ABL & 1));
-
     f32x4 Y[2][4];
-    if (WINO_ABL & 8) {
-#pragma unroll
-      for (int g = 0; g < 2; ++g)
-#pragma unroll
-        for (int ji = 0; ji < 4; ++ji) Y[g][ji] = *(const f32x4*)(buf + off[ji + g] + (g * 4 + ji) * 64) * wt[g * 4 + ji];
-    } else
     switch (fa) {
-      case 0: wino_compute<0>(buf, off, wt, Y, dma, wave, lxyzq, W, H, D); break;
-      case 1: wino_compute<1>(buf, off, wt, Y, dma, wave, lxyzq, W, H, D); break;
-      case 2: wino_compute<2>(buf, off, wt, Y, dma, wave, lxyzq, W, H, D); break;
-      default: wino_compute<3>(buf, off, wt, Y, dma, wave, lxyzq, W, H, D); break;
+      case 0: wino_compute<0>(buf, off, wt, Y); break;
+      case 1: wino_compute<1>(buf, off, wt, Y); break;
+      case 2: wino_compute<2>(buf, off, wt, Y); break;
+      default: wino_compute<3>(buf, off, wt, Y); break;
     }
     TS(1);
     lds_barrier();                                              // every wave is done reading the halo
     TS(2);
 
-    // partial outputs of z-frequency fa -> LDS (reusing the halo buffer), 1 KiB blocks indexed
-    // [wave][g][tyb][j], 64 float4 slots each at (L ^ ((L >> 3) & 7)), L = x*4 + channel quarter:
-    // the writers' 8-lane groups and the readers' 16-lane groups both hit distinct bank slots, and a
-    // reader wave gets one x-contiguous 1 KiB output row per instruction
+    // next tile's halo: in flight during the exchange / epilogue below and, for the CU, under the MFMA phase
+    // of the other resident workgroup
+    int nx = cx + 1, ny = cy, nz = cz, nn = cn;
+    if (nx == tiles_x) { nx = 0; ++ny; }
+    if (ny == tiles_y) { ny = 0; ++nz; }
+    if (nz == tiles_z) { nz = 0; ++nn; }
+    issue_dma(nx, ny, nz, nn, t + 1 < t_end);
+    TS(3);
+
+    // partial outputs of z-frequency fa -> LDS, 1 KiB blocks indexed [wave][g][tyb][j], 64 float4 slots each
+    // at (L ^ ((L >> 3) & 7)), L = x*4 + channel quarter: the writers' 8-lane groups and the readers' 16-lane
+    // groups both hit distinct bank slots, and a reader wave gets one x-contiguous 1 KiB output row per
+    // instruction
 #pragma unroll
     for (int g = 0; g < 2; ++g)
 #pragma unroll
       for (int ji = 0; ji < 4; ++ji)
-        *(f32x4*)(buf + wave * 8192 + g * 4096 + (ji >> 1) * 1024 + pw[ji & 1]) = Y[g][ji];
+        *(f32x4*)(px + fa * 8192 + g * 4096 + (ji >> 1) * 1024 + pw[ji & 1]) = Y[g][ji];
 
-    // this wave finishes rows y = 2fa, 2fa+1 of its z-half: lane = x*4 + channel quarter
-    int tt = t;
-    const int bx = tt % tiles_x; tt /= tiles_x;
-    const int by = tt % tiles_y; tt /= tiles_y;
-    const int bz = tt % tiles_z; tt /= tiles_z;
+    // this wave finishes rows y = 2fa, 2fa+1 of the tile: lane = x*4 + channel quarter
+    const int bx = cx, by = cy, bz = cz, tt = cn;
     const int gx = bx * TXw + ex;
+    const bool xok = gx < W;
     int voxi[4];
     bool okv[4];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int zo = 0; zo < 2; ++zo) {
-        const int gz = bz * TZw + 2 * half + zo, gy = by * TYw + 2 * fa + j;
-        okv[j * 2 + zo] = gx < W && gy < H && gz < D;
-        voxi[j * 2 + zo] = okv[j * 2 + zo] ? (gz * H + gy) * W + gx : 0;
+        const int gz = bz * TZw + zo, gy = by * TYw + 2 * fa + j;       // wave-uniform: scalar unit
+        const bool rowok = gy < H && gz < D;
+        const int rowbase = rowok ? (gz * H + gy) * W : 0;
+        okv[j * 2 + zo] = xok && rowok;
+        voxi[j * 2 + zo] = okv[j * 2 + zo] ? rowbase + gx : 0;
       }
     f32x4 pyv[4];
     float pnv[4];
@@ -313,75 +317,77 @@ __global__ void __launch_bounds__(512) conv3d_c16_wino_kernel(
         pnv[k] = (okv[k] && pnbase) ? pnbase[voxi[k]] : 1.f;
       }
     }
-    TS(3);
-    lds_barrier();                                              // all partials are in LDS
     TS(4);
+    lds_barrier();                                              // all partials are in LDS
+    TS(5);
 
-    if (WINO_ABL & 2) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); lds_barrier();
-      continue;
-    }
     f32x4 o[4];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       f32x4 p[4];
 #pragma unroll
       for (int a2 = 0; a2 < 4; ++a2)
-        p[a2] = *(const f32x4*)(buf + (a2 + 4 * half) * 8192 + fa * 2048 + j * 1024 + pr);
+        p[a2] = *(const f32x4*)(px + a2 * 8192 + fa * 2048 + j * 1024 + pr);
       o[j * 2 + 0] = p[0] + p[1] + p[2];                        // z output transform
       o[j * 2 + 1] = p[1] - p[2] - p[3];
     }
-    // tile t+1's halo (issued from inside this iteration's compute phase) must have landed, and every wave
-    // must have consumed the partials, before the buffers swap roles.  Waiting here, BEFORE this tile's
-    // stores are issued, keeps the stores out of the wait: they drain behind the next tile's MFMAs.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    TS(5);
-    lds_barrier();
-    TS(6);
-    TS(7);
 
     unsigned char* ybase = (unsigned char*)(y + (long)tt * nvox * 16) + eq * 16;
     float* nbase = norm_out ? norm_out + (long)tt * nvox : nullptr;
+    f32x4 v[4];
+    float rn[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      f32x4 v;
-      float r_ = 1.f;
-      if (prev_y != nullptr) {
-        const f32x4 yp = pyv[k];
-        v = o[k] * out_scale;
-        if (prev_flags & LF_EPI_PIXELNORM) {
-          const float dot = quad_sum(v[0] * yp[0] + v[1] * yp[1] + v[2] * yp[2] + v[3] * yp[3]) * (1.f / 16.f);
-          const float rinv = fast_rcp(pnv[k]);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = (v[e] - yp[e] * dot) * rinv;
-        }
-        if (prev_flags & LF_EPI_LRELU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = yp[e] > 0.f ? v[e] : v[e] * slope;
-        }
-      } else {
+      rn[k] = 1.f;
+      if (prev_y == nullptr) {
         float ss = 0.f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float u = o[k][e] * out_scale + bv4[e];
           if (flags & LF_EPI_LRELU) u = fmaxf(u, u * slope);
-          v[e] = u;
+          v[k][e] = u;
           ss += u * u;
         }
         if (flags & LF_EPI_PIXELNORM) {
           const float tq = quad_sum(ss) * (1.f / 16.f) + eps;
           const float rinv = fast_rsqrt(tq);
-          r_ = tq * rinv;
-          v[0] *= rinv; v[1] *= rinv; v[2] *= rinv; v[3] *= rinv;
+          rn[k] = tq * rinv;
+          v[k] *= rinv;
+        }
+      }
+    }
+    // the next halo (and, for the gradient form, the previous layer's activations) must have arrived
+    // before the tile's last barrier; this tile's stores are issued after the wait so they stay out of it
+    // and drain behind the next tile's MFMAs
+    TS(6);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TS(7);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (prev_y != nullptr) {
+        const f32x4 yp = pyv[k];
+        v[k] = o[k] * out_scale;
+        if (prev_flags & LF_EPI_PIXELNORM) {
+          const float dot = quad_sum(v[k][0] * yp[0] + v[k][1] * yp[1] + v[k][2] * yp[2] + v[k][3] * yp[3]) * (1.f / 16.f);
+          const float rinv = fast_rcp(pnv[k]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[k][e] = (v[k][e] - yp[e] * dot) * rinv;
+        }
+        if (prev_flags & LF_EPI_LRELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[k][e] = yp[e] > 0.f ? v[k][e] : v[k][e] * slope;
         }
       }
       if (okv[k]) {
-        *(f32x4*)(ybase + (unsigned)(voxi[k] * 64)) = v;
-        if (!(WINO_ABL & 16) && prev_y == nullptr && (flags & LF_EPI_PIXELNORM) && nbase != nullptr && eq == 0) nbase[voxi[k]] = r_;
+        *(f32x4*)(ybase + (unsigned)(voxi[k] * 64)) = v[k];
+        if (!(WINO_ABL & 16) && prev_y == nullptr && (flags & LF_EPI_PIXELNORM) && nbase != nullptr && eq == 0) nbase[voxi[k]] = rn[k];
         if (amax_out != nullptr)
-          wave_amax = fmaxf(wave_amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+          wave_amax = fmaxf(wave_amax, fmaxf(fmaxf(fabsf(v[k][0]), fabsf(v[k][1])), fmaxf(fabsf(v[k][2]), fabsf(v[k][3]))));
       }
     }
+    TS(8);
+    lds_barrier();                                              // next halo visible to all; partials consumed
+    cx = nx; cy = ny; cz = nz; cn = nn;
   }
   if (amax_out != nullptr) {
     float m = wave_amax;
@@ -414,7 +420,7 @@ extern "C" int lf_conv3d_c16_wino(const float* x, const float* upack, const floa
     cus = (hipGetDevice(&dev) == hipSuccess &&
            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
   }
-  const size_t shmem = (size_t)2 * BUFw + 1024;                  // 139,264 B + 1 KiB DMA scratch
+  const size_t shmem = (size_t)LDSw;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)conv3d_c16_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -422,8 +428,9 @@ extern "C" int lf_conv3d_c16_wino(const float* x, const float* upack, const floa
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  const unsigned grid = (unsigned)(pt < cus ? pt : cus);
-  hipLaunchKernelGGL(conv3d_c16_wino_kernel, dim3(grid), dim3(512), shmem, (hipStream_t)stream, x, upack, bias, y,
+  const long want = 2L * cus;                                     // two resident workgroups per CU
+  const unsigned grid = (unsigned)(pt < want ? pt : want);
+  hipLaunchKernelGGL(conv3d_c16_wino_kernel, dim3(grid), dim3(256), shmem, (hipStream_t)stream, x, upack, bias, y,
                      norm_out, N, D, H, W, ptx, pty, ptz, (int)pt, he, flags, slope, eps, prev_y, prev_norm, prev_flags,
                      amax_out);
   return lf_launch_status();
