@@ -379,7 +379,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_wino_kernel(
         }
       }
       if (okv[k]) {
-        *(f32x4*)(ybase + (unsigned)(voxi[k] * 64)) = v[k];
+        __builtin_nontemporal_store(v[k], (f32x4*)(ybase + (unsigned)(voxi[k] * 64)));   // streamed: L2 is for halos
         if (!(WINO_ABL & 16) && prev_y == nullptr && (flags & LF_EPI_PIXELNORM) && nbase != nullptr && eq == 0) nbase[voxi[k]] = rn[k];
         if (amax_out != nullptr)
           wave_amax = fmaxf(wave_amax, fmaxf(fmaxf(fabsf(v[k][0]), fabsf(v[k][1])), fmaxf(fabsf(v[k][2]), fabsf(v[k][3]))));

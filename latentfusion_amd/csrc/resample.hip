@@ -14,14 +14,22 @@ struct Tap {
   float mx, my, mz;             // d(ix)/d(gx) incl. border-clip mask (0 outside the volume)
 };
 
+// i-th point of torch.linspace(0, 1, size): start + step*i in the first half, end - step*(size-1-i) in the
+// second (ATen's symmetric formula), step = 1/(size-1) computed once on the host
+__device__ __forceinline__ float lattice01(int i, int size, float step) {
+  return (i < size / 2) ? step * (float)i : 1.f - step * (float)(size - 1 - i);
+}
+
+struct Steps { float w, h, d; };                              // 1/(W-1), 1/(H-1), 1/(D-1) (0 for size 1)
+
 template <int KIND>
 __device__ __forceinline__ void eval_grid(const float* __restrict__ cf, int x, int y, int z,
-                                          int W, int H, int D, float& gx, float& gy, float& gz,
+                                          int W, int H, int D, Steps st, float& gx, float& gy, float& gz,
                                           float& a, float& b, float& k) {
   // lattice coordinates in [0,1] (torch.linspace(0,1,S): geometry.py:476-480)
-  a = W > 1 ? (float)x / (float)(W - 1) : 0.f;
-  b = H > 1 ? (float)y / (float)(H - 1) : 0.f;
-  k = D > 1 ? (float)z / (float)(D - 1) : 0.f;
+  a = lattice01(x, W, st.w);
+  b = lattice01(y, H, st.h);
+  k = lattice01(z, D, st.d);
   if (KIND == LF_MAP_O2C) {
     const float ak = a * k, bk = b * k;
     gx = cf[0] + cf[3] * a + cf[6] * b + cf[9] * k + cf[12] * ak + cf[15] * bk;
@@ -67,46 +75,48 @@ __device__ __forceinline__ Tap make_tap(float gx, float gy, float gz, int W, int
 }
 
 // VEC = 4: one thread per (voxel, 4-channel group), C % 4 == 0.  VEC = 1: one thread per (voxel, channel).
+// A block covers a compact 2^lx x 2^ly x 2^lz output tile (4x4x4 for C = 16), so that the 8-corner
+// footprints of its voxels overlap in L1; 32-bit index math only.
 template <int KIND, int VEC>
 __global__ void __launch_bounds__(256) resample_fwd_kernel(
     const float* __restrict__ vol, long vol_bstride, const float* __restrict__ coef,
-    float* __restrict__ out, int N, int D, int H, int W, int C) {
+    float* __restrict__ out, int N, int D, int H, int W, int C, int lpt, int lx, int ly, int lz, int nbz, Steps st) {
+  // lpt = threads cooperating on one voxel (<= 256); tile = (1<<lx, 1<<ly, 1<<lz) voxels per block
   const int lpv = C / VEC;
-  const long per_sample = (long)D * H * W * lpv;
-  const int n = blockIdx.y;
+  const int n = blockIdx.z / nbz, bz = blockIdx.z - n * nbz;
+  const int slot = threadIdx.x / lpt, q0 = threadIdx.x - slot * lpt;
+  if (slot >= (1 << (lx + ly + lz))) return;
+  const int x = (blockIdx.x << lx) + (slot & ((1 << lx) - 1));
+  const int y = (blockIdx.y << ly) + ((slot >> lx) & ((1 << ly) - 1));
+  const int z = (bz << lz) + (slot >> (lx + ly));
+  if (x >= W || y >= H || z >= D) return;
   const float* cf = coef + (long)n * LF_MAP_COEFS;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < per_sample;
-       idx += (long)gridDim.x * blockDim.x) {
-    const int q = (int)(idx % lpv);
-    long v = idx / lpv;
-    const int x = (int)(v % W); v /= W;
-    const int y = (int)(v % H);
-    const int z = (int)(v / H);
-    float gx, gy, gz, a, b, k;
-    eval_grid<KIND>(cf, x, y, z, W, H, D, gx, gy, gz, a, b, k);
-    const Tap t = make_tap(gx, gy, gz, W, H, D);
-    const float* base = vol + (long)n * vol_bstride + (long)q * VEC;
-    const long sW = C, sH = (long)W * C, sD = (long)H * W * C;
-    const float wx1 = t.tx, wx0 = 1.f - t.tx, wy1 = t.ty, wy0 = 1.f - t.ty, wz1 = t.tz, wz0 = 1.f - t.tz;
-    const long o00 = t.z0 * sD + t.y0 * sH, o01 = t.z0 * sD + t.y1 * sH;
-    const long o10 = t.z1 * sD + t.y0 * sH, o11 = t.z1 * sD + t.y1 * sH;
-    const long x0 = t.x0 * sW, x1 = t.x1 * sW;
-    const long oo = (((long)n * D + z) * H + y) * W + x;
+  float gx, gy, gz, a, b, k;
+  eval_grid<KIND>(cf, x, y, z, W, H, D, st, gx, gy, gz, a, b, k);
+  const Tap t = make_tap(gx, gy, gz, W, H, D);
+  const float wx1 = t.tx, wx0 = 1.f - t.tx, wy1 = t.ty, wy0 = 1.f - t.ty, wz1 = t.tz, wz0 = 1.f - t.tz;
+  const float w000 = wx0 * wy0 * wz0, w001 = wx1 * wy0 * wz0, w010 = wx0 * wy1 * wz0, w011 = wx1 * wy1 * wz0;
+  const float w100 = wx0 * wy0 * wz1, w101 = wx1 * wy0 * wz1, w110 = wx0 * wy1 * wz1, w111 = wx1 * wy1 * wz1;
+  const int r00 = (t.z0 * H + t.y0) * W, r01 = (t.z0 * H + t.y1) * W;        // voxel indices of the 4 rows
+  const int r10 = (t.z1 * H + t.y0) * W, r11 = (t.z1 * H + t.y1) * W;
+  const float* base = vol + (long)n * vol_bstride;
+  float* orow = out + ((long)n * D * H * W + ((long)z * H + y) * W + x) * C;
+  for (int q = q0; q < lpv; q += lpt) {
+    const int co = q * VEC;
     if (VEC == 4) {
-      const f32x4 v000 = *(const f32x4*)(base + o00 + x0), v001 = *(const f32x4*)(base + o00 + x1);
-      const f32x4 v010 = *(const f32x4*)(base + o01 + x0), v011 = *(const f32x4*)(base + o01 + x1);
-      const f32x4 v100 = *(const f32x4*)(base + o10 + x0), v101 = *(const f32x4*)(base + o10 + x1);
-      const f32x4 v110 = *(const f32x4*)(base + o11 + x0), v111 = *(const f32x4*)(base + o11 + x1);
-      f32x4 r = v000 * (wx0 * wy0 * wz0) + v001 * (wx1 * wy0 * wz0) + v010 * (wx0 * wy1 * wz0) +
-                v011 * (wx1 * wy1 * wz0) + v100 * (wx0 * wy0 * wz1) + v101 * (wx1 * wy0 * wz1) +
-                v110 * (wx0 * wy1 * wz1) + v111 * (wx1 * wy1 * wz1);
-      *(f32x4*)(out + oo * C + (long)q * 4) = r;
+      const f32x4 v000 = *(const f32x4*)(base + (long)(r00 + t.x0) * C + co), v001 = *(const f32x4*)(base + (long)(r00 + t.x1) * C + co);
+      const f32x4 v010 = *(const f32x4*)(base + (long)(r01 + t.x0) * C + co), v011 = *(const f32x4*)(base + (long)(r01 + t.x1) * C + co);
+      const f32x4 v100 = *(const f32x4*)(base + (long)(r10 + t.x0) * C + co), v101 = *(const f32x4*)(base + (long)(r10 + t.x1) * C + co);
+      const f32x4 v110 = *(const f32x4*)(base + (long)(r11 + t.x0) * C + co), v111 = *(const f32x4*)(base + (long)(r11 + t.x1) * C + co);
+      const f32x4 r = v000 * w000 + v001 * w001 + v010 * w010 + v011 * w011 + v100 * w100 + v101 * w101 + v110 * w110 +
+                      v111 * w111;
+      __builtin_nontemporal_store(r, (f32x4*)(orow + co));     // streamed output: keep L2 for the gathered volume
     } else {
-      float r = base[o00 + x0] * (wx0 * wy0 * wz0) + base[o00 + x1] * (wx1 * wy0 * wz0) +
-                base[o01 + x0] * (wx0 * wy1 * wz0) + base[o01 + x1] * (wx1 * wy1 * wz0) +
-                base[o10 + x0] * (wx0 * wy0 * wz1) + base[o10 + x1] * (wx1 * wy0 * wz1) +
-                base[o11 + x0] * (wx0 * wy1 * wz1) + base[o11 + x1] * (wx1 * wy1 * wz1);
-      out[oo * C + q] = r;
+      const float r = base[(long)(r00 + t.x0) * C + co] * w000 + base[(long)(r00 + t.x1) * C + co] * w001 +
+                      base[(long)(r01 + t.x0) * C + co] * w010 + base[(long)(r01 + t.x1) * C + co] * w011 +
+                      base[(long)(r10 + t.x0) * C + co] * w100 + base[(long)(r10 + t.x1) * C + co] * w101 +
+                      base[(long)(r11 + t.x0) * C + co] * w110 + base[(long)(r11 + t.x1) * C + co] * w111;
+      orow[co] = r;
     }
   }
 }
@@ -126,44 +136,41 @@ template <int VEC>
 __global__ void __launch_bounds__(256) resample_bwd_coef_kernel(
     const float* __restrict__ gout, const float* __restrict__ vol, long vol_bstride,
     const float* __restrict__ coef, float* __restrict__ partial, int nblk, int vpb,
-    int N, int D, int H, int W, int C, int lpv) {
+    int N, int D, int H, int W, int C, int lpv, Steps st) {
   // lpv = lanes cooperating on one voxel: a power of two <= 64 with lpv * VEC >= C
   const int n = blockIdx.y;
   const float* cf = coef + (long)n * LF_MAP_COEFS;
-  const long nvox = (long)D * H * W;
-  const long v_begin = (long)blockIdx.x * vpb;
-  const long v_end = min(v_begin + (long)vpb, nvox);
+  const int nvox = D * H * W;                                  // < 2^31 (checked by the launcher)
+  const int v_begin = blockIdx.x * vpb;
+  const int v_end = min(v_begin + vpb, nvox);
   const int q = threadIdx.x % lpv;
   const int vslot = threadIdx.x / lpv;
   const int vstep = blockDim.x / lpv;
   float acc[18];
 #pragma unroll
   for (int i = 0; i < 18; ++i) acc[i] = 0.f;
-  const long sW = C, sH = (long)W * C, sD = (long)H * W * C;
   // all lanes of a wave iterate the same number of times so the shuffles below are convergent
-  const long iters = (v_end - v_begin + vstep - 1) / vstep;
-  for (long it = 0; it < iters; ++it) {
-    const long v = v_begin + it * vstep + vslot;
+  const int iters = (v_end - v_begin + vstep - 1) / vstep;
+  for (int it = 0; it < iters; ++it) {
+    const int v = v_begin + it * vstep + vslot;
     const bool live = v < v_end;
     float hx = 0.f, hy = 0.f, hz = 0.f, a = 0.f, b = 0.f, k = 0.f;
     if (live && q * VEC < C) {
-      long vv = v;
-      const int x = (int)(vv % W); vv /= W;
-      const int y = (int)(vv % H);
-      const int z = (int)(vv / H);
+      const int zy = v / W, x = v - zy * W;
+      const int z = zy / H, y = zy - z * H;
       float gx, gy, gz;
-      eval_grid<LF_MAP_O2C>(cf, x, y, z, W, H, D, gx, gy, gz, a, b, k);
+      eval_grid<LF_MAP_O2C>(cf, x, y, z, W, H, D, st, gx, gy, gz, a, b, k);
       const Tap t = make_tap(gx, gy, gz, W, H, D);
       const float* base = vol + (long)n * vol_bstride + (long)q * VEC;
       const float* g = gout + (((long)n * nvox + v) * C) + (long)q * VEC;
-      const long o00 = t.z0 * sD + t.y0 * sH, o01 = t.z0 * sD + t.y1 * sH;
-      const long o10 = t.z1 * sD + t.y0 * sH, o11 = t.z1 * sD + t.y1 * sH;
-      const long x0 = t.x0 * sW, x1 = t.x1 * sW;
+      const long o00 = (long)((t.z0 * H + t.y0) * W) * C, o01 = (long)((t.z0 * H + t.y1) * W) * C;
+      const long o10 = (long)((t.z1 * H + t.y0) * W) * C, o11 = (long)((t.z1 * H + t.y1) * W) * C;
+      const long x0 = (long)t.x0 * C, x1 = (long)t.x1 * C;
       const float wx1 = t.tx, wx0 = 1.f - t.tx, wy1 = t.ty, wy0 = 1.f - t.ty, wz1 = t.tz, wz0 = 1.f - t.tz;
       float dx = 0.f, dy = 0.f, dz = 0.f;
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
-        const float go = g[e];
+        const float go = __builtin_nontemporal_load(g + e);     // streamed once: keep L2 for the gathered volume
         const float v000 = base[o00 + x0 + e], v001 = base[o00 + x1 + e];
         const float v010 = base[o01 + x0 + e], v011 = base[o01 + x1 + e];
         const float v100 = base[o10 + x0 + e], v101 = base[o10 + x1 + e];
@@ -230,7 +237,7 @@ __global__ void __launch_bounds__(256) resample_bwd_coef_reduce(const float* __r
 template <int KIND>
 __global__ void __launch_bounds__(256) resample_bwd_vol_kernel(
     const float* __restrict__ gout, const float* __restrict__ coef, float* __restrict__ gvol,
-    long gvol_bstride, int N, int D, int H, int W, int C) {
+    long gvol_bstride, int N, int D, int H, int W, int C, Steps st) {
   const long per_sample = (long)D * H * W * C;
   const int n = blockIdx.y;
   const float* cf = coef + (long)n * LF_MAP_COEFS;
@@ -242,7 +249,7 @@ __global__ void __launch_bounds__(256) resample_bwd_vol_kernel(
     const int y = (int)(v % H);
     const int z = (int)(v / H);
     float gx, gy, gz, a, b, k;
-    eval_grid<KIND>(cf, x, y, z, W, H, D, gx, gy, gz, a, b, k);
+    eval_grid<KIND>(cf, x, y, z, W, H, D, st, gx, gy, gz, a, b, k);
     const Tap t = make_tap(gx, gy, gz, W, H, D);
     const float go = gout[(long)n * per_sample + idx];
     float* base = gvol + (long)n * gvol_bstride + c;
@@ -261,6 +268,14 @@ __global__ void __launch_bounds__(256) resample_bwd_vol_kernel(
 
 bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
+Steps make_steps(int D, int H, int W) {
+  Steps st;
+  st.w = W > 1 ? 1.0f / (float)(W - 1) : 0.f;
+  st.h = H > 1 ? 1.0f / (float)(H - 1) : 0.f;
+  st.d = D > 1 ? 1.0f / (float)(D - 1) : 0.f;
+  return st;
+}
+
 }  // namespace
 
 extern "C" int lf_resample3d_fwd(const float* vol, int vol_n, const float* coef, int kind, float* out,
@@ -269,11 +284,21 @@ extern "C" int lf_resample3d_fwd(const float* vol, int vol_n, const float* coef,
   if (vol_n != 1 && vol_n != N) return LF_EINVAL;
   if (kind != LF_MAP_O2C && kind != LF_MAP_C2O) return LF_EINVAL;
   const long bstride = vol_n == 1 ? 0 : (long)D * H * W * C;
+  if ((long)D * H * W >= 0x7fffffffL) return LF_EINVAL;
   const bool vec = (C % 4 == 0) && lf_aligned16(vol) && lf_aligned16(out);
-  const long items = (long)D * H * W * (vec ? C / 4 : C);
-  dim3 grid((unsigned)min((items + 255) / 256, (long)65535 * 16), N), block(256);
+  const int lpv = vec ? C / 4 : C;
+  const int lpt = lpv < 256 ? lpv : 256;
+  int lg = 0;                                            // log2(voxels per block), rounded down
+  while ((2 << lg) * lpt <= 256) ++lg;
+  int tlx, tly, tlz;                                     // log2 tile extents
+  if (lg >= 6) { tlx = (lg + 2) / 3; tly = (lg + 1) / 3; tlz = lg / 3; }      // 6:(2,2,2) 7:(3,2,2) 8:(3,3,2)
+  else         { tlx = lg < 2 ? lg : 2; tly = lg - tlx < 2 ? lg - tlx : 2; tlz = lg - tlx - tly; }   // 5:(2,2,1) 4:(2,2,0) ...
+  const int nbz = (D + (1 << tlz) - 1) >> tlz;
+  if ((long)nbz * N > 65535 || ((H + (1 << tly) - 1) >> tly) > 65535) return LF_EINVAL;
+  dim3 grid((unsigned)((W + (1 << tlx) - 1) >> tlx), (unsigned)((H + (1 << tly) - 1) >> tly), (unsigned)(nbz * N)), block(256);
+  const Steps st = make_steps(D, H, W);
   hipStream_t s = (hipStream_t)stream;
-#define LAUNCH(K, V) hipLaunchKernelGGL((resample_fwd_kernel<K, V>), grid, block, 0, s, vol, bstride, coef, out, N, D, H, W, C)
+#define LAUNCH(K, V) hipLaunchKernelGGL((resample_fwd_kernel<K, V>), grid, block, 0, s, vol, bstride, coef, out, N, D, H, W, C, lpt, tlx, tly, tlz, nbz, st)
   if (kind == LF_MAP_O2C) { if (vec) LAUNCH(LF_MAP_O2C, 4); else LAUNCH(LF_MAP_O2C, 1); }
   else                    { if (vec) LAUNCH(LF_MAP_C2O, 4); else LAUNCH(LF_MAP_C2O, 1); }
 #undef LAUNCH
@@ -293,6 +318,7 @@ extern "C" int lf_resample3d_bwd_coef(const float* gout, const float* vol, int v
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0) return LF_EINVAL;
   if (vol_n != 1 && vol_n != N) return LF_EINVAL;
   if (scratch_bytes < lf_resample3d_bwd_coef_scratch_bytes(N, D, H, W)) return LF_ENOSPC;
+  if ((long)D * H * W >= 0x7fffffffL) return LF_EINVAL;
   const long nvox = (long)D * H * W;
   const int vpb = bwd_vox_per_block(nvox, N);
   const int nblk = (int)((nvox + vpb - 1) / vpb);
@@ -307,9 +333,9 @@ extern "C" int lf_resample3d_bwd_coef(const float* gout, const float* vol, int v
   while (lpv < groups) lpv <<= 1;
   if (lpv > 64) return LF_EINVAL;                       // C > 256 (vec) / C > 64 (scalar)
   if (vec)
-    hipLaunchKernelGGL((resample_bwd_coef_kernel<4>), grid, block, 0, s, gout, vol, bstride, coef, partial, nblk, vpb, N, D, H, W, C, lpv);
+    hipLaunchKernelGGL((resample_bwd_coef_kernel<4>), grid, block, 0, s, gout, vol, bstride, coef, partial, nblk, vpb, N, D, H, W, C, lpv, make_steps(D, H, W));
   else
-    hipLaunchKernelGGL((resample_bwd_coef_kernel<1>), grid, block, 0, s, gout, vol, bstride, coef, partial, nblk, vpb, N, D, H, W, C, lpv);
+    hipLaunchKernelGGL((resample_bwd_coef_kernel<1>), grid, block, 0, s, gout, vol, bstride, coef, partial, nblk, vpb, N, D, H, W, C, lpv, make_steps(D, H, W));
   int st = lf_launch_status();
   if (st) return st;
   hipLaunchKernelGGL(resample_bwd_coef_reduce, dim3(N), dim3(256), 0, s, partial, nblk, gcoef);
@@ -325,9 +351,9 @@ extern "C" int lf_resample3d_bwd_vol(const float* gout, const float* coef, int k
   dim3 grid((unsigned)min((items + 255) / 256, (long)65535 * 16), N), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (kind == LF_MAP_O2C)
-    hipLaunchKernelGGL((resample_bwd_vol_kernel<LF_MAP_O2C>), grid, block, 0, s, gout, coef, gvol, bstride, N, D, H, W, C);
+    hipLaunchKernelGGL((resample_bwd_vol_kernel<LF_MAP_O2C>), grid, block, 0, s, gout, coef, gvol, bstride, N, D, H, W, C, make_steps(D, H, W));
   else if (kind == LF_MAP_C2O)
-    hipLaunchKernelGGL((resample_bwd_vol_kernel<LF_MAP_C2O>), grid, block, 0, s, gout, coef, gvol, bstride, N, D, H, W, C);
+    hipLaunchKernelGGL((resample_bwd_vol_kernel<LF_MAP_C2O>), grid, block, 0, s, gout, coef, gvol, bstride, N, D, H, W, C, make_steps(D, H, W));
   else
     return LF_EINVAL;
   return lf_launch_status();
