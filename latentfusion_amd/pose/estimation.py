@@ -288,7 +288,12 @@ class BatchedOptimizer:
         b1, b2, eps = 0.9, 0.999, 1e-8
         bc1, bc2 = 1 - b1 ** self.t, 1 - b2 ** self.t
         dev = self.params[0].device
-        host = torch.tensor([[l / bc1 for l in lr_rows], list(lr_rows)], dtype=torch.float32)
+        # pinned staging (two alternating buffers: the copy of step t-2 has long completed), so that the upload
+        # never makes the host wait for the stream
+        if not hasattr(self, '_pin') or self._pin[0].shape[1] != len(lr_rows):
+            self._pin = [torch.empty(2, len(lr_rows), dtype=torch.float32, pin_memory=True) for _ in range(2)]
+        host = self._pin[self.t & 1]
+        host.copy_(torch.tensor([[l / bc1 for l in lr_rows], list(lr_rows)], dtype=torch.float32))
         both = host.to(dev, non_blocking=True)
         wd = 1e-2 if self.name == 'adamw' else 0.0
         stream = torch.cuda.current_stream().cuda_stream
@@ -453,16 +458,48 @@ class GradientPoseEstimator(PoseEstimator):
         st['step'] += 1
         return st['converge_count'] >= self.converge_patience
 
-    def _iterate_engine(self, st):
-        """Same iteration on the fused engine: ONE device->host transfer (losses + parameters)."""
-        eng, P, step, target_obs = st['engine'], st['P'], st['step'], st['target']
+    def _engine_weights(self, st, step):
         optim_weights = copy.copy(self.loss_weights)
         if self.loss_schedules:
             optim_weights.update({k: v.get(step) for k, v in self.loss_schedules.items()})
-            eng.set_weights(optim_weights)
+            st['engine'].set_weights(optim_weights)
+        return optim_weights
+
+    def _engine_launch(self, st, step):
+        """Enqueues forward + backward of iteration `step` and the asynchronous read-back of its losses and
+        parameters (pinned buffer + event); nothing here waits for the GPU."""
+        eng, P = st['engine'], st['P']
+        optim_weights = self._engine_weights(st, step)
         with torch.no_grad():
             losses, gparams = eng.forward_backward(st['cam'], need_grad=True)
-            host = torch.cat((losses[:, :5], P.detach()), dim=1).cpu()            # the one D2H sync per iteration
+            dev = torch.cat((losses[:, :5], P.detach()), dim=1)
+        slot = st.setdefault('pinned', {})
+        key = step & 1
+        if key not in slot or slot[key].shape != dev.shape:
+            slot[key] = torch.empty(dev.shape, dtype=dev.dtype, pin_memory=True)
+        slot[key].copy_(dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return {'step': step, 'gparams': gparams, 'host': slot[key], 'event': ev, 'weights': optim_weights}
+
+    def _iterate_engine(self, st):
+        """Same iteration on the fused engine, software-pipelined against the host: the optimiser step of
+        iteration t needs only the learning rates decided after t-1, so it and the whole forward/backward of
+        t+1 are enqueued BEFORE the host waits for iteration t's losses (ranking, plateau scheduler,
+        convergence test).  Every quantity is computed exactly as in the sequential order; if the loop stops
+        at t the already-enqueued forward/backward of t+1 is simply never read.  ONE device->host transfer
+        (losses + parameters) per iteration."""
+        eng, P, step, target_obs = st['engine'], st['P'], st['step'], st['target']
+        cur = st.pop('inflight', None)
+        if cur is None or cur['step'] != step:
+            cur = self._engine_launch(st, step)
+        P.grad = cur['gparams']
+        st['opt'].step(st['sched'].lr)                                # lr after scheduler.step(loss[t-1])
+        if st.get('max_steps') is None or step + 1 < st['max_steps']:
+            st['inflight'] = self._engine_launch(st, step + 1)        # keeps the GPU busy while the host ranks
+        cur['event'].synchronize()                                    # the one D2H sync per iteration
+        host = cur['host'].clone()
+        optim_weights = cur['weights']
         comp = {k: host[:, i] for i, k in enumerate(eng.LOSS_KEYS)}
         rank = sum(self.loss_weights.get(k, 0.0) * comp[k] for k in eng.LOSS_KEYS)
         rank_host = rank.tolist()
@@ -478,8 +515,6 @@ class GradientPoseEstimator(PoseEstimator):
                 **{f'{k}_loss': v for k, v in comp.items()}, **{f'{k}_weight': v for k, v in optim_weights.items()},
                 'delta': delta, 'converge_count': st['converge_count'], 'angle_dist': angle, 'trans_dist': trans,
                 'optim_loss': host[:, 4].clone(), 'rank_loss': rank.clone()})
-        P.grad = gparams
-        st['opt'].step(st['sched'].lr)
         st['sched'].step(rank_host)
         if delta < self.converge_threshold:
             st['converge_count'] += 1
@@ -490,6 +525,7 @@ class GradientPoseEstimator(PoseEstimator):
 
     def _optimize_camera(self, z_obj, target_obs, cameras, iters, ranking):
         st = self.start(z_obj, target_obs, cameras, ranking)
+        st['max_steps'] = iters                                       # no speculative launch past the last iteration
         for _ in range(iters):
             if self.iterate(st):
                 break
