@@ -64,6 +64,12 @@ class Camera:
     def to(self, device):
         return self._map(lambda t: t.to(device))
 
+    def cpu(self):                                       # the reference's Camera is an nn.Module: .cpu()/.cuda() exist
+        return self.to('cpu')
+
+    def cuda(self, device=None):
+        return self.to('cuda' if device is None else device)
+
     def clone(self):
         return self._map(lambda t: t.clone())
 

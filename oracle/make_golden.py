@@ -451,21 +451,32 @@ def g12_latent_code(lf):
                              'latent_loss': ld['latent'].clone()})
 
 
+def g13_metrics(lf):
+    """Pose metrics (pose/metrics.py:19-109) on random model points and camera pairs."""
+    from latentfusion.pose import metrics
+    g = torch.Generator().manual_seed(70)
+    points = (torch.rand(1500, 3, generator=g) - 0.5) * torch.tensor([0.6, 0.4, 0.3])
+    gt = rand_cameras(lf, 3, seed=71)
+    ev = rand_cameras(lf, 3, seed=72)
+    ev.log_quaternion = gt.log_quaternion + 0.1 * torch.randn(3, 3, generator=g)
+    ev.translation = gt.translation + 0.02 * torch.randn(3, 3, generator=g)
+    out = []
+    for i in range(3):
+        m = metrics.camera_metrics(gt[i], ev[i], points, 0.35)
+        out.append({k: float(v) for k, v in m.items()})
+    save('g13_metrics', {'points': points, 'gt': cam_dict(gt), 'ev': cam_dict(ev), 'scale': 0.35, 'metrics': out})
+
+
 def main():
     lf = refharness.load_reference()
     import latentfusion.recon.utils  # noqa
     torch.set_num_threads(8)
-    g0_preprocess(lf)
-    g1_camera(lf)
-    g2_resample(lf)
-    g3_block(lf)
-    g4_fusers(lf)
-    g5_decode(lf)
-    g6_loss(lf)
-    g7_g10_loop(lf)
-    g9_ibr(lf)
-    g11_released_like(lf)
-    g12_latent_code(lf)
+    gens = [g0_preprocess, g1_camera, g2_resample, g3_block, g4_fusers, g5_decode, g6_loss, g7_g10_loop, g9_ibr,
+            g11_released_like, g12_latent_code, g13_metrics]
+    only = sys.argv[1:]                                  # e.g. `python oracle/make_golden.py g13` regenerates one group
+    for fn in gens:
+        if not only or any(fn.__name__.startswith(o + '_') or fn.__name__ == o for o in only):
+            fn(lf)
 
 
 if __name__ == '__main__':

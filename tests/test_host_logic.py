@@ -337,3 +337,25 @@ def test_from_checkpoint_training_format(golden, tmp_path):
     for k, v in g['photographer']['state_dict'].items():
         assert torch.equal(model.photographer.state_dict()[k], v)
     assert type(model.fuser).__name__ == 'GRUFuser'
+
+
+def test_pose_metrics_golden(golden):
+    """pose/metrics.py (rotation/translation distance, ADD, ADD-S, ADD-sym, Proj2D) against values computed
+    by the reference's own metrics module (oracle/make_golden.py:g13_metrics)."""
+    from latentfusion_amd.pose import metrics
+    g = golden('g13_metrics')
+    gt, ev = prod_camera(g['gt']), prod_camera(g['ev'])
+    got = metrics.camera_metrics(gt, ev, g['points'], g['scale'])
+    assert isinstance(got, list) and len(got) == 3
+    for m, want in zip(got, g['metrics']):
+        assert set(m) == set(want)
+        for k, v in want.items():
+            assert abs(float(m[k]) - v) <= 1e-5 * max(1.0, abs(v)), (k, float(m[k]), v)
+    one = metrics.camera_metrics(gt[1], ev[1], g['points'], g['scale'], use_add_s=False)
+    assert 'add_s' not in one and abs(float(one['add']) - g['metrics'][1]['add']) < 1e-6
+    cat = metrics.concat_camera_metrics(got)
+    assert len(cat['add']) == 3
+    # ADD-S <= ADD always; identical cameras score zero
+    assert all(float(m['add_s']) <= float(m['add']) + 1e-7 for m in got)
+    same = metrics.camera_metrics(gt[0], gt[0], g['points'], 1.0)
+    assert same['rotation_dist'] < 1e-3 and float(same['add']) < 1e-6
