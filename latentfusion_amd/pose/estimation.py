@@ -79,8 +79,10 @@ class PoseEstimator:
 
     @classmethod
     def initial_pose(cls, target_obs):
-        raise NotImplementedError('translation initialisation from depth (pose/initialization.py) is outside the '
-                                  'hot path: pass camera= / cameras= to estimate()')
+        """Translation from the target's depth and mask, identity rotation (reference :148-164)."""
+        from . import initialization
+        return initialization.estimate_initial_pose(target_obs.depth, target_obs.mask, target_obs.camera.intrinsic,
+                                                    target_obs.camera.width, target_obs.camera.height)
 
     def estimate(self, z_obj, target_obs, **kwargs):
         if len(target_obs) > 1:

@@ -467,12 +467,51 @@ def g13_metrics(lf):
     save('g13_metrics', {'points': points, 'gt': cam_dict(gt), 'ev': cam_dict(ev), 'scale': 0.35, 'metrics': out})
 
 
+def g14_initial_pose(lf):
+    """estimate_initial_pose (pose/initialization.py:59-99).  skimage is absent from this image: its
+    binary_erosion / disk (published algorithm: scipy.ndimage.binary_erosion with border_value=True over a
+    Euclidean disk) are supplied from scipy for the duration of the call; the reference discards the eroded
+    mask anyway (initialization.py:41-42)."""
+    import numpy as np
+    import scipy.ndimage as ndi
+    from latentfusion.pose import initialization as ini
+
+    class _Morph:
+        @staticmethod
+        def disk(r):
+            L = np.arange(-r, r + 1)
+            X, Y = np.meshgrid(L, L)
+            return (X ** 2 + Y ** 2 <= r ** 2).astype(np.uint8)
+
+        @staticmethod
+        def binary_erosion(img, selem=None):
+            return ndi.binary_erosion(img, structure=selem, border_value=True)
+    old, ini.morphology = ini.morphology, _Morph
+    try:
+        obs = synth_obs(lf, 2, seed=80)
+        depth = obs.depth[:, :, ::2, ::2].clone()                       # 240 x 320 keeps the fixture small
+        mask = obs.mask[:, :, ::2, ::2].clone()
+        g = torch.Generator().manual_seed(81)
+        # outliers for the MAD rejection and holes (depth 0 inside the mask)
+        depth[:, :, 120:123, 150:154] = 3.0
+        depth[:, :, 100:106, 160:166] = 0.0
+        depth = depth + 0.01 * torch.randn(depth.shape, generator=g) * mask
+        cam = ini.estimate_initial_pose(depth, mask, obs.camera.intrinsic, 320, 240)
+        save('g14_initial_pose', {'depth': depth, 'mask': mask.bool(), 'K': obs.camera.intrinsic.clone(),
+                                  'width': 320, 'height': 240,
+                                  'translation': cam.translation.clone(), 'log_q': cam.log_quaternion.clone(),
+                                  'extrinsic': cam.extrinsic.clone(),
+                                  'viewports': ini._masks_to_viewports(mask, 10.0).clone()})
+    finally:
+        ini.morphology = old
+
+
 def main():
     lf = refharness.load_reference()
     import latentfusion.recon.utils  # noqa
     torch.set_num_threads(8)
     gens = [g0_preprocess, g1_camera, g2_resample, g3_block, g4_fusers, g5_decode, g6_loss, g7_g10_loop, g9_ibr,
-            g11_released_like, g12_latent_code, g13_metrics]
+            g11_released_like, g12_latent_code, g13_metrics, g14_initial_pose]
     only = sys.argv[1:]                                  # e.g. `python oracle/make_golden.py g13` regenerates one group
     for fn in gens:
         if not only or any(fn.__name__.startswith(o + '_') or fn.__name__ == o for o in only):

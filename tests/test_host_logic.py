@@ -359,3 +359,25 @@ def test_pose_metrics_golden(golden):
     assert all(float(m['add_s']) <= float(m['add']) + 1e-7 for m in got)
     same = metrics.camera_metrics(gt[0], gt[0], g['points'], 1.0)
     assert same['rotation_dist'] < 1e-3 and float(same['add']) < 1e-6
+
+
+def test_initial_pose_golden(golden):
+    """pose/initialization.py against the reference (golden g14): mask viewports, MAD outlier rejection,
+    translation estimate, identity rotation; PoseEstimator.initial_pose goes through it."""
+    from latentfusion_amd.modules.geometry import Camera
+    from latentfusion_amd.observation import Observation
+    from latentfusion_amd.pose import estimation, initialization
+    g = golden('g14_initial_pose')
+    mask = g['mask'].float()
+    close(initialization._masks_to_viewports(mask, 10.0), g['viewports'], atol=0, rtol=0)
+    cam = initialization.estimate_initial_pose(g['depth'], mask, g['K'], g['width'], g['height'])
+    close(cam.translation, g['translation'], atol=1e-6, rtol=1e-6)
+    close(cam.log_quaternion, g['log_q'], atol=1e-7, rtol=0)
+    close(cam.extrinsic, g['extrinsic'], atol=1e-6, rtol=1e-6)
+    obs = Observation(None, g['depth'][:1], mask[:1], Camera(g['K'][:1], torch.eye(4).unsqueeze(0), width=g['width'], height=g['height']))
+    cam1 = estimation.PoseEstimator.initial_pose(obs)
+    close(cam1.translation, g['translation'][:1], atol=1e-6, rtol=1e-6)
+    # the erosion itself (discarded by the reference's guard, see the module docstring) is a real erosion
+    m = torch.zeros(1, 9, 9, dtype=torch.bool)
+    m[0, 2:7, 2:7] = True
+    assert initialization._erode_mask(m, size=1) is m
