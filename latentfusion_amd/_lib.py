@@ -75,6 +75,11 @@ def lib():
             _build.build(verbose=False)
         except Exception as e:  # noqa: BLE001
             raise LFHipError(f'liblf_hip.so is missing at {LIB_PATH} and could not be built: {e}') from e
+    # PyTorch-ROCm ships its own libamdhip64.so and opens it by path.  If liblf_hip.so (linked against the
+    # system HIP runtime) were loaded first, the process would end up with TWO HIP runtimes and the one torch
+    # did not initialise would see no device.  Importing torch first makes the loader bind liblf_hip.so's
+    # libamdhip64 dependency to the copy that is already resident.
+    import torch  # noqa: F401
     try:
         handle = ctypes.CDLL(LIB_PATH)
     except OSError as e:

@@ -646,6 +646,7 @@ __global__ void __launch_bounds__(256) conv1x1_kernel(
 }  // namespace
 
 extern "C" int lf_conv3x3_cout_padded(int Cout) {
+  lf_clear_error();
   const int c16 = (Cout + 15) & ~15;
   if (c16 <= 16) return 16;
   if (c16 <= 32) return 32;
@@ -653,6 +654,7 @@ extern "C" int lf_conv3x3_cout_padded(int Cout) {
 }
 
 extern "C" int lf_conv1x1_cout_padded(int Cout) {
+  lf_clear_error();
   const int c16 = (Cout + 15) & ~15;
   if (c16 <= 16) return 16;
   if (c16 <= 32) return 32;
@@ -726,6 +728,7 @@ static int conv3x3_launch(const float* x, const float* wpack, const float* bias,
 extern "C" int lf_conv3x3_fwd(const float* x, const float* wpack, const float* bias, float* y, float* norm_out,
                               int dims, int N, int D, int H, int W, int Cin, int Cout,
                               float he, unsigned flags, float slope, float eps, void* stream) {
+  lf_clear_error();
   return conv3x3_launch(x, wpack, bias, y, norm_out, dims, N, D, H, W, Cin, Cout, he, flags, slope, eps, stream,
                         nullptr, nullptr, 0);
 }
@@ -733,6 +736,7 @@ extern "C" int lf_conv3x3_fwd(const float* x, const float* wpack, const float* b
 extern "C" int lf_conv3x3_bwd_data(const float* gy, const float* wpack_t, float* gx, int dims, int N, int D, int H, int W,
                                    int Cin, int Cout, float he, const float* prev_y, const float* prev_norm,
                                    unsigned prev_flags, float slope, void* stream) {
+  lf_clear_error();
   return conv3x3_launch(gy, wpack_t, nullptr, gx, nullptr, dims, N, D, H, W, Cin, Cout, he, 0, slope, 0.f, stream,
                         prev_y, prev_norm, prev_flags);
 }
@@ -782,6 +786,7 @@ extern "C" int lf_conv1x1_fwd(const float* x, const float* wpack, const float* b
                               int Cout, long y_batch_stride, int y_row_stride, int y_slice_channels,
                               long y_slice_stride,
                               float he, unsigned flags, float slope, float eps, void* stream) {
+  lf_clear_error();
   return conv1x1_launch(x, wpack, bias, y, norm_out, N, P, Cin, ksl, x_batch_stride, x_slice_stride, Cout,
                         y_batch_stride, y_row_stride, y_slice_channels, y_slice_stride, he, flags, slope, eps, stream,
                         nullptr, nullptr, 0);
@@ -791,6 +796,7 @@ extern "C" int lf_conv1x1_bwd_data(const float* gy, const float* wpack_t, float*
                                    long y_batch_stride, int y_row_stride, int y_slice_channels, long y_slice_stride,
                                    float he, const float* prev_y, const float* prev_norm, unsigned prev_flags,
                                    float slope, float* amax_out, void* stream) {
+  lf_clear_error();
   return conv1x1_launch(gy, wpack_t, nullptr, gx, nullptr, N, P, Cin, 1, (long)P * Cin, 0, Cout, y_batch_stride,
                         y_row_stride, y_slice_channels, y_slice_stride, he, 0, slope, 0.f, stream, prev_y, prev_norm,
                         prev_flags, amax_out);

@@ -406,6 +406,7 @@ extern "C" int lf_conv3d_c16_wino(const float* x, const float* upack, const floa
                                   int N, int D, int H, int W, float he, unsigned flags, float slope, float eps,
                                   const float* prev_y, const float* prev_norm, unsigned prev_flags,
                                   float* amax_out, void* stream) {
+  lf_clear_error();
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0) return LF_EINVAL;
   if ((long)D * H * W * 64 >= 0x7fffffffL || !(slope > 0.f && slope < 1.f)) return LF_EINVAL;
   if (!lf_aligned16(x) || !lf_aligned16(y) || !lf_aligned16(upack) || (bias && !lf_aligned16(bias))) return LF_EALIGN;

@@ -371,6 +371,7 @@ constexpr int LOSS_NBLK = 240;    // blocks per sample over the 480x640 frame (5
 
 extern "C" int lf_camera_coefs(const float* params, const float* intrinsics, float cube_size, float z_span,
                                int crop_h, int crop_w, float* coefs, float* jac, int N, void* stream) {
+  lf_clear_error();
   if (N <= 0 || crop_h <= 0 || crop_w <= 0 || cube_size <= 0.f) return LF_EINVAL;
   hipLaunchKernelGGL(camera_coefs_kernel, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, params, intrinsics,
                      cube_size, z_span, crop_h, crop_w, coefs, jac, N);
@@ -378,6 +379,7 @@ extern "C" int lf_camera_coefs(const float* params, const float* intrinsics, flo
 }
 
 extern "C" int lf_camera_coefs_bwd(const float* gcoefs, const float* jac, float* gparams, int N, void* stream) {
+  lf_clear_error();
   if (N <= 0) return LF_EINVAL;
   hipLaunchKernelGGL(camera_coefs_bwd_kernel, dim3((N * NP + 63) / 64), dim3(64), 0, (hipStream_t)stream, gcoefs, jac,
                      gparams, N);
@@ -393,6 +395,7 @@ extern "C" int lf_pose_loss_fwd(const float* logits, const float* coefs, const f
                                 const float* target_mask, const float* weights, float* sums, float* losses,
                                 float* gsums, void* scratch, size_t scratch_bytes,
                                 int N, int h, int w, int H, int W, void* stream) {
+  lf_clear_error();
   if (N <= 0 || h <= 1 || w <= 1 || H <= 0 || W <= 0) return LF_EINVAL;
   if (scratch_bytes < lf_pose_loss_scratch_bytes(N, h, w, H, W)) return LF_ENOSPC;
   hipStream_t s = (hipStream_t)stream;
@@ -409,6 +412,7 @@ extern "C" int lf_pose_loss_fwd(const float* logits, const float* coefs, const f
 extern "C" int lf_pose_loss_bwd(const float* logits, const float* coefs, const float* target_depth,
                                 const float* target_mask, const float* gsums, float* glogits, float* gcoefs,
                                 void* scratch, size_t scratch_bytes, int N, int h, int w, int H, int W, void* stream) {
+  lf_clear_error();
   if (N <= 0 || h <= 1 || w <= 1 || H <= 0 || W <= 0) return LF_EINVAL;
   if (scratch_bytes < lf_pose_loss_scratch_bytes(N, h, w, H, W)) return LF_ENOSPC;
   hipStream_t s = (hipStream_t)stream;

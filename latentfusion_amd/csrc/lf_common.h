@@ -8,6 +8,10 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// hipGetLastError() is sticky per thread and shared with every other HIP user in the process (the host
+// framework included): each entry point clears it first so that lf_launch_status() reports only its own launch.
+static inline void lf_clear_error() { (void)hipGetLastError(); }
+
 static inline int lf_launch_status() {
   hipError_t e = hipGetLastError();
   return (int)e;

@@ -28,6 +28,7 @@ __global__ void adam_step_kernel(float* __restrict__ p, const float* __restrict_
 extern "C" int lf_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                             const float* step_size, const float* lr, float bias_correction2_sqrt,
                             float beta1, float beta2, float eps, float weight_decay, int N, int P, void* stream) {
+  lf_clear_error();
   if (N <= 0 || P <= 0) return LF_EINVAL;
   hipLaunchKernelGGL(adam_step_kernel, dim3((N * P + 127) / 128), dim3(128), 0, (hipStream_t)stream, params, grads, exp_avg,
                      exp_avg_sq, step_size, lr, bias_correction2_sqrt, beta1, beta2, eps, weight_decay, N, P);

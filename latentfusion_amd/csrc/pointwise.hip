@@ -162,16 +162,19 @@ int launch_rows(const float* a, const float* b, const float* nrm_in, float* out,
 }  // namespace
 
 extern "C" int lf_pixelnorm_fwd(const float* x, float* y, float* norm_out, long rows, int C, float eps, void* stream) {
+  lf_clear_error();
   return launch_rows<0>(x, nullptr, nullptr, y, norm_out, rows, C, LF_EPI_PIXELNORM, 0.f, eps, (hipStream_t)stream);
 }
 
 extern "C" int lf_epilogue_bwd(const float* gy, const float* y, const float* norm, float* gp,
                                long rows, int C, unsigned flags, float slope, void* stream) {
+  lf_clear_error();
   if ((flags & LF_EPI_PIXELNORM) && norm == nullptr) return LF_EINVAL;
   return launch_rows<1>(gy, y, norm, gp, nullptr, rows, C, flags, slope, 0.f, (hipStream_t)stream);
 }
 
 extern "C" int lf_nchw_to_nhwc(const float* src, float* dst, int N, int C, long P, void* stream) {
+  lf_clear_error();
   if (N <= 0 || C <= 0 || P <= 0) return LF_EINVAL;
   dim3 grid((unsigned)((P + 31) / 32), (unsigned)((C + 31) / 32), N);
   hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, dst, C, P);
@@ -179,6 +182,7 @@ extern "C" int lf_nchw_to_nhwc(const float* src, float* dst, int N, int C, long 
 }
 
 extern "C" int lf_nhwc_to_nchw(const float* src, float* dst, int N, int C, long P, void* stream) {
+  lf_clear_error();
   if (N <= 0 || C <= 0 || P <= 0) return LF_EINVAL;
   if (P > 0x7fffffffL) return LF_EINVAL;
   // src [n][P][C] -> dst [n][C][P]: the same transpose with R = P, Q = C
@@ -189,6 +193,7 @@ extern "C" int lf_nhwc_to_nchw(const float* src, float* dst, int N, int C, long 
 
 extern "C" int lf_lift_unfold(const float* src, const float* norm_or_null, float* dst,
                               int N, long P, int C0, int S, void* stream) {
+  lf_clear_error();
   if (N <= 0 || P <= 0 || C0 <= 0 || S <= 0) return LF_EINVAL;
   const size_t shmem = (size_t)C0 * S * sizeof(float);
   if (shmem > 64 * 1024) return LF_EINVAL;
@@ -197,9 +202,11 @@ extern "C" int lf_lift_unfold(const float* src, const float* norm_or_null, float
   return lf_launch_status();
 }
 
-extern "C" int lf_abi_version(void) { return LF_ABI_VERSION; }
+extern "C" int lf_abi_version(void) {
+  lf_clear_error(); return LF_ABI_VERSION; }
 
 extern "C" int lf_device_name(char* buf, int buflen) {
+  lf_clear_error();
   hipDeviceProp_t prop;
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);

@@ -280,6 +280,7 @@ Steps make_steps(int D, int H, int W) {
 
 extern "C" int lf_resample3d_fwd(const float* vol, int vol_n, const float* coef, int kind, float* out,
                                  int N, int D, int H, int W, int C, void* stream) {
+  lf_clear_error();
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0) return LF_EINVAL;
   if (vol_n != 1 && vol_n != N) return LF_EINVAL;
   if (kind != LF_MAP_O2C && kind != LF_MAP_C2O) return LF_EINVAL;
@@ -315,6 +316,7 @@ extern "C" size_t lf_resample3d_bwd_coef_scratch_bytes(int N, int D, int H, int 
 extern "C" int lf_resample3d_bwd_coef(const float* gout, const float* vol, int vol_n, const float* coef,
                                       float* gcoef, void* scratch, size_t scratch_bytes,
                                       int N, int D, int H, int W, int C, void* stream) {
+  lf_clear_error();
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0) return LF_EINVAL;
   if (vol_n != 1 && vol_n != N) return LF_EINVAL;
   if (scratch_bytes < lf_resample3d_bwd_coef_scratch_bytes(N, D, H, W)) return LF_ENOSPC;
@@ -344,6 +346,7 @@ extern "C" int lf_resample3d_bwd_coef(const float* gout, const float* vol, int v
 
 extern "C" int lf_resample3d_bwd_vol(const float* gout, const float* coef, int kind, float* gvol, int vol_n,
                                      int N, int D, int H, int W, int C, void* stream) {
+  lf_clear_error();
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0) return LF_EINVAL;
   if (vol_n != 1 && vol_n != N) return LF_EINVAL;
   const long bstride = vol_n == 1 ? 0 : (long)D * H * W * C;

@@ -121,6 +121,7 @@ static int resize_dims(int dims, int up, int Di, int Hi, int Wi, int& Do, int& H
 
 extern "C" int lf_resize_fwd(const float* x, float* y, int dims, int N, int D, int H, int W, int C, int linear, int up,
                              void* stream) {
+  lf_clear_error();
   int Do, Ho, Wo;
   if (N <= 0 || C <= 0 || resize_dims(dims, up, D, H, W, Do, Ho, Wo)) return LF_EINVAL;
   const long items = (long)Do * Ho * Wo * C;
@@ -131,6 +132,7 @@ extern "C" int lf_resize_fwd(const float* x, float* y, int dims, int N, int D, i
 
 extern "C" int lf_resize_bwd(const float* gy, float* gx, int dims, int N, int D, int H, int W, int C, int linear, int up,
                              void* stream) {
+  lf_clear_error();
   int Do, Ho, Wo;
   if (N <= 0 || C <= 0 || resize_dims(dims, up, D, H, W, Do, Ho, Wo)) return LF_EINVAL;
   const long items = (long)D * H * W * C;
