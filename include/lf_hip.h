@@ -161,6 +161,16 @@ int lf_conv3d_c16_wino(const float* x, const float* upack, const float* bias, fl
                        const float* prev_y, const float* prev_norm, unsigned prev_flags,
                        float* amax_out, void* stream);
 
+/* Weight gradient of the He-equalised conv (training step; autograd of equalized.py:57-64):
+ *   gw[tap][co][ci] = scale * sum_v gpre[v][co] * x[v + tap][ci],   tap = (kz*3 + ky)*3 + kx, zero padding,
+ * dims = 3 (27 taps), 2 (9 taps, D = 1) or 0 (pointwise: one tap, rows = N*D*H*W).  x, gpre channels-last
+ * [N][D][H][W][C]; gpre is the gradient w.r.t. the pre-activation (after lf_epilogue_bwd); scale = he.
+ * x == NULL: all-ones single-channel input, i.e. gw[0][co][0] = sum_v gpre[v][co] (bias gradient, scale 1).
+ * Deterministic: per-block partials in `scratch` (lf_conv_bwd_weight_scratch_bytes), fixed-order fp64 sum. */
+size_t lf_conv_bwd_weight_scratch_bytes(int dims, int N, int D, int H, int W, int Cin, int Cout);
+int lf_conv_bwd_weight(const float* x, const float* gpre, float* gw, void* scratch, size_t scratch_bytes,
+                       int dims, int N, int D, int H, int W, int Cin, int Cout, float scale, void* stream);
+
 /* Standalone PixelNorm over the last (channel) axis of [rows][C], in place allowed.
  * norm_out[rows] receives sqrt(mean+eps).  modules/__init__.py:14-15. */
 int lf_pixelnorm_fwd(const float* x, float* y, float* norm_out, long rows, int C, float eps, void* stream);

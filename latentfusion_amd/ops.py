@@ -309,9 +309,33 @@ def _epilogue_bwd(gy, y, norm, flags):
     return gp
 
 
+def conv_bwd_weight(x, gp, dims, cin, he):
+    """Weight and bias gradients of y = conv(x, W) * he + b from the pre-activation gradient `gp`
+    (lf_conv_bwd_weight).  x, gp: channels-last (N,C,[D,]H,W), or plain [rows][C] matrices for dims = 0.
+    Returns (gw [taps][Cout][Cin], gb [Cout])."""
+    L = _lib.lib()
+    if dims == 0:
+        rows, cout = gp.shape[0], gp.shape[1]
+        N, D, H, W = 1, 1, 1, rows
+    else:
+        N, cout = gp.shape[0], gp.shape[1]
+        D, H, W = (gp.shape[2:] if dims == 3 else (1,) + tuple(gp.shape[2:]))
+    taps = {0: 1, 2: 9, 3: 27}[dims]
+    gw = torch.empty(taps, cout, cin, device=gp.device, dtype=torch.float32)
+    gb = torch.empty(1, cout, 1, device=gp.device, dtype=torch.float32)
+    nbytes = max(L.lf_conv_bwd_weight_scratch_bytes(dims, N, D, H, W, cin, cout),
+                 L.lf_conv_bwd_weight_scratch_bytes(0, N, D, H, W, 0, cout))
+    scratch = torch.empty(nbytes // 4 + 1, device=gp.device, dtype=torch.float32)
+    check(L.lf_conv_bwd_weight(_ptr(x), _ptr(gp), _ptr(gw), _ptr(scratch), scratch.numel() * 4, dims, N, D, H, W, cin, cout,
+                               he, _stream()), 'lf_conv_bwd_weight')
+    check(L.lf_conv_bwd_weight(None, _ptr(gp), _ptr(gb), _ptr(scratch), scratch.numel() * 4, 0, N, D, H, W, 0, cout,
+                               1.0, _stream()), 'lf_conv_bwd_weight')
+    return gw, gb.reshape(cout)
+
+
 class _Conv3x3(torch.autograd.Function):
-    """x -> epilogue(conv3x3(x, W) * he + b).  Data gradient only: the hot loop never needs
-    weight gradients; asking for them raises."""
+    """x -> epilogue(conv3x3(x, W) * he + b).  The input is kept for the weight gradient only when the
+    weight or bias asks for one (the pose loop never does)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, flags):
@@ -322,21 +346,27 @@ class _Conv3x3(torch.autograd.Function):
         y, norm = _conv3x3_raw(x, wpack, bias.detach() if bias is not None else None, weight.shape[0], he, flags, True)
         ctx.flags, ctx.he = flags, he
         ctx.weight = weight
+        ctx.x = x if (weight.requires_grad or (bias is not None and bias.requires_grad)) else None
         ctx.save_for_backward(y, norm) if norm is not None else ctx.save_for_backward(y)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            raise NotImplementedError('weight gradients are outside the inference hot path (training step: SURVEY 8f)')
         saved = ctx.saved_tensors
         y = saved[0]
         norm = saved[1] if len(saved) > 1 else None
         gp = _epilogue_bwd(cl(gy), y, norm, ctx.flags)
         w = ctx.weight
-        wpack_t = _cached(w, 'c3b', lambda: pack_conv3x3(w, transpose=True))
-        gx, _ = _conv3x3_raw(gp, wpack_t, None, w.shape[1], ctx.he, 0, False)
-        return gx, None, None, None
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            wpack_t = _cached(w, 'c3b', lambda: pack_conv3x3(w, transpose=True))
+            gx, _ = _conv3x3_raw(gp, wpack_t, None, w.shape[1], ctx.he, 0, False)
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dims = w.dim() - 2
+            gwt, gb = conv_bwd_weight(ctx.x, gp, dims, w.shape[1], ctx.he)
+            k = (3,) * dims
+            gw = gwt.reshape(*k, w.shape[0], w.shape[1]).permute(dims, dims + 1, *range(dims)).contiguous()
+        return gx, gw if ctx.needs_input_grad[1] else None, gb if ctx.needs_input_grad[2] else None, None
 
 
 def conv3x3(x, weight, bias, lrelu=True, pixelnorm=True):
@@ -376,25 +406,31 @@ class _Conv1x1(torch.autograd.Function):
         y = empty_cl((N, cout) + tuple(x.shape[2:]), x.device)
         norm = _conv1x1_raw(x, wpack, bias.detach() if bias is not None else None, N, P, cin, 1, P * cin, 0, cout, y, he, flags)
         ctx.flags, ctx.he, ctx.weight = flags, he, weight
+        ctx.x = x if (weight.requires_grad or (bias is not None and bias.requires_grad)) else None
         ctx.save_for_backward(y, norm) if norm is not None else ctx.save_for_backward(y)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            raise NotImplementedError('weight gradients are outside the inference hot path (training step: SURVEY 8f)')
         saved = ctx.saved_tensors
         y = saved[0]
         norm = saved[1] if len(saved) > 1 else None
         gp = _epilogue_bwd(cl(gy), y, norm, ctx.flags)
         w = ctx.weight
         cout, cin = w.shape[0], w.shape[1]
-        wpack_t = _cached(w, 'c1b', lambda: pack_conv1x1(w.reshape(cout, cin).t()))
-        N = gp.shape[0]
-        P = gp[0, 0].numel()
-        gx = empty_cl((N, cin) + tuple(gp.shape[2:]), gp.device)
-        _conv1x1_raw(gp, wpack_t, None, N, P, cout, 1, P * cout, 0, cin, gx, ctx.he, 0)
-        return gx, None, None, None
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            wpack_t = _cached(w, 'c1b', lambda: pack_conv1x1(w.reshape(cout, cin).t()))
+            N = gp.shape[0]
+            P = gp[0, 0].numel()
+            gx = empty_cl((N, cin) + tuple(gp.shape[2:]), gp.device)
+            _conv1x1_raw(gp, wpack_t, None, N, P, cout, 1, P * cout, 0, cin, gx, ctx.he, 0)
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            rows = gp.numel() // cout                                       # channels-last: plain [rows][C] matrices
+            gwt, gb = conv_bwd_weight(ctx.x.permute(0, *range(2, ctx.x.dim()), 1).reshape(rows, cin),
+                                      gp.permute(0, *range(2, gp.dim()), 1).reshape(rows, cout), 0, cin, ctx.he)
+            gw = gwt.reshape(w.shape)
+        return gx, gw if ctx.needs_input_grad[1] else None, gb if ctx.needs_input_grad[2] else None, None
 
 
 def conv1x1(x, weight, bias, lrelu=False, pixelnorm=False):
@@ -423,13 +459,12 @@ class _FactorProject(torch.autograd.Function):
         norm = _conv1x1_raw(x, wpack, bias.detach() if bias is not None else None, N, H * W, C, D,
                             D * H * W * C, H * W * C, cout, y, he, flags)
         ctx.flags, ctx.he, ctx.weight, ctx.xshape = flags, he, weight, x.shape
+        ctx.x = x if (weight.requires_grad or (bias is not None and bias.requires_grad)) else None
         ctx.save_for_backward(y, norm)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            raise NotImplementedError('weight gradients are outside the inference hot path (training step: SURVEY 8f)')
         y, norm = ctx.saved_tensors
         gp = _epilogue_bwd(cl(gy), y, norm, ctx.flags)
         N, C, D, H, W = ctx.xshape
@@ -441,7 +476,13 @@ class _FactorProject(torch.autograd.Function):
         gx = empty_cl((N, C, D, H, W), gp.device)
         _conv1x1_raw(gp, wt, None, N, H * W, cout, 1, H * W * cout, 0, D * C, gx, ctx.he, 0,
                      yaddr=(D * H * W * C, C, C, H * W * C))
-        return gx, None, None
+        gw = gb = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            # rows = pixels, K = (c, d) in the reference's order c*D + d: one copy of the volume (training only)
+            xr = ctx.x.permute(0, 3, 4, 1, 2).reshape(N * H * W, C * D)
+            gwt, gb = conv_bwd_weight(xr.contiguous(), gp.permute(0, 2, 3, 1).reshape(N * H * W, cout), 0, C * D, ctx.he)
+            gw = gwt.reshape(w.shape)
+        return gx, gw if ctx.needs_input_grad[1] else None, gb if ctx.needs_input_grad[2] else None
 
 
 def factor_project(x, weight, bias):

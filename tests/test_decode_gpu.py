@@ -5,6 +5,9 @@ North-star tolerance: rendered depth / mask within 1e-3 relative of the referenc
 import pytest
 import torch
 
+import lf_oracle as O
+from lf_oracle import nets
+
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
 
@@ -165,3 +168,32 @@ def test_g12_latent_code_on_hip(golden):
     close(zt, g['z_target_latent'], atol=3e-4, rtol=3e-3)
     close(zp, g['z_pred_latent'], atol=3e-4, rtol=3e-3)
     close(ld['latent'], g['latent_loss'], atol=1e-4, rtol=1e-3)
+
+
+@pytest.mark.parametrize('variant', ['factor', 'sum'])
+def test_photographer_parameter_gradients(golden, variant):
+    """Training-step side: d(loss)/d(every Photographer weight and bias) through the HIP
+    weight-gradient kernels against autograd of the CPU oracle on the same checkpoint and inputs."""
+    import copy
+    from latentfusion_amd.recon.models import Photographer
+    r = golden('g5_decode')[variant]
+    ck = copy.deepcopy(r['ck'])
+    osd = {k: v.clone().requires_grad_(True) for k, v in ck['state_dict'].items()}
+    ocam = O.Cam(r['cam']['K'], r['cam']['log_q'], r['cam']['t'], viewport=r['cam']['viewport'], z_span=r['cam']['z_span'],
+                 width=r['cam']['width'], height=r['cam']['height'])
+    y, _, _ = nets.decode({'args': ck['args'], 'state_dict': osd}, r['z_obj'], ocam, apply_mask=True)
+    ((y['depth_logits'] * r['wd']).sum() + (y['mask_logits'] * r['wm']).sum()).backward()
+    ph = Photographer.from_checkpoint(r['ck']).to(DEV)
+    ph.requires_grad_(True)
+    cam = prod_camera(r['cam'])
+    yp, _, _ = ph.decode(r['z_obj'].to(DEV), cam, return_latent=True, apply_mask=True)
+    ((yp['depth_logits'] * r['wd'].to(DEV)).sum() + (yp['mask_logits'] * r['wm'].to(DEV)).sum()).backward()
+    checked = 0
+    for name, p in ph.named_parameters():
+        want = osd[name].grad
+        assert want is not None and p.grad is not None, name
+        # relative L2 per tensor (same LeakyReLU slope-flip sensitivity as the camera gradients above)
+        rel = ((p.grad.cpu() - want).norm() / want.norm().clamp(min=1e-6)).item()
+        assert rel < 1e-2, (name, rel)
+        checked += 1
+    assert checked >= 10

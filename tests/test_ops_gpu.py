@@ -139,17 +139,21 @@ def test_conv3x3_vs_torch(dims, cin, cout, S):
     g = torch.Generator().manual_seed(dims * 1000 + cin * 10 + cout)
     shape = (2, cin) + (S,) * dims
     x = torch.randn(shape, generator=g, requires_grad=True)
-    w = torch.randn((cout, cin) + (3,) * dims, generator=g)
-    b = torch.randn(cout, generator=g) * 0.1
+    w = torch.randn((cout, cin) + (3,) * dims, generator=g, requires_grad=True)
+    b = (torch.randn(cout, generator=g) * 0.1).requires_grad_(True)
     sd = {'c.module.weight': w, 'c.bias': b}
     want = nets.act_norm(nets.eq_conv(x, sd, 'c', 1))
     gw = torch.randn(want.shape, generator=g)
     (want * gw).sum().backward()
     xd = x.detach().to(DEV).requires_grad_(True)
-    got = ops.conv3x3(xd, w.to(DEV), b.to(DEV), lrelu=True, pixelnorm=True)
+    wd, bd = w.detach().to(DEV).requires_grad_(True), b.detach().to(DEV).requires_grad_(True)
+    got = ops.conv3x3(xd, wd, bd, lrelu=True, pixelnorm=True)
     close(got, want, atol=3e-5)
     (got * gw.to(DEV)).sum().backward()
     close(xd.grad, x.grad, atol=3e-4, rtol=1e-3)
+    # weight / bias gradients (lf_conv_bwd_weight: training step)
+    close(wd.grad, w.grad, atol=2e-4 * w.grad.abs().max().item(), rtol=1e-3)
+    close(bd.grad, b.grad, atol=2e-4 * b.grad.abs().max().item(), rtol=1e-3)
 
 
 @pytest.mark.parametrize('cin,cout,act,norm', [(16, 2, False, False), (4, 16, True, False), (35, 16, True, True),
@@ -158,8 +162,8 @@ def test_conv1x1_vs_torch(cin, cout, act, norm):
     from latentfusion_amd import ops
     g = torch.Generator().manual_seed(cin * 7 + cout)
     x = torch.randn(2, cin, 9, 11, generator=g, requires_grad=True)
-    w = torch.randn(cout, cin, 1, 1, generator=g)
-    b = torch.randn(cout, generator=g) * 0.1
+    w = torch.randn(cout, cin, 1, 1, generator=g, requires_grad=True)
+    b = (torch.randn(cout, generator=g) * 0.1).requires_grad_(True)
     want = nets.eq_conv(x, {'c.module.weight': w, 'c.bias': b}, 'c', 0)
     if act:
         want = torch.nn.functional.leaky_relu(want, 0.2)
@@ -168,10 +172,13 @@ def test_conv1x1_vs_torch(cin, cout, act, norm):
     gw = torch.randn(want.shape, generator=g)
     (want * gw).sum().backward()
     xd = x.detach().to(DEV).requires_grad_(True)
-    got = ops.conv1x1(xd, w.to(DEV), b.to(DEV), lrelu=act, pixelnorm=norm)
+    wd, bd = w.detach().to(DEV).requires_grad_(True), b.detach().to(DEV).requires_grad_(True)
+    got = ops.conv1x1(xd, wd, bd, lrelu=act, pixelnorm=norm)
     close(got, want, atol=3e-5)
     (got * gw.to(DEV)).sum().backward()
     close(xd.grad, x.grad, atol=3e-4, rtol=1e-3)
+    close(wd.grad, w.grad, atol=2e-4 * w.grad.abs().max().item(), rtol=1e-3)
+    close(bd.grad, b.grad, atol=2e-4 * b.grad.abs().max().item(), rtol=1e-3)
 
 
 @pytest.mark.parametrize('C,S,cout', [(16, 16, 16), (32, 8, 16), (16, 12, 8)])
@@ -179,16 +186,19 @@ def test_factor_projection_vs_torch(C, S, cout):
     from latentfusion_amd import ops
     g = torch.Generator().manual_seed(C + S)
     x = torch.randn(2, C, S, S, S, generator=g, requires_grad=True)
-    w = torch.randn(cout, C * S, 1, 1, generator=g)
-    b = torch.randn(cout, generator=g) * 0.1
+    w = torch.randn(cout, C * S, 1, 1, generator=g, requires_grad=True)
+    b = (torch.randn(cout, generator=g) * 0.1).requires_grad_(True)
     want = nets.act_norm(nets.eq_conv(x.view(2, C * S, S, S), {'c.module.weight': w, 'c.bias': b}, 'c', 0))
     gw = torch.randn(want.shape, generator=g)
     (want * gw).sum().backward()
     xd = x.detach().to(DEV).requires_grad_(True)
-    got = ops.factor_project(xd, w.to(DEV), b.to(DEV))
+    wd, bd = w.detach().to(DEV).requires_grad_(True), b.detach().to(DEV).requires_grad_(True)
+    got = ops.factor_project(xd, wd, bd)
     close(got, want, atol=5e-5)
     (got * gw.to(DEV)).sum().backward()
     close(xd.grad, x.grad, atol=3e-4, rtol=1e-3)
+    close(wd.grad, w.grad, atol=2e-4 * w.grad.abs().max().item(), rtol=1e-3)
+    close(bd.grad, b.grad, atol=2e-4 * b.grad.abs().max().item(), rtol=1e-3)
 
 
 @pytest.mark.parametrize('cin,c0,S', [(16, 8, 16), (16, 16, 8), (12, 4, 8)])
