@@ -491,13 +491,18 @@ def factor_project(x, weight, bias):
 
 def lift(x, weight, bias, out_size):
     """FactorProjection2d3d (modules/geometry.py:711-728): 1x1 conv to C0*S channels, LeakyReLU,
-    PixelNorm over ALL C0*S channels, viewed as (V,C0,S,H,W).  Inference-only (no autograd)."""
+    PixelNorm over ALL C0*S channels, viewed as (V,C0,S,H,W).  The fused unfold below is the inference path;
+    when a gradient is wanted the same result is composed from the differentiable pointwise conv and a
+    layout copy."""
     L = _lib.lib()
     _req(x, 'x')
     x = cl(x)
     V, cin, H, W = x.shape
     cs = weight.shape[0]
     c0 = cs // out_size
+    if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)):
+        y = conv1x1(x, weight, bias, lrelu=True, pixelnorm=True)            # (V, c0*S, H, W), channel = c*S + d
+        return cl(y.view(V, c0, out_size, H, W))
     he = he_constant(weight)
     wpack = _cached(weight, 'c1f', lambda: pack_conv1x1(weight.reshape(cs, cin)))
     P = H * W

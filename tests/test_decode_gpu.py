@@ -197,3 +197,60 @@ def test_photographer_parameter_gradients(golden, variant):
         assert rel < 1e-2, (name, rel)
         checked += 1
     assert checked >= 10
+
+
+@pytest.mark.parametrize('tag', ['gru', 'pool_mean'])
+def test_generator_parameter_gradients_end_to_end(golden, tag):
+    """One generator step's backward: Sculptor.encode + fuser + Photographer.decode,
+    L1 on depth + BCE on the mask logits, gradients of EVERY sculptor / fuser / photographer parameter
+    on the HIP path (weight-gradient kernels, volume splat, differentiable lift) against autograd of the
+    CPU oracle with the same checkpoints and inputs."""
+    import copy
+    import torch.nn.functional as F
+    from latentfusion_amd.recon import fusion
+    from latentfusion_amd.recon.models import Photographer, Sculptor
+    g = golden('g10_encode_' + tag)
+    pck = golden('g7_adam_trace')['photographer']              # SYN(16,8) photographer, same volume size / channels
+    o = g['obs_pre']
+    gen = torch.Generator().manual_seed(3)
+    tgt_depth = torch.rand(1, 2, 1, 16, 16, generator=gen) * 2 - 1
+    tgt_mask = (torch.rand(1, 2, 1, 16, 16, generator=gen) > 0.5).float()
+
+    def objective(y):
+        return F.l1_loss(y['depth'], tgt_depth.to(y['depth'].device)) + \
+            F.binary_cross_entropy_with_logits(y['mask_logits'], tgt_mask.to(y['depth'].device))
+
+    # oracle
+    cks = {k: {**ck, 'state_dict': {n: v.clone().requires_grad_(True) for n, v in ck.get('state_dict', {}).items()}}
+           for k, ck in (('s', g['sculptor']), ('f', g['fuser']), ('p', pck))}
+    oc = o['cam']
+    ocam = O.Cam(oc['K'], oc['log_q'], oc['t'], viewport=oc['viewport'], z_span=oc['z_span'], width=oc['width'],
+                 height=oc['height'])
+    z = nets.encode(cks['s'], cks['f'], ocam, o['color'], o['depth'], o['mask'])
+    rcam = ocam[:2] if hasattr(ocam, '__getitem__') else ocam
+    y, _, _ = nets.decode(cks['p'], z, rcam, apply_mask=False)
+    objective(y).backward()
+
+    # HIP
+    sc = Sculptor.from_checkpoint(g['sculptor']).to(DEV)
+    fu = fusion.from_checkpoint(g['fuser']).to(DEV)
+    ph = Photographer.from_checkpoint(pck).to(DEV)
+    for m in (sc, fu, ph):
+        m.requires_grad_(True)
+    cam = prod_camera(oc)
+    zp, _ = sc.encode(fu, cam, o['color'].unsqueeze(0).to(DEV), o['depth'].unsqueeze(0).to(DEV), o['mask'].unsqueeze(0).to(DEV))
+    close(zp, z, atol=1e-4, rtol=1e-3)
+    yp, _, _ = ph.decode(zp, cam[:2], return_latent=True, apply_mask=False)
+    objective(yp).backward()
+    checked = 0
+    for key, mod in (('s', sc), ('f', fu), ('p', ph)):
+        for name, p in mod.named_parameters():
+            want = cks[key]['state_dict'][name].grad
+            if want is None:                                     # parameter not on this path (unused head)
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0, (key, name)
+                continue
+            assert p.grad is not None, (key, name)
+            rel = ((p.grad.cpu() - want).norm() / want.norm().clamp(min=1e-8)).item()
+            assert rel < 2e-2, (key, name, rel)
+            checked += 1
+    assert checked >= 25
