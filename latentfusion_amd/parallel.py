@@ -122,3 +122,22 @@ def gather_losses(local_losses, n_total, group=None):
     parts = [torch.empty_like(pad) for _ in range(size)]
     dist.all_gather(parts, pad, group=group)
     return torch.cat([p[:e - b] for p, (b, e) in zip(parts, counts)])
+
+
+# ---------------------------------------------------------------------------------------------
+# data-parallel training (BASELINE cfg 5): gradient all-reduce over flat buckets
+# ---------------------------------------------------------------------------------------------
+def allreduce_flat_(flat, group=None, bucket_bytes=64 << 20):
+    """In-place mean of a flat fp32 gradient buffer over the ranks, in `bucket_bytes` pieces: a handful of
+    large RCCL all-reduces (ring: bound by one xGMI link, so fewer/larger beats per-parameter traffic)
+    instead of the reference's per-forward parameter broadcast (torchutils.py:133-170).  Returns `flat`."""
+    rank, size = world()
+    if size == 1:
+        return flat
+    step = max(1, bucket_bytes // flat.element_size())
+    handles = [dist.all_reduce(flat[i:i + step], op=dist.ReduceOp.SUM, group=group, async_op=True)
+               for i in range(0, flat.numel(), step)]
+    for h in handles:
+        h.wait()
+    flat.div_(size)
+    return flat

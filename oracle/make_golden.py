@@ -506,12 +506,37 @@ def g14_initial_pose(lf):
         ini.morphology = old
 
 
+def g15_losses(lf):
+    """Training losses (latentfusion/losses.py:33-100) on random maps.  trainutils.get_recon_criterion
+    (trainutils.py:114-133) cannot be imported here (tensorboard is absent); its five non-VGG branches are
+    one-liners over torch.nn and losses.HardPixelLoss and are written out below."""
+    from torch import nn
+    from latentfusion import losses
+
+    def get_recon_criterion(name, k):
+        return {'l1': lambda: nn.L1Loss(), 'smooth_l1': lambda: nn.SmoothL1Loss(),
+                'hard_l1': lambda: losses.HardPixelLoss(nn.L1Loss, k=k),
+                'hard_smooth_l1': lambda: losses.HardPixelLoss(nn.SmoothL1Loss, k=k),
+                'binary_cross_entropy': lambda: nn.BCEWithLogitsLoss(reduction='none')}[name]()
+    g = torch.Generator().manual_seed(90)
+    x = torch.randn(2, 3, 1, 12, 12, generator=g)
+    y = torch.randn(2, 3, 1, 12, 12, generator=g)
+    m = torch.rand(2, 3, 1, 12, 12, generator=g)
+    out = {}
+    for name in ('l1', 'smooth_l1', 'hard_l1', 'hard_smooth_l1', 'binary_cross_entropy'):
+        crit = get_recon_criterion(name, 37)
+        out[name] = losses.reduce_loss(crit(x, (y > 0).float() if name == 'binary_cross_entropy' else y)).clone()
+    out['beta_0.01'] = losses.beta_prior_loss(m, 0.01, 0.01).clone()
+    out['beta_2_3_sum'] = losses.beta_prior_loss(m, 2.0, 3.0, reduction='sum').clone()
+    save('g15_losses', {'x': x, 'y': y, 'm': m, 'k': 37, 'out': out})
+
+
 def main():
     lf = refharness.load_reference()
     import latentfusion.recon.utils  # noqa
     torch.set_num_threads(8)
     gens = [g0_preprocess, g1_camera, g2_resample, g3_block, g4_fusers, g5_decode, g6_loss, g7_g10_loop, g9_ibr,
-            g11_released_like, g12_latent_code, g13_metrics, g14_initial_pose]
+            g11_released_like, g12_latent_code, g13_metrics, g14_initial_pose, g15_losses]
     only = sys.argv[1:]                                  # e.g. `python oracle/make_golden.py g13` regenerates one group
     for fn in gens:
         if not only or any(fn.__name__.startswith(o + '_') or fn.__name__ == o for o in only):

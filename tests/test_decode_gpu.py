@@ -254,3 +254,61 @@ def test_generator_parameter_gradients_end_to_end(golden, tag):
             assert rel < 2e-2, (key, name, rel)
             checked += 1
     assert checked >= 25
+
+
+def test_generator_training_step(golden):
+    """recon/training.GeneratorStep (loss composition of train_reconstruct.py:491-516, flat Adam with the
+    reference's betas): loss terms equal the oracle's on the same batch, the first update moves every
+    parameter by lr * g / (|g| + eps) with the oracle's gradient sign, and repeated steps on one batch
+    reduce the loss."""
+    import torch.nn.functional as F
+    from latentfusion_amd import losses as L
+    from latentfusion_amd.recon import fusion, training
+    from latentfusion_amd.recon.models import Photographer, Sculptor
+    g = golden('g10_encode_gru')
+    pck = golden('g7_adam_trace')['photographer']
+    o, oc = g['obs_pre'], g['obs_pre']['cam']
+    gen = torch.Generator().manual_seed(5)
+    tgt_depth = torch.rand(1, 4, 1, 16, 16, generator=gen) * 2 - 1
+    tgt_mask = (torch.rand(1, 4, 1, 16, 16, generator=gen) > 0.5).float()
+    kw = dict(g_depth_recon_loss_type='hard_smooth_l1', g_depth_recon_loss_k=100, g_depth_recon_loss_weight=25.0,
+              g_mask_recon_loss_weight=25.0, g_mask_beta_loss_weight=0.5, g_mask_beta_loss_param=0.01, generator_lr=1e-3)
+
+    # oracle: same objective through the CPU restatement
+    cks = {k: {**ck, 'state_dict': {n: v.clone().requires_grad_(True) for n, v in ck.get('state_dict', {}).items()}}
+           for k, ck in (('s', g['sculptor']), ('f', g['fuser']), ('p', pck))}
+    ocam = O.Cam(oc['K'], oc['log_q'], oc['t'], viewport=oc['viewport'], z_span=oc['z_span'], width=oc['width'],
+                 height=oc['height'])
+    z = nets.encode(cks['s'], cks['f'], ocam, o['color'], o['depth'], o['mask'])
+    y, _, _ = nets.decode(cks['p'], z, ocam, apply_mask=False)
+    want = {'depth_recon': L.reduce_loss(L.get_recon_criterion('hard_smooth_l1', 100)(y['depth'], tgt_depth)),
+            'mask_recon': L.reduce_loss(L.get_recon_criterion('binary_cross_entropy')(y['mask_logits'], tgt_mask)),
+            'mask_beta': L.beta_prior_loss(y['mask'], 0.01, 0.01)}
+    want['total'] = 25.0 * want['depth_recon'] + 25.0 * want['mask_recon'] + 0.5 * want['mask_beta']
+    want['total'].backward()
+
+    sc = Sculptor.from_checkpoint(g['sculptor']).to(DEV)
+    fu = fusion.from_checkpoint(g['fuser']).to(DEV)
+    ph = Photographer.from_checkpoint(pck).to(DEV)
+    step = training.GeneratorStep(sc, fu, ph, **kw)
+    before = step.flat.data.clone()
+    cam = prod_camera(oc)
+    batch = {'in': {'camera': cam, 'image': o['color'].unsqueeze(0).to(DEV), 'mask': o['mask'].unsqueeze(0).to(DEV),
+                    'depth': o['depth'].unsqueeze(0).to(DEV)},
+             'out_gt': {'camera': cam, 'depth': tgt_depth.to(DEV), 'mask': tgt_mask.to(DEV)}}
+    got = step.run_iteration(batch)
+    for k in ('depth_recon', 'mask_recon', 'mask_beta', 'total'):
+        close(got[k], want[k], atol=1e-5, rtol=1e-4)
+    # first Adam step with betas (0, 0.99): delta = -lr * g / (|g| + eps)
+    delta = (step.flat.data - before).cpu()
+    ograd = torch.cat([cks[key]['state_dict'][n].grad.reshape(-1)
+                       for key, mod in (('s', sc), ('p', ph), ('f', fu)) for n, _ in mod.named_parameters()])
+    assert delta.shape == ograd.shape
+    big = ograd.abs() > 1e-5 * ograd.abs().max()
+    agree = (torch.sign(delta[big]) == -torch.sign(ograd[big])).float().mean().item()
+    assert agree > 0.995, agree
+    assert float(delta.abs().max()) <= 1e-3 * 1.0001
+    first = float(got['total'])
+    for _ in range(4):
+        last = step.run_iteration(batch)
+    assert float(last['total']) < first

@@ -381,3 +381,21 @@ def test_initial_pose_golden(golden):
     m = torch.zeros(1, 9, 9, dtype=torch.bool)
     m[0, 2:7, 2:7] = True
     assert initialization._erode_mask(m, size=1) is m
+
+
+def test_training_losses_golden(golden):
+    """losses.py (hard-pixel mining, reductions, Beta prior, criterion factory) against the reference's
+    own modules (golden g15); optimiser factory keeps the reference's betas."""
+    from latentfusion_amd import losses
+    g = golden('g15_losses')
+    x, y, m = g['x'], g['y'], g['m']
+    for name in ('l1', 'smooth_l1', 'hard_l1', 'hard_smooth_l1', 'binary_cross_entropy'):
+        crit = losses.get_recon_criterion(name, g['k'])
+        got = losses.reduce_loss(crit(x, (y > 0).float() if name == 'binary_cross_entropy' else y))
+        close(got, g['out'][name], atol=1e-6, rtol=1e-6)
+    close(losses.beta_prior_loss(m, 0.01, 0.01), g['out']['beta_0.01'], atol=1e-6, rtol=1e-6)
+    close(losses.beta_prior_loss(m, 2.0, 3.0, reduction='sum'), g['out']['beta_2_3_sum'], atol=1e-4, rtol=1e-6)
+    with pytest.raises(ValueError):
+        losses.get_recon_criterion('nope')
+    opt = losses.get_optimizer([torch.nn.Parameter(torch.zeros(3))], 'adam', 1e-3)
+    assert opt.defaults['betas'] == (0.0, 0.99)

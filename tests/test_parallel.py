@@ -91,3 +91,31 @@ def test_shard_range_partition():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(size - 1))
             assert max(e - b for b, e in spans) - min(e - b for b, e in spans) <= 1
+
+
+def _allreduce_worker(rank, size, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=size)
+    from latentfusion_amd import parallel
+    flat = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+    parallel.allreduce_flat_(flat, bucket_bytes=1024)          # 256 floats per bucket -> 4 collectives
+    q.put((rank, flat.clone()))
+    dist.destroy_process_group()
+
+
+def test_flat_gradient_allreduce_world2():
+    """Bucketed mean all-reduce of the flat gradient buffer (data-parallel training step)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29650 + (os.getpid() % 200)
+    ps = [ctx.Process(target=_allreduce_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(60)
+    want = torch.arange(1000, dtype=torch.float32) * 1.5
+    for r in (0, 1):
+        assert torch.equal(got[r], want)
