@@ -69,6 +69,107 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
   if (co < Cout && ci < Cin) gw[((long)tap * Cout + co) * Cin + ci] = (float)(s * (double)scale);
 }
 
+
+// ---- 3-D, 16 -> 16 channels: persistent LDS-staged kernel -------------------------------------------
+// One 512-thread workgroup per CU walks 2 x 8 x 16-voxel tiles: the x halo (4 x 10 x 18 voxels) and the gpre
+// tile arrive by LDS-DMA (double-buffered, zero fill outside the volume), every wave owns two x-rows of the
+// tile and keeps all 27 tap accumulators (108 VGPRs) across its whole tile range; the per-wave partial sums
+// are written once at the end and summed by wgrad_reduce_kernel in a fixed order.
+constexpr int WTZ = 2, WTY = 8, WTX = 16, WHZ = 4, WHY = 10, WHX = 18;
+constexpr int WHALO = WHZ * WHY * WHX;                          // 720 voxels
+constexpr int WPH = (WHALO * 4 + 63) / 64;                      // 45 halo pieces (1 KiB)
+constexpr int WPG = WTZ * WTY * WTX * 4 / 64;                   // 16 gpre pieces
+constexpr int WBUF = (WPH + WPG) * 1024;                        // 62,464 B per buffer
+constexpr int WNIT = (WPH + WPG + 7) / 8;                       // 8 pieces per wave
+
+__global__ void __launch_bounds__(512) wgrad3d_c16_kernel(
+    const float* __restrict__ x, const float* __restrict__ gp, float* __restrict__ partial,
+    int N, int D, int H, int W, int tiles_x, int tiles_y, int tiles_z, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15, k = lane >> 4;
+  const int nb = gridDim.x;
+  const int lb = (nb % 8 == 0) ? (blockIdx.x % 8) * (nb / 8) + blockIdx.x / 8 : blockIdx.x;   // XCD-aware ranges
+  const int per = (ntiles + nb - 1) / nb;
+  const int t_begin = lb * per;
+  const int t_end = min(t_begin + per, ntiles);
+  const long nvox = (long)D * H * W;
+  const unsigned sample_bytes = (unsigned)(nvox * 64);
+
+  f32x4 acc[27];
+#pragma unroll
+  for (int t = 0; t < 27; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (t_begin < t_end) {
+    // DMA piece constants: local voxel coordinates + 16-byte quarter; halo pieces first, then gpre pieces
+    int lxyzq[WNIT];
+#pragma unroll
+    for (int it = 0; it < WNIT; ++it) {
+      const int s = wave + 8 * it;
+      const int p = (s < WPH ? s : s - WPH) * 64 + lane;
+      const int v = p >> 2, q = p & 3;
+      int lx, ly, lz;
+      bool ok;
+      if (s < WPH) { lx = v % WHX; ly = (v / WHX) % WHY; lz = v / (WHX * WHY); ok = v < WHALO; }
+      else         { lx = v & 15; ly = (v >> 4) & 7; lz = v >> 7; ok = s < WPH + WPG; }
+      lxyzq[it] = ok ? (lx | (ly << 8) | (lz << 16) | (q << 24)) : -1;
+    }
+    auto issue = [&](int t, int bufsel) {
+      int tt = t;
+      const int bx = tt % tiles_x; tt /= tiles_x;
+      const int by = tt % tiles_y; tt /= tiles_y;
+      const int bz = tt % tiles_z; tt /= tiles_z;
+      __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long)tt * nvox * 16), 0, sample_bytes, 0x00020000);
+      __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)(gp + (long)tt * nvox * 16), 0, sample_bytes, 0x00020000);
+      unsigned char* dst = smem + bufsel * WBUF;
+#pragma unroll
+      for (int it = 0; it < WNIT; ++it) {
+        const int s = wave + 8 * it;
+        if (s >= WPH + WPG) continue;                              // wave-uniform
+        const int halo = s < WPH ? 1 : 0;
+        const int gx = bx * WTX - halo + (lxyzq[it] & 0xff), gy = by * WTY - halo + ((lxyzq[it] >> 8) & 0xff),
+                  gz = bz * WTZ - halo + ((lxyzq[it] >> 16) & 0xff);
+        const bool ok = (unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H && (unsigned)gz < (unsigned)D && lxyzq[it] >= 0;
+        const int voff = ok ? ((gz * H + gy) * W + gx) * 64 + ((lxyzq[it] >> 24) << 4) : 0x7fffffff;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(halo ? rx : rg, (__attribute__((address_space(3))) void*)(dst + s * 1024), 16, voff, 0, 0, 0);
+      }
+    };
+    // per-lane LDS byte offsets: A = gpre[voxel k of the group][channel m], B = x[same voxel + tap][channel m]
+    const int a_lane = WPH * 1024 + ((2 * wave) * 16 + k) * 64 + m * 4;                 // + (j*16 + 4*xg)*64
+    const int rz = (2 * wave) >> 3, ry = (2 * wave) & 7;                               // first of the wave's two rows
+    const int b_lane = ((rz * WHY + ry) * WHX + k) * 64 + m * 4;                       // + (j*18 + 4*xg + tap offset)*64
+
+    issue(t_begin, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int t = t_begin; t < t_end; ++t) {
+      const int cur = (t - t_begin) & 1;
+      const unsigned char* buf = smem + cur * WBUF;
+      if (t + 1 < t_end) issue(t + 1, cur ^ 1);
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const int j = g >> 2, xg = g & 3;                             // row j of the wave's pair, 4-voxel group xg
+        const float a = *(const float*)(buf + a_lane + (j * 16 + 4 * xg) * 64);
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap) {
+          const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
+          const float b = *(const float*)(buf + b_lane + (((kz * WHY) + ky + j) * WHX + 4 * xg + kx) * 64);
+          acc[tap] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[tap], 0, 0, 0);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  }
+  // per-wave partials: block index = workgroup * 8 + wave (wgrad_reduce_kernel sums them in this order)
+  float* out = partial + ((long)(blockIdx.x * 8 + wave) * 27) * 256;
+#pragma unroll
+  for (int tap = 0; tap < 27; ++tap)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[tap * 256 + (4 * k + i) * 16 + m] = acc[tap][i];
+}
+
 struct WgradPlan { int taps, nct, ncit, chunk, nblk; };
 
 bool wgrad_plan(int dims, long total, int Cin, int Cout, bool ones, WgradPlan& p) {
@@ -77,9 +178,9 @@ bool wgrad_plan(int dims, long total, int Cin, int Cout, bool ones, WgradPlan& p
   p.taps = dims == 3 ? 27 : (dims == 2 ? 9 : 1);
   p.nct = (Cout + 15) / 16;
   p.ncit = ones ? 1 : (Cin + 15) / 16;
-  // enough blocks to fill the chip for small problems, at most ~2048 partials per output for big ones
+  // enough blocks to fill the chip for small problems, at most ~512 partials per output for big ones
   long chunk = 1024;
-  while ((total + chunk - 1) / chunk > 2048) chunk *= 2;
+  while ((total + chunk - 1) / chunk > 512) chunk *= 2;
   p.chunk = (int)chunk;
   p.nblk = (int)((total + chunk - 1) / chunk);
   return (long)p.nct * p.ncit <= 65535;
@@ -87,7 +188,22 @@ bool wgrad_plan(int dims, long total, int Cin, int Cout, bool ones, WgradPlan& p
 
 }  // namespace
 
+static int wgrad_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, v = 0;
+    cus = (hipGetDevice(&dev) == hipSuccess &&
+           hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+  }
+  return cus;
+}
+
+static bool wgrad_fast3d(int dims, int N, int D, int H, int W, int Cin, int Cout) {
+  return dims == 3 && Cin == 16 && Cout == 16 && (long)D * H * W * 64 < 0x7fffffffL && (long)N * D * H * W >= 8192;
+}
+
 extern "C" size_t lf_conv_bwd_weight_scratch_bytes(int dims, int N, int D, int H, int W, int Cin, int Cout) {
+  if (wgrad_fast3d(dims, N, D, H, W, Cin, Cout)) return (size_t)wgrad_cus() * 8 * 27 * 256 * sizeof(float);
   WgradPlan p;
   if (!wgrad_plan(dims, (long)N * D * H * W, Cin > 0 ? Cin : 1, Cout, Cin <= 0, p)) return 0;
   return (size_t)p.nblk * p.taps * p.nct * p.ncit * 256 * sizeof(float);
@@ -98,6 +214,29 @@ extern "C" int lf_conv_bwd_weight(const float* x, const float* gpre, float* gw, 
   lf_clear_error();
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || gpre == nullptr || gw == nullptr) return LF_EINVAL;
   const bool ones = (x == nullptr);
+  if (!ones && wgrad_fast3d(dims, N, D, H, W, Cin, Cout) && lf_aligned16(x) && lf_aligned16(gpre)) {
+    const int cus = wgrad_cus();
+    if (scratch_bytes < (size_t)cus * 8 * 27 * 256 * sizeof(float)) return LF_ENOSPC;
+    const int ptx = (W + WTX - 1) / WTX, pty = (H + WTY - 1) / WTY, ptz = (D + WTZ - 1) / WTZ;
+    const long pt = (long)ptx * pty * ptz * N;
+    if (pt > 0x7fffffffL) return LF_EINVAL;
+    const size_t shmem = (size_t)2 * WBUF;
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute((const void*)wgrad3d_c16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+      if (e != hipSuccess) return (int)e;
+      attr_set = true;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    // every workgroup writes its 8 x 27 x 256 partials (zeros when it has no tiles), so the grid is always `cus`
+    hipLaunchKernelGGL(wgrad3d_c16_kernel, dim3(cus), dim3(512), shmem, s, x, gpre, (float*)scratch, N, D, H, W, ptx, pty,
+                       ptz, (int)pt);
+    int st = lf_launch_status();
+    if (st) return st;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(27, 1), dim3(256), 0, s, (const float*)scratch, gw, cus * 8, 27, 1, 1, 16, 16,
+                       scale);
+    return lf_launch_status();
+  }
   if (ones) Cin = 1;
   WgradPlan p;
   if (!wgrad_plan(dims, (long)N * D * H * W, Cin, Cout, ones, p)) return LF_EINVAL;

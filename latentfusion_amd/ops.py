@@ -314,6 +314,15 @@ def conv_bwd_weight(x, gp, dims, cin, he):
     (lf_conv_bwd_weight).  x, gp: channels-last (N,C,[D,]H,W), or plain [rows][C] matrices for dims = 0.
     Returns (gw [taps][Cout][Cin], gb [Cout])."""
     L = _lib.lib()
+    if dims == 3 and gp.shape[1] == 16 and cin > 16:
+        # the LDS-staged 16 -> 16 kernel is ~4x faster than the generic one even with the slice copies:
+        # the weight gradient of a wider input is the concatenation of the gradients of its channel chunks
+        parts, gb = [], None
+        for c0 in range(0, cin, 16):
+            c1 = min(c0 + 16, cin)
+            gw_c, gb = conv_bwd_weight(cl(x[:, c0:c1]), gp, dims, c1 - c0, he)
+            parts.append(gw_c)
+        return torch.cat(parts, dim=2), gb
     if dims == 0:
         rows, cout = gp.shape[0], gp.shape[1]
         N, D, H, W = 1, 1, 1, rows
