@@ -342,6 +342,12 @@ def conv_bwd_weight(x, gp, dims, cin, he):
     return gw, gb.reshape(cout)
 
 
+def _wino_ok(x, weight):
+    """The Winograd kernel serves 3-D 16 -> 16 convolutions on volumes of at least one 2x8x16 tile row."""
+    return (x.dim() == 5 and tuple(weight.shape[:2]) == (16, 16) and x.shape[1] == 16
+            and (x.shape[2] * x.shape[3] * x.shape[4]) * 64 < 2 ** 31)
+
+
 class _Conv3x3(torch.autograd.Function):
     """x -> epilogue(conv3x3(x, W) * he + b).  The input is kept for the weight gradient only when the
     weight or bias asks for one (the pose loop never does)."""
@@ -351,8 +357,12 @@ class _Conv3x3(torch.autograd.Function):
         _req(x, 'x'), _req(weight, 'weight')
         x = cl(x)
         he = he_constant(weight)
-        wpack = _cached(weight, 'c3f', lambda: pack_conv3x3(weight))
-        y, norm = _conv3x3_raw(x, wpack, bias.detach() if bias is not None else None, weight.shape[0], he, flags, True)
+        b = bias.detach() if bias is not None else None
+        if _wino_ok(x, weight):                               # 3-D 16 -> 16: the all-fp32 Winograd kernel
+            y, norm = conv3d_c16_wino(x, _cached(weight, 'w3f', lambda: pack_conv3d_c16_wino(weight)), b, he, flags)
+        else:
+            wpack = _cached(weight, 'c3f', lambda: pack_conv3x3(weight))
+            y, norm = _conv3x3_raw(x, wpack, b, weight.shape[0], he, flags, True)
         ctx.flags, ctx.he = flags, he
         ctx.weight = weight
         ctx.x = x if (weight.requires_grad or (bias is not None and bias.requires_grad)) else None
@@ -368,8 +378,11 @@ class _Conv3x3(torch.autograd.Function):
         w = ctx.weight
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            wpack_t = _cached(w, 'c3b', lambda: pack_conv3x3(w, transpose=True))
-            gx, _ = _conv3x3_raw(gp, wpack_t, None, w.shape[1], ctx.he, 0, False)
+            if _wino_ok(gp, w):
+                gx, _ = conv3d_c16_wino(gp, _cached(w, 'w3b', lambda: pack_conv3d_c16_wino(w, transpose=True)), None, ctx.he, 0)
+            else:
+                wpack_t = _cached(w, 'c3b', lambda: pack_conv3x3(w, transpose=True))
+                gx, _ = _conv3x3_raw(gp, wpack_t, None, w.shape[1], ctx.he, 0, False)
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             dims = w.dim() - 2
             gwt, gb = conv_bwd_weight(ctx.x, gp, dims, w.shape[1], ctx.he)
