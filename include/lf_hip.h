@@ -161,6 +161,16 @@ int lf_conv3d_c16_wino(const float* x, const float* upack, const float* bias, fl
                        const float* prev_y, const float* prev_norm, unsigned prev_flags,
                        float* amax_out, void* stream);
 
+/* 2-D grid sampling of planar images, F.grid_sample(align_corners=False) semantics: the crop / zoom
+ * (geometry.py:20-44,287-354; zeros padding), Camera.uncrop (geometry.py:261-285; border padding) and the
+ * image-based-rendering warps (ibr.py:52-93).  img [N][C][H][W], grid [N][Ho][Wo][2] = (x, y) in [-1,1],
+ * out / gout [N][C][Ho][Wo]; bilinear = 1 | 0 (nearest, round-half-even); border = 1 (replicate) | 0 (zeros).
+ * bwd: gimg (zero-initialised by the caller, accumulated with float atomics) and/or ggrid may be NULL. */
+int lf_grid_sample2d_fwd(const float* img, const float* grid, float* out, int N, int C, int H, int W, int Ho, int Wo,
+                         int bilinear, int border, void* stream);
+int lf_grid_sample2d_bwd(const float* img, const float* grid, const float* gout, float* gimg, float* ggrid,
+                         int N, int C, int H, int W, int Ho, int Wo, int bilinear, int border, void* stream);
+
 /* Weight gradient of the He-equalised conv (training step; autograd of equalized.py:57-64):
  *   gw[tap][co][ci] = scale * sum_v gpre[v][co] * x[v + tap][ci],   tap = (kz*3 + ky)*3 + kx, zero padding,
  * dims = 3 (27 taps), 2 (9 taps, D = 1) or 0 (pointwise: one tap, rows = N*D*H*W).  x, gpre channels-last

@@ -8,7 +8,7 @@ import math
 import torch
 from torch.nn import functional as F
 
-from . import three
+from . import image_ops, three
 from .three.batchview import b2bv, bv2b
 
 
@@ -71,8 +71,8 @@ def reproject_views(image_in, depth_in, depth_out, camera_in, camera_out):
     cam_rep = camera_out.repeat_interleave(v_i)
     depth_tf = three.transform_coord_grid(obj, cam_rep.obj_to_cam)[..., 2].unsqueeze(1)
     depth_tf = cam_rep.normalize_depth(depth_tf)
-    image_re = F.grid_sample(image.float(), grid.float(), mode='bilinear', align_corners=False)
-    depth_re = F.grid_sample(depth_tf.float(), grid.float(), mode='bilinear', align_corners=False)
+    image_re = image_ops._sample(image, grid, 'bilinear', 'zeros')
+    depth_re = image_ops._sample(depth_tf, grid, 'bilinear', 'zeros')
     return b2bv(image_re, v_i), b2bv(depth_re, v_i)
 
 

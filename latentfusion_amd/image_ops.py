@@ -5,11 +5,21 @@ grid_sample with zeros padding over a box; `uncrop` = Camera.uncrop (:261-285): 
 back into the frame with border padding.  Both run once per observation (pre-processing) or
 on (N,1,H,W) maps in the pose loss.
 
-Status: served by ATen's grid_sampler on the device (same arithmetic as the reference); the
-pose-loop use is superseded by the fused HIP loss kernel where available (see pose/loss.py).
+Device tensors go through `lf_grid_sample2d_*` (csrc/sample2d.hip); the pose loop's uncrop is fused into
+the HIP loss kernels (engine.py).  Host tensors (an Observation that has not been moved to the GPU yet,
+the CPU test-suite) are resampled by ATen on the host: that is host-side pre-processing, not a fallback
+of the device path -- every device tensor takes the HIP kernel or raises.
 """
 import torch
 import torch.nn.functional as F
+
+from . import ops
+
+
+def _sample(image, grid, mode, padding):
+    if image.is_cuda:
+        return ops.grid_sample2d(image, grid, mode, padding)
+    return F.grid_sample(image.float(), grid.float(), mode=mode, padding_mode=padding, align_corners=False)
 
 
 def crop_boxes(image, boxes, target_size, scale_mode):
@@ -25,7 +35,7 @@ def crop_boxes(image, boxes, target_size, scale_mode):
         gx = torch.linspace(x0 / W, x1 / W, target_size, device=image.device) * 2 - 1
         grids.append(torch.stack((gx[None, :].expand(target_size, -1), gy[:, None].expand(-1, target_size)), dim=-1))
     grid = torch.stack(grids, dim=0)
-    return F.grid_sample(image.float(), grid.float(), mode=scale_mode, padding_mode='zeros', align_corners=False)
+    return _sample(image, grid, scale_mode, 'zeros')
 
 
 def uncrop(image, viewport, height, width, scale_mode):
@@ -37,5 +47,4 @@ def uncrop(image, viewport, height, width, scale_mode):
     vw = (viewport[:, 2] - viewport[:, 0]).view(-1, 1, 1)
     gy = ((yy - viewport[:, 1].view(-1, 1, 1)) / vh * 2 - 1).expand(-1, -1, width)
     gx = ((xx - viewport[:, 0].view(-1, 1, 1)) / vw * 2 - 1).expand(-1, height, -1)
-    return F.grid_sample(image.float(), torch.stack((gx, gy), dim=-1), mode=scale_mode, padding_mode='border',
-                         align_corners=False)
+    return _sample(image, torch.stack((gx, gy), dim=-1), scale_mode, 'border')

@@ -543,6 +543,49 @@ def lift(x, weight, bias, out_size):
 
 
 # ---------------------------------------------------------------------------------------------
+# 2-D grid sampling (image crops / uncrops / IBR warps)
+# ---------------------------------------------------------------------------------------------
+class _GridSample2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, grid, bilinear, border):
+        L = _lib.lib()
+        _req(img, 'image')
+        img, grid = img.float().contiguous(), grid.float().contiguous()
+        N, C, H, W = img.shape
+        Ho, Wo = grid.shape[1], grid.shape[2]
+        if grid.shape[0] != N or grid.shape[3] != 2:
+            raise ValueError('grid must be (N, Ho, Wo, 2)')
+        out = torch.empty(N, C, Ho, Wo, device=img.device, dtype=torch.float32)
+        check(L.lf_grid_sample2d_fwd(_ptr(img), _ptr(grid), _ptr(out), N, C, H, W, Ho, Wo, int(bilinear), int(border), _stream()),
+              'lf_grid_sample2d_fwd')
+        ctx.save_for_backward(img, grid)
+        ctx.mode = (int(bilinear), int(border))
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        L = _lib.lib()
+        img, grid = ctx.saved_tensors
+        N, C, H, W = img.shape
+        Ho, Wo = grid.shape[1], grid.shape[2]
+        gimg = torch.zeros_like(img) if ctx.needs_input_grad[0] else None
+        ggrid = torch.empty_like(grid) if ctx.needs_input_grad[1] else None
+        if gimg is None and ggrid is None:
+            return None, None, None, None
+        check(L.lf_grid_sample2d_bwd(_ptr(img), _ptr(grid), _ptr(gout.float().contiguous()),
+                                     _ptr(gimg) if gimg is not None else None, _ptr(ggrid) if ggrid is not None else None,
+                                     N, C, H, W, Ho, Wo, ctx.mode[0], ctx.mode[1], _stream()), 'lf_grid_sample2d_bwd')
+        return gimg, ggrid, None, None
+
+
+def grid_sample2d(img, grid, mode='bilinear', padding_mode='zeros'):
+    """F.grid_sample(img, grid, mode, padding_mode, align_corners=False) for 4-D inputs on the HIP path."""
+    if mode not in ('bilinear', 'nearest') or padding_mode not in ('zeros', 'border'):
+        raise ValueError(f'unsupported mode {mode!r} / padding {padding_mode!r}')
+    return _GridSample2d.apply(img, grid, mode == 'bilinear', padding_mode == 'border')
+
+
+# ---------------------------------------------------------------------------------------------
 # standalone PixelNorm / rescale
 # ---------------------------------------------------------------------------------------------
 class _PixelNorm(torch.autograd.Function):

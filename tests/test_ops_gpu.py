@@ -252,3 +252,24 @@ def test_resize_vs_torch(dims, mode, factor, S, C):
     close(got, want, atol=1e-6)
     (got * gw.to(DEV)).sum().backward()
     close(xd.grad, x.grad, atol=1e-5)
+
+
+@pytest.mark.parametrize('mode,padding', [('bilinear', 'zeros'), ('bilinear', 'border'), ('nearest', 'zeros'),
+                                          ('nearest', 'border')])
+def test_grid_sample2d_vs_torch(mode, padding):
+    """lf_grid_sample2d_fwd/bwd against ATen's CPU grid_sample (align_corners=False): values, image gradient
+    and grid gradient, with sample points inside, on the edges of and outside the image."""
+    from latentfusion_amd import ops
+    g = torch.Generator().manual_seed(11)
+    img = torch.randn(3, 4, 13, 17, generator=g, requires_grad=True)
+    grid = (torch.rand(3, 9, 11, 2, generator=g) * 2.6 - 1.3).requires_grad_(True)
+    want = torch.nn.functional.grid_sample(img, grid, mode=mode, padding_mode=padding, align_corners=False)
+    w = torch.randn(want.shape, generator=g)
+    (want * w).sum().backward()
+    imd, grd = img.detach().to(DEV).requires_grad_(True), grid.detach().to(DEV).requires_grad_(True)
+    got = ops.grid_sample2d(imd, grd, mode, padding)
+    close(got, want, atol=1e-5, rtol=1e-5)
+    (got * w.to(DEV)).sum().backward()
+    close(imd.grad, img.grad, atol=1e-5, rtol=1e-4)
+    if mode == 'bilinear':
+        close(grd.grad, grid.grad, atol=1e-4, rtol=1e-3)
