@@ -16,10 +16,10 @@ b = torch.zeros(16).cuda()
 for _ in range(3):
     y = x.clone()            # calibration: 1 GiB in, 1 GiB out
 torch.cuda.synchronize()
-for _ in range(3):
-    y = ops.conv3x3(x, w, b)
-torch.cuda.synchronize()
 from latentfusion_amd._lib import LF_EPI_LRELU, LF_EPI_PIXELNORM  # noqa: E402
+for _ in range(3):                   # direct implicit-GEMM kernel (conv3d_c16_persistent_kernel)
+    y, _n = ops._conv3x3_raw(x, ops.pack_conv3x3(w), b, 16, ops.he_constant(w), LF_EPI_LRELU | LF_EPI_PIXELNORM, True)
+torch.cuda.synchronize()
 up = ops.pack_conv3d_c16_wino(w)
 for _ in range(3):
     y, _n = ops.conv3d_c16_wino(x, up, b, ops.he_constant(w), LF_EPI_LRELU | LF_EPI_PIXELNORM)
