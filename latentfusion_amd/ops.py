@@ -73,12 +73,23 @@ def _ptr(t):
 # ---------------------------------------------------------------------------------------------
 # weight packing (host side, cached per parameter version)
 # ---------------------------------------------------------------------------------------------
+_WEIGHT_EPOCH = 0
+
+
+def invalidate_weight_packs():
+    """Call after writing parameters through a raw pointer (e.g. lf_adam_step on a flat buffer): such writes
+    do not bump torch's version counters, so the cached packs must be told."""
+    global _WEIGHT_EPOCH
+    _WEIGHT_EPOCH += 1
+
+
 def _cached(key_tensor, tag, fn):
     """Memoises a packed layout ON the parameter object (so it dies with it and can never be
     confused with another tensor that later reuses the same device address); re-packs when the
-    parameter is modified in place (version counter) or moved."""
+    parameter is modified in place (version counter), moved, or when an optimiser that writes through
+    raw pointers announced an update (invalidate_weight_packs)."""
     store = key_tensor.__dict__.setdefault('_lf_pack', {})
-    stamp = (key_tensor._version, key_tensor.data_ptr())
+    stamp = (key_tensor._version, key_tensor.data_ptr(), _WEIGHT_EPOCH)
     hit = store.get(tag)
     if hit is None or hit[0] != stamp:
         hit = (stamp, fn())

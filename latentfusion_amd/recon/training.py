@@ -17,7 +17,7 @@ import math
 import torch
 import torch.nn.functional as F
 
-from .. import _lib, losses, parallel
+from .. import _lib, losses, ops, parallel
 
 
 class FlatParameters:
@@ -72,6 +72,7 @@ class FlatAdam:
         _lib.check(L.lf_adam_step(self.flat.data.data_ptr(), self.flat.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
                                   rows[0:1].data_ptr(), rows[1:2].data_ptr(), math.sqrt(bc2), b1, b2, self.eps,
                                   self.weight_decay, 1, n, torch.cuda.current_stream().cuda_stream), 'lf_adam_step')
+        ops.invalidate_weight_packs()                     # the kernel wrote the weights behind torch's back
 
 
 class GeneratorStep:

@@ -308,6 +308,18 @@ def test_generator_training_step(golden):
     agree = (torch.sign(delta[big]) == -torch.sign(ograd[big])).float().mean().item()
     assert agree > 0.995, agree
     assert float(delta.abs().max()) <= 1e-3 * 1.0001
+    # the updated WEIGHTS (not only the biases, which kernels read in place) must be what the next forward
+    # uses: a model rebuilt from the updated state dicts gives the same loss
+    after = step.run_iteration(batch, train=False)
+    sc2 = Sculptor.from_checkpoint({'args': g['sculptor']['args'], 'state_dict': {k: v.detach().clone() for k, v in sc.state_dict().items()}}).to(DEV)
+    fu2 = fusion.from_checkpoint({**g['fuser'], 'state_dict': {k: v.detach().clone() for k, v in fu.state_dict().items()}}).to(DEV)
+    ph2 = Photographer.from_checkpoint({'args': pck['args'], 'state_dict': {k: v.detach().clone() for k, v in ph.state_dict().items()}}).to(DEV)
+    with torch.no_grad():
+        z2, _ = sc2.encode(fu2, cam, batch['in']['image'], None, batch['in']['mask'])
+        y2, _, _ = ph2.decode(z2, cam, return_latent=True, apply_mask=False)
+    d2 = L.reduce_loss(L.get_recon_criterion('hard_smooth_l1', 100)(y2['depth'], tgt_depth.to(DEV)))
+    close(after['depth_recon'], d2, atol=1e-6, rtol=1e-5)
+    assert abs(float(after['total']) - float(got['total'])) > 1e-4
     first = float(got['total'])
     for _ in range(4):
         last = step.run_iteration(batch)
