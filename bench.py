@@ -46,7 +46,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-iters', type=int, default=1)
     ap.add_argument('--no-alt', action='store_true', help='skip the secondary f16x3 measurement')
-    ap.add_argument('--conv-mode', default='winograd', choices=['fp32', 'winograd', 'f16x3'],
+    ap.add_argument('--conv-mode', default='winograd', choices=['fp32', 'winograd', 'f16x3', 'winograd_f16x3'],
                     help="conv3d kernels of the engine: 'winograd' (default; F(2^3,3^3) minimal filtering, all-fp32 "
                          "arithmetic), 'fp32' (direct implicit GEMM on the fp32 MFMA) or 'f16x3' (split precision)")
     return ap.parse_args()
@@ -151,30 +151,32 @@ def main():
 
     elapsed, timer = timed_loop(est, st)
     alt = None
-    if a.conv_mode != 'f16x3' and not a.no_alt and C == 16:
+    if a.conv_mode in ('fp32', 'winograd') and not a.no_alt and C == 16:
         # secondary line (never `value`): the same loop with the split-precision conv3d kernels
         del est, st
         torch.cuda.empty_cache()
-        est2 = estimation.load_from_config(cfg, model, converge_patience=10 ** 6, conv_mode='f16x3')
+        est2 = estimation.load_from_config(cfg, model, converge_patience=10 ** 6, conv_mode='winograd_f16x3')
         st2 = est2.start(z_obj, target, init.zoom(None, model.input_size, model.camera_dist).to(dev))
         el2, tm2 = timed_loop(est2, st2)
-        d2 = [e0.elapsed_time(e1) for n_, e0, e1 in tm2 if n_ == 'conv3d_c16_split']
-        alt = {'conv_mode': 'f16x3 (each fp32 product as 3 f16 MFMAs, fp32 accumulate; max error vs fp64 <= the fp32 '
-                            'kernel\'s, tests/test_engine_gpu.py::test_split_precision_conv_matches_fp32_and_fp64)',
+        d2 = [e0.elapsed_time(e1) for n_, e0, e1 in tm2 if n_ == 'conv3d_c16_wino_split']
+        alt = {'conv_mode': 'winograd_f16x3 (Winograd with fp32 transforms; each Winograd-domain product as 3 f16 MFMAs, '
+                            'fp32 accumulate; error vs fp64 within the fp32 kernels\', '
+                            'tests/test_engine_gpu.py::test_winograd_conv3d_matches_fp64)',
                'value': world * a.steps / el2, 'unit': 'iters/s', 'ms_per_step': el2 / a.steps * 1e3,
                'conv_avg_launch_ms': sum(d2) / max(len(d2), 1)}
 
     # roofline of the dominant kernel: conv3d_c16_persistent_kernel (fused conv3d C->C block; 2 forward +
     # 2 data-gradient launches per iteration), HIP events recorded on the launch stream in the timed region
-    name = {'fp32': f'conv3x3_3d_{C}x{C}', 'winograd': 'conv3d_c16_wino', 'f16x3': 'conv3d_c16_split'}[a.conv_mode]
+    name = {'fp32': f'conv3x3_3d_{C}x{C}', 'winograd': 'conv3d_c16_wino', 'f16x3': 'conv3d_c16_split',
+            'winograd_f16x3': 'conv3d_c16_wino_split'}[a.conv_mode]
     durs = [e0.elapsed_time(e1) for n_, e0, e1 in timer if n_ == name]
     conv_ms = sum(durs) / max(len(durs), 1)
     flops = 2.0 * 27 * C * C * (S ** 3) * N                        # algorithmic flops per launch
     achieved = flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     # f16x3 issues 3 f16 MFMA products per algorithmic product: price it against dense-f16 peak / 3
-    peak = FP32_MFMA_PEAK_TFLOPS if a.conv_mode != 'f16x3' else F16_MFMA_PEAK_TFLOPS / 3.0
+    peak = FP32_MFMA_PEAK_TFLOPS if a.conv_mode in ('fp32', 'winograd') else F16_MFMA_PEAK_TFLOPS / 3.0
     kname = {'fp32': 'conv3d_c16_persistent_kernel', 'winograd': 'conv3d_c16_wino_kernel',
-             'f16x3': 'conv3d_c16_f16x3_kernel'}[a.conv_mode]
+             'f16x3': 'conv3d_c16_f16x3_kernel', 'winograd_f16x3': 'conv3d_c16_wino_f16x3_kernel'}[a.conv_mode]
     # Winograd F(2^3,3^3) executes 64 multiplies per 2x2x2 outputs instead of 216: `achieved` stays the
     # ALGORITHMIC (direct-convolution) flops per launch / time, so it may exceed the fp32 MFMA peak
     roof_note = None
@@ -199,7 +201,7 @@ def main():
         'metric': 'pose-optim iters/sec (reconstruct+render+backward), 16 views, 128^3 voxels',
         'value': value, 'unit': 'iters/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
         'ms_per_step': elapsed / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32' if a.conv_mode != 'f16x3' else 'f32 (conv3d products split into 3 f16 MFMAs, fp32 accumulate)', 'data': 'synthetic (SYN(S,C) random-init weights, synthetic observations)',
+        'dtype': 'f32' if a.conv_mode in ('fp32', 'winograd') else 'f32 (conv3d products split into 3 f16 MFMAs, fp32 accumulate)', 'data': 'synthetic (SYN(S,C) random-init weights, synthetic observations)',
         'config': {'workload': f'SYN({S},{C}) latent volume, {V} reference views, adam_quick pose loop, '
                                f'{N} pose samples per iteration, one object per GPU',
                    'fuser': a.fuser, 'pose_samples': N, 'ref_views': V, 'volume': S, 'channels': C,

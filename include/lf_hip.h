@@ -128,7 +128,7 @@ int lf_conv1x1_bwd_data(const float* gy, const float* wpack_t, float* gx, int N,
                         long y_batch_stride, int y_row_stride, int y_slice_channels, long y_slice_stride,
                         float he, const float* prev_y, const float* prev_norm, unsigned prev_flags,
                         float slope, float* amax_out, void* stream);
-/* (amax_out, optional: zero-initialised device scalar that receives max|gx| when prev_y != NULL;
+/* (amax_out, optional: zero-initialised LF_AMAX_FLOATS-float buffer that receives max|gx| when prev_y != NULL;
  *  consumed by lf_conv3d_c16_split as amax_in.) */
 
 /* Split-precision ("f16x3") variant of the fused conv3d 16->16 block and of its data gradient:
@@ -139,7 +139,10 @@ int lf_conv1x1_bwd_data(const float* gy, const float* wpack_t, float* gx, int N,
  * lf_conv3d_c16_split_pairs),
  * lf_conv3d_c16_split_wpack_halfs() elements (host-packed).  amax_in (device scalar, may be NULL):
  * max-abs of x, used to pre-scale tiny gradient tensors by a power of two (undone exactly);
- * amax_out (may be NULL, zero-initialised by the caller): receives max-abs of the output. */
+ * amax_out (may be NULL, zero-initialised by the caller): receives max-abs of the output.
+ * Both are LF_AMAX_FLOATS-float buffers of partial maxima (one slot per 128-byte line; the maximum over the
+ * buffer is the value): producers spread their atomic maxima over the slots, consumers reduce them. */
+#define LF_AMAX_FLOATS 2048
 size_t lf_conv3d_c16_split_wpack_halfs(void);
 void lf_conv3d_c16_split_pairs(int* taps28);   /* tap indices (kz*9+ky*3+kx; -1 = zero) of the 14 K-slot pairs */
 int lf_conv3d_c16_split(const float* x, const void* wsplit, const float* bias, float* y, float* norm_out,
@@ -160,6 +163,17 @@ int lf_conv3d_c16_wino(const float* x, const float* upack, const float* bias, fl
                        int N, int D, int H, int W, float he, unsigned flags, float slope, float eps,
                        const float* prev_y, const float* prev_norm, unsigned prev_flags,
                        float* amax_out, void* stream);
+
+/* Winograd F(2x2x2,3x3x3) with split-precision products: transforms in fp32, every Winograd-domain product
+ * from three v_mfma_f32_16x16x16_f16 (U_hi.V_hi + U_hi.V_lo + U_lo.V_hi, fp32 accumulate).  Same semantics
+ * as lf_conv3d_c16_wino; amax_in / amax_out as in lf_conv3d_c16_split.
+ * upack: lf_conv3d_c16_wino_split_upack_halfs() f16 values, [4 a][16 b*4+c][hi, lo][64 lanes l][4 j]
+ *        = split of U[a][b][c][cout = l & 15][cin = (l >> 4) * 4 + j]. */
+size_t lf_conv3d_c16_wino_split_upack_halfs(void);
+int lf_conv3d_c16_wino_split(const float* x, const void* upack, const float* bias, float* y, float* norm_out,
+                             int N, int D, int H, int W, float he, unsigned flags, float slope, float eps,
+                             const float* prev_y, const float* prev_norm, unsigned prev_flags,
+                             const float* amax_in, float* amax_out, void* stream);
 
 /* 2-D grid sampling of planar images, F.grid_sample(align_corners=False) semantics: the crop / zoom
  * (geometry.py:20-44,287-354; zeros padding), Camera.uncrop (geometry.py:261-285; border padding) and the

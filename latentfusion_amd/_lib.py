@@ -15,6 +15,7 @@ LF_EPI_PIXELNORM = 2
 LF_MAP_O2C = 0
 LF_MAP_C2O = 1
 LF_MAP_COEFS = 20
+LF_AMAX_FLOATS = 2048          # floats of a max-abs side-channel buffer (include/lf_hip.h)
 
 P = c_void_p
 # name -> (restype, argtypes); mirrors include/lf_hip.h one to one
@@ -42,6 +43,9 @@ SIGNATURES = {
     'lf_conv3d_c16_wino_upack_floats': (c_size_t, []),
     'lf_conv3d_c16_wino': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint, c_float, c_float, P, P,
                                    c_uint, P, P]),
+    'lf_conv3d_c16_wino_split_upack_halfs': (c_size_t, []),
+    'lf_conv3d_c16_wino_split': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint, c_float, c_float, P, P,
+                                         c_uint, P, P, P]),
     'lf_grid_sample2d_fwd': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     'lf_grid_sample2d_bwd': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     'lf_conv_bwd_weight_scratch_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),

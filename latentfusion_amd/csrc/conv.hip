@@ -129,7 +129,7 @@ __device__ __forceinline__ void epilogue_store(f32x4 (&acc)[NT][NR], const long 
   if (amax_out != nullptr) {                       // max-abs of what this wave wrote (order-independent)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) lane_amax = fmaxf(lane_amax, __shfl_xor(lane_amax, o, 64));
-    if (lane == 0 && lane_amax > 0.f) atomicMax((unsigned int*)amax_out, __float_as_uint(lane_amax));
+    lf_amax_publish(amax_out, lane_amax, lane);
   }
 }
 

@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(512, 2) conv3d_c16_f16x3_kernel(
   // power-of-two input scale from the tensor's max-abs (gradient launches); 1 otherwise
   float in_scale = 1.f;
   if (amax_in != nullptr) {
-    const float am = *amax_in;
+    const float am = lf_amax_read(amax_in, lane);
     if (am > 0.f && am < 3.0e38f) {
       int ex;
       frexpf(am, &ex);                                               // am = m * 2^ex, m in [0.5, 1)
@@ -308,7 +308,7 @@ __global__ void __launch_bounds__(512, 2) conv3d_c16_f16x3_kernel(
     float m = wave_amax;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if (lane == 0 && m > 0.f) atomicMax((unsigned int*)amax_out, __float_as_uint(m));   // non-negative floats order as uints
+    lf_amax_publish(amax_out, m, lane);
   }
 }
 

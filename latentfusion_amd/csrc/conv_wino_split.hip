@@ -1,37 +1,13 @@
-// Winograd F(2x2x2, 3x3x3) form of the fused 16 -> 16 channel conv3d block step (gfx950).
-//
-//   y = PixelNorm(LeakyReLU(conv3d(x, W) * he + b))            latentfusion/modules/blocks.py:152-158
-//                                                              latentfusion/modules/equalized.py:57-64
-// and, with transposed/flipped weights and `prev_*` set, the data gradient fused with the previous
-// layer's LeakyReLU'/PixelNorm' (autograd of the same lines).
-//
-// All arithmetic is fp32 (v_mfma_f32_16x16x4_f32 + fp32 VALU transforms).  The minimal-filtering
-// identity  Y = A^T[(G w G^T) . (B^T d B)]A  applied along z, y and x needs 64 multiplies per 2x2x2
-// outputs instead of 216, so the MFMA work per voxel drops 3.375x; measured against fp64 the result is
-// as close as the direct fp32 kernel's (tests/test_ops_gpu.py::test_winograd_conv3d_*).
-//
-// Work split: 256-thread workgroups, TWO per CU (2 x 79,872 B of LDS), each persistent over its own range
-// of 2 x 8 x 16-voxel tiles.  The two workgroups of a CU are not synchronised with each other, so one's
-// exchange / epilogue / DMA-wait phases run under the other's MFMA phase (on gfx950 the fp32 MFMA and the
-// fp32 VALU share the SIMD's issue pipe -- measured: they do not overlap -- so everything that is not an
-// MFMA has to be either few instructions or hidden this way).
-//   * wave w owns z-frequency a = w of the tile; the 16 (y,x)-frequency matrices U[a][b][c]
-//     (16 cout x 16 cin each) live in 64 VGPRs for the whole launch;
-//   * MFMA columns = 16 Winograd tiles (2 in y x 8 in x), lane group kg = lane >> 4 carries input
-//     channels 4kg..4kg+3 (B operand) and receives output channels 4kg..4kg+3 (D operand);
-//   * per 16-tile group: 32 ds_read_b128 of the fp32 halo (two z planes combined on the fly),
-//     x/y input transforms in registers, 64 MFMAs, y/x output transform in registers;
-//   * the four z-frequency partials of a tile meet through LDS, then every wave finishes a quarter of the
-//     outputs: z output transform, He scale, bias, LeakyReLU, PixelNorm (DPP quad reduction), and one
-//     x-contiguous 1 KiB row per store instruction.
-// The halo is fetched with LDS-DMA (issued as soon as the previous tile's halo has been consumed) in a
-// bank-swizzled order: voxel slot = (z*10 + y)*18 + (x&1)*9 + (x>>1), 16-byte quarter q stored at
-// q ^ s, s = 2*((slot>>2)&1) + ((y>>1)&1)  ->  every ds_read_b128 lane group hits 16 distinct slots
-// (SQ_LDS_BANK_CONFLICT = 0).
+// Winograd F(2x2x2, 3x3x3) conv3d 16 -> 16 with SPLIT-PRECISION products: same structure as conv_wino.hip
+// (z-frequency per wave, bank-swizzled LDS-DMA halo, partial exchange through LDS, two workgroups per CU), but
+// every Winograd-domain product  U . V  is formed from three f16 MFMAs accumulating in fp32,
+//      U_hi.V_hi + U_hi.V_lo + U_lo.V_hi        (x = x_hi + x_lo, both f16; dropped term <= 2^-22 |U||V|),
+// on v_mfma_f32_16x16x16_f16.  The f16 matrix pipe runs beside the fp32 VALU (the fp32 MFMA does not), so
+// the transforms -- which stay in fp32 -- are all that is left on the issue pipe.  Tiny tensors (gradients)
+// are pre-scaled by a power of two taken from the producer's max-abs side output and un-scaled exactly in
+// the epilogue, like lf_conv3d_c16_split.  Opt-in (`conv_mode='winograd_f16x3'`); measured error against
+// fp64 is within the all-fp32 kernels' (tests/test_engine_gpu.py).
 #include "lf_common.h"
-#ifndef WINO_ABL
-#define WINO_ABL 0
-#endif
 
 namespace {
 
@@ -72,6 +48,7 @@ __device__ __forceinline__ float fast_rcp(float x) {
 // MFMA <-> VALU wait states are inserted by the compiler, which does not look inside asm (feeding the
 // B operand of an MFMA straight from this asm gave wrong results on gfx950).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 pk_sub(f32x4 a, f32x4 b) {
   f32x2 lo, hi;
   const f32x2 alo = {a[0], a[1]}, ahi = {a[2], a[3]}, blo = {b[0], b[1]}, bhi = {b[2], b[3]};
@@ -104,7 +81,8 @@ __device__ __forceinline__ void dma_piece(const DmaTile& d, int it, int wave, in
 
 template <int A>
 __device__ __forceinline__ void wino_compute(const unsigned char* __restrict__ buf, const int (&off)[8][2],
-                                              const float (&wt)[64], f32x4 (&Y)[2][4]) {
+                                              const f16x4 (&whi)[16], const f16x4 (&wlo)[16], float in_scale,
+                                              f32x4 (&Y)[2][4]) {
   // z input transform of frequency A: d0-d2, d1+d2, d2-d1, d1-d3
   constexpr int DZ0 = (A == 0) ? 0 : (A == 2 ? 2 : 1);
   constexpr int DZ1 = (A == 0) ? 2 : (A == 1 ? 2 : (A == 2 ? 1 : 3));
@@ -136,10 +114,14 @@ __device__ __forceinline__ void wino_compute(const unsigned char* __restrict__ b
                       : (b == 1) ? (vx[1][c] + vx[2][c])
                       : (b == 2) ? (vx[2][c] - vx[1][c])
                                  : (vx[1][c] - vx[3][c]);
+        // split the fp32 Winograd-domain value into f16 hi + lo (exact to 22 bits) and multiply in three terms
+        const f32x4 vs = v * in_scale;
+        const f16x4 vhi = __builtin_convertvector(vs, f16x4);
+        const f16x4 vlo = __builtin_convertvector(vs - __builtin_convertvector(vhi, f32x4), f16x4);
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[(b * 4 + c) * 4 + i], v[i], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x16f16(whi[b * 4 + c], vlo, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x16f16(wlo[b * 4 + c], vhi, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x16f16(whi[b * 4 + c], vhi, acc, 0, 0, 0);
         m[c] = acc;
       }
       // x output transform, then accumulate the y output transform
@@ -153,13 +135,13 @@ __device__ __forceinline__ void wino_compute(const unsigned char* __restrict__ b
   }
 }
 
-__global__ void __launch_bounds__(256, 2) conv3d_c16_wino_kernel(
-    const float* __restrict__ x, const float* __restrict__ upack, const float* __restrict__ bias,
+__global__ void __launch_bounds__(256, 2) conv3d_c16_wino_f16x3_kernel(
+    const float* __restrict__ x, const f16x4* __restrict__ upack, const float* __restrict__ bias,
     float* __restrict__ y, float* __restrict__ norm_out,
     int N, int D, int H, int W, int tiles_x, int tiles_y, int tiles_z, int ntiles,
     float he, unsigned flags, float slope, float eps,
     const float* __restrict__ prev_y, const float* __restrict__ prev_norm, unsigned prev_flags,
-    float* __restrict__ amax_out) {
+    const float* __restrict__ amax_in, float* __restrict__ amax_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const buf = smem;                              // halo
   unsigned char* const px = smem + BUFw;                        // partial exchange
@@ -218,11 +200,21 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_wino_kernel(
   const int ex = lane >> 2, eq = lane & 3;
 
   // ---- transformed weights of this wave's z-frequency: [16 (b,c)][4 k-chunks], lane-major in memory ----
-  float wt[64];
+  f16x4 whi[16], wlo[16];                                     // [16 (b,c)] x {hi, lo}: A operands, K = 4 cin per lane group
   {
-    const float* up = upack + (long)fa * 64 * 64 + lane;
+    const f16x4* up = upack + (long)fa * 16 * 2 * 64 + lane;
 #pragma unroll
-    for (int k = 0; k < 64; ++k) wt[k] = up[k * 64];
+    for (int k = 0; k < 16; ++k) { whi[k] = up[(k * 2 + 0) * 64]; wlo[k] = up[(k * 2 + 1) * 64]; }
+  }
+  // power-of-two input scale from the tensor's max-abs (gradient launches); 1 otherwise
+  float in_scale = 1.f;
+  if (amax_in != nullptr) {
+    const float am = lf_amax_read(amax_in, lane);
+    if (am > 0.f && am < 3.0e38f) {
+      int ex;
+      frexpf(am, &ex);                                          // am = m * 2^ex, m in [0.5, 1)
+      in_scale = ldexpf(1.f, 9 - ex);                           // max maps into [2^8, 2^9): x8 transform growth stays in f16 range
+    }
   }
   f32x4 bv4 = (f32x4){0.f, 0.f, 0.f, 0.f};
   if (bias != nullptr) bv4 = *(const f32x4*)(bias + eq * 4);
@@ -246,30 +238,22 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_wino_kernel(
     for (int it = 0; it < NITw; ++it) dma_piece(d, it, fa, lxyzq[it], W, H, D);
   };
 
-  const float out_scale = he;
+  const float out_scale = he / in_scale;
   float wave_amax = 0.f;
 
   issue_dma(cx, cy, cz, cn, true);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   lds_barrier();
 
-#if WINO_ABL & 16
-#define TS(k) do { if (blockIdx.x == 11 && lane == 0) ((unsigned*)norm_out)[((t - t_begin) * 4 + fa) * 16 + (k)] = (unsigned)__builtin_readcyclecounter(); } while (0)
-#else
-#define TS(k) do {} while (0)
-#endif
   for (int t = t_begin; t < t_end; ++t) {
-    TS(0);
     f32x4 Y[2][4];
     switch (fa) {
-      case 0: wino_compute<0>(buf, off, wt, Y); break;
-      case 1: wino_compute<1>(buf, off, wt, Y); break;
-      case 2: wino_compute<2>(buf, off, wt, Y); break;
-      default: wino_compute<3>(buf, off, wt, Y); break;
+      case 0: wino_compute<0>(buf, off, whi, wlo, in_scale, Y); break;
+      case 1: wino_compute<1>(buf, off, whi, wlo, in_scale, Y); break;
+      case 2: wino_compute<2>(buf, off, whi, wlo, in_scale, Y); break;
+      default: wino_compute<3>(buf, off, whi, wlo, in_scale, Y); break;
     }
-    TS(1);
     lds_barrier();                                              // every wave is done reading the halo
-    TS(2);
 
     // next tile's halo: in flight during the exchange / epilogue below and, for the CU, under the MFMA phase
     // of the other resident workgroup
@@ -278,7 +262,6 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_wino_kernel(
     if (ny == tiles_y) { ny = 0; ++nz; }
     if (nz == tiles_z) { nz = 0; ++nn; }
     issue_dma(nx, ny, nz, nn, t + 1 < t_end);
-    TS(3);
 
     // partial outputs of z-frequency fa -> LDS, 1 KiB blocks indexed [wave][g][tyb][j], 64 float4 slots each
     // at (L ^ ((L >> 3) & 7)), L = x*4 + channel quarter: the writers' 8-lane groups and the readers' 16-lane
@@ -317,9 +300,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_wino_kernel(
         pnv[k] = (okv[k] && pnbase) ? pnbase[voxi[k]] : 1.f;
       }
     }
-    TS(4);
     lds_barrier();                                              // all partials are in LDS
-    TS(5);
 
     f32x4 o[4];
 #pragma unroll
@@ -359,9 +340,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_wino_kernel(
     // the next halo (and, for the gradient form, the previous layer's activations) must have arrived
     // before the tile's last barrier; this tile's stores are issued after the wait so they stay out of it
     // and drain behind the next tile's MFMAs
-    TS(6);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    TS(7);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if (prev_y != nullptr) {
@@ -380,12 +359,11 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_wino_kernel(
       }
       if (okv[k]) {
         __builtin_nontemporal_store(v[k], (f32x4*)(ybase + (unsigned)(voxi[k] * 64)));   // streamed: L2 is for halos
-        if (!(WINO_ABL & 16) && prev_y == nullptr && (flags & LF_EPI_PIXELNORM) && nbase != nullptr && eq == 0) nbase[voxi[k]] = rn[k];
+        if (prev_y == nullptr && (flags & LF_EPI_PIXELNORM) && nbase != nullptr && eq == 0) nbase[voxi[k]] = rn[k];
         if (amax_out != nullptr)
           wave_amax = fmaxf(wave_amax, fmaxf(fmaxf(fabsf(v[k][0]), fabsf(v[k][1])), fmaxf(fabsf(v[k][2]), fabsf(v[k][3]))));
       }
     }
-    TS(8);
     lds_barrier();                                              // next halo visible to all; partials consumed
     cx = nx; cy = ny; cz = nz; cn = nn;
   }
@@ -399,13 +377,13 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_wino_kernel(
 
 }  // namespace
 
-// floats of the transformed-weight pack: [4 z-freq][16 (y,x)-freq][4 k-chunks][64 lanes]
-extern "C" size_t lf_conv3d_c16_wino_upack_floats(void) { return (size_t)4 * 16 * 4 * 64; }
+// halfs of the split transformed-weight pack: [4 z-freq][16 (y,x)-freq][hi, lo][64 lanes][4 cin]
+extern "C" size_t lf_conv3d_c16_wino_split_upack_halfs(void) { return (size_t)4 * 16 * 2 * 64 * 4; }
 
-extern "C" int lf_conv3d_c16_wino(const float* x, const float* upack, const float* bias, float* y, float* norm_out,
-                                  int N, int D, int H, int W, float he, unsigned flags, float slope, float eps,
-                                  const float* prev_y, const float* prev_norm, unsigned prev_flags,
-                                  float* amax_out, void* stream) {
+extern "C" int lf_conv3d_c16_wino_split(const float* x, const void* upack, const float* bias, float* y, float* norm_out,
+                                        int N, int D, int H, int W, float he, unsigned flags, float slope, float eps,
+                                        const float* prev_y, const float* prev_norm, unsigned prev_flags,
+                                        const float* amax_in, float* amax_out, void* stream) {
   lf_clear_error();
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0) return LF_EINVAL;
   if ((long)D * H * W * 64 >= 0x7fffffffL || !(slope > 0.f && slope < 1.f)) return LF_EINVAL;
@@ -424,15 +402,15 @@ extern "C" int lf_conv3d_c16_wino(const float* x, const float* upack, const floa
   const size_t shmem = (size_t)LDSw;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv3d_c16_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute((const void*)conv3d_c16_wino_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)shmem);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
   const long want = 2L * cus;                                     // two resident workgroups per CU
   const unsigned grid = (unsigned)(pt < want ? pt : want);
-  hipLaunchKernelGGL(conv3d_c16_wino_kernel, dim3(grid), dim3(256), shmem, (hipStream_t)stream, x, upack, bias, y,
-                     norm_out, N, D, H, W, ptx, pty, ptz, (int)pt, he, flags, slope, eps, prev_y, prev_norm, prev_flags,
-                     amax_out);
+  hipLaunchKernelGGL(conv3d_c16_wino_f16x3_kernel, dim3(grid), dim3(256), shmem, (hipStream_t)stream, x,
+                     (const f16x4*)upack, bias, y, norm_out, N, D, H, W, ptx, pty, ptz, (int)pt, he, flags, slope, eps, prev_y,
+                     prev_norm, prev_flags, amax_in, amax_out);
   return lf_launch_status();
 }

@@ -26,4 +26,25 @@ __device__ __forceinline__ float lf_wave_sum(float v) {
   return v;
 }
 
+// Max-abs side channel between kernels (power-of-two pre-scaling of split-precision inputs): LF_AMAX_SLOTS
+// partial maxima, one per 128-byte line, so that the producers' atomic maxima spread over the L2 channels
+// instead of serialising on one address (131k waves on one address cost ~0.7 ms).  The buffer is
+// LF_AMAX_FLOATS floats, zero-initialised by the caller; non-negative floats order like unsigned ints.
+#define LF_AMAX_SLOTS 64
+#define LF_AMAX_STRIDE 32
+static_assert(LF_AMAX_FLOATS == LF_AMAX_SLOTS * LF_AMAX_STRIDE, "lf_hip.h: LF_AMAX_FLOATS");
+
+__device__ __forceinline__ void lf_amax_publish(float* base, float wave_max, int lane) {
+  if (lane == 0 && wave_max > 0.f)
+    atomicMax((unsigned int*)(base + (blockIdx.x % LF_AMAX_SLOTS) * LF_AMAX_STRIDE), __float_as_uint(wave_max));
+}
+
+// whole-wave read: every lane returns the maximum over the slots
+__device__ __forceinline__ float lf_amax_read(const float* base, int lane) {
+  float m = base[(lane % LF_AMAX_SLOTS) * LF_AMAX_STRIDE];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  return m;
+}
+
 __device__ __forceinline__ float lf_lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }

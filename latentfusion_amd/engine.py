@@ -129,9 +129,10 @@ class RenderLoopEngine:
         'fp32'     direct implicit-GEMM on the fp32 MFMA (works for every channel count);
         'winograd' F(2x2x2,3x3x3) minimal filtering, all-fp32 arithmetic (fp32 MFMA + fp32 transforms);
         'f16x3'    direct, each fp32 product from three f16 MFMAs with fp32 accumulation;
+        'winograd_f16x3'  Winograd with fp32 transforms and three-term f16 products (fastest; opt-in);
         'auto'     (default) 'winograd' when the blocks are 16->16, else 'fp32'.
         All three stay within the fp32 kernel's distance of an fp64 reference (tests/test_engine_gpu.py)."""
-        if conv_mode not in ('auto', 'fp32', 'winograd', 'f16x3'):
+        if conv_mode not in ('auto', 'fp32', 'winograd', 'f16x3', 'winograd_f16x3'):
             raise ValueError(conv_mode)
         self.ph = photographer
         self.cube = photographer.cube_size
@@ -158,6 +159,11 @@ class RenderLoopEngine:
         self.split = self.wino = None
         if conv_mode == 'f16x3':
             self.split = [(ops.pack_conv3d_c16_split(w), ops.pack_conv3d_c16_split(w, transpose=True)) for w, *_ in self.convs]
+        elif conv_mode == 'winograd_f16x3':
+            self.split = [(ops.pack_conv3d_c16_wino_split(w), ops.pack_conv3d_c16_wino_split(w, transpose=True))
+                          for w, *_ in self.convs]
+            # trilinear resampling is a convex combination: max|x0| <= max|z_obj|
+            self.z_amax = ops.amax_buffer(self.z.abs().max(), dev)
         elif conv_mode == 'winograd':
             self.wino = [(ops.pack_conv3d_c16_wino(w), ops.pack_conv3d_c16_wino(w, transpose=True)) for w, *_ in self.convs]
         pw = photographer.projection_block.conv.module.weight
@@ -194,7 +200,10 @@ class RenderLoopEngine:
         acts, norms = [x0], []
         flags = LF_EPI_LRELU | LF_EPI_PIXELNORM
         for li_, (w, b, he, wp, _wt) in enumerate(self.convs):
-            if self.split is not None:
+            if self.conv_mode == 'winograd_f16x3':
+                y, nrm = ops.conv3d_c16_wino_split(acts[-1], self.split[li_][0], b, he, flags,
+                                                   amax_in=self.z_amax if li_ == 0 else None)
+            elif self.split is not None:
                 y, nrm = ops.conv3d_c16_split(acts[-1], self.split[li_][0], b, he, flags)
             elif self.wino is not None:
                 y, nrm = ops.conv3d_c16_wino(acts[-1], self.wino[li_][0], b, he, flags)
@@ -230,17 +239,20 @@ class RenderLoopEngine:
             # so no separate epilogue-backward pass touches the (N,16,S,S,S) volumes
             # max-abs of each gradient volume (order-independent atomic max inside the producing kernel):
             # lets the split kernels pre-scale tiny gradients by an exact power of two
-            amax = torch.zeros(nconv + 1, device=dev, dtype=torch.float32) if self.split is not None else None
+            amax = ops.amax_buffer(None, dev, rows=nconv + 1) if self.split is not None else None
             check(L.lf_conv1x1_bwd_data(gp.data_ptr(), ppack_t.data_ptr(), g.data_ptr(), n, S * S, cout, S * Cl,
                                         S * S * S * Cl, Cl, Cl, S * S * Cl, phe, acts[nconv].data_ptr(),
                                         norms[nconv - 1].data_ptr(), flags, ops.SLOPE,
-                                        amax[nconv:].data_ptr() if amax is not None else None, s), 'lf_conv1x1_bwd_data')
+                                        amax[nconv].data_ptr() if amax is not None else None, s), 'lf_conv1x1_bwd_data')
             for i in range(nconv - 1, -1, -1):
                 w, b, he, _wp, wt = self.convs[i]
                 prev = (acts[i], norms[i - 1], flags) if i > 0 else None
-                if self.split is not None:
-                    g, _ = ops.conv3d_c16_split(g, self.split[i][1], None, he, 0, prev=prev, amax_in=amax[i + 1:i + 2],
-                                                amax_out=amax[i:i + 1])
+                if self.conv_mode == 'winograd_f16x3':
+                    g, _ = ops.conv3d_c16_wino_split(g, self.split[i][1], None, he, 0, prev=prev,
+                                                     amax_in=amax[i + 1], amax_out=amax[i])
+                elif self.split is not None:
+                    g, _ = ops.conv3d_c16_split(g, self.split[i][1], None, he, 0, prev=prev, amax_in=amax[i + 1],
+                                                amax_out=amax[i])
                 elif self.wino is not None:
                     g, _ = ops.conv3d_c16_wino(g, self.wino[i][1], None, he, 0, prev=prev)
                 else:

@@ -125,6 +125,15 @@ def pack_conv1x1(weight2d):
     return out.contiguous()
 
 
+def amax_buffer(value=None, device='cuda', rows=1):
+    """Zeroed max-abs side-channel buffer(s) (rows x LF_AMAX_FLOATS); `value` (a tensor) pre-loads slot 0 of
+    row 0, e.g. a maximum computed on the host side of the ABI."""
+    buf = torch.zeros(rows, _lib.LF_AMAX_FLOATS, device=device, dtype=torch.float32)
+    if value is not None:
+        buf[0, 0] = value.reshape(()).to(device)
+    return buf
+
+
 def pack_conv3d_c16_split(weight, transpose=False):
     """[16,16,3,3,3] fp32 -> f16 hi/lo packs [14 pairs][hi,lo][16 cout][32 = 2 taps x 16 cin] for
     lf_conv3d_c16_split (the second tap of the last pair is zero)."""
@@ -179,6 +188,38 @@ def pack_conv3d_c16_wino(weight, transpose=False):
     U = U.reshape(4, 16, 16, 4, 4)                                          # [a][bc][cout][kg][i]
     U = U.permute(0, 1, 4, 3, 2).reshape(4, 16, 4, 64)                      # [a][bc][i][lane = kg*16 + cout]
     return U.float().contiguous()
+
+
+def pack_conv3d_c16_wino_split(weight, transpose=False):
+    """Winograd-domain weights split into f16 hi + lo: [4 a][16 bc][hi, lo][64 lanes][4 cin] for
+    lf_conv3d_c16_wino_split (lane = (cin // 4) * 16 + cout)."""
+    w = weight.detach()
+    if transpose:
+        w = w.transpose(0, 1).flip(dims=(2, 3, 4))
+    assert tuple(w.shape) == (16, 16, 3, 3, 3)
+    G = torch.tensor(_WINO_G, dtype=torch.float64, device=w.device)
+    U = torch.einsum('ai,bj,ck,omijk->abcom', G, G, G, w.double()).float()  # [a][b][c][cout][cin]
+    U = U.reshape(4, 16, 16, 4, 4).permute(0, 1, 3, 2, 4).reshape(4, 16, 64, 4)   # [a][bc][lane = kg*16 + cout][j]
+    hi = U.half()
+    lo = (U - hi.float()).half()
+    return torch.stack((hi, lo), dim=2).contiguous()                        # [4][16][2][64][4]
+
+
+def conv3d_c16_wino_split(x, upack, bias, he, flags, prev=None, amax_in=None, amax_out=None):
+    """Launch lf_conv3d_c16_wino_split on a channels-last (N,16,D,H,W) tensor."""
+    L = _lib.lib()
+    N, _, D, H, W = x.shape
+    y = empty_cl((N, 16, D, H, W), x.device)
+    norm = torch.empty(N * D * H * W, device=x.device, dtype=torch.float32) if (flags & LF_EPI_PIXELNORM) else None
+    py, pn, pf = (prev[0], prev[1], prev[2]) if prev is not None else (None, None, 0)
+    with _timed('conv3d_c16_wino_split'):
+        check(L.lf_conv3d_c16_wino_split(_ptr(x), _ptr(upack), _ptr(bias) if bias is not None else None, _ptr(y),
+                                         _ptr(norm) if norm is not None else None, N, D, H, W, he, flags, SLOPE, PN_EPS,
+                                         _ptr(py) if py is not None else None, _ptr(pn) if pn is not None else None, pf,
+                                         _ptr(amax_in) if amax_in is not None else None,
+                                         _ptr(amax_out) if amax_out is not None else None, _stream()),
+              'lf_conv3d_c16_wino_split')
+    return y, norm
 
 
 def conv3d_c16_wino(x, upack, bias, he, flags, prev=None, amax_out=None):

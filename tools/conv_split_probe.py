@@ -38,7 +38,7 @@ print(f'vs fp64 (interior block): exact-fp32 kernel {(ref[sl].cpu().double() - y
       f'f16x3 kernel {(got[sl].cpu().double() - y64[sl]).abs().max().item():.3e}')
 # gradient-scale input (tiny values) through the data-gradient form with amax scaling
 gsmall = x * 3e-7
-amax = gsmall.abs().max().reshape(1)
+amax = ops.amax_buffer(gsmall.abs().max(), 'cuda')
 wt = ops.pack_conv3x3(w, transpose=True)
 gref = ops.conv3x3_bwd_data(gsmall, wt, 16, he, None)
 gsp, _ = ops.conv3d_c16_split(gsmall, ops.pack_conv3d_c16_split(w, transpose=True), None, he, 0, amax_in=amax)

@@ -43,10 +43,10 @@ for shape in ((2, 16, 10, 20, 40), (1, 16, 5, 7, 9), (3, 16, 4, 8, 16)):
     # fused previous-layer backward
     prev = (ref, nref, flags)
     gref2 = ops.conv3x3_bwd_data(xd, ops.pack_conv3x3(w, transpose=True), 16, he, prev)
-    amax = torch.zeros(1, device='cuda')
+    amax = ops.amax_buffer(None, 'cuda')
     gw2, _ = ops.conv3d_c16_wino(xd, upt, None, he, 0, prev=prev, amax_out=amax)
     torch.cuda.synchronize()
-    print(f'     fused prev-bwd: wino vs direct {(gw2 - gref2).abs().max().item():.3e} (max |g| {gref2.abs().max().item():.3e}); amax {amax.item():.6e} vs {gw2.abs().max().item():.6e}')
+    print(f'     fused prev-bwd: wino vs direct {(gw2 - gref2).abs().max().item():.3e} (max |g| {gref2.abs().max().item():.3e}); amax {amax.max().item():.6e} vs {gw2.abs().max().item():.6e}')
 
 x = ops.cl(torch.randn(N, 16, S, S, S, generator=g).cuda())
 x = x / torch.sqrt((x ** 2).mean(dim=1, keepdim=True))
@@ -56,7 +56,12 @@ torch.cuda.synchronize()
 err = (got - ref).abs()
 print(f'S={S} N={N} fwd: wino vs direct max {err.max().item():.3e} rms {err.pow(2).mean().sqrt().item():.3e}; norm max rel {((ngot - nref).abs() / nref).max().item():.3e}')
 wp = ops.pack_conv3x3(w)
+us, ust = ops.pack_conv3d_c16_wino_split(w), ops.pack_conv3d_c16_wino_split(w, transpose=True)
+gs, _ = ops.conv3d_c16_wino_split(x, us, b, he, flags)
+print(f'split-winograd vs direct: max {(gs - ref).abs().max().item():.3e}')
 for name, fn in (('direct fp32 MFMA', lambda: ops._conv3x3_raw(x, wp, b, 16, he, flags, True)),
+                 ('winograd f16x3  ', lambda: ops.conv3d_c16_wino_split(x, us, b, he, flags)),
+                 ('winograd f16x3 bwd', lambda: ops.conv3d_c16_wino_split(x, ust, None, he, 0, prev=(ref, nref, flags))),
                  ('winograd fp32   ', lambda: ops.conv3d_c16_wino(x, up, b, he, flags)),
                  ('winograd bwd+prev', lambda: ops.conv3d_c16_wino(x, upt, None, he, 0, prev=(ref, nref, flags)))):
     for _ in range(2):
