@@ -175,6 +175,16 @@ int lf_conv3d_c16_wino_split(const float* x, const void* upack, const float* bia
                              const float* prev_y, const float* prev_norm, unsigned prev_flags,
                              const float* amax_in, float* amax_out, void* stream);
 
+/* Gate arithmetic of the convolutional GRU fuser, inference path (modules/gru.py:30-43; no tanh on the
+ * candidate).  `rec` is the channels-last record [x | state] (rec_stride floats per voxel, state at
+ * rec_off) that the gate convolutions read; ur = [update | reset] pre-activations (2*Ch per voxel).
+ *   stage A: u = sigmoid(ur[:Ch]);  rec.state = h * sigmoid(ur[Ch:])
+ *   stage B: h_out = h * (1 - u) + cand * u;  rec.state = h_out (rec may be NULL) */
+int lf_gru_stage_a(const float* ur, const float* h, float* u, float* rec, long nvox, int Ch, int rec_stride, int rec_off,
+                   void* stream);
+int lf_gru_stage_b(const float* h, const float* u, const float* cand, float* h_out, float* rec, long nvox, int Ch,
+                   int rec_stride, int rec_off, void* stream);
+
 /* 2-D grid sampling of planar images, F.grid_sample(align_corners=False) semantics: the crop / zoom
  * (geometry.py:20-44,287-354; zeros padding), Camera.uncrop (geometry.py:261-285; border padding) and the
  * image-based-rendering warps (ibr.py:52-93).  img [N][C][H][W], grid [N][Ho][Wo][2] = (x, y) in [-1,1],

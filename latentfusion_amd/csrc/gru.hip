@@ -1,0 +1,61 @@
+// Gate arithmetic of the convolutional GRU fuser (latentfusion/modules/gru.py:30-43, recon/fusion.py:188-197)
+// for the inference path: the three gate convolutions read ONE channels-last record [x (Cx) | state (Ch)] per
+// voxel, so the element-wise steps write straight into the state slots of that record instead of building
+// new concatenations:
+//   stage A:  u = sigmoid(ur[0:Ch]);  rec.state = h * sigmoid(ur[Ch:2Ch])          (input of the out gate)
+//   stage B:  h' = h * (1 - u) + c * u;  rec.state = h'                               (input of the next step)
+// (no tanh on the candidate: SURVEY Q13).  One thread per (voxel, channel); the arithmetic mirrors the ATen
+// expression order (separate multiplies and add, no fma contraction).
+#include "lf_common.h"
+
+namespace {
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ void __launch_bounds__(256) gru_stage_a_kernel(const float* __restrict__ ur, const float* __restrict__ h,
+                                                          float* __restrict__ u, float* __restrict__ rec, long nvox, int Ch,
+                                                          int rec_stride, int rec_off) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= nvox * Ch) return;
+  const long v = idx / Ch;
+  const int c = (int)(idx - v * Ch);
+  const float uu = sigmoidf_(ur[v * 2 * Ch + c]);
+  const float rr = sigmoidf_(ur[v * 2 * Ch + Ch + c]);
+  u[idx] = uu;
+  rec[v * rec_stride + rec_off + c] = __fmul_rn(h[idx], rr);
+}
+
+__global__ void __launch_bounds__(256) gru_stage_b_kernel(const float* __restrict__ h, const float* __restrict__ u,
+                                                          const float* __restrict__ cand, float* __restrict__ h_out,
+                                                          float* __restrict__ rec, long nvox, int Ch, int rec_stride,
+                                                          int rec_off) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= nvox * Ch) return;
+  const long v = idx / Ch;
+  const int c = (int)(idx - v * Ch);
+  const float uu = u[idx];
+  const float hn = __fadd_rn(__fmul_rn(h[idx], __fsub_rn(1.f, uu)), __fmul_rn(cand[idx], uu));
+  h_out[idx] = hn;
+  if (rec != nullptr) rec[v * rec_stride + rec_off + c] = hn;
+}
+
+}  // namespace
+
+extern "C" int lf_gru_stage_a(const float* ur, const float* h, float* u, float* rec, long nvox, int Ch, int rec_stride,
+                              int rec_off, void* stream) {
+  lf_clear_error();
+  if (nvox <= 0 || Ch <= 0 || rec_stride < rec_off + Ch || rec_off < 0 || nvox * Ch >= 0x7fffffff00L) return LF_EINVAL;
+  hipLaunchKernelGGL(gru_stage_a_kernel, dim3((unsigned)((nvox * Ch + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ur, h, u,
+                     rec, nvox, Ch, rec_stride, rec_off);
+  return lf_launch_status();
+}
+
+extern "C" int lf_gru_stage_b(const float* h, const float* u, const float* cand, float* h_out, float* rec, long nvox, int Ch,
+                              int rec_stride, int rec_off, void* stream) {
+  lf_clear_error();
+  if (nvox <= 0 || Ch <= 0 || nvox * Ch >= 0x7fffffff00L) return LF_EINVAL;
+  if (rec != nullptr && (rec_stride < rec_off + Ch || rec_off < 0)) return LF_EINVAL;
+  hipLaunchKernelGGL(gru_stage_b_kernel, dim3((unsigned)((nvox * Ch + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h, u, cand,
+                     h_out, rec, nvox, Ch, rec_stride, rec_off);
+  return lf_launch_status();
+}

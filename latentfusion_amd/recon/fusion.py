@@ -162,12 +162,48 @@ class GRUFuser(_ArgsFuser):
         return {'in_channels': self.in_channels, 'cube_size': self.cube_size}
 
     def forward(self, z_obj, z_cam_mid, z_obj_mid, camera):
+        if (not torch.is_grad_enabled() and z_obj.is_cuda and z_obj.shape[0] == 1 and z_obj.dim() == 6
+                and self.conv_module != EqualizedConv2d):
+            return self._forward_inference(z_obj), {}
         h = z_obj[:, 0]
         coords = (utils.get_normalized_pixel_coords(h) if self.conv_module == EqualizedConv2d
                   else utils.get_normalized_voxel_coords(h))
         for i in range(1, z_obj.shape[1]):
             h = self.gru(torch.cat((z_obj[:, i], coords), dim=1), h)
         return h.unsqueeze(1), {}
+
+    def _forward_inference(self, z_obj):
+        """Same recurrence without the three concatenations and five element-wise passes per view: one
+        channels-last record [z_i | coords | state] per voxel feeds a merged update+reset convolution and the
+        out convolution; the gate arithmetic (lf_gru_stage_a/b) writes the state slots in place."""
+        from .. import _lib, ops
+        L = _lib.lib()
+        cell = self.gru
+        V, C = z_obj.shape[1], z_obj.shape[2]
+        D, H, W = z_obj.shape[3:]
+        dev = z_obj.device
+        nvox = D * H * W
+        rec = ops.empty_cl((1, 2 * C + 3, D, H, W), dev)
+        rec[:, C:C + 3] = utils.get_normalized_voxel_coords(z_obj[:, 0])
+        h = ops.cl(z_obj[:, 0]).clone()
+        w_ur = torch.cat((cell.update_gate.module.weight, cell.reset_gate.module.weight), dim=0).detach()
+        b_ur = torch.cat((cell.update_gate.bias, cell.reset_gate.bias), dim=0).detach() \
+            if cell.update_gate.bias is not None else None
+        w_o, b_o = cell.out_gate.module.weight.detach(), cell.out_gate.bias
+        u = torch.empty(nvox * C, device=dev, dtype=torch.float32)
+        s = torch.cuda.current_stream().cuda_stream
+        rec[:, C + 3:] = h
+        for i in range(1, V):
+            rec[:, :C] = z_obj[:, i]
+            ur = ops.conv3x3(rec, w_ur, b_ur, lrelu=False, pixelnorm=False)
+            _lib.check(L.lf_gru_stage_a(ur.data_ptr(), h.data_ptr(), u.data_ptr(), rec.data_ptr(), nvox, C, 2 * C + 3, C + 3, s),
+                       'lf_gru_stage_a')
+            cand = ops.conv3x3(rec, w_o, b_o.detach() if b_o is not None else None, lrelu=False, pixelnorm=False)
+            h_new = torch.empty_like(h)
+            _lib.check(L.lf_gru_stage_b(h.data_ptr(), u.data_ptr(), cand.data_ptr(), h_new.data_ptr(),
+                                        rec.data_ptr() if i + 1 < V else None, nvox, C, 2 * C + 3, C + 3, s), 'lf_gru_stage_b')
+            h = h_new
+        return h.unsqueeze(1)
 
 
 class LSTMFuser(_ArgsFuser):

@@ -324,3 +324,19 @@ def test_generator_training_step(golden):
     for _ in range(4):
         last = step.run_iteration(batch)
     assert float(last['total']) < first
+
+
+def test_gru_fuser_inference_path_equals_general_path(golden):
+    """GRUFuser's inference path (merged update+reset convolution, in-place state record, lf_gru_stage_a/b)
+    against the module's general (autograd) path on the same weights and views."""
+    from latentfusion_amd.recon import fusion
+    g = golden('g10_encode_gru')
+    fu = fusion.from_checkpoint(g['fuser']).to(DEV)
+    gen = torch.Generator().manual_seed(21)
+    z = torch.randn(1, 5, 8, 12, 10, 14, generator=gen).to(DEV)          # (B=1, V=5, C=8, D, H, W), non-cubic
+    with torch.no_grad():
+        fast, _ = fu(z, None, None, None)
+    with torch.enable_grad():
+        slow, _ = fu(z.clone().requires_grad_(True), None, None, None)
+    assert fast.shape == slow.shape == (1, 1, 8, 12, 10, 14)
+    close(fast, slow, atol=2e-6, rtol=1e-5)
