@@ -373,3 +373,35 @@ def test_g7_gradient_loop_split_precision(golden):
         clear = (top2[:, 1] - top2[:, 0]) > 6e-2
         assert (torch.argmin(out[mode], dim=1) == torch.argmin(out['fp32'], dim=1))[clear].all()
         assert torch.argmin(out[mode][0]) == torch.argmin(out['fp32'][0])
+
+
+def test_conv3d_c16_kernels_on_random_shapes():
+    """Winograd / split-Winograd / weight-gradient kernels against the direct fp32 kernels on random small and
+    ragged volumes (single-plane, narrower than a tile, odd sizes): guards the tile-boundary handling."""
+    import random
+    from latentfusion_amd import ops
+    from latentfusion_amd._lib import LF_EPI_LRELU, LF_EPI_PIXELNORM
+    rnd = random.Random(7)
+    g = torch.Generator().manual_seed(7)
+    flags = LF_EPI_LRELU | LF_EPI_PIXELNORM
+    shapes = [(1, 1, 1, 1), (1, 1, 7, 3), (2, 3, 1, 17), (1, 2, 8, 16), (3, 5, 9, 33)]
+    shapes += [(rnd.choice([1, 2, 3]), rnd.randint(1, 21), rnd.randint(1, 37), rnd.randint(1, 45)) for _ in range(10)]
+    for N, D, H, W in shapes:
+        x = ops.cl(torch.randn(N, 16, D, H, W, generator=g).to(DEV))
+        w = torch.randn(16, 16, 3, 3, 3, generator=g).to(DEV)
+        b = (torch.randn(16, generator=g) * 0.1).to(DEV)
+        he = ops.he_constant(w)
+        ref, nref = ops._conv3x3_raw(x, ops.pack_conv3x3(w), b, 16, he, flags, True)
+        got, ngot = ops.conv3d_c16_wino(x, ops.pack_conv3d_c16_wino(w), b, he, flags)
+        gs, _ = ops.conv3d_c16_wino_split(x, ops.pack_conv3d_c16_wino_split(w), b, he, flags)
+        prev = (ref, nref, flags)
+        gref = ops.conv3x3_bwd_data(x, ops.pack_conv3x3(w, transpose=True), 16, he, prev)
+        gw, _ = ops.conv3d_c16_wino(x, ops.pack_conv3d_c16_wino(w, transpose=True), None, he, 0, prev=prev)
+        assert (got - ref).abs().max().item() < 5e-5, (N, D, H, W)
+        assert (gs - ref).abs().max().item() < 5e-5, (N, D, H, W)
+        assert (ngot - nref).abs().max().item() < 5e-5, (N, D, H, W)
+        assert (gw - gref).abs().max().item() < 5e-5 * max(gref.abs().max().item(), 1.0), (N, D, H, W)
+        gwt, _ = ops.conv_bwd_weight(x, ref, 3, 16, he)
+        want = torch.nn.grad.conv3d_weight(x.double().cpu(), (16, 16, 3, 3, 3), ref.double().cpu(), padding=1) * he
+        gotw = gwt.reshape(3, 3, 3, 16, 16).permute(3, 4, 0, 1, 2).double().cpu()
+        assert (gotw - want).abs().max().item() < 1e-4 * max(want.abs().max().item(), 1e-3), (N, D, H, W)
