@@ -27,6 +27,13 @@ class Observation:
                      'is_normalized': kwargs.get('is_normalized', False), 'is_prepared': kwargs.get('is_prepared', False)}
 
     @classmethod
+    def from_dataset(cls, dataset, inds=None):
+        """Batch of the dataset items `inds` (all by default) as one Observation (reference :73-79)."""
+        inds = range(len(dataset)) if inds is None else [int(i) for i in inds]
+        items = [dataset[i] for i in inds]
+        return cls.from_dict({k: torch.stack([it[k] for it in items], dim=0) for k in items[0]})
+
+    @classmethod
     def from_dict(cls, d):
         h, w = d['color'].shape[-2:]
         return cls(d['color'], d['depth'].unsqueeze(-3), d['mask'].unsqueeze(-3).float(),

@@ -55,3 +55,13 @@ def extrinsic_to_position(extrinsic):
     extrinsic, squeezed = ensure_batch_dim(extrinsic, 2)
     pos = (extrinsic[:, :3, :3].transpose(1, 2) @ extrinsic[:, :3, 3:]).squeeze(-1)
     return pos.squeeze(0) if squeezed else pos
+
+
+def translate_matrix(matrix, offset):
+    """Shifts the frame the transform maps FROM by `offset` (reference rigid.py:53-63): inv(inv(M) + t)."""
+    single = matrix.dim() == 2
+    m = matrix.unsqueeze(0) if single else matrix
+    out = inverse_transform(m)
+    out[:, :3, 3] += offset
+    out = inverse_transform(out)
+    return out.squeeze(0) if single else out

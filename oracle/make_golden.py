@@ -531,12 +531,86 @@ def g15_losses(lf):
     save('g15_losses', {'x': x, 'y': y, 'm': m, 'k': 37, 'out': out})
 
 
+def make_bop_fixture(root):
+    """A tiny scene in the BOP `lm` layout (48 x 36 images, 5 frames, two objects per frame) written with
+    PIL/json only: data for both readers, no reference code involved."""
+    import json
+    import numpy as np
+    from PIL import Image
+    rng = np.random.RandomState(3)
+    ds, scene = os.path.join(root, 'lm'), os.path.join(root, 'lm', 'test', '000002')
+    for d in ('models', 'models_eval'):
+        os.makedirs(os.path.join(ds, d), exist_ok=True)
+    for d in ('rgb', 'depth', 'mask_visib'):
+        os.makedirs(os.path.join(scene, d), exist_ok=True)
+    info = {'2': {'diameter': 247.5, 'min_x': -107.8, 'min_y': -60.9, 'min_z': -109.7, 'size_x': 215.7, 'size_y': 121.9,
+                  'size_z': 219.4},
+            '5': {'diameter': 201.4, 'min_x': -50.4, 'min_y': -90.9, 'min_z': -96.9, 'size_x': 100.8, 'size_y': 181.8,
+                  'size_z': 193.7}}
+    json.dump(info, open(os.path.join(ds, 'models_eval', 'models_info.json'), 'w'))
+    verts = rng.uniform(-100, 100, size=(12, 3))
+    with open(os.path.join(ds, 'models_eval', 'obj_000002.ply'), 'w') as f:
+        f.write('ply\nformat ascii 1.0\nelement vertex 12\nproperty float x\nproperty float y\nproperty float z\nend_header\n')
+        for v in verts:
+            f.write('%.4f %.4f %.4f\n' % tuple(v))
+    cam, gt = {}, {}
+    for fi in range(5):
+        cam[str(fi)] = {'cam_K': [572.4, 0.0, 24.0 + fi, 0.0, 573.6, 18.0, 0.0, 0.0, 1.0], 'depth_scale': 1.0 if fi % 2 else 0.1}
+        objs = []
+        for oid in ((5, 2) if fi % 2 else (2, 5)):
+            a = rng.uniform(-3, 3, size=3)
+            q = np.concatenate(([np.cos(np.linalg.norm(a) / 2)], np.sin(np.linalg.norm(a) / 2) * a / np.linalg.norm(a)))
+            w, x, y, z = q
+            R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                          [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                          [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+            objs.append({'obj_id': oid, 'cam_R_m2c': [float(v) for v in R.reshape(-1)],
+                         'cam_t_m2c': [float(v) for v in rng.uniform(-80, 80, size=2)] + [float(rng.uniform(600, 1100))]})
+        gt[str(fi)] = objs
+        Image.fromarray(rng.randint(0, 256, size=(36, 48, 3)).astype(np.uint8)).save(os.path.join(scene, 'rgb', '%06d.png' % fi))
+        Image.fromarray(rng.randint(0, 20000, size=(36, 48)).astype(np.uint16)).save(os.path.join(scene, 'depth', '%06d.png' % fi))
+        for oi in range(2):
+            m = np.zeros((36, 48), np.uint8)
+            m[8 + oi * 3:26, 10 + fi:30 + oi * 5] = 255
+            Image.fromarray(m).save(os.path.join(scene, 'mask_visib', '%06d_%06d.png' % (fi, oi)))
+    json.dump(cam, open(os.path.join(scene, 'scene_camera.json'), 'w'))
+    json.dump(gt, open(os.path.join(scene, 'scene_gt.json'), 'w'))
+
+
+def g16_bop_reader(lf):
+    """latentfusion/datasets/bop.py on the fixture tree tests/golden/bop_fixture (the reference's `np.bool` is
+    restored for the call, it was removed from numpy)."""
+    import numpy as np
+    from pathlib import Path
+    root = os.path.join(OUT, 'bop_fixture')
+    if not os.path.isdir(root):
+        make_bop_fixture(root)
+    had = hasattr(np, 'bool')
+    if not had:
+        np.bool = bool
+    try:
+        from latentfusion.datasets.bop import BOPDataset
+        out = {}
+        for center in (False, True):
+            ds = BOPDataset(Path(root) / 'lm', Path(root) / 'lm' / 'test' / '000002', object_id=2, center_object=center)
+            items = [ds[i] for i in range(len(ds))]
+            out[center] = {'len': len(ds), 'ids': ds.get_ids(), 'object_scale': ds.object_scale,
+                           'centroid': ds.centroid.clone(), 'quaternions': ds.quaternions.clone(),
+                           'items': [{k: v.clone() for k, v in it.items()} for it in items],
+                           'sample_evenly_3': ds.sample_evenly(3).clone(),
+                           'denorm_E': ds.denormalize_extrinsic(items[1]['extrinsic']).clone()}
+        save('g16_bop_reader', out)
+    finally:
+        if not had:
+            del np.bool
+
+
 def main():
     lf = refharness.load_reference()
     import latentfusion.recon.utils  # noqa
     torch.set_num_threads(8)
     gens = [g0_preprocess, g1_camera, g2_resample, g3_block, g4_fusers, g5_decode, g6_loss, g7_g10_loop, g9_ibr,
-            g11_released_like, g12_latent_code, g13_metrics, g14_initial_pose, g15_losses]
+            g11_released_like, g12_latent_code, g13_metrics, g14_initial_pose, g15_losses, g16_bop_reader]
     only = sys.argv[1:]                                  # e.g. `python oracle/make_golden.py g13` regenerates one group
     for fn in gens:
         if not only or any(fn.__name__.startswith(o + '_') or fn.__name__ == o for o in only):

@@ -399,3 +399,39 @@ def test_training_losses_golden(golden):
         losses.get_recon_criterion('nope')
     opt = losses.get_optimizer([torch.nn.Parameter(torch.zeros(3))], 'adam', 1e-3)
     assert opt.defaults['betas'] == (0.0, 0.99)
+
+
+def test_bop_reader_golden(golden):
+    """datasets/bop.BOPDataset on the committed BOP-layout fixture (tests/golden/bop_fixture) against what the
+    reference's reader produced from the same files (golden g16): items, scale, quaternions, view sampling,
+    centring; plus Observation.from_dataset and the intrinsics JSON helper."""
+    from pathlib import Path
+    from latentfusion_amd.datasets.bop import BOPDataset, read_ply_vertices
+    from latentfusion_amd.observation import Observation
+    from latentfusion_amd.pose import bop as pbop
+    g = golden('g16_bop_reader')
+    root = Path(__file__).parent / 'golden' / 'bop_fixture' / 'lm'
+    for center in (False, True):
+        ds = BOPDataset(root, root / 'test' / '000002', object_id=2, center_object=center)
+        r = g[center]
+        assert len(ds) == r['len'] and ds.get_ids() == r['ids']
+        assert abs(ds.object_scale - r['object_scale']) < 1e-12
+        close(ds.centroid, r['centroid'], atol=0, rtol=0)
+        close(ds.quaternions, r['quaternions'], atol=1e-6, rtol=1e-6)
+        for i in range(len(ds)):
+            it = ds[i]
+            for k, v in r['items'][i].items():
+                assert it[k].dtype == v.dtype and it[k].shape == v.shape, k
+                close(it[k].float(), v.float(), atol=1e-6, rtol=1e-6)
+        assert torch.equal(ds.sample_evenly(3), r['sample_evenly_3'])
+        close(ds.denormalize_extrinsic(ds[1]['extrinsic']), r['denorm_E'], atol=1e-4, rtol=1e-5)
+    obs = Observation.from_dataset(ds, [0, 3])
+    assert obs.color.shape == (2, 3, 36, 48) and obs.depth.shape == (2, 1, 36, 48) and obs.mask.shape == (2, 1, 36, 48)
+    assert len(obs.camera) == 2
+    pts = ds.load_pointcloud()
+    assert pts.shape == (12, 3)
+    close(pts, torch.tensor(read_ply_vertices(ds.pointcloud_path)) * ds.object_scale, atol=0, rtol=0)
+    with pytest.raises(ValueError):
+        BOPDataset(root.parent, root / 'test' / '000002', object_id=2)
+    K = pbop.parse_camera_intrinsics({'fx': 572.4, 'fy': 573.6, 'cx': 325.3, 'cy': 242.0})
+    assert K.shape == (3, 4) and float(K[0, 2]) == pytest.approx(325.3)
