@@ -175,6 +175,22 @@ int lf_conv3d_c16_wino_split(const float* x, const void* upack, const float* bia
                              const float* prev_y, const float* prev_norm, unsigned prev_flags,
                              const float* amax_in, float* amax_out, void* stream);
 
+/* Winograd F(2x2x2,3x3x3) for wide 3-D convolutions in three stages (input transform, 64 library GEMMs
+ * M[f] = V[f] @ U[f] on the host side, output transform with the fused epilogue).  x, y channels-last;
+ * V [64][T][Cin], M [64][T][Cout], T = lf_wino3d_tiles(N, D, H, W), frequency f = (a*4 + b)*4 + c (z, y, x);
+ * U[f][cin][cout] = ((G (x) G (x) G) w)[cout][cin][a][b][c].  Cin, Cout multiples of 4.  PixelNorm is fused for
+ * Cout <= 256; for wider outputs the rows are stored un-normalised (then run lf_pixelnorm_fwd). */
+long lf_wino3d_tiles(int N, int D, int H, int W);
+int lf_wino3d_input_transform(const float* x, float* V, int N, int D, int H, int W, int C, void* stream);
+int lf_wino3d_output_transform(const float* M, const float* bias, float* y, float* norm_out, int N, int D, int H, int W,
+                               int C, float he, unsigned flags, float slope, float eps, void* stream);
+
+/* 2-D counterpart, F(2x2,3x3): V [16][T][Cin], M [16][T][Cout], T = lf_wino2d_tiles(N, H, W), f = b*4 + c (y, x). */
+long lf_wino2d_tiles(int N, int H, int W);
+int lf_wino2d_input_transform(const float* x, float* V, int N, int H, int W, int C, void* stream);
+int lf_wino2d_output_transform(const float* M, const float* bias, float* y, float* norm_out, int N, int H, int W,
+                               int C, float he, unsigned flags, float slope, float eps, void* stream);
+
 /* Gate arithmetic of the convolutional GRU fuser, inference path (modules/gru.py:30-43; no tanh on the
  * candidate).  `rec` is the channels-last record [x | state] (rec_stride floats per voxel, state at
  * rec_off) that the gate convolutions read; ur = [update | reset] pre-activations (2*Ch per voxel).

@@ -46,6 +46,12 @@ SIGNATURES = {
     'lf_conv3d_c16_wino_split_upack_halfs': (c_size_t, []),
     'lf_conv3d_c16_wino_split': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint, c_float, c_float, P, P,
                                          c_uint, P, P, P]),
+    'lf_wino3d_tiles': (c_long, [c_int, c_int, c_int, c_int]),
+    'lf_wino3d_input_transform': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    'lf_wino3d_output_transform': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_uint, c_float, c_float, P]),
+    'lf_wino2d_tiles': (c_long, [c_int, c_int, c_int]),
+    'lf_wino2d_input_transform': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    'lf_wino2d_output_transform': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint, c_float, c_float, P]),
     'lf_gru_stage_a': (c_int, [P, P, P, P, c_long, c_int, c_int, c_int, P]),
     'lf_gru_stage_b': (c_int, [P, P, P, P, P, c_long, c_int, c_int, c_int, P]),
     'lf_grid_sample2d_fwd': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),

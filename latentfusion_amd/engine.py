@@ -151,12 +151,19 @@ class RenderLoopEngine:
                 w = conv.module.weight
                 self.convs.append((w, conv.bias, ops.he_constant(w), ops.pack_conv3x3(w), ops.pack_conv3x3(w, transpose=True)))
         c16 = self.C == 16 and len(self.convs) > 0 and all(tuple(w.shape[:2]) == (16, 16) for w, *_ in self.convs)
+        wide = len(self.convs) > 0 and all(w.shape[0] >= 64 and w.shape[1] >= 64 and w.shape[0] % 4 == 0
+                                           and w.shape[1] % 4 == 0 for w, *_ in self.convs)
         if conv_mode == 'auto':
-            conv_mode = 'winograd' if c16 else 'fp32'
-        if conv_mode != 'fp32' and not c16:
+            conv_mode = 'winograd' if (c16 or wide) else 'fp32'
+        if conv_mode not in ('fp32', 'winograd') and not c16:
             raise NotImplementedError(f'{conv_mode} mode is implemented for 16->16 camera blocks')
+        if conv_mode == 'winograd' and not (c16 or wide):
+            raise NotImplementedError('winograd mode needs 16->16 or wide (>= 64 channel) camera blocks')
         self.conv_mode = conv_mode
-        self.split = self.wino = None
+        self.split = self.wino = self.wgemm = None
+        if conv_mode == 'winograd' and not c16:
+            # wide blocks (released model: 256 -> 256 on 16^3): three-stage Winograd over library GEMMs
+            self.wgemm = [(ops.pack_conv3d_wino_gemm(w), ops.pack_conv3d_wino_gemm(w, transpose=True)) for w, *_ in self.convs]
         if conv_mode == 'f16x3':
             self.split = [(ops.pack_conv3d_c16_split(w), ops.pack_conv3d_c16_split(w, transpose=True)) for w, *_ in self.convs]
         elif conv_mode == 'winograd_f16x3':
@@ -164,7 +171,7 @@ class RenderLoopEngine:
                           for w, *_ in self.convs]
             # trilinear resampling is a convex combination: max|x0| <= max|z_obj|
             self.z_amax = ops.amax_buffer(self.z.abs().max(), dev)
-        elif conv_mode == 'winograd':
+        elif conv_mode == 'winograd' and c16:
             self.wino = [(ops.pack_conv3d_c16_wino(w), ops.pack_conv3d_c16_wino(w, transpose=True)) for w, *_ in self.convs]
         pw = photographer.projection_block.conv.module.weight
         cout, C, D = pw.shape[0], self.convs[-1][0].shape[0] if self.convs else self.C, self.S
@@ -207,6 +214,8 @@ class RenderLoopEngine:
                 y, nrm = ops.conv3d_c16_split(acts[-1], self.split[li_][0], b, he, flags)
             elif self.wino is not None:
                 y, nrm = ops.conv3d_c16_wino(acts[-1], self.wino[li_][0], b, he, flags)
+            elif self.wgemm is not None:
+                y, nrm = ops.conv3d_wino_gemm(acts[-1], self.wgemm[li_][0], b, he, flags)
             else:
                 y, nrm = ops._conv3x3_raw(acts[-1], wp, b, w.shape[0], he, flags, True)
             acts.append(y)
@@ -263,7 +272,10 @@ class RenderLoopEngine:
             for i in range(nconv - 1, -1, -1):
                 w, b, he, _wp, wt = self.convs[i]
                 gpre = ops._epilogue_bwd(g, acts[i + 1], norms[i], flags)
-                g, _ = ops._conv3x3_raw(gpre, wt, None, w.shape[1], he, 0, False)
+                if self.wgemm is not None:
+                    g, _ = ops.conv3d_wino_gemm(gpre, self.wgemm[i][1], None, he, 0)
+                else:
+                    g, _ = ops._conv3x3_raw(gpre, wt, None, w.shape[1], he, 0, False)
         gcoef18 = torch.empty(n, 18, device=dev, dtype=torch.float32)
         nbytes = L.lf_resample3d_bwd_coef_scratch_bytes(n, S, S, S)
         scratch = torch.empty(nbytes // 4 + 1, device=dev, dtype=torch.float32)

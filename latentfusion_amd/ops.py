@@ -237,6 +237,76 @@ def conv3d_c16_wino(x, upack, bias, he, flags, prev=None, amax_out=None):
     return y, norm
 
 
+def pack_conv3d_wino_gemm(weight, transpose=False):
+    """[Cout,Cin,3,3(,3)] -> U [64 | 16 f][Cin][Cout], f = (a*4+b)*4+c (3-D) or b*4+c (2-D), for the three-stage
+    Winograd path (lf_wino3d_* / lf_wino2d_*): U[f][ci][co] = ((G x ..) w)[co][ci][f], evaluated in fp64."""
+    w = weight.detach()
+    if transpose:
+        w = w.transpose(0, 1).flip(dims=tuple(range(2, w.dim())))
+    G = torch.tensor(_WINO_G, dtype=torch.float64, device=w.device)
+    if w.dim() == 5:
+        U = torch.einsum('ai,bj,ck,omijk->abcmo', G, G, G, w.double())      # [a][b][c][cin][cout]
+        return U.reshape(64, w.shape[1], w.shape[0]).float().contiguous()
+    U = torch.einsum('bj,ck,omjk->bcmo', G, G, w.double())                  # [b][c][cin][cout]
+    return U.reshape(16, w.shape[1], w.shape[0]).float().contiguous()
+
+
+def conv3d_wino_gemm(x, U, bias, he, flags):
+    """Wide 3-D conv as Winograd F(2x2x2,3x3x3): input transform (HIP) -> 64 batched fp32 GEMMs (rocBLAS via
+    torch.bmm) -> output transform with the fused epilogue (HIP).  Returns (y, norm or None)."""
+    L = _lib.lib()
+    if x.dim() == 4:
+        return _conv2d_wino_gemm(x, U, bias, he, flags)
+    N, cin, D, H, W = x.shape
+    cout = U.shape[2]
+    T = L.lf_wino3d_tiles(N, D, H, W)
+    V = torch.empty(64, T, cin, device=x.device, dtype=torch.float32)
+    with _timed('wino3d_input'):
+        check(L.lf_wino3d_input_transform(_ptr(x), _ptr(V), N, D, H, W, cin, _stream()), 'lf_wino3d_input_transform')
+    with _timed('wino3d_gemm'):
+        M = torch.bmm(V, U)
+    del V
+    y = empty_cl((N, cout, D, H, W), x.device)
+    pn = bool(flags & LF_EPI_PIXELNORM)
+    norm = torch.empty(N * D * H * W, device=x.device, dtype=torch.float32) if pn else None
+    with _timed('wino3d_output'):
+        check(L.lf_wino3d_output_transform(_ptr(M), _ptr(bias) if bias is not None else None, _ptr(y),
+                                           _ptr(norm) if norm is not None else None, N, D, H, W, cout, he, flags, SLOPE,
+                                           PN_EPS, _stream()), 'lf_wino3d_output_transform')
+    if pn and cout > 256:
+        check(L.lf_pixelnorm_fwd(_ptr(y), _ptr(y), _ptr(norm), N * D * H * W, cout, PN_EPS, _stream()), 'lf_pixelnorm_fwd')
+    return y, norm
+
+
+def _conv2d_wino_gemm(x, U, bias, he, flags):
+    L = _lib.lib()
+    N, cin, H, W = x.shape
+    cout = U.shape[2]
+    T = L.lf_wino2d_tiles(N, H, W)
+    V = torch.empty(16, T, cin, device=x.device, dtype=torch.float32)
+    with _timed('wino2d_input'):
+        check(L.lf_wino2d_input_transform(_ptr(x), _ptr(V), N, H, W, cin, _stream()), 'lf_wino2d_input_transform')
+    with _timed('wino2d_gemm'):
+        M = torch.bmm(V, U)
+    del V
+    y = empty_cl((N, cout, H, W), x.device)
+    pn = bool(flags & LF_EPI_PIXELNORM)
+    norm = torch.empty(N * H * W, device=x.device, dtype=torch.float32) if pn else None
+    with _timed('wino2d_output'):
+        check(L.lf_wino2d_output_transform(_ptr(M), _ptr(bias) if bias is not None else None, _ptr(y),
+                                           _ptr(norm) if norm is not None else None, N, H, W, cout, he, flags, SLOPE, PN_EPS,
+                                           _stream()), 'lf_wino2d_output_transform')
+    if pn and cout > 256:
+        check(L.lf_pixelnorm_fwd(_ptr(y), _ptr(y), _ptr(norm), N * H * W, cout, PN_EPS, _stream()), 'lf_pixelnorm_fwd')
+    return y, norm
+
+
+def _wino_gemm_ok(x, weight):
+    """Wide 2-D / 3-D 3x3 convolutions where the transforms amortise over the channels."""
+    return (x.dim() == weight.dim() and x.dim() in (4, 5) and weight.shape[0] >= 64 and weight.shape[1] >= 64
+            and weight.shape[0] % 4 == 0 and weight.shape[1] % 4 == 0)
+
+
 def he_constant(weight):
     """sqrt(2 / fan_in)  (modules/equalized.py:66-74)."""
     return math.sqrt(2.0 / weight[0].numel())
@@ -412,6 +482,8 @@ class _Conv3x3(torch.autograd.Function):
         b = bias.detach() if bias is not None else None
         if _wino_ok(x, weight):                               # 3-D 16 -> 16: the all-fp32 Winograd kernel
             y, norm = conv3d_c16_wino(x, _cached(weight, 'w3f', lambda: pack_conv3d_c16_wino(weight)), b, he, flags)
+        elif _wino_gemm_ok(x, weight):                        # wide 3-D: three-stage Winograd over library GEMMs
+            y, norm = conv3d_wino_gemm(x, _cached(weight, 'g3f', lambda: pack_conv3d_wino_gemm(weight)), b, he, flags)
         else:
             wpack = _cached(weight, 'c3f', lambda: pack_conv3x3(weight))
             y, norm = _conv3x3_raw(x, wpack, b, weight.shape[0], he, flags, True)
@@ -432,6 +504,8 @@ class _Conv3x3(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if _wino_ok(gp, w):
                 gx, _ = conv3d_c16_wino(gp, _cached(w, 'w3b', lambda: pack_conv3d_c16_wino(w, transpose=True)), None, ctx.he, 0)
+            elif _wino_gemm_ok(gp, w):
+                gx, _ = conv3d_wino_gemm(gp, _cached(w, 'g3b', lambda: pack_conv3d_wino_gemm(w, transpose=True)), None, ctx.he, 0)
             else:
                 wpack_t = _cached(w, 'c3b', lambda: pack_conv3x3(w, transpose=True))
                 gx, _ = _conv3x3_raw(gp, wpack_t, None, w.shape[1], ctx.he, 0, False)

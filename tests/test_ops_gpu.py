@@ -130,7 +130,8 @@ def test_block_golden(golden, key):
 
 
 @pytest.mark.parametrize('dims,cin,cout,S', [(3, 16, 16, 16), (3, 19, 8, 8), (3, 32, 32, 8), (2, 16, 32, 16),
-                                             (2, 32, 16, 24), (3, 8, 48, 6), (2, 64, 80, 8), (3, 16, 16, 20), (3, 35, 16, 16)])
+                                             (2, 32, 16, 24), (3, 8, 48, 6), (2, 64, 80, 8), (3, 16, 16, 20), (3, 35, 16, 16), (3, 64, 64, 7), (3, 72, 132, 6), (3, 260, 64, 5), (2, 64, 64, 13), (2, 196, 128, 9),
+                                             (2, 68, 320, 6)])
 def test_conv3x3_vs_torch(dims, cin, cout, S):
     """Fused conv+He+bias+LeakyReLU+PixelNorm against the same chain of ATen CPU ops, fwd and
     data-gradient; covers multi-chunk Cin, multi-tile Cout (incl. the unfused-PixelNorm path
