@@ -65,6 +65,10 @@ class Equalized(nn.Module):
     def weight(self):                       # He constant, like the reference attribute
         return ops.he_constant(self.module.weight)
 
+    def get_he_constant(self):
+        """sqrt(2 / fan_in) (reference equalized.py:66-74)."""
+        return ops.he_constant(self.module.weight)
+
     def forward(self, x, fuse_act=False, fuse_norm=False):
         if self.kernel_size == 3:
             return ops.conv3x3(x, self.module.weight, self.bias, lrelu=fuse_act, pixelnorm=fuse_norm)

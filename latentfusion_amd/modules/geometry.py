@@ -241,6 +241,67 @@ class Camera:
         self.quaternion = quat.qmul(self.quaternion, q)
         return self
 
+    @property
+    def fov_u(self):
+        """reference :199-201 (note the argument order atan2(f, size/2))."""
+        return torch.atan2(self.fu, self.viewport_width / 2.0)
+
+    @property
+    def fov_v(self):
+        return torch.atan2(self.fv, self.viewport_height / 2.0)
+
+    @property
+    def direction(self):
+        # the reference property reads `self.posiiton` (sic, :227-229) and therefore always raises
+        raise AttributeError("'Camera' object has no attribute 'posiiton'")
+
+    # ---- viewport lattices (reference :469-553): corner-aligned linspace, SURVEY Q3 -----------------------
+    def pixel_coords_uvz(self, out_size):
+        """(u, v, z) pixel/depth coordinates of an out_size (D,H,W) camera-frustum lattice, each (B,D,H,W)."""
+        if isinstance(out_size, int):
+            out_size = (out_size, out_size, out_size)
+        dev = self.device
+        z, v, u = torch.meshgrid(torch.linspace(0.0, 1.0, out_size[0], device=dev),
+                                 torch.linspace(0.0, 1.0, out_size[1], device=dev),
+                                 torch.linspace(0.0, 1.0, out_size[2], device=dev), indexing='ij')
+        n = self.length
+        u = u.unsqueeze(0).expand(n, -1, -1, -1) * self.viewport_width.view(-1, 1, 1, 1) + self.viewport[:, 0].view(-1, 1, 1, 1)
+        v = v.unsqueeze(0).expand(n, -1, -1, -1) * self.viewport_height.view(-1, 1, 1, 1) + self.viewport[:, 1].view(-1, 1, 1, 1)
+        z = z.unsqueeze(0).expand(n, -1, -1, -1) * self.z_span + self.znear.view(-1, 1, 1, 1)
+        return u, v, z
+
+    def pixel_coords_uv(self, out_size):
+        if isinstance(out_size, int):
+            out_size = (out_size, out_size)
+        dev = self.device
+        v, u = torch.meshgrid(torch.linspace(0.0, 1.0, out_size[0], device=dev),
+                              torch.linspace(0.0, 1.0, out_size[1], device=dev), indexing='ij')
+        n = self.length
+        u = u.expand(n, -1, -1) * self.viewport_width.view(-1, 1, 1) + self.viewport[:, 0].view(-1, 1, 1)
+        v = v.expand(n, -1, -1) * self.viewport_height.view(-1, 1, 1) + self.viewport[:, 1].view(-1, 1, 1)
+        return u, v
+
+    def camera_coords(self, out_size):
+        """Camera-space (x, y, z) of the frustum lattice (what ObjectToCameraTransform samples at)."""
+        u, v, z = self.pixel_coords_uvz(out_size)
+        x = (u - self.u0.view(-1, 1, 1, 1)) / self.fu.view(-1, 1, 1, 1) * z
+        y = (v - self.v0.view(-1, 1, 1, 1)) / self.fv.view(-1, 1, 1, 1) * z
+        return x, y, z
+
+    def depth_camera_coords(self, depth):
+        """Back-projection of a viewport depth map to camera space: (x, y, z), each (B,H,W)."""
+        u, v = self.pixel_coords_uv((depth.shape[-2], depth.shape[-1]))
+        z = depth.view_as(u)
+        x = (u - self.u0.view(-1, 1, 1)) / self.fu.view(-1, 1, 1) * z
+        y = (v - self.v0.view(-1, 1, 1)) / self.fv.view(-1, 1, 1) * z
+        return x, y, z
+
+    def depth_object_coords(self, depth):
+        xx, yy, zz = self.depth_camera_coords(depth)
+        grid = torch.stack((xx, yy, zz), dim=-1)
+        obj = three.transform_coords(three.grid_to_coords(grid), self.cam_to_obj).view_as(grid)
+        return obj[..., 0], obj[..., 1], obj[..., 2]
+
     # ---- depth range mapping (reference :555-565) ------------------------------------------
     def denormalize_depth(self, depth, eps=0.01):
         zn = (self.znear - eps).view(*depth.shape[:-3], 1, 1, 1)
@@ -350,6 +411,12 @@ class BaseTransformBlock(nn.Module):
             raise NotImplementedError("only padding_mode='border' (the reference default) is implemented")
         self.cube_size = cube_size
         self.padding_mode = padding_mode
+
+    def get_obj_coords(self, size, device=None):
+        """Homogeneous (x, y, z, 1) coordinates of the object-cube lattice, (size^3, 4) (reference :599-611)."""
+        lin = torch.linspace(-self.cube_size / 2, self.cube_size / 2, size, device=device)
+        z, y, x = torch.meshgrid(lin, lin, lin, indexing='ij')
+        return torch.stack((x, y, z, torch.ones_like(x)), dim=-1).view(-1, 4)
 
 
 class ObjectToCameraTransform(BaseTransformBlock):

@@ -39,6 +39,20 @@ class BaseUNet(nn.Module):
     def out_channels(self):
         return sum(self._out_channels) if self._out_channels is not None else self.up_block_config[-1]
 
+    @classmethod
+    def from_checkpoint(cls, checkpoint):
+        """reference unet.py:42-46 (the stored `conv_module` name is dropped; the subclass fixes it)."""
+        args = dict(checkpoint['args'])
+        args.pop('conv_module', None)
+        model = cls(**args)
+        model.load_state_dict(checkpoint['state_dict'])
+        return model
+
+    def create_checkpoint(self):
+        return {'args': {'in_channels': self._in_channels, 'out_channels': self._out_channels,
+                         'block_config': self.block_config, 'conv_module': None},
+                'state_dict': {k: v.cpu() for k, v in self.state_dict().items()}}
+
     def bottleneck_size(self, in_size):
         return in_size // (2 ** (self.block_config[0].count('I') + self.block_config[0].count('D')))
 

@@ -395,6 +395,16 @@ class GradientPoseEstimator(PoseEstimator):
             return None
         return RenderLoopEngine(ph, z_obj, target_obs, self.loss_weights, conv_mode=self.conv_mode)
 
+    @classmethod
+    def get_optimizer(cls, name, *args, **kwargs):
+        """torch.optim factory of the reference (:566-577).  The loop itself uses BatchedOptimizer, which applies
+        the same update rules to all N samples in one launch."""
+        from torch import optim
+        table = {'adamw': optim.AdamW, 'adam': optim.Adam, 'sgd': optim.SGD, 'adagrad': optim.Adagrad}
+        if name not in table:
+            raise ValueError(f'Unknow optimizer {name!r}')
+        return table[name](*args, **kwargs)
+
     def start(self, z_obj, target_obs, cameras, ranking=None):
         """Creates the per-run loop state (parameters, optimiser, schedulers); `cameras` must
         already be zoomed and on the device.  Exposed so that bench.py can time `iterate`."""

@@ -124,6 +124,10 @@ class ConvGRUCell(nn.Module):
         self.reset_gate = conv_module(in_channels + hidden_channels, hidden_channels, kernel_size, padding=pad, bias=bias)
         self.out_gate = conv_module(in_channels + hidden_channels, hidden_channels, kernel_size, padding=pad, bias=bias)
 
+    def init_hidden(self, b, h, w):
+        """reference gru.py:45-46 (2-D zero state on the current device)."""
+        return torch.zeros(b, self.hidden_dim, h, w, device=self.update_gate.module.weight.device)
+
     def forward(self, x, h_cur):
         x_in = torch.cat([x, h_cur], dim=1)
         update = torch.sigmoid(self.update_gate(x_in))

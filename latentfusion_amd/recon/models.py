@@ -102,6 +102,10 @@ class Sculptor(_Checkpointed):
         return self.image_encoder.output_size(self.in_size)
 
     @property
+    def image_bottleneck_size(self):
+        return self.image_encoder.bottleneck_size(self.in_size)
+
+    @property
     def camera_out_size(self):
         return self.image_out_size // (2 ** self.camera_config.count('D'))
 
@@ -179,6 +183,10 @@ class Photographer(_Checkpointed):
     @property
     def camera_out_size(self):
         return self.object_out_size * (2 ** self.camera_config.count('U'))
+
+    @property
+    def image_bottleneck_size(self):
+        return self.image_decoder.bottleneck_size(self.camera_out_size)
 
     @property
     def out_size(self):

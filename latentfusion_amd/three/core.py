@@ -53,3 +53,30 @@ def transform_coord_grid(grid, transform):
 
 def grid_to_coords(grid):
     return grid.view(grid.size(0), -1, grid.size(-1))
+
+
+def spherical_to_cartesian(theta, phi, r=1.0):
+    """reference core.py:89-93 (z uses theta, as there)."""
+    return torch.stack((r * torch.cos(theta) * torch.sin(phi), r * torch.sin(theta) * torch.sin(phi), r * torch.cos(theta)), dim=-1)
+
+
+def points_bound(points):
+    return torch.stack((torch.min(points, dim=0)[0], torch.max(points, dim=0)[0]), dim=1)
+
+
+def points_radius(points):
+    centroid = points_bound(points).mean(dim=1).unsqueeze(0)
+    return torch.norm(points - centroid, dim=1).max()
+
+
+def points_diameter(points):
+    return 2 * points_radius(points)
+
+
+def points_centroid(points):
+    return points_bound(points).mean(dim=1)
+
+
+def points_bounding_size(points):
+    bounds = points_bound(points)
+    return torch.norm(bounds[:, 1] - bounds[:, 0])

@@ -136,3 +136,11 @@ def angular_distance(q1, q2, eps=1e-7):
     """Pairwise geodesic distance 2 acos|<q1,q2>| -> (N1,N2)  (reference :372-377)."""
     d = (normalize(q1) @ normalize(q2).t()).abs().clamp(-1.0 + eps, 1.0 - eps)
     return 2 * torch.acos(d)
+
+
+def from_spherical(theta, phi, r=1.0):
+    """Pure quaternion of a spherical direction (reference quaternion.py:248-254; only z is scaled by r)."""
+    x = torch.cos(theta) * torch.sin(phi)
+    y = torch.sin(theta) * torch.sin(phi)
+    z = r * torch.cos(phi)
+    return torch.stack((torch.zeros_like(x), x, y, z), dim=-1)

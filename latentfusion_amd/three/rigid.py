@@ -65,3 +65,18 @@ def translate_matrix(matrix, offset):
     out[:, :3, 3] += offset
     out = inverse_transform(out)
     return out.squeeze(0) if single else out
+
+
+def scale_matrix(matrix, scale):
+    """Scales the frame the transform maps FROM (reference rigid.py:66-76): inv(scale_t(inv(M)))."""
+    single = matrix.dim() == 2
+    m = matrix.unsqueeze(0) if single else matrix
+    out = inverse_transform(m)
+    out[:, :3, 3] *= scale
+    out = inverse_transform(out)
+    return out.squeeze(0) if single else out
+
+
+def extrinsic_to_quat(extrinsic):
+    rot, _ = decompose(extrinsic)
+    return quaternion.mat_to_quat(rot[..., :3, :3])

@@ -605,12 +605,50 @@ def g16_bop_reader(lf):
             del np.bool
 
 
+def g17_api_helpers(lf):
+    """Small host-side helpers of the API surface: Camera lattices / back-projection, object lattice, point-set
+    statistics, spherical helpers, rigid-matrix edits, batch/view concat, distances, functional."""
+    import latentfusion.functional as LF
+    from latentfusion import distances, three
+    from latentfusion.modules.geometry import CameraToObjectTransform
+    g = torch.Generator().manual_seed(110)
+    cam = rand_cameras(lf, 2, zoomed_size=8, dist=1.3, seed=111)
+    depth = 0.8 + 0.4 * torch.rand(2, 1, 5, 6, generator=g)
+    pts = torch.randn(40, 3, generator=g)
+    th, ph = torch.rand(7, generator=g) * 3, torch.rand(7, generator=g) * 3
+    E = cam.extrinsic.clone()
+    a, b = torch.randn(6, 4, generator=g), torch.randn(6, 4, generator=g)
+    t4 = torch.randn(4, 3, 5, 5, generator=g)
+    out = {
+        'cam': cam_dict(cam), 'depth': depth, 'pts': pts, 'th': th, 'ph': ph, 'E': E, 'a': a, 'b': b, 't4': t4,
+        'fov_u': cam.fov_u.clone(), 'fov_v': cam.fov_v.clone(),
+        'uvz': [t.clone() for t in cam.pixel_coords_uvz((3, 4, 5))], 'uv': [t.clone() for t in cam.pixel_coords_uv((4, 5))],
+        'cc': [t.clone() for t in cam.camera_coords(4)], 'dcc': [t.clone() for t in cam.depth_camera_coords(depth)],
+        'doc': [t.clone() for t in cam.depth_object_coords(depth)],
+        'obj_coords': CameraToObjectTransform(1.0).get_obj_coords(4).clone(),
+        'bound': three.points_bound(pts), 'radius': three.points_radius(pts), 'diameter': three.points_diameter(pts),
+        'centroid': three.points_centroid(pts), 'bsize': three.points_bounding_size(pts),
+        's2c': three.spherical_to_cartesian(th, ph, 2.0), 'qsph': three.quaternion.from_spherical(th, ph, 2.0),
+        'scale_m': three.scale_matrix(E, 1.7), 'translate_m': three.translate_matrix(E, torch.tensor([0.1, -0.2, 0.3])),
+        'e2q': three.extrinsic_to_quat(E),
+        'vcat': three.vcat((torch.arange(12.).view(6, 2), torch.arange(100., 106.).view(3, 2)), batch_size=3),
+        'vsplit': [t.clone() for t in three.vsplit(torch.arange(18.).view(9, 2), [1, 2])],
+        'cosd': distances.cosine_distance(a, b), 'pair_c': distances.pairwise_distance(a, b),
+        'pair_e': distances.pairwise_distance(a, b, metric='euclidean'), 'dist_c': distances.distance(a, b, dim=1),
+        'dist_e': distances.distance(a, b, metric='euclidean', dim=1),
+        'outer': {m: distances.outer_distance(a, b, metric=m) for m in ('cosine', 'euclidean', 'inner', 'ols_coef')},
+        'norm': LF.normalize(t4, (0.1, 0.2, 0.3), (0.5, 0.6, 0.7)), 'denorm': LF.denormalize(t4, (0.1, 0.2, 0.3), (0.5, 0.6, 0.7)),
+        'unit': LF.unit_normalize(t4, 1), 'amp': LF.absolute_max_pool(t4, 0),
+    }
+    save('g17_api_helpers', out)
+
+
 def main():
     lf = refharness.load_reference()
     import latentfusion.recon.utils  # noqa
     torch.set_num_threads(8)
     gens = [g0_preprocess, g1_camera, g2_resample, g3_block, g4_fusers, g5_decode, g6_loss, g7_g10_loop, g9_ibr,
-            g11_released_like, g12_latent_code, g13_metrics, g14_initial_pose, g15_losses, g16_bop_reader]
+            g11_released_like, g12_latent_code, g13_metrics, g14_initial_pose, g15_losses, g16_bop_reader, g17_api_helpers]
     only = sys.argv[1:]                                  # e.g. `python oracle/make_golden.py g13` regenerates one group
     for fn in gens:
         if not only or any(fn.__name__.startswith(o + '_') or fn.__name__ == o for o in only):

@@ -435,3 +435,51 @@ def test_bop_reader_golden(golden):
         BOPDataset(root.parent, root / 'test' / '000002', object_id=2)
     K = pbop.parse_camera_intrinsics({'fx': 572.4, 'fy': 573.6, 'cx': 325.3, 'cy': 242.0})
     assert K.shape == (3, 4) and float(K[0, 2]) == pytest.approx(325.3)
+
+
+def test_api_helpers_golden(golden):
+    """The small host-side helpers that complete the reference's API surface (Camera lattices and
+    back-projection, object lattice, point statistics, spherical helpers, rigid edits, batch/view concat,
+    distances, functional) against the reference's own output (golden g17)."""
+    from latentfusion_amd import distances, functional as LF, three, utils
+    from latentfusion_amd.modules.geometry import CameraToObjectTransform
+    g = golden('g17_api_helpers')
+    cam = prod_camera(g['cam'])
+    close(cam.fov_u, g['fov_u']); close(cam.fov_v, g['fov_v'])
+    for got, want in zip(cam.pixel_coords_uvz((3, 4, 5)), g['uvz']):
+        close(got, want, atol=1e-6)
+    for got, want in zip(cam.pixel_coords_uv((4, 5)), g['uv']):
+        close(got, want, atol=1e-6)
+    for got, want in zip(cam.camera_coords(4), g['cc']):
+        close(got, want, atol=1e-6)
+    for got, want in zip(cam.depth_camera_coords(g['depth']), g['dcc']):
+        close(got, want, atol=1e-6)
+    for got, want in zip(cam.depth_object_coords(g['depth']), g['doc']):
+        close(got, want, atol=1e-5)
+    with pytest.raises(AttributeError):
+        cam.direction                                            # the reference property has a typo and raises
+    close(CameraToObjectTransform(1.0).get_obj_coords(4), g['obj_coords'], atol=0, rtol=0)
+    pts, th, ph, E = g['pts'], g['th'], g['ph'], g['E']
+    close(three.points_bound(pts), g['bound'], atol=0, rtol=0)
+    close(three.points_radius(pts), g['radius']); close(three.points_diameter(pts), g['diameter'])
+    close(three.points_centroid(pts), g['centroid']); close(three.points_bounding_size(pts), g['bsize'])
+    close(three.spherical_to_cartesian(th, ph, 2.0), g['s2c']); close(three.quaternion.from_spherical(th, ph, 2.0), g['qsph'])
+    close(three.scale_matrix(E, 1.7), g['scale_m'], atol=1e-6)
+    close(three.translate_matrix(E, torch.tensor([0.1, -0.2, 0.3])), g['translate_m'], atol=1e-6)
+    close(three.extrinsic_to_quat(E), g['e2q'], atol=1e-6)
+    close(three.vcat((torch.arange(12.).view(6, 2), torch.arange(100., 106.).view(3, 2)), batch_size=3), g['vcat'], atol=0, rtol=0)
+    for got, want in zip(three.vsplit(torch.arange(18.).view(9, 2), [1, 2]), g['vsplit']):
+        close(got, want, atol=0, rtol=0)
+    a, b, t4 = g['a'], g['b'], g['t4']
+    close(distances.cosine_distance(a, b), g['cosd']); close(distances.pairwise_distance(a, b), g['pair_c'])
+    close(distances.pairwise_distance(a, b, metric='euclidean'), g['pair_e'])
+    close(distances.distance(a, b, dim=1), g['dist_c']); close(distances.distance(a, b, metric='euclidean', dim=1), g['dist_e'])
+    for m, want in g['outer'].items():
+        close(distances.outer_distance(a, b, metric=m), want, atol=1e-6)
+    close(LF.normalize(t4, (0.1, 0.2, 0.3), (0.5, 0.6, 0.7)), g['norm']); close(LF.denormalize(t4, (0.1, 0.2, 0.3), (0.5, 0.6, 0.7)), g['denorm'])
+    close(LF.unit_normalize(t4, 1), g['unit']); close(LF.absolute_max_pool(t4, 0), g['amp'], atol=0, rtol=0)
+    assert utils.list_arg(int)('1,2,3') == [1, 2, 3] and utils.list_arg()('') == []
+    assert utils.block_config_arg()('16,D,32:32,U,16') == [[16, 'D', 32], [32, 'U', 16]]
+    assert utils.flatten_list([[1], [2, 3]]) == [1, 2, 3]
+    with pytest.raises(ValueError):
+        utils.list_choices_arg(['a'])('a,b')
