@@ -41,6 +41,18 @@ class HardPixelLoss(nn.Module):
         return reduce_loss(loss, self.reduction)
 
 
+def lsgan_loss(input, target, reduction='mean'):
+    """Least-squares GAN loss (losses.py:75-77)."""
+    return reduce_loss((input.squeeze() - target) ** 2, reduction=reduction)
+
+
+def multiscale_lsgan_loss(inputs, target, reduction='mean'):
+    loss = 0
+    for x in inputs:
+        loss = loss + lsgan_loss(x, target, reduction)
+    return loss
+
+
 def _log_beta(alpha, beta):
     alpha, beta = torch.tensor(alpha), torch.tensor(beta)
     return torch.lgamma(alpha) + torch.lgamma(beta) - torch.lgamma(alpha + beta)

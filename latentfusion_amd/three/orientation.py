@@ -42,3 +42,53 @@ def evenly_distributed_quats(n, hemisphere=False, hemisphere_pole=(0.0, 0.0, 1.0
                              upright_up=(0.0, 0.0, 1.0)):
     rays = evenly_distributed_points(n, hemisphere, hemisphere_pole)
     return random_quat_from_ray(-rays, upright_up if upright else None)
+
+
+def spiral_orbit(n, c=16):
+    """n pure quaternions spiralling from pole to pole (reference orientation.py:9-13)."""
+    phi = torch.linspace(0, math.pi, n)
+    return q.from_spherical(phi, c * phi)
+
+
+def _check_up(up, n):
+    if not torch.is_tensor(up):
+        up = torch.tensor(up, dtype=torch.float32)
+    if up.dim() == 1:
+        up = up.expand(n, -1)
+    return normalize(up)
+
+
+def _is_ray_in_segment(ray, up, min_angle, max_angle):
+    angle = torch.acos((up * ray).sum(dim=-1))
+    return (min_angle <= angle) & (angle <= max_angle)
+
+
+def sample_segment_rays(n, up, min_angle, max_angle):
+    """Rejection-samples unit rays whose angle to `up` lies in [min_angle, max_angle] (reference :29-40)."""
+    up = _check_up(up, n)
+    rays = normalize(torch.randn(n, 3))
+    num_invalid = n
+    while num_invalid > 0:
+        valid = _is_ray_in_segment(rays, up, min_angle, max_angle)
+        num_invalid = int((~valid).sum().item())
+        rays[~valid] = normalize(torch.randn(num_invalid, 3))
+    return normalize(rays)
+
+
+def sample_hemisphere_rays(n, up):
+    """Uniform rays reflected into the hemisphere around `up` (reference :43-67)."""
+    up = _check_up(up, n)
+    rays = normalize(torch.randn(n, 3))
+    dot = (up * rays).sum(dim=-1)
+    rays[dot < 0] = rays[dot < 0] - 2 * dot[dot < 0, None] * up[dot < 0]
+    return rays
+
+
+def sample_segment_quats(n, up, min_angle, max_angle):
+    """Random yaw about `up`, then tilt into the sphere segment (reference :95-123)."""
+    up = _check_up(up, n)
+    yaw_quat = q.from_axis_angle(up, torch.rand(n) * math.pi * 2.0)
+    rays = sample_segment_rays(n, up, min_angle, max_angle)
+    pivot = torch.cross(up, rays, dim=-1)
+    angles = torch.acos((up * rays).sum(dim=-1))
+    return q.qmul(q.from_axis_angle(pivot, angles), yaw_quat)

@@ -107,3 +107,15 @@ def relative_device_id(abs_device_id):
 def absolute_device_id(rel_device_id):
     ids = _visible_devices()
     return int(ids[rel_device_id]) if ids is not None else int(rel_device_id)
+
+
+def pbar(*args, **kwargs):
+    import tqdm.auto
+    kwargs.setdefault('dynamic_ncols', True)
+    return tqdm.auto.tqdm(*args, **kwargs)
+
+
+def trange(*args, **kwargs):
+    import tqdm.auto
+    kwargs.setdefault('dynamic_ncols', True)
+    return tqdm.auto.trange(*args, **kwargs)

@@ -643,12 +643,36 @@ def g17_api_helpers(lf):
     save('g17_api_helpers', out)
 
 
+def g18_training_prep(lf):
+    """Training-side host helpers: process_batch (recon/utils.py:68-127) on a 2 x 2-view synthetic batch and the
+    seeded orientation samplers (three/orientation.py:9-123); torch's global RNG is seeded before each call."""
+    from latentfusion import three
+    from latentfusion.recon import utils as RU
+    obs = synth_obs(lf, 4, seed=120)
+    one = {'extrinsic': obs.camera.extrinsic.view(2, 2, 4, 4).clone(), 'intrinsic': obs.camera.intrinsic.view(2, 2, 3, 4).clone(),
+           'mask': obs.mask.view(2, 2, 480, 640)[..., ::8, ::8].clone(), 'render': obs.color.view(2, 2, 3, 480, 640)[..., ::8, ::8].clone(),
+           'depth': obs.depth.view(2, 2, 480, 640)[..., ::8, ::8].clone()}
+    one['intrinsic'][..., :2, :] /= 8.0                                       # 60 x 80 frames keep the fixture small
+    batch = {'in': one, 'out_gt': one}                                       # (stored once)
+    torch.manual_seed(7)
+    out = RU.process_batch(batch, 1.0, 1.5, 24, 'cpu')
+    res = {k: {'image': v['image'].clone(), 'mask': v['mask'].clone(), 'depth': v['depth'].clone(), 'cam': cam_dict(v['camera'])}
+           for k, v in out.items()}
+    samp = {}
+    for name, args in (('sample_hemisphere_rays', (9, (0., 0., 1.))), ('sample_segment_rays', (9, (0., 0., 1.), 0.2, 1.0)),
+                       ('sample_segment_quats', (9, (0., 1., 0.), 0.2, 1.0))):
+        torch.manual_seed(5)
+        samp[name] = getattr(three.orientation, name)(*args).clone()
+    samp['spiral_orbit'] = three.orientation.spiral_orbit(7).clone()
+    save('g18_training_prep', {'batch_views': one, 'out': res, 'samplers': samp})
+
+
 def main():
     lf = refharness.load_reference()
     import latentfusion.recon.utils  # noqa
     torch.set_num_threads(8)
     gens = [g0_preprocess, g1_camera, g2_resample, g3_block, g4_fusers, g5_decode, g6_loss, g7_g10_loop, g9_ibr,
-            g11_released_like, g12_latent_code, g13_metrics, g14_initial_pose, g15_losses, g16_bop_reader, g17_api_helpers]
+            g11_released_like, g12_latent_code, g13_metrics, g14_initial_pose, g15_losses, g16_bop_reader, g17_api_helpers, g18_training_prep]
     only = sys.argv[1:]                                  # e.g. `python oracle/make_golden.py g13` regenerates one group
     for fn in gens:
         if not only or any(fn.__name__.startswith(o + '_') or fn.__name__ == o for o in only):
