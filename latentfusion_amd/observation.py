@@ -87,6 +87,61 @@ class Observation:
         mask, _ = camera.zoom(self.mask, target_size, target_dist, scale_mode='nearest')
         return self._new(color, depth, mask, new_camera, is_zoomed=True)
 
+    # ---- disk format of the reference (observation.py:164-223): cameras.json + %04d.{color,depth,mask}.png ----
+    def save(self, path):
+        """PNG colour (8-bit), depth (16-bit millimetres of the stored unit) and mask per view + cameras.json."""
+        import json
+        from pathlib import Path
+
+        import numpy as np
+        from PIL import Image
+
+        from .utils import MyEncoder
+        path = Path(path)
+        path.mkdir(exist_ok=True, parents=True)
+        cam = self.camera.to('cpu')
+        camera_json = cam.to_kwargs()
+        camera_json['meta'] = self.meta
+        with open(path / 'cameras.json', 'w') as f:
+            json.dump(camera_json, f, indent=2, cls=MyEncoder)
+        color, depth, mask = self.color.cpu(), self.depth.cpu(), self.mask.cpu()
+        for i in range(len(self)):
+            Image.fromarray((255.0 * color[i].permute(1, 2, 0).numpy()).astype(np.uint8)).save(path / f'{i:04d}.color.png')
+            Image.fromarray((1000.0 * depth[i][0]).numpy().astype(np.uint16)).save(path / f'{i:04d}.depth.png')
+            Image.fromarray(mask[i][0].numpy().astype(np.uint8) * 255).save(path / f'{i:04d}.mask.png')
+
+    @classmethod
+    def load(cls, path, frames=None) -> 'Observation':
+        import json
+        from pathlib import Path
+
+        import numpy as np
+        from PIL import Image
+        path = Path(path)
+        with open(path / 'cameras.json', 'r') as f:
+            camera_json = json.load(f)
+        meta = camera_json.pop('meta', {})
+        cameras = Camera(**{k: torch.tensor(v, dtype=torch.float32) if isinstance(v, list) else v
+                            for k, v in camera_json.items()})
+        inds = list(range(len(cameras))) if frames is None else ([frames] if isinstance(frames, int) else list(frames))
+        cameras = cameras[inds]
+        color = torch.stack([torch.tensor(np.array(Image.open(path / f'{i:04d}.color.png')).astype(np.float32) / 255.0)
+                             .permute(2, 0, 1) for i in inds], dim=0)
+        depth = torch.stack([torch.tensor(np.array(Image.open(path / f'{i:04d}.depth.png')).astype(np.float32) / 1000.0)
+                             .unsqueeze(0) for i in inds], dim=0)
+        mask = torch.stack([torch.tensor(np.array(Image.open(path / f'{i:04d}.mask.png')).astype(bool)).float().unsqueeze(0)
+                            for i in inds], dim=0)
+        return cls(color, depth, mask, cameras, **meta)
+
+    def estimate_camera(self) -> Camera:
+        """Camera with the translation estimated from depth + mask (reference :284-287)."""
+        from .pose.initialization import estimate_initial_pose
+        return estimate_initial_pose(self.depth, self.mask, self.camera.intrinsic, self.camera.width,
+                                     self.camera.height).to(self.device)
+
+    def zoom_estimate(self, target_dist, target_size):
+        return self.zoom(target_dist, target_size, camera=self.estimate_camera())
+
     def uncrop(self, camera=None):
         camera = self.camera if camera is None else camera
         color, new_camera = camera.uncrop(self.color, scale_mode='bilinear')

@@ -119,3 +119,20 @@ def trange(*args, **kwargs):
     import tqdm.auto
     kwargs.setdefault('dynamic_ncols', True)
     return tqdm.auto.trange(*args, **kwargs)
+
+
+import json as _json
+
+
+class MyEncoder(_json.JSONEncoder):
+    """JSON encoder that writes paths as strings and tensors as nested lists (reference utils.py:97-104)."""
+
+    def default(self, obj):
+        import pathlib
+
+        import torch
+        if isinstance(obj, pathlib.PurePath):
+            return str(obj)
+        if torch.is_tensor(obj):
+            return obj.tolist()
+        return _json.JSONEncoder.default(self, obj)

@@ -505,3 +505,25 @@ def test_training_prep_golden(golden):
     close(three.orientation.spiral_orbit(7), g['samplers']['spiral_orbit'], atol=0, rtol=0)
     t = torch.randn(3, 4, 5, 6)
     assert RU.repeat_tensor_as(t, torch.zeros(2, 7, 3, 4, 5, 6)).shape == (2, 7, 3, 4, 5, 6)
+
+
+def test_observation_save_load_roundtrip(tmp_path):
+    """Observation.save / load in the reference's disk format (cameras.json + per-view PNGs): round trip within
+    the 8-bit colour / millimetre depth quantisation; estimate_camera / zoom_estimate run."""
+    from latentfusion_amd import synth
+    from latentfusion_amd.observation import Observation
+    obs = synth.make_observation(3, seed=4, device='cpu')
+    obs.save(tmp_path / 'obs')
+    assert (tmp_path / 'obs' / 'cameras.json').exists() and (tmp_path / 'obs' / '0002.depth.png').exists()
+    back = Observation.load(tmp_path / 'obs')
+    assert back.color.shape == obs.color.shape and len(back.camera) == 3
+    assert (back.color - obs.color).abs().max().item() <= 1.0 / 255.0 + 1e-6
+    assert (back.depth - obs.depth).abs().max().item() <= 1e-3 + 1e-6
+    assert torch.equal(back.mask, obs.mask)
+    close(back.camera.extrinsic, obs.camera.extrinsic, atol=1e-5, rtol=1e-5)
+    one = Observation.load(tmp_path / 'obs', frames=1)
+    assert len(one) == 1 and torch.equal(one.mask, obs.mask[1:2])
+    cam = obs.estimate_camera()
+    assert cam.translation.shape == (3, 3) and float(cam.translation[:, 2].min()) > 0.5
+    z = obs.zoom_estimate(1.5, 32)
+    assert z.color.shape[-2:] == (32, 32)
