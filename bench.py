@@ -46,6 +46,9 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-iters', type=int, default=1)
     ap.add_argument('--no-alt', action='store_true', help='skip the secondary f16x3 measurement')
+    ap.add_argument('--sharded-build', action='store_true',
+                    help='(opt-in, N > 1) also reconstruct ONE object with its reference views sharded over the ranks and '
+                         'fused by an RCCL collective (parallel.build_latent_object_sharded); reported as `sharded_build`')
     ap.add_argument('--conv-mode', default='winograd', choices=['fp32', 'winograd', 'f16x3', 'winograd_f16x3'],
                     help="conv3d kernels of the engine: 'winograd' (default; F(2^3,3^3) minimal filtering, all-fp32 "
                          "arithmetic), 'fp32' (direct implicit GEMM on the fp32 MFMA) or 'f16x3' (split precision)")
@@ -194,6 +197,25 @@ def main():
         except Exception:                                           # noqa: BLE001
             traffic = None
 
+    sharded = None
+    if a.sharded_build:
+        # every rank builds the SAME model and observation; views are split over the ranks and the per-view
+        # volumes meet in one collective (all-reduce for pool fusers, ordered all-gather for GRU/LSTM)
+        from latentfusion_amd import parallel
+        model0, _ = synth.build_model(S, C, a.fuser, seed=12345, device=dev)
+        obs0 = synth.make_observation(V, seed=54321, device=dev)
+        for rep in range(2):                                       # second pass = warm
+            barrier()
+            t0 = time.perf_counter()
+            z_sh = parallel.build_latent_object_sharded(model0, obs0)
+            barrier()
+            t_sh = time.perf_counter() - t0
+        z_full = model0.build_latent_object(obs0)                  # local full build for comparison
+        err = (z_sh - z_full).abs().max().item()
+        sharded = {'t_s': t_sh, 'fuser': a.fuser, 'views': V, 'ranks': world, 'max_abs_diff_vs_local_build': err,
+                   'volume_MB': z_full.numel() * 4 / 1e6}
+        del model0, obs0, z_sh, z_full
+
     if rank != 0:
         return
     value = world * a.steps / elapsed
@@ -221,6 +243,8 @@ def main():
                                          f'(oracle, after 1 warm-up iteration; latent volume taken from the GPU build)'}
     if alt is not None:
         out['alt'] = alt
+    if sharded is not None:
+        out['sharded_build'] = sharded
     print(json.dumps(out))
 
 
