@@ -19,11 +19,11 @@ from torch.utils.data import Dataset
 
 from .. import three
 
-LINEMOD_ID_TO_NAME = {
-    '000001': 'ape', '000002': 'benchvise', '000003': 'bowl', '000004': 'camera', '000005': 'can', '000006': 'cat',
-    '000007': 'mug', '000008': 'driller', '000009': 'duck', '000010': 'eggbox', '000011': 'glue', '000012': 'holepuncher',
-    '000013': 'iron', '000014': 'lamp', '000015': 'phone',
-}
+_LINEMOD_NAMES = ('ape benchvise bowl camera can cat mug driller duck eggbox glue holepuncher iron lamp phone').split()
+LINEMOD_ID_TO_NAME = {f'{i:06d}': name for i, name in enumerate(_LINEMOD_NAMES, start=1)}
+
+# dataset directory name -> (scale that maps the model diameter to the working unit, folder of the meshes)
+_LAYOUTS = {'lm': (1.0, 'models'), 'lmo': (1.0, 'models'), 'tless': (0.60, 'models_reconst')}
 
 
 def read_ply_vertices(path):
@@ -65,14 +65,10 @@ class BOPDataset(Dataset):
     def __init__(self, dataset_path, scene_path, object_id, center_object=False, object_scale=None):
         super().__init__()
         self.dataset_path, self.scene_path, self.object_id = Path(dataset_path), Path(scene_path), object_id
-        if self.dataset_path.name in ('lm', 'lmo'):
-            base_obj_scale = 1.0
-            self.models_path = self.dataset_path / 'models'
-        elif self.dataset_path.name == 'tless':
-            base_obj_scale = 0.60
-            self.models_path = self.dataset_path / 'models_reconst'
-        else:
+        if self.dataset_path.name not in _LAYOUTS:
             raise ValueError(f'Unknown dataset type {self.dataset_path.name}')
+        base_obj_scale, mesh_dir = _LAYOUTS[self.dataset_path.name]
+        self.models_path = self.dataset_path / mesh_dir
         self.model_path = self.models_path / f'obj_{self.object_id:06d}.ply'
         self.pointcloud_path = self.dataset_path / 'models_eval' / f'obj_{self.object_id:06d}.ply'
         with open(self.dataset_path / 'models_eval' / 'models_info.json', 'r') as f:
@@ -80,9 +76,8 @@ class BOPDataset(Dataset):
         self.center_object = center_object
         self.object_scale = base_obj_scale / self.model_info['diameter'] if object_scale is None else object_scale
         self.image_scale = 1.0
-        mi = self.model_info
-        self.bounds = torch.tensor([(mi['min_x'], mi['min_x'] + mi['size_x']), (mi['min_y'], mi['min_y'] + mi['size_y']),
-                                    (mi['min_z'], mi['min_z'] + mi['size_z'])])
+        self.bounds = torch.tensor([(self.model_info[f'min_{ax}'], self.model_info[f'min_{ax}'] + self.model_info[f'size_{ax}'])
+                                    for ax in 'xyz'])
         self.centroid = self.bounds.mean(dim=1)
         self.depth_dir, self.mask_dir, self.color_dir = (self.scene_path / 'depth', self.scene_path / 'mask_visib',
                                                          self.scene_path / 'rgb')
@@ -145,29 +140,31 @@ class BOPDataset(Dataset):
     def _load_depth(self, path):
         return self._load(path, np.float32)
 
+    # dataset units <-> working units: optional re-centring on the model's bounding-box centre, then the
+    # translation is scaled so that the object has unit diameter (x base scale); intrinsics follow image_scale
+    def _recentre(self, extrinsic, sign):
+        return three.translate_matrix(extrinsic, sign * self.centroid.to(extrinsic.device)) if self.center_object else extrinsic
+
     def normalize_extrinsic(self, extrinsic):
-        extrinsic = extrinsic.clone()
-        if self.center_object:
-            extrinsic = three.translate_matrix(extrinsic, -self.centroid.to(extrinsic.device))
-        extrinsic[..., :3, 3] *= self.object_scale
-        return extrinsic
+        out = self._recentre(extrinsic.clone(), -1.0)
+        out[..., :3, 3] *= self.object_scale
+        return out
 
     def denormalize_extrinsic(self, extrinsic):
-        extrinsic = extrinsic.clone()
-        extrinsic[..., :3, 3] /= self.object_scale
-        if self.center_object:
-            extrinsic = three.translate_matrix(extrinsic, self.centroid.to(extrinsic.device))
-        return extrinsic
+        out = extrinsic.clone()
+        out[..., :3, 3] /= self.object_scale
+        return self._recentre(out, 1.0)
+
+    def _scale_intrinsic(self, intrinsic, factor):
+        out = intrinsic.clone()
+        out[..., :2, :] *= factor
+        return out
 
     def normalize_intrinsic(self, intrinsic):
-        intrinsic = intrinsic.clone()
-        intrinsic[..., :2, :] *= self.image_scale
-        return intrinsic
+        return self._scale_intrinsic(intrinsic, self.image_scale)
 
     def denormalize_intrinsic(self, intrinsic):
-        intrinsic = intrinsic.clone()
-        intrinsic[..., :2, :] /= self.image_scale
-        return intrinsic
+        return self._scale_intrinsic(intrinsic, 1.0 / self.image_scale)
 
     def sample_evenly(self, n):
         """Indices of `n` views whose camera positions are spread by farthest-point sampling."""

@@ -1,41 +1,38 @@
-"""Small tensor helpers (latentfusion/functional.py:4-49)."""
+"""Small tensor helpers of the reference (latentfusion/functional.py:4-49): feature taps of a sequential
+module, per-channel (de)normalisation of CHW / NCHW images, unit normalisation, signed max-magnitude pooling."""
 import torch
 
 
 def extract_features(x, submodule, layers):
-    outputs = []
-    for name, module in submodule.named_children():
-        x = module(x)
+    """Runs the children of `submodule` in order and collects the outputs of those named in `layers`."""
+    taps = []
+    for name, child in submodule.named_children():
+        x = child(x)
         if name in layers:
-            outputs.append(x)
-    return outputs
+            taps.append(x)
+    return taps
 
 
-def _stats(tensor, mean, std):
-    mean = torch.as_tensor(mean, dtype=torch.float32, device=tensor.device)
-    std = torch.as_tensor(std, dtype=torch.float32, device=tensor.device)
-    if tensor.dim() == 4:
-        return mean[None, :, None, None], std[None, :, None, None]
-    if tensor.dim() == 3:
-        return mean[:, None, None], std[:, None, None]
-    raise ValueError(f'Unsupported number of dimensions ({tensor.dim()}.')
+def _per_channel(tensor, values):
+    """`values` (one per channel) shaped to broadcast against a CHW or NCHW tensor."""
+    if tensor.dim() not in (3, 4):
+        raise ValueError(f'Unsupported number of dimensions ({tensor.dim()}.')
+    v = torch.as_tensor(values, dtype=torch.float32, device=tensor.device)
+    return v.view(*([1] * (tensor.dim() - 3)), -1, 1, 1)
 
 
 def normalize(tensor, mean, std):
-    mean, std = _stats(tensor, mean, std)
-    return (tensor - mean) / std
+    return (tensor - _per_channel(tensor, mean)) / _per_channel(tensor, std)
 
 
 def denormalize(tensor, mean, std):
-    mean, std = _stats(tensor, mean, std)
-    return (tensor * std) + mean
+    return tensor * _per_channel(tensor, std) + _per_channel(tensor, mean)
 
 
 def unit_normalize(tensor, dim, eps=1e-3):
-    return tensor / (eps + torch.norm(tensor, dim=dim, keepdim=True))
+    return tensor / (tensor.norm(dim=dim, keepdim=True) + eps)
 
 
 def absolute_max_pool(tensor, dim):
-    """Signed value of the largest magnitude along `dim` (kept dimension)."""
-    _, index = tensor.abs().max(dim=dim, keepdim=True)
-    return torch.gather(tensor, dim, index)
+    """Along `dim` (kept), the entry of largest magnitude with its sign."""
+    return tensor.take_along_dim(tensor.abs().argmax(dim=dim, keepdim=True), dim=dim)

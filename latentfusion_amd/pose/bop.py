@@ -1,14 +1,17 @@
-"""Camera-intrinsics JSON of the BOP tool-chain (latentfusion/pose/bop.py:6-19)."""
+"""Camera-intrinsics JSON of the BOP tool-chain ({"fx", "fy", "cx", "cy"} -> 3 x 4 matrix;
+latentfusion/pose/bop.py:6-19)."""
 import json
 
 import torch
 
 
 def parse_camera_intrinsics(d):
-    return torch.tensor([[d['fx'], 0.0, d['cx'], 0.0], [0.0, d['fy'], d['cy'], 0.0], [0.0, 0.0, 1.0, 0.0]],
-                        dtype=torch.float32)
+    K = torch.zeros(3, 4, dtype=torch.float32)
+    K[0, 0], K[1, 1], K[2, 2] = float(d['fx']), float(d['fy']), 1.0
+    K[0, 2], K[1, 2] = float(d['cx']), float(d['cy'])
+    return K
 
 
 def load_camera_intrinsics(path):
-    with open(path, 'r') as f:
-        return parse_camera_intrinsics(json.load(f))
+    with open(path) as fh:
+        return parse_camera_intrinsics(json.load(fh))
