@@ -130,17 +130,25 @@ __device__ __forceinline__ void wino_compute(const unsigned char* __restrict__ b
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       f32x4 m[4];
+      // two frequencies of the row advance together, one k-chunk at a time: a 16x16x4 f32 MFMA can issue every
+      // 32 cycles but its result feeds a dependent one only after 40, so a single back-to-back chain would bubble
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const f32x4 v = (b == 0) ? (vx[0][c] - vx[2][c])
-                      : (b == 1) ? (vx[1][c] + vx[2][c])
-                      : (b == 2) ? (vx[2][c] - vx[1][c])
-                                 : (vx[1][c] - vx[3][c]);
-        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int cp = 0; cp < 4; cp += 2) {
+        f32x4 v[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int c = cp + h;
+          v[h] = (b == 0) ? (vx[0][c] - vx[2][c])
+               : (b == 1) ? (vx[1][c] + vx[2][c])
+               : (b == 2) ? (vx[2][c] - vx[1][c])
+                          : (vx[1][c] - vx[3][c]);
+          m[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[(b * 4 + c) * 4 + i], v[i], acc, 0, 0, 0);
-        m[c] = acc;
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+            m[cp + h] = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[(b * 4 + cp + h) * 4 + i], v[h][i], m[cp + h], 0, 0, 0);
       }
       // x output transform, then accumulate the y output transform
       const f32x4 t0 = m[0] + m[1] + m[2];
