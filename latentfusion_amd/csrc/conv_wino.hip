@@ -104,12 +104,14 @@ __device__ __forceinline__ void dma_piece(const DmaTile& d, int it, int wave, in
 
 template <int A>
 __device__ __forceinline__ void wino_compute(const unsigned char* __restrict__ buf, const int (&off)[8][2],
-                                              const float (&wt)[64], f32x4 (&Y)[2][4]) {
+                                              const float (&wt)[64], unsigned char* __restrict__ pdst,
+                                              const int (&pw)[2]) {
   // z input transform of frequency A: d0-d2, d1+d2, d2-d1, d1-d3
   constexpr int DZ0 = (A == 0) ? 0 : (A == 2 ? 2 : 1);
   constexpr int DZ1 = (A == 0) ? 2 : (A == 1 ? 2 : (A == 2 ? 1 : 3));
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
+    f32x4 Yg[4];                                              // (j, i) outputs of this group, z-frequency A
     f32x4 vx[4][4];                                           // [dy][x-frequency c]
 #pragma unroll
     for (int dy = 0; dy < 4; ++dy) {
@@ -153,11 +155,17 @@ __device__ __forceinline__ void wino_compute(const unsigned char* __restrict__ b
       // x output transform, then accumulate the y output transform
       const f32x4 t0 = m[0] + m[1] + m[2];
       const f32x4 t1 = m[1] - m[2] - m[3];
-      if (b == 0) { Y[g][0] = t0; Y[g][1] = t1; }
-      if (b == 1) { Y[g][0] += t0; Y[g][1] += t1; Y[g][2] = t0; Y[g][3] = t1; }
-      if (b == 2) { Y[g][0] += t0; Y[g][1] += t1; Y[g][2] = pk_sub(Y[g][2], t0); Y[g][3] = pk_sub(Y[g][3], t1); }
-      if (b == 3) { Y[g][2] = pk_sub(Y[g][2], t0); Y[g][3] = pk_sub(Y[g][3], t1); }
+      if (b == 0) { Yg[0] = t0; Yg[1] = t1; }
+      if (b == 1) { Yg[0] += t0; Yg[1] += t1; Yg[2] = t0; Yg[3] = t1; }
+      if (b == 2) { Yg[0] += t0; Yg[1] += t1; Yg[2] = pk_sub(Yg[2], t0); Yg[3] = pk_sub(Yg[3], t1); }
+      if (b == 3) { Yg[2] = pk_sub(Yg[2], t0); Yg[3] = pk_sub(Yg[3], t1); }
     }
+    // partial outputs of z-frequency A -> the exchange region (separate from the halo, free since the last
+    // barrier of the previous tile): 1 KiB blocks [wave][g][tyb][j], 64 float4 slots each at (L ^ ((L >> 3) & 7)),
+    // L = x*4 + channel quarter -- the writers' 8-lane groups and the readers' 16-lane groups both hit distinct
+    // bank slots, and a reader wave gets one x-contiguous 1 KiB output row per instruction
+#pragma unroll
+    for (int ji = 0; ji < 4; ++ji) *(f32x4*)(pdst + g * 4096 + (ji >> 1) * 1024 + pw[ji & 1]) = Yg[ji];
   }
 }
 
@@ -268,15 +276,14 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_wino_kernel(
 #endif
   for (int t = t_begin; t < t_end; ++t) {
     TS(0);
-    f32x4 Y[2][4];
     switch (fa) {
-      case 0: wino_compute<0>(buf, off, wt, Y); break;
-      case 1: wino_compute<1>(buf, off, wt, Y); break;
-      case 2: wino_compute<2>(buf, off, wt, Y); break;
-      default: wino_compute<3>(buf, off, wt, Y); break;
+      case 0: wino_compute<0>(buf, off, wt, px + fa * 8192, pw); break;
+      case 1: wino_compute<1>(buf, off, wt, px + fa * 8192, pw); break;
+      case 2: wino_compute<2>(buf, off, wt, px + fa * 8192, pw); break;
+      default: wino_compute<3>(buf, off, wt, px + fa * 8192, pw); break;
     }
     TS(1);
-    lds_barrier();                                              // every wave is done reading the halo
+    lds_barrier();                                  // every wave is done reading the halo; all partials are in LDS
     TS(2);
 
     // next tile's halo: in flight during the exchange / epilogue below and, for the CU, under the MFMA phase
@@ -287,16 +294,6 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_wino_kernel(
     if (nz == tiles_z) { nz = 0; ++nn; }
     issue_dma(nx, ny, nz, nn, t + 1 < t_end);
     TS(3);
-
-    // partial outputs of z-frequency fa -> LDS, 1 KiB blocks indexed [wave][g][tyb][j], 64 float4 slots each
-    // at (L ^ ((L >> 3) & 7)), L = x*4 + channel quarter: the writers' 8-lane groups and the readers' 16-lane
-    // groups both hit distinct bank slots, and a reader wave gets one x-contiguous 1 KiB output row per
-    // instruction
-#pragma unroll
-    for (int g = 0; g < 2; ++g)
-#pragma unroll
-      for (int ji = 0; ji < 4; ++ji)
-        *(f32x4*)(px + fa * 8192 + g * 4096 + (ji >> 1) * 1024 + pw[ji & 1]) = Y[g][ji];
 
     // this wave finishes rows y = 2fa, 2fa+1 of the tile: lane = x*4 + channel quarter
     const int bx = cx, by = cy, bz = cz, tt = cn;
@@ -326,7 +323,6 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_wino_kernel(
       }
     }
     TS(4);
-    lds_barrier();                                              // all partials are in LDS
     TS(5);
 
     f32x4 o[4];
