@@ -38,9 +38,11 @@ namespace {
 constexpr int TZw = 2, TYw = 8, TXw = 16;
 constexpr int HZw = TZw + 2, HYw = TYw + 2, HXw = TXw + 2;     // 4 x 10 x 18 halo
 constexpr int HALOw = HZw * HYw * HXw;                          // 720 voxels
-constexpr int NSLOTw = (HALOw * 4 + 63) / 64;                   // 45 DMA pieces of 1 KiB
-constexpr int NITw = (NSLOTw + 3) / 4;                          // 12 pieces per wave (the last only for wave 0)
-constexpr int BUFw = NSLOTw * 1024;                             // 46,080 B halo buffer
+constexpr int HALFw = 2 * HYw * HXw;                            // 360 voxels: two z planes of the halo
+constexpr int HALFBw = HALFw * 64;                              // 23,040 B
+constexpr int NSLOTw = (HALFw * 4 + 63) / 64;                   // 23 pieces of 1 KiB per half (the last one half full)
+constexpr int NITw = (NSLOTw + 3) / 4;                          // 6 pieces per wave and half
+constexpr int BUFw = 2 * HALFBw;                                // 46,080 B halo buffer
 constexpr int PXw = 4 * 8192;                                   // 32,768 B partial-exchange region
 constexpr int LDSw = BUFw + PXw + 1024;                         // + 1 KiB DMA scratch = 79,872 B (two workgroups per CU)
 
@@ -83,29 +85,30 @@ __device__ __forceinline__ f32x4 pk_sub(f32x4 a, f32x4 b) {
 // One tile's LDS-DMA job (wave-uniform part).
 struct DmaTile {
   __amdgpu_buffer_rsrc_t rs;
-  unsigned char* dst;
-  unsigned char* scratch;
   int ox, oy, oz;
   bool on;
 };
 
-__device__ __forceinline__ void dma_piece(const DmaTile& d, int it, int wave, int lxyzq, int W, int H, int D) {
-  // branch-free: a piece that must not be fetched (no next tile; twelfth piece of waves 1-3) is pointed at
-  // a scratch KiB of LDS with every lane out of range, which just writes zeros there
-  const int s = wave + 4 * it;
-  const bool live = d.on && s < NSLOTw;                                       // wave-uniform
-  const int gx = d.ox + (lxyzq & 0xff), gy = d.oy + ((lxyzq >> 8) & 0xff), gz = d.oz + ((lxyzq >> 16) & 0xff);
-  const bool ok = (unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H && (unsigned)gz < (unsigned)D && lxyzq >= 0;
-  const int addr = ((gz * H + gy) * W + gx) * 64 + ((lxyzq >> 24) << 4);
-  const int voff = (ok && live) ? addr : 0x7fffffff;                          // out of range -> the DMA writes zeros
-  unsigned char* dst = live ? d.dst + s * 1024 : d.scratch;
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(d.rs, (__attribute__((address_space(3))) void*)dst, 16, voff, 0, 0, 0);
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4 halo_piece(const DmaTile& d, int it, int wave, unsigned packed, int W, int H, int D) {
+  // branch-free: lanes outside the volume, padding lanes and pieces that must not be fetched (no next tile)
+  // use an out-of-range buffer offset, which reads zeros.
+  // `packed` holds two pieces' lane constants, 16 bits each: lx | ly << 5 | lz << 9 | quarter << 11 | pad << 15
+  const int sh = (it & 1) * 16;
+  const int gx = d.ox + (int)((packed >> sh) & 31), gy = d.oy + (int)((packed >> (sh + 5)) & 15);
+  const int gz = d.oz + (int)((packed >> (sh + 9)) & 3);
+  const bool ok = (unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H && (unsigned)gz < (unsigned)D &&
+                  ((packed >> (sh + 15)) & 1) == 0;
+  const int addr = ((gz * H + gy) * W + gx) * 64 + (int)(((packed >> (sh + 11)) & 3) << 4);
+  const int voff = (ok && d.on) ? addr : 0x7fffffff;
+  return __builtin_amdgcn_raw_buffer_load_b128(d.rs, voff, 0, 0);
 }
 
 template <int A>
 __device__ __forceinline__ void wino_compute(const unsigned char* __restrict__ buf, const int (&off)[8][2],
                                               const float (&wt)[64], unsigned char* __restrict__ pdst,
-                                              const int (&pw)[2]) {
+                                              const int (&pw)[2], unsigned* tsp = nullptr) {
+#define CTS(k) do { if ((WINO_ABL & 32) && tsp != nullptr) tsp[k] = (unsigned)__builtin_readcyclecounter(); } while (0)
   // z input transform of frequency A: d0-d2, d1+d2, d2-d1, d1-d3
   constexpr int DZ0 = (A == 0) ? 0 : (A == 2 ? 2 : 1);
   constexpr int DZ1 = (A == 0) ? 2 : (A == 1 ? 2 : (A == 2 ? 1 : 3));
@@ -113,22 +116,42 @@ __device__ __forceinline__ void wino_compute(const unsigned char* __restrict__ b
   for (int g = 0; g < 2; ++g) {
     f32x4 Yg[4];                                              // (j, i) outputs of this group, z-frequency A
     f32x4 vx[4][4];                                           // [dy][x-frequency c]
+    // the halo is read half a row (2 z planes x 2 x positions = 4 ds_read_b128) ahead of the half row being
+    // transformed; the fences stop the scheduler from folding this back into load-wait-use pairs, which
+    // exposes the full LDS latency sixteen times per group
+    f32x4 raw[2][4];
+    auto load_half = [&](int hh, f32x4 (&r)[4]) {
+      const int dy = hh >> 1;
 #pragma unroll
-    for (int dy = 0; dy < 4; ++dy) {
-      f32x4 d[4];
-#pragma unroll
-      for (int dx = 0; dx < 4; ++dx) {
+      for (int e = 0; e < 2; ++e) {
+        const int dx = (hh & 1) * 2 + e;
         const int ca = ((DZ0 * 10 + 4 * g + dy) * 18 + (dx & 1) * 9 + (dx >> 1));
         const int cb = ((DZ1 * 10 + 4 * g + dy) * 18 + (dx & 1) * 9 + (dx >> 1));
-        const f32x4 va = *(const f32x4*)(buf + off[ca & 7][dy >> 1] + ca * 64);
-        const f32x4 vb = *(const f32x4*)(buf + off[cb & 7][dy >> 1] + cb * 64);
-        d[dx] = (A == 1) ? (va + vb) : pk_sub(va, vb);
+        r[2 * e] = *(const f32x4*)(buf + off[ca & 7][dy >> 1] + ca * 64);
+        r[2 * e + 1] = *(const f32x4*)(buf + off[cb & 7][dy >> 1] + cb * 64);
       }
-      vx[dy][0] = pk_sub(d[0], d[2]);
-      vx[dy][1] = d[1] + d[2];
-      vx[dy][2] = pk_sub(d[2], d[1]);
-      vx[dy][3] = pk_sub(d[1], d[3]);
+    };
+    load_half(0, raw[0]);
+    f32x4 d[4];
+#pragma unroll
+    for (int hh = 0; hh < 8; ++hh) {
+      if (hh < 7) load_half(hh + 1, raw[(hh + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      const int dy = hh >> 1;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const f32x4 va = raw[hh & 1][2 * e], vb = raw[hh & 1][2 * e + 1];
+        d[(hh & 1) * 2 + e] = (A == 1) ? (va + vb) : pk_sub(va, vb);
+      }
+      if (hh & 1) {
+        vx[dy][0] = pk_sub(d[0], d[2]);
+        vx[dy][1] = d[1] + d[2];
+        vx[dy][2] = pk_sub(d[2], d[1]);
+        vx[dy][3] = pk_sub(d[1], d[3]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
+    CTS(9 + 2 * g);
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       f32x4 m[4];
@@ -166,7 +189,9 @@ __device__ __forceinline__ void wino_compute(const unsigned char* __restrict__ b
     // bank slots, and a reader wave gets one x-contiguous 1 KiB output row per instruction
 #pragma unroll
     for (int ji = 0; ji < 4; ++ji) *(f32x4*)(pdst + g * 4096 + (ji >> 1) * 1024 + pw[ji & 1]) = Yg[ji];
+    CTS(10 + 2 * g);
   }
+#undef CTS
 }
 
 __global__ void __launch_bounds__(256, 2) conv3d_c16_wino_kernel(
@@ -198,7 +223,9 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_wino_kernel(
   const unsigned sample_bytes = (unsigned)(nvox * 64);
 
   // ---- LDS-DMA piece constants: LDS slot p = piece*64 + lane holds quarter (p&3)^s of voxel slot p>>2 ----
-  int lxyzq[NITw];                                              // lx | ly << 8 | lz << 16 | quarter << 24
+  // ---- halo piece constants: within a half (two z planes), LDS slot p = piece*64 + lane holds quarter (p&3)^s of
+  // voxel slot p>>2.  (360 slots per half is a multiple of 8, so the swizzle is the same in both halves.) ----
+  unsigned lxyzq[NITw / 2];                                     // two pieces per register, see halo_piece()
 #pragma unroll
   for (int it = 0; it < NITw; ++it) {
     const int p = (fa + 4 * it) * 64 + lane;
@@ -208,8 +235,10 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_wino_kernel(
     const int lx = 2 * xa + xl, ly = row % HYw, lz = row / HYw;
     const int s = (((vs >> 2) & 1) << 1) | ((ly >> 1) & 1);
     const int q = (p & 3) ^ s;
-    lxyzq[it] = (vs < HALOw) ? (lx | (ly << 8) | (lz << 16) | (q << 24)) : -1;           // padding lanes / pieces
+    const unsigned c = (vs < HALFw) ? (unsigned)(lx | (ly << 5) | (lz << 9) | (q << 11)) : 0x8000u;   // padding lanes / pieces
+    if (it & 1) lxyzq[it >> 1] |= c << 16; else lxyzq[it >> 1] = c;
   }
+  const bool last_piece_ok = ((fa + 4 * (NITw - 1)) * 64 + lane) < HALFw * 4;      // piece 22: lanes 0-31; 23: none
 
   // ---- B-operand addressing: byte offset of (lane's tile, channel quarter) for the 8 slot residues ----
   // (rows dy = 2,3 sit one (y>>1) step further: their quarter swizzle differs in bit 0)
@@ -246,27 +275,53 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_wino_kernel(
   // tile coordinates are stepped, not divided: (cx, cy, cz, cn) = tile t, (nx, ny, nz, nn) = tile t + 1
   int cx, cy, cz, cn;
   {
-    int tt = t_begin;
+    int tt = t_begin;                                            // z fastest: a workgroup walks up columns of tiles
+    cz = tt % tiles_z; tt /= tiles_z;
     cx = tt % tiles_x; tt /= tiles_x;
-    cy = tt % tiles_y; tt /= tiles_y;
-    cz = tt % tiles_z; cn = tt / tiles_z;
+    cy = tt % tiles_y; cn = tt / tiles_y;
   }
-  auto issue_dma = [&](int bx, int by, int bz, int bn, bool on) {
+  // The halo slides along z: the upper two planes of a tile's halo are the lower two of the next tile up the
+  // column, so they are moved LDS -> LDS and only two new planes (22.5 KiB) are fetched per tile; at the bottom of a
+  // column all four planes are fetched.  Everything is staged through registers: requested right after the
+  // barrier that frees the halo buffer, in flight under the exchange / epilogue arithmetic, written to LDS
+  // (linear: piece * 1 KiB + lane * 16 within a half) just before the tile's last barrier.  (The vector-memory
+  // path of a CU sustains only ~16 B/clk on this access pattern and blocks the issuing wave while its queue is
+  // full, so halving the bytes shortens the non-MFMA phase of every tile.)
+  u32x4 hlo[NITw], hhi[NITw];
+  auto halo_fetch = [&](int bx, int by, int bz, int bn, bool on, bool slide) {
     DmaTile d;
     d.ox = bx * TXw - 1; d.oy = by * TYw - 1; d.oz = bz * TZw - 1;
     d.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long)(on ? bn : 0) * nvox * 16), 0, sample_bytes, 0x00020000);
-    d.dst = buf;
-    d.scratch = smem + BUFw + PXw;
     d.on = on;
+    // (opaque to the optimiser: otherwise the unpacked fields are hoisted out of the tile loop into 40+ registers)
 #pragma unroll
-    for (int it = 0; it < NITw; ++it) dma_piece(d, it, fa, lxyzq[it], W, H, D);
+    for (int i = 0; i < NITw / 2; ++i) asm volatile("" : "+v"(lxyzq[i]));
+    if (slide) {                                                // wave-uniform
+#pragma unroll
+      for (int it = 0; it < NITw; ++it) hlo[it] = *(const u32x4*)(buf + HALFBw + (fa + 4 * it) * 1024 + lane * 16);
+    } else {
+#pragma unroll
+      for (int it = 0; it < NITw; ++it) hlo[it] = halo_piece(d, it, fa, lxyzq[it >> 1], W, H, D);
+    }
+    d.oz += 2;
+#pragma unroll
+    for (int it = 0; it < NITw; ++it) hhi[it] = halo_piece(d, it, fa, lxyzq[it >> 1], W, H, D);
   };
-
+  auto halo_commit = [&]() {
+#pragma unroll
+    for (int it = 0; it < NITw; ++it) {
+      unsigned char* dst = buf + (fa + 4 * it) * 1024 + lane * 16;
+      if (it < NITw - 1 || last_piece_ok) {
+        *(u32x4*)dst = hlo[it];
+        *(u32x4*)(dst + HALFBw) = hhi[it];
+      }
+    }
+  };
   const float out_scale = he;
   float wave_amax = 0.f;
 
-  issue_dma(cx, cy, cz, cn, true);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  halo_fetch(cx, cy, cz, cn, true, false);
+  halo_commit();
   lds_barrier();
 
 #if WINO_ABL & 16
@@ -276,11 +331,16 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_wino_kernel(
 #endif
   for (int t = t_begin; t < t_end; ++t) {
     TS(0);
+#if WINO_ABL & 16
+    unsigned* const tsp = (blockIdx.x == 11 && lane == 0) ? (unsigned*)norm_out + ((t - t_begin) * 4 + fa) * 16 : nullptr;
+#else
+    unsigned* const tsp = nullptr;
+#endif
     switch (fa) {
-      case 0: wino_compute<0>(buf, off, wt, px + fa * 8192, pw); break;
-      case 1: wino_compute<1>(buf, off, wt, px + fa * 8192, pw); break;
-      case 2: wino_compute<2>(buf, off, wt, px + fa * 8192, pw); break;
-      default: wino_compute<3>(buf, off, wt, px + fa * 8192, pw); break;
+      case 0: wino_compute<0>(buf, off, wt, px + fa * 8192, pw, tsp); break;
+      case 1: wino_compute<1>(buf, off, wt, px + fa * 8192, pw, tsp); break;
+      case 2: wino_compute<2>(buf, off, wt, px + fa * 8192, pw, tsp); break;
+      default: wino_compute<3>(buf, off, wt, px + fa * 8192, pw, tsp); break;
     }
     TS(1);
     lds_barrier();                                  // every wave is done reading the halo; all partials are in LDS
@@ -288,11 +348,10 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_wino_kernel(
 
     // next tile's halo: in flight during the exchange / epilogue below and, for the CU, under the MFMA phase
     // of the other resident workgroup
-    int nx = cx + 1, ny = cy, nz = cz, nn = cn;
+    int nx = cx, ny = cy, nz = cz + 1, nn = cn;
+    if (nz == tiles_z) { nz = 0; ++nx; }
     if (nx == tiles_x) { nx = 0; ++ny; }
-    if (ny == tiles_y) { ny = 0; ++nz; }
-    if (nz == tiles_z) { nz = 0; ++nn; }
-    issue_dma(nx, ny, nz, nn, t + 1 < t_end);
+    if (ny == tiles_y) { ny = 0; ++nn; }
     TS(3);
 
     // this wave finishes rows y = 2fa, 2fa+1 of the tile: lane = x*4 + channel quarter
@@ -323,6 +382,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_wino_kernel(
       }
     }
     TS(4);
+    halo_fetch(nx, ny, nz, nn, t + 1 < t_end, nz != 0);
     TS(5);
 
     f32x4 o[4];
@@ -364,7 +424,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_wino_kernel(
     // before the tile's last barrier; this tile's stores are issued after the wait so they stay out of it
     // and drain behind the next tile's MFMAs
     TS(6);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    halo_commit();
     TS(7);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {

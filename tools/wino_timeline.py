@@ -34,7 +34,7 @@ for _ in range(3):
     assert f(x.data_ptr(), up.data_ptr(), b.data_ptr(), y.data_ptr(), nrm.data_ptr(), N, S, S, S, he, flags, 0.2, 1e-8, None, None, 0, None, torch.cuda.current_stream().cuda_stream) == 0
 torch.cuda.synchronize()
 ts = nrm[:128 * 4 * 16].cpu().numpy().view(np.uint32).reshape(128, 4, 16).astype(np.int64)
-names = ['compute', 'B1 wait', 'DMA issue', 'Pwrite+idx', 'B2 wait', 'Pread+math', 'vmcnt wait', 'stores', 'B3 wait(to next top)']
+names = ['compute+Pwrite', 'B1 wait', 'DMA issue', 'idx+prev loads', '-', 'Pread+math', 'vmcnt wait', 'stores', 'B2 wait(to next top)']
 for wv in (0, 1, 3):
     d = []
     for k in range(8):
@@ -42,3 +42,5 @@ for wv in (0, 1, 3):
     d.append(np.mean((ts[9:121, wv, 0] - ts[8:120, wv, 8]) & 0xffffffff))
     tot = np.mean((ts[9:121, wv, 0] - ts[8:120, wv, 0]) & 0xffffffff)
     print(f'wave {wv}: total {tot:.0f} ticks/tile: ' + ', '.join(f'{n} {v:.0f}' for n, v in zip(names, d)))
+    c = [np.mean((ts[8:120, wv, b] - ts[8:120, wv, a]) & 0xffffffff) for a, b in ((0, 9), (9, 10), (10, 11), (11, 12))]
+    print('         compute split: ' + ', '.join(f'{n} {v:.0f}' for n, v in zip(('g0 load+xform', 'g0 MFMA+out', 'g1 load+xform', 'g1 MFMA+out'), c)))
