@@ -24,9 +24,10 @@
 //   * the four z-frequency partials of a tile meet through LDS, then every wave finishes a quarter of the
 //     outputs: z output transform, He scale, bias, LeakyReLU, PixelNorm (DPP quad reduction), and one
 //     x-contiguous 1 KiB row per store instruction.
-// The halo is fetched with LDS-DMA (issued as soon as the previous tile's halo has been consumed) in a
-// bank-swizzled order: voxel slot = (z*10 + y)*18 + (x&1)*9 + (x>>1), 16-byte quarter q stored at
-// q ^ s, s = 2*((slot>>2)&1) + ((y>>1)&1)  ->  every ds_read_b128 lane group hits 16 distinct slots
+// The halo (4 x 10 x 18 voxels, fp32) slides along z: a workgroup walks up a column of tiles, moves the upper two
+// planes of the halo LDS -> LDS and fetches only the two new planes (22.5 KiB) per tile, staged through registers
+// under the exchange / epilogue phase.  LDS layout: voxel slot = (z*10 + y)*18 + (x&1)*9 + (x>>1), 16-byte quarter
+// q stored at q ^ s, s = 2*((slot>>2)&1) + ((y>>1)&1)  ->  every ds_read_b128 lane group hits 16 distinct slots
 // (SQ_LDS_BANK_CONFLICT = 0).
 #include "lf_common.h"
 #ifndef WINO_ABL
@@ -82,27 +83,7 @@ __device__ __forceinline__ f32x4 pk_sub(f32x4 a, f32x4 b) {
   return (f32x4){lo[0], lo[1], hi[0], hi[1]};
 }
 
-// One tile's LDS-DMA job (wave-uniform part).
-struct DmaTile {
-  __amdgpu_buffer_rsrc_t rs;
-  int ox, oy, oz;
-  bool on;
-};
-
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ u32x4 halo_piece(const DmaTile& d, int it, int wave, unsigned packed, int W, int H, int D) {
-  // branch-free: lanes outside the volume, padding lanes and pieces that must not be fetched (no next tile)
-  // use an out-of-range buffer offset, which reads zeros.
-  // `packed` holds two pieces' lane constants, 16 bits each: lx | ly << 5 | lz << 9 | quarter << 11 | pad << 15
-  const int sh = (it & 1) * 16;
-  const int gx = d.ox + (int)((packed >> sh) & 31), gy = d.oy + (int)((packed >> (sh + 5)) & 15);
-  const int gz = d.oz + (int)((packed >> (sh + 9)) & 3);
-  const bool ok = (unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H && (unsigned)gz < (unsigned)D &&
-                  ((packed >> (sh + 15)) & 1) == 0;
-  const int addr = ((gz * H + gy) * W + gx) * 64 + (int)(((packed >> (sh + 11)) & 3) << 4);
-  const int voff = (ok && d.on) ? addr : 0x7fffffff;
-  return __builtin_amdgcn_raw_buffer_load_b128(d.rs, voff, 0, 0);
-}
 
 template <int A>
 __device__ __forceinline__ void wino_compute(const unsigned char* __restrict__ buf, const int (&off)[8][2],
@@ -224,8 +205,14 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_wino_kernel(
 
   // ---- LDS-DMA piece constants: LDS slot p = piece*64 + lane holds quarter (p&3)^s of voxel slot p>>2 ----
   // ---- halo piece constants: within a half (two z planes), LDS slot p = piece*64 + lane holds quarter (p&3)^s of
-  // voxel slot p>>2.  (360 slots per half is a multiple of 8, so the swizzle is the same in both halves.) ----
-  unsigned lxyzq[NITw / 2];                                     // two pieces per register, see halo_piece()
+  // voxel slot p>>2.  (360 slots per half is a multiple of 8, so the swizzle is the same in both halves.)
+  // Per piece a lane keeps only its byte offset relative to the half's first voxel; x / y range violations (possible
+  // only in the first / last tile of a row or column of tiles) are five flag bits per piece in one register, z range
+  // violations fall outside the buffer descriptor's range on their own and read zeros. ----
+  enum { F_XLO = 1, F_XHI = 2, F_YLO = 4, F_YHI = 8, F_PAD = 16, F_ALL6 = 0x2108421 };
+  const int xlim = W - (tiles_x - 1) * TXw + 1, ylim = H - (tiles_y - 1) * TYw + 1;   // first invalid lx / ly in the last tile
+  int hrel[NITw];
+  unsigned hflags = 0;
 #pragma unroll
   for (int it = 0; it < NITw; ++it) {
     const int p = (fa + 4 * it) * 64 + lane;
@@ -233,10 +220,12 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_wino_kernel(
     const int row = vs / HXw, rem = vs - row * HXw;
     const int xl = rem / 9, xa = rem - xl * 9;
     const int lx = 2 * xa + xl, ly = row % HYw, lz = row / HYw;
-    const int s = (((vs >> 2) & 1) << 1) | ((ly >> 1) & 1);
-    const int q = (p & 3) ^ s;
-    const unsigned c = (vs < HALFw) ? (unsigned)(lx | (ly << 5) | (lz << 9) | (q << 11)) : 0x8000u;   // padding lanes / pieces
-    if (it & 1) lxyzq[it >> 1] |= c << 16; else lxyzq[it >> 1] = c;
+    const int sw = (((vs >> 2) & 1) << 1) | ((ly >> 1) & 1);
+    const int q = (p & 3) ^ sw;
+    const bool pad = vs >= HALFw;
+    hrel[it] = pad ? 0 : ((lz * H + ly) * W + lx) * 64 + q * 16;
+    const unsigned f = pad ? F_PAD : ((lx == 0 ? F_XLO : 0) | (lx >= xlim ? F_XHI : 0) | (ly == 0 ? F_YLO : 0) | (ly >= ylim ? F_YHI : 0));
+    hflags |= f << (5 * it);
   }
   const bool last_piece_ok = ((fa + 4 * (NITw - 1)) * 64 + lane) < HALFw * 4;      // piece 22: lanes 0-31; 23: none
 
@@ -269,8 +258,6 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_wino_kernel(
 #pragma unroll
     for (int k = 0; k < 64; ++k) wt[k] = up[k * 64];
   }
-  f32x4 bv4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-  if (bias != nullptr) bv4 = *(const f32x4*)(bias + eq * 4);
 
   // tile coordinates are stepped, not divided: (cx, cy, cz, cn) = tile t, (nx, ny, nz, nn) = tile t + 1
   int cx, cy, cz, cn;
@@ -288,24 +275,37 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_wino_kernel(
   // path of a CU sustains only ~16 B/clk on this access pattern and blocks the issuing wave while its queue is
   // full, so halving the bytes shortens the non-MFMA phase of every tile.)
   u32x4 hlo[NITw], hhi[NITw];
-  auto halo_fetch = [&](int bx, int by, int bz, int bn, bool on, bool slide) {
-    DmaTile d;
-    d.ox = bx * TXw - 1; d.oy = by * TYw - 1; d.oz = bz * TZw - 1;
-    d.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long)(on ? bn : 0) * nvox * 16), 0, sample_bytes, 0x00020000);
-    d.on = on;
-    // (opaque to the optimiser: otherwise the unpacked fields are hoisted out of the tile loop into 40+ registers)
+  auto fetch_half = [&](u32x4 (&dst)[NITw], __amdgpu_buffer_rsrc_t rs, int base, unsigned sel) {
+    // (opaque to the optimiser, or base + hrel[] of every branch is hoisted out of the tile loop into registers)
 #pragma unroll
-    for (int i = 0; i < NITw / 2; ++i) asm volatile("" : "+v"(lxyzq[i]));
-    if (slide) {                                                // wave-uniform
+    for (int i = 0; i < NITw; ++i) asm volatile("" : "+v"(hrel[i]));
+    if (sel == 0) {                                             // wave-uniform: interior tile, one VALU add per piece
+#pragma unroll
+      for (int it = 0; it < NITw; ++it) dst[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, base + hrel[it], 0, 0);
+    } else {
+      const unsigned bad = hflags & sel;
+#pragma unroll
+      for (int it = 0; it < NITw; ++it)
+        dst[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, (bad & (31u << (5 * it))) ? 0x7fffffff : base + hrel[it], 0, 0);
+    }
+  };
+  auto halo_fetch = [&](int bx, int by, int bz, int bn, bool on, bool slide) {
+    // everything wave-uniform here runs on the scalar unit
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long)(on ? bn : 0) * nvox * 16), 0,
+                                                                        on ? sample_bytes : 0u, 0x00020000);
+    const int base = (((bz * TZw - 1) * H + (by * TYw - 1)) * W + (bx * TXw - 1)) * 64;
+    unsigned sel = 0;
+    if (bx == 0) sel |= F_XLO * F_ALL6;
+    if (bx == tiles_x - 1) sel |= F_XHI * F_ALL6;
+    if (by == 0) sel |= F_YLO * F_ALL6;
+    if (by == tiles_y - 1) sel |= F_YHI * F_ALL6;
+    if (slide) {
 #pragma unroll
       for (int it = 0; it < NITw; ++it) hlo[it] = *(const u32x4*)(buf + HALFBw + (fa + 4 * it) * 1024 + lane * 16);
     } else {
-#pragma unroll
-      for (int it = 0; it < NITw; ++it) hlo[it] = halo_piece(d, it, fa, lxyzq[it >> 1], W, H, D);
+      fetch_half(hlo, rs, base, sel);
     }
-    d.oz += 2;
-#pragma unroll
-    for (int it = 0; it < NITw; ++it) hhi[it] = halo_piece(d, it, fa, lxyzq[it >> 1], W, H, D);
+    fetch_half(hhi, rs, base + 2 * H * W * 64, sel);
   };
   auto halo_commit = [&]() {
 #pragma unroll
@@ -380,6 +380,13 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_wino_kernel(
         pyv[k] = okv[k] ? *(const f32x4*)(pybase + voxi[k] * 16 + eq * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
         pnv[k] = (okv[k] && pnbase) ? pnbase[voxi[k]] : 1.f;
       }
+    }
+    // (bias is re-read per tile -- an L1 hit queued ahead of the halo -- rather than held in four registers)
+    f32x4 bv4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {
+      const float* bp = bias;
+      asm volatile("" : "+s"(bp));
+      if (bp != nullptr) bv4 = *(const f32x4*)(bp + eq * 4);
     }
     TS(4);
     halo_fetch(nx, ny, nz, nn, t + 1 < t_end, nz != 0);
