@@ -35,6 +35,7 @@ extern "C" {
 /* epilogue flags of the conv entry points */
 #define LF_EPI_LRELU     1u   /* y = max(y, slope*y)                                         */
 #define LF_EPI_PIXELNORM 2u   /* y = y / sqrt(mean_c(y^2) + eps); also writes the norm       */
+#define LF_EPI_ADD       4u   /* (prev_flags of lf_conv3d_c16_wino only) prev_y is an addend  */
 
 /* grid-map kinds of the 3-D resampler */
 #define LF_MAP_O2C 0   /* bilinear polynomial map (ObjectToCameraTransform)                  */
@@ -157,7 +158,10 @@ int lf_conv3d_c16_split(const float* x, const void* wsplit, const float* bias, f
  * upack: lf_conv3d_c16_wino_upack_floats() floats, [4 z-freq a][16 (y,x)-freq b*4+c][4 k-chunks i][64 lanes l]
  *        = U[a][b][c][cout = l & 15][cin = (l >> 4) * 4 + i],  U = (G (x) G (x) G) w  with
  *        G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]  (host-packed, once per weight update).
- * amax_out (may be NULL, zero-initialised by the caller): receives max-abs of the output. */
+ * amax_out (may be NULL, zero-initialised by the caller): receives max-abs of the output.
+ * prev_flags == LF_EPI_ADD: forward form with an addend, y = epilogue(conv(x) * he + bias + prev_y), prev_y in
+ * y's layout -- a convolution over concatenated inputs evaluated as a sum of 16-channel pieces (the ConvGRU
+ * gates, modules/gru.py:37-42). */
 size_t lf_conv3d_c16_wino_upack_floats(void);
 int lf_conv3d_c16_wino(const float* x, const float* upack, const float* bias, float* y, float* norm_out,
                        int N, int D, int H, int W, float he, unsigned flags, float slope, float eps,
@@ -193,11 +197,13 @@ int lf_wino2d_output_transform(const float* M, const float* bias, float* y, floa
 
 /* Gate arithmetic of the convolutional GRU fuser, inference path (modules/gru.py:30-43; no tanh on the
  * candidate).  `rec` is the channels-last record [x | state] (rec_stride floats per voxel, state at
- * rec_off) that the gate convolutions read; ur = [update | reset] pre-activations (2*Ch per voxel).
- *   stage A: u = sigmoid(ur[:Ch]);  rec.state = h * sigmoid(ur[Ch:])
+ * rec_off) that the gate convolutions read; upre / rpre = update / reset pre-activations, pre_stride floats
+ * per voxel (one merged [update | reset] convolution: rpre = upre + Ch, pre_stride = 2*Ch; two 16-channel
+ * Winograd convolutions: separate tensors, pre_stride = Ch).
+ *   stage A: u = sigmoid(upre);  rec.state = h * sigmoid(rpre)
  *   stage B: h_out = h * (1 - u) + cand * u;  rec.state = h_out (rec may be NULL) */
-int lf_gru_stage_a(const float* ur, const float* h, float* u, float* rec, long nvox, int Ch, int rec_stride, int rec_off,
-                   void* stream);
+int lf_gru_stage_a(const float* upre, const float* rpre, int pre_stride, const float* h, float* u, float* rec,
+                   long nvox, int Ch, int rec_stride, int rec_off, void* stream);
 int lf_gru_stage_b(const float* h, const float* u, const float* cand, float* h_out, float* rec, long nvox, int Ch,
                    int rec_stride, int rec_off, void* stream);
 

@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'liblf_hip.so')
 
 LF_EPI_LRELU = 1
 LF_EPI_PIXELNORM = 2
+LF_EPI_ADD = 4
 LF_MAP_O2C = 0
 LF_MAP_C2O = 1
 LF_MAP_COEFS = 20
@@ -52,7 +53,7 @@ SIGNATURES = {
     'lf_wino2d_tiles': (c_long, [c_int, c_int, c_int]),
     'lf_wino2d_input_transform': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     'lf_wino2d_output_transform': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint, c_float, c_float, P]),
-    'lf_gru_stage_a': (c_int, [P, P, P, P, c_long, c_int, c_int, c_int, P]),
+    'lf_gru_stage_a': (c_int, [P, P, c_int, P, P, P, c_long, c_int, c_int, c_int, P]),
     'lf_gru_stage_b': (c_int, [P, P, P, P, P, c_long, c_int, c_int, c_int, P]),
     'lf_grid_sample2d_fwd': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     'lf_grid_sample2d_bwd': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),

@@ -318,6 +318,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_wino_kernel(
     }
   };
   const float out_scale = he;
+  const bool addmode = prev_y != nullptr && (prev_flags & LF_EPI_ADD);      // prev_y is an addend, not a saved activation
   float wave_amax = 0.f;
 
   halo_fetch(cx, cy, cz, cn, true, false);
@@ -410,11 +411,12 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_wino_kernel(
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       rn[k] = 1.f;
-      if (prev_y == nullptr) {
+      if (prev_y == nullptr || addmode) {
         float ss = 0.f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float u = o[k][e] * out_scale + bv4[e];
+          if (addmode) u += pyv[k][e];
           if (flags & LF_EPI_LRELU) u = fmaxf(u, u * slope);
           v[k][e] = u;
           ss += u * u;
@@ -435,7 +437,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_wino_kernel(
     TS(7);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      if (prev_y != nullptr) {
+      if (prev_y != nullptr && !addmode) {
         const f32x4 yp = pyv[k];
         v[k] = o[k] * out_scale;
         if (prev_flags & LF_EPI_PIXELNORM) {
@@ -451,7 +453,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_wino_kernel(
       }
       if (okv[k]) {
         __builtin_nontemporal_store(v[k], (f32x4*)(ybase + (unsigned)(voxi[k] * 64)));   // streamed: L2 is for halos
-        if (!(WINO_ABL & 16) && prev_y == nullptr && (flags & LF_EPI_PIXELNORM) && nbase != nullptr && eq == 0) nbase[voxi[k]] = rn[k];
+        if (!(WINO_ABL & 16) && (prev_y == nullptr || addmode) && (flags & LF_EPI_PIXELNORM) && nbase != nullptr && eq == 0) nbase[voxi[k]] = rn[k];
         if (amax_out != nullptr)
           wave_amax = fmaxf(wave_amax, fmaxf(fmaxf(fabsf(v[k][0]), fabsf(v[k][1])), fmaxf(fabsf(v[k][2]), fabsf(v[k][3]))));
       }
@@ -481,7 +483,9 @@ extern "C" int lf_conv3d_c16_wino(const float* x, const float* upack, const floa
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0) return LF_EINVAL;
   if ((long)D * H * W * 64 >= 0x7fffffffL || !(slope > 0.f && slope < 1.f)) return LF_EINVAL;
   if (!lf_aligned16(x) || !lf_aligned16(y) || !lf_aligned16(upack) || (bias && !lf_aligned16(bias))) return LF_EALIGN;
-  if (prev_y != nullptr && (flags != 0 || bias != nullptr)) return LF_EINVAL;
+  const bool add = prev_y != nullptr && (prev_flags & LF_EPI_ADD);
+  if (add && prev_flags != LF_EPI_ADD) return LF_EINVAL;
+  if (prev_y != nullptr && !add && (flags != 0 || bias != nullptr)) return LF_EINVAL;
   if ((prev_flags & LF_EPI_PIXELNORM) && prev_y != nullptr && prev_norm == nullptr) return LF_EINVAL;
   const int ptx = (W + TXw - 1) / TXw, pty = (H + TYw - 1) / TYw, ptz = (D + TZw - 1) / TZw;
   const long pt = (long)ptx * pty * ptz * N;

@@ -12,15 +12,16 @@ namespace {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
-__global__ void __launch_bounds__(256) gru_stage_a_kernel(const float* __restrict__ ur, const float* __restrict__ h,
+__global__ void __launch_bounds__(256) gru_stage_a_kernel(const float* __restrict__ upre, const float* __restrict__ rpre,
+                                                          int pre_stride, const float* __restrict__ h,
                                                           float* __restrict__ u, float* __restrict__ rec, long nvox, int Ch,
                                                           int rec_stride, int rec_off) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= nvox * Ch) return;
   const long v = idx / Ch;
   const int c = (int)(idx - v * Ch);
-  const float uu = sigmoidf_(ur[v * 2 * Ch + c]);
-  const float rr = sigmoidf_(ur[v * 2 * Ch + Ch + c]);
+  const float uu = sigmoidf_(upre[v * pre_stride + c]);
+  const float rr = sigmoidf_(rpre[v * pre_stride + c]);
   u[idx] = uu;
   rec[v * rec_stride + rec_off + c] = __fmul_rn(h[idx], rr);
 }
@@ -41,12 +42,13 @@ __global__ void __launch_bounds__(256) gru_stage_b_kernel(const float* __restric
 
 }  // namespace
 
-extern "C" int lf_gru_stage_a(const float* ur, const float* h, float* u, float* rec, long nvox, int Ch, int rec_stride,
-                              int rec_off, void* stream) {
+extern "C" int lf_gru_stage_a(const float* upre, const float* rpre, int pre_stride, const float* h, float* u, float* rec,
+                              long nvox, int Ch, int rec_stride, int rec_off, void* stream) {
   lf_clear_error();
   if (nvox <= 0 || Ch <= 0 || rec_stride < rec_off + Ch || rec_off < 0 || nvox * Ch >= 0x7fffffff00L) return LF_EINVAL;
-  hipLaunchKernelGGL(gru_stage_a_kernel, dim3((unsigned)((nvox * Ch + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ur, h, u,
-                     rec, nvox, Ch, rec_stride, rec_off);
+  if (pre_stride < Ch) return LF_EINVAL;
+  hipLaunchKernelGGL(gru_stage_a_kernel, dim3((unsigned)((nvox * Ch + 255) / 256)), dim3(256), 0, (hipStream_t)stream, upre, rpre,
+                     pre_stride, h, u, rec, nvox, Ch, rec_stride, rec_off);
   return lf_launch_status();
 }
 

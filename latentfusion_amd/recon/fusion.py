@@ -177,9 +177,13 @@ class GRUFuser(_ArgsFuser):
         return h.unsqueeze(1), {}
 
     def _forward_inference(self, z_obj):
-        """Same recurrence without the three concatenations and five element-wise passes per view: one
-        channels-last record [z_i | coords | state] per voxel feeds a merged update+reset convolution and the
-        out convolution; the gate arithmetic (lf_gru_stage_a/b) writes the state slots in place."""
+        """Same recurrence without the three concatenations and five element-wise passes per view.
+
+        16-channel volumes: every gate convolution over [z_i | coords | state] is evaluated as a sum of 16 -> 16
+        Winograd convolutions (lf_conv3d_c16_wino, the addend form): coords part once per object, z_i part, then
+        the state part added on top; the gate arithmetic (lf_gru_stage_a/b) works on plain 16-channel tensors.
+        Other widths: one channels-last record [z_i | coords | state] per voxel feeds a merged update+reset
+        convolution and the out convolution; the gate arithmetic writes the state slots in place."""
         from .. import _lib, ops
         L = _lib.lib()
         cell = self.gru
@@ -187,21 +191,62 @@ class GRUFuser(_ArgsFuser):
         D, H, W = z_obj.shape[3:]
         dev = z_obj.device
         nvox = D * H * W
+        s = torch.cuda.current_stream().cuda_stream
+        gates = (cell.update_gate, cell.reset_gate, cell.out_gate)
+        coords = utils.get_normalized_voxel_coords(z_obj[:, 0])
+        if C == 16 and nvox * 64 < 2 ** 31:
+            he = ops.he_constant(cell.update_gate.module.weight)
+
+            def packs(gate):
+                w = gate.module.weight
+
+                def make():
+                    wd = w.detach()
+                    wc = wd.new_zeros(16, 16, 3, 3, 3)
+                    wc[:, :3] = wd[:, C:C + 3]
+                    return tuple(ops.pack_conv3d_c16_wino(p) for p in (wd[:, :C].contiguous(), wc, wd[:, C + 3:].contiguous()))
+                return ops._cached(w, 'gru_wino', make)
+            c16 = ops.empty_cl((1, 16, D, H, W), dev).zero_()
+            c16[:, :3] = coords
+            add = (None, None, _lib.LF_EPI_ADD)
+            # coords part + bias of every gate, once per object
+            base = []
+            for g in gates:
+                b = g.bias.detach() if g.bias is not None else None
+                base.append(ops.conv3d_c16_wino(c16, packs(g)[1], b, he, 0)[0])
+            del c16
+            h = ops.cl(z_obj[:, 0]).clone()
+            u = torch.empty(nvox * C, device=dev, dtype=torch.float32)
+            rh = ops.empty_cl((1, C, D, H, W), dev)
+            for i in range(1, V):
+                zi = ops.cl(z_obj[:, i])
+                pre = []
+                for k in (0, 1):
+                    xk = ops.conv3d_c16_wino(zi, packs(gates[k])[0], None, he, 0, prev=(base[k],) + add[1:])[0]
+                    pre.append(ops.conv3d_c16_wino(h, packs(gates[k])[2], None, he, 0, prev=(xk,) + add[1:])[0])
+                _lib.check(L.lf_gru_stage_a(pre[0].data_ptr(), pre[1].data_ptr(), C, h.data_ptr(), u.data_ptr(), rh.data_ptr(),
+                                            nvox, C, C, 0, s), 'lf_gru_stage_a')
+                xo = ops.conv3d_c16_wino(zi, packs(gates[2])[0], None, he, 0, prev=(base[2],) + add[1:])[0]
+                cand = ops.conv3d_c16_wino(rh, packs(gates[2])[2], None, he, 0, prev=(xo,) + add[1:])[0]
+                h_new = torch.empty_like(h)
+                _lib.check(L.lf_gru_stage_b(h.data_ptr(), u.data_ptr(), cand.data_ptr(), h_new.data_ptr(), None, nvox, C, C, 0, s),
+                           'lf_gru_stage_b')
+                h = h_new
+            return h.unsqueeze(1)
         rec = ops.empty_cl((1, 2 * C + 3, D, H, W), dev)
-        rec[:, C:C + 3] = utils.get_normalized_voxel_coords(z_obj[:, 0])
+        rec[:, C:C + 3] = coords
         h = ops.cl(z_obj[:, 0]).clone()
         w_ur = torch.cat((cell.update_gate.module.weight, cell.reset_gate.module.weight), dim=0).detach()
         b_ur = torch.cat((cell.update_gate.bias, cell.reset_gate.bias), dim=0).detach() \
             if cell.update_gate.bias is not None else None
         w_o, b_o = cell.out_gate.module.weight.detach(), cell.out_gate.bias
         u = torch.empty(nvox * C, device=dev, dtype=torch.float32)
-        s = torch.cuda.current_stream().cuda_stream
         rec[:, C + 3:] = h
         for i in range(1, V):
             rec[:, :C] = z_obj[:, i]
             ur = ops.conv3x3(rec, w_ur, b_ur, lrelu=False, pixelnorm=False)
-            _lib.check(L.lf_gru_stage_a(ur.data_ptr(), h.data_ptr(), u.data_ptr(), rec.data_ptr(), nvox, C, 2 * C + 3, C + 3, s),
-                       'lf_gru_stage_a')
+            _lib.check(L.lf_gru_stage_a(ur.data_ptr(), ur.data_ptr() + 4 * C, 2 * C, h.data_ptr(), u.data_ptr(), rec.data_ptr(),
+                                        nvox, C, 2 * C + 3, C + 3, s), 'lf_gru_stage_a')
             cand = ops.conv3x3(rec, w_o, b_o.detach() if b_o is not None else None, lrelu=False, pixelnorm=False)
             h_new = torch.empty_like(h)
             _lib.check(L.lf_gru_stage_b(h.data_ptr(), u.data_ptr(), cand.data_ptr(), h_new.data_ptr(),

@@ -340,3 +340,23 @@ def test_gru_fuser_inference_path_equals_general_path(golden):
         slow, _ = fu(z.clone().requires_grad_(True), None, None, None)
     assert fast.shape == slow.shape == (1, 1, 8, 12, 10, 14)
     close(fast, slow, atol=2e-6, rtol=1e-5)
+
+
+def test_gru_fuser_winograd_inference_path():
+    """16-channel volumes: the gate convolutions run as sums of 16 -> 16 Winograd convolutions (addend form of
+    lf_conv3d_c16_wino; coords part once per object).  Same recurrence as the module's general path
+    (modules/gru.py:37-43) up to fp32 summation order; odd sizes exercise partial tiles on every axis."""
+    from latentfusion_amd.recon import fusion
+    torch.manual_seed(5)
+    fu = fusion.GRUFuser(16).to(DEV)
+    with torch.no_grad():
+        for gate in (fu.gru.update_gate, fu.gru.reset_gate, fu.gru.out_gate):
+            gate.bias.normal_(0.0, 0.3)
+    gen = torch.Generator().manual_seed(22)
+    z = torch.randn(1, 4, 16, 9, 12, 21, generator=gen).to(DEV)
+    with torch.no_grad():
+        fast, _ = fu(z, None, None, None)
+    with torch.enable_grad():
+        slow, _ = fu(z.clone().requires_grad_(True), None, None, None)
+    assert fast.shape == slow.shape == (1, 1, 16, 9, 12, 21)
+    close(fast, slow, atol=2e-5, rtol=1e-4)
