@@ -33,6 +33,17 @@
 #ifndef WINO_ABL
 #define WINO_ABL 0
 #endif
+// wave priorities (s_setprio) of the three phases of a tile: halo reads + input transforms (latency-bound: LDS),
+// the MFMA chains (throughput-bound) and the exchange / epilogue / halo fetch (latency-bound: LDS, HBM)
+#ifndef WINO_PL
+#define WINO_PL 2
+#endif
+#ifndef WINO_PM
+#define WINO_PM 1
+#endif
+#ifndef WINO_PN
+#define WINO_PN 3
+#endif
 
 namespace {
 
@@ -112,6 +123,7 @@ __device__ __forceinline__ void wino_compute(const unsigned char* __restrict__ b
         r[2 * e + 1] = *(const f32x4*)(buf + off[cb & 7][dy >> 1] + cb * 64);
       }
     };
+    __builtin_amdgcn_s_setprio(WINO_PL);
     load_half(0, raw[0]);
     f32x4 d[4];
 #pragma unroll
@@ -133,6 +145,7 @@ __device__ __forceinline__ void wino_compute(const unsigned char* __restrict__ b
       __builtin_amdgcn_sched_barrier(0);
     }
     CTS(9 + 2 * g);
+    __builtin_amdgcn_s_setprio(WINO_PM);
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       f32x4 m[4];
@@ -346,6 +359,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_wino_kernel(
     TS(1);
     lds_barrier();                                  // every wave is done reading the halo; all partials are in LDS
     TS(2);
+    __builtin_amdgcn_s_setprio(WINO_PN);
 
     // next tile's halo: in flight during the exchange / epilogue below and, for the CU, under the MFMA phase
     // of the other resident workgroup
