@@ -96,9 +96,16 @@ __device__ __forceinline__ f32x4 pk_sub(f32x4 a, f32x4 b) {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-template <int A>
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// SPLIT = false: all-fp32 products, wt = U[a][(b,c)][k-chunk] for v_mfma_f32_16x16x4_f32.
+// SPLIT = true : every Winograd-domain product U.V from three v_mfma_f32_16x16x16_f16 accumulating in fp32,
+//                U_hi.V_hi + U_hi.V_lo + U_lo.V_hi  (x = x_hi + x_lo, both f16; dropped term <= 2^-22 |U||V|);
+//                whi / wlo = the two halves of U, V is split on the fly after scaling by the power of two in_scale.
+template <int A, bool SPLIT>
 __device__ __forceinline__ void wino_compute(const unsigned char* __restrict__ buf, const int (&off)[8][2],
-                                              const float (&wt)[64], unsigned char* __restrict__ pdst,
+                                              const float (&wt)[64], const f16x4 (&whi)[16], const f16x4 (&wlo)[16],
+                                              float in_scale, unsigned char* __restrict__ pdst,
                                               const int (&pw)[2], unsigned* tsp = nullptr) {
 #define CTS(k) do { if ((WINO_ABL & 32) && tsp != nullptr) tsp[k] = (unsigned)__builtin_readcyclecounter(); } while (0)
   // z input transform of frequency A: d0-d2, d1+d2, d2-d1, d1-d3
@@ -163,11 +170,28 @@ __device__ __forceinline__ void wino_compute(const unsigned char* __restrict__ b
                           : (vx[1][c] - vx[3][c]);
           m[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
+        if constexpr (!SPLIT) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+          for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int h = 0; h < 2; ++h)
-            m[cp + h] = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[(b * 4 + cp + h) * 4 + i], v[h][i], m[cp + h], 0, 0, 0);
+            for (int h = 0; h < 2; ++h)
+              m[cp + h] = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[(b * 4 + cp + h) * 4 + i], v[h][i], m[cp + h], 0, 0, 0);
+        } else {
+          // fp32 Winograd-domain value -> f16 hi + lo (exact to 22 bits), three product terms
+          f16x4 vhi[2], vlo[2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const f32x4 vs = v[h] * in_scale;
+            vhi[h] = __builtin_convertvector(vs, f16x4);
+            vlo[h] = __builtin_convertvector(vs - __builtin_convertvector(vhi[h], f32x4), f16x4);
+          }
+#pragma unroll
+          for (int h = 0; h < 2; ++h) m[cp + h] = __builtin_amdgcn_mfma_f32_16x16x16f16(whi[b * 4 + cp + h], vlo[h], m[cp + h], 0, 0, 0);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) m[cp + h] = __builtin_amdgcn_mfma_f32_16x16x16f16(wlo[b * 4 + cp + h], vhi[h], m[cp + h], 0, 0, 0);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) m[cp + h] = __builtin_amdgcn_mfma_f32_16x16x16f16(whi[b * 4 + cp + h], vhi[h], m[cp + h], 0, 0, 0);
+        }
       }
       // x output transform, then accumulate the y output transform
       const f32x4 t0 = m[0] + m[1] + m[2];
@@ -188,13 +212,14 @@ __device__ __forceinline__ void wino_compute(const unsigned char* __restrict__ b
 #undef CTS
 }
 
-__global__ void __launch_bounds__(256, 2) conv3d_c16_wino_kernel(
+template <bool SPLIT>
+__device__ __forceinline__ void conv3d_c16_wino_body(
     const float* __restrict__ x, const float* __restrict__ upack, const float* __restrict__ bias,
     float* __restrict__ y, float* __restrict__ norm_out,
     int N, int D, int H, int W, int tiles_x, int tiles_y, int tiles_z, int ntiles,
     float he, unsigned flags, float slope, float eps,
     const float* __restrict__ prev_y, const float* __restrict__ prev_norm, unsigned prev_flags,
-    float* __restrict__ amax_out) {
+    const float* __restrict__ amax_in, float* __restrict__ amax_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const buf = smem;                              // halo
   unsigned char* const px = smem + BUFw;                        // partial exchange
@@ -264,12 +289,28 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_wino_kernel(
   const int pr = (lane ^ ((lane >> 3) & 7)) * 16;              // reader: lane = x*4 + quarter
   const int ex = lane >> 2, eq = lane & 3;
 
-  // ---- transformed weights of this wave's z-frequency: [16 (b,c)][4 k-chunks], lane-major in memory ----
+  // ---- transformed weights of this wave's z-frequency, lane-major in memory: fp32 [16 (b,c)][4 k-chunks], or
+  // f16 [16 (b,c)][hi, lo] x 4 cin per lane (A operands, K = 4 cin per lane group) ----
   float wt[64];
-  {
+  f16x4 whi[16], wlo[16];
+  float in_scale = 1.f;
+  if constexpr (!SPLIT) {
     const float* up = upack + (long)fa * 64 * 64 + lane;
 #pragma unroll
     for (int k = 0; k < 64; ++k) wt[k] = up[k * 64];
+  } else {
+    const f16x4* up = (const f16x4*)upack + (long)fa * 16 * 2 * 64 + lane;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { whi[k] = up[(k * 2 + 0) * 64]; wlo[k] = up[(k * 2 + 1) * 64]; }
+    // power-of-two input scale from the tensor's max-abs (gradient launches); 1 otherwise
+    if (amax_in != nullptr) {
+      const float am = lf_amax_read(amax_in, lane);
+      if (am > 0.f && am < 3.0e38f) {
+        int ex;
+        frexpf(am, &ex);                                          // am = m * 2^ex, m in [0.5, 1)
+        in_scale = ldexpf(1.f, 9 - ex);                           // max maps into [2^8, 2^9): x8 transform growth stays in f16 range
+      }
+    }
   }
 
   // tile coordinates are stepped, not divided: (cx, cy, cz, cn) = tile t, (nx, ny, nz, nn) = tile t + 1
@@ -330,7 +371,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_wino_kernel(
       }
     }
   };
-  const float out_scale = he;
+  const float out_scale = he / in_scale;
   const bool addmode = prev_y != nullptr && (prev_flags & LF_EPI_ADD);      // prev_y is an addend, not a saved activation
   float wave_amax = 0.f;
 
@@ -351,10 +392,10 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_wino_kernel(
     unsigned* const tsp = nullptr;
 #endif
     switch (fa) {
-      case 0: wino_compute<0>(buf, off, wt, px + fa * 8192, pw, tsp); break;
-      case 1: wino_compute<1>(buf, off, wt, px + fa * 8192, pw, tsp); break;
-      case 2: wino_compute<2>(buf, off, wt, px + fa * 8192, pw, tsp); break;
-      default: wino_compute<3>(buf, off, wt, px + fa * 8192, pw, tsp); break;
+      case 0: wino_compute<0, SPLIT>(buf, off, wt, whi, wlo, in_scale, px + fa * 8192, pw, tsp); break;
+      case 1: wino_compute<1, SPLIT>(buf, off, wt, whi, wlo, in_scale, px + fa * 8192, pw, tsp); break;
+      case 2: wino_compute<2, SPLIT>(buf, off, wt, whi, wlo, in_scale, px + fa * 8192, pw, tsp); break;
+      default: wino_compute<3, SPLIT>(buf, off, wt, whi, wlo, in_scale, px + fa * 8192, pw, tsp); break;
     }
     TS(1);
     lds_barrier();                                  // every wave is done reading the halo; all partials are in LDS
@@ -484,16 +525,29 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_wino_kernel(
   }
 }
 
-}  // namespace
+__global__ void __launch_bounds__(256, 2) conv3d_c16_wino_kernel(
+    const float* __restrict__ x, const float* __restrict__ upack, const float* __restrict__ bias,
+    float* __restrict__ y, float* __restrict__ norm_out, int N, int D, int H, int W, int tiles_x, int tiles_y, int tiles_z,
+    int ntiles, float he, unsigned flags, float slope, float eps, const float* __restrict__ prev_y,
+    const float* __restrict__ prev_norm, unsigned prev_flags, float* __restrict__ amax_out) {
+  conv3d_c16_wino_body<false>(x, upack, bias, y, norm_out, N, D, H, W, tiles_x, tiles_y, tiles_z, ntiles, he, flags, slope, eps,
+                              prev_y, prev_norm, prev_flags, nullptr, amax_out);
+}
 
-// floats of the transformed-weight pack: [4 z-freq][16 (y,x)-freq][4 k-chunks][64 lanes]
-extern "C" size_t lf_conv3d_c16_wino_upack_floats(void) { return (size_t)4 * 16 * 4 * 64; }
+__global__ void __launch_bounds__(256, 2) conv3d_c16_wino_f16x3_kernel(
+    const float* __restrict__ x, const float* __restrict__ upack, const float* __restrict__ bias,
+    float* __restrict__ y, float* __restrict__ norm_out, int N, int D, int H, int W, int tiles_x, int tiles_y, int tiles_z,
+    int ntiles, float he, unsigned flags, float slope, float eps, const float* __restrict__ prev_y,
+    const float* __restrict__ prev_norm, unsigned prev_flags, const float* __restrict__ amax_in,
+    float* __restrict__ amax_out) {
+  conv3d_c16_wino_body<true>(x, upack, bias, y, norm_out, N, D, H, W, tiles_x, tiles_y, tiles_z, ntiles, he, flags, slope, eps,
+                             prev_y, prev_norm, prev_flags, amax_in, amax_out);
+}
 
-extern "C" int lf_conv3d_c16_wino(const float* x, const float* upack, const float* bias, float* y, float* norm_out,
-                                  int N, int D, int H, int W, float he, unsigned flags, float slope, float eps,
-                                  const float* prev_y, const float* prev_norm, unsigned prev_flags,
-                                  float* amax_out, void* stream) {
-  lf_clear_error();
+template <typename K, typename... Extra>
+int launch_wino(K kernel, const float* x, const void* upack, const float* bias, float* y, float* norm_out, int N, int D,
+                int H, int W, float he, unsigned flags, float slope, float eps, const float* prev_y, const float* prev_norm,
+                unsigned prev_flags, void* stream, Extra... extra) {
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0) return LF_EINVAL;
   if ((long)D * H * W * 64 >= 0x7fffffffL || !(slope > 0.f && slope < 1.f)) return LF_EINVAL;
   if (!lf_aligned16(x) || !lf_aligned16(y) || !lf_aligned16(upack) || (bias && !lf_aligned16(bias))) return LF_EALIGN;
@@ -511,17 +565,41 @@ extern "C" int lf_conv3d_c16_wino(const float* x, const float* upack, const floa
            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
   }
   const size_t shmem = (size_t)LDSw;
-  static bool attr_set = false;
+  static bool attr_set = false;                                 // (one instance per kernel: the template is per K)
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv3d_c16_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)shmem);
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
   const long want = 2L * cus;                                     // two resident workgroups per CU
   const unsigned grid = (unsigned)(pt < want ? pt : want);
-  hipLaunchKernelGGL(conv3d_c16_wino_kernel, dim3(grid), dim3(256), shmem, (hipStream_t)stream, x, upack, bias, y,
-                     norm_out, N, D, H, W, ptx, pty, ptz, (int)pt, he, flags, slope, eps, prev_y, prev_norm, prev_flags,
-                     amax_out);
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), shmem, (hipStream_t)stream, x, (const float*)upack, bias, y, norm_out, N, D,
+                     H, W, ptx, pty, ptz, (int)pt, he, flags, slope, eps, prev_y, prev_norm, prev_flags, extra...);
   return lf_launch_status();
+}
+
+}  // namespace
+
+// floats of the transformed-weight pack: [4 z-freq][16 (y,x)-freq][4 k-chunks][64 lanes]
+extern "C" size_t lf_conv3d_c16_wino_upack_floats(void) { return (size_t)4 * 16 * 4 * 64; }
+
+extern "C" int lf_conv3d_c16_wino(const float* x, const float* upack, const float* bias, float* y, float* norm_out,
+                                  int N, int D, int H, int W, float he, unsigned flags, float slope, float eps,
+                                  const float* prev_y, const float* prev_norm, unsigned prev_flags,
+                                  float* amax_out, void* stream) {
+  lf_clear_error();
+  return launch_wino(conv3d_c16_wino_kernel, x, upack, bias, y, norm_out, N, D, H, W, he, flags, slope, eps, prev_y, prev_norm,
+                     prev_flags, stream, amax_out);
+}
+
+// halfs of the split transformed-weight pack: [4 z-freq][16 (y,x)-freq][hi, lo][64 lanes][4 cin]
+extern "C" size_t lf_conv3d_c16_wino_split_upack_halfs(void) { return (size_t)4 * 16 * 2 * 64 * 4; }
+
+extern "C" int lf_conv3d_c16_wino_split(const float* x, const void* upack, const float* bias, float* y, float* norm_out,
+                                        int N, int D, int H, int W, float he, unsigned flags, float slope, float eps,
+                                        const float* prev_y, const float* prev_norm, unsigned prev_flags,
+                                        const float* amax_in, float* amax_out, void* stream) {
+  lf_clear_error();
+  return launch_wino(conv3d_c16_wino_f16x3_kernel, x, upack, bias, y, norm_out, N, D, H, W, he, flags, slope, eps, prev_y,
+                     prev_norm, prev_flags, stream, amax_in, amax_out);
 }
