@@ -456,7 +456,7 @@ __device__ __forceinline__ void conv3d_c16_wino_body(
       for (int a2 = 0; a2 < 4; ++a2)
         p[a2] = *(const f32x4*)(px + a2 * 8192 + fa * 2048 + j * 1024 + pr);
       o[j * 2 + 0] = p[0] + p[1] + p[2];                        // z output transform
-      o[j * 2 + 1] = p[1] - p[2] - p[3];
+      o[j * 2 + 1] = pk_sub(pk_sub(p[1], p[2]), p[3]);
     }
 
     unsigned char* ybase = (unsigned char*)(y + (long)tt * nvox * 16) + eq * 16;

@@ -45,12 +45,19 @@ def run(f, y, nrm, gout):
                      y.data_ptr(), nrm.data_ptr(), flags, None, st)
 
 
+# `path:fwd` / `path:bwd` restricts a variant to one of the two calls (builds with a hard-wired epilogue)
+specs = [(a.split(':') + ['both'])[:2] for a in sys.argv[1:]]
+sys.argv[1:] = [a for a, _ in specs]
+only = [o for _, o in specs]
 fs = [bind(p) for p in sys.argv[1:]]
 outs = []
-for f in fs:
+for i, f in enumerate(fs):
     y, nrm, go = torch.empty_like(x), torch.empty(N * S ** 3, device='cuda'), torch.empty_like(x)
-    bw = run(f, y, nrm, go)
-    assert bw() == 0
+    bw = run(fs[0] if only[i] == 'bwd' else f, y, nrm, go)
+    if only[i] != 'fwd':
+        assert bw() == 0
+    else:
+        go.copy_(outs[0][2])
     torch.cuda.synchronize()
     outs.append((y, nrm, go, bw))
 for i, p in enumerate(sys.argv[1:]):
@@ -61,6 +68,9 @@ for r in range(ROUNDS):
     for i, f in enumerate(fs):
         y, nrm, go, bw = outs[i]
         for which, acc in ((0, tf), (1, tb)):
+            if only[i] == ('bwd', 'fwd')[which]:
+                acc[i].append(float('nan'))
+                continue
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(5):
