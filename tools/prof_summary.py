@@ -52,6 +52,17 @@ def main(db, out):
                   f'{"kernel":100s} {"calls":>7s} {"total_us":>12s} {"pct_busy":>8s}']
         for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:30]:
             lines.append(f'{k:100s} {c:7d} {t:12.1f} {100 * t / busy:8.2f}')
+    if len(marks) >= 3:
+        # every launch of the pose loop (first to last O2C launch): the per-kernel averages bench.py's HIP events
+        # must agree with (the whole-trace table above also counts the reconstruct phase's smaller launches)
+        loop = rows[marks[0]:marks[-1]]
+        agg = collections.defaultdict(list)
+        for n, s, e in loop:
+            agg[short(n)].append((e - s) / 1e3)
+        lines += ['', f'# pose loop only ({len(marks) - 1} iterations, first to last O2C launch): {len(loop)} dispatches',
+                  f'{"kernel":100s} {"calls":>7s} {"total_us":>12s} {"avg_us":>10s} {"min_us":>10s} {"max_us":>10s}']
+        for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:12]:
+            lines.append(f'{k:100s} {len(v):7d} {sum(v):12.1f} {sum(v) / len(v):10.1f} {min(v):10.1f} {max(v):10.1f}')
     open(out, 'w').write('\n'.join(lines) + '\n')
     print('\n'.join(lines[:70]))
 
