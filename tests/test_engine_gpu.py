@@ -405,3 +405,40 @@ def test_conv3d_c16_kernels_on_random_shapes():
         want = torch.nn.grad.conv3d_weight(x.double().cpu(), (16, 16, 3, 3, 3), ref.double().cpu(), padding=1) * he
         gotw = gwt.reshape(3, 3, 3, 16, 16).permute(3, 4, 0, 1, 2).double().cpu()
         assert (gotw - want).abs().max().item() < 1e-4 * max(want.abs().max().item(), 1e-3), (N, D, H, W)
+
+
+@pytest.mark.parametrize('shape', [(4, 16, 14, 48, 96), (3, 16, 22, 64, 64), (1, 16, 30, 40, 200), (8, 16, 32, 64, 64)])
+def test_winograd_sliding_halo_and_addend(shape):
+    """Volumes with more tiles than resident workgroups, so every workgroup walks several tiles of a column and
+    the halo slides along z (LDS -> LDS move + two fetched planes), with tile ranges that start and end in the
+    middle of columns; both precisions, forward and fused backward, against the direct fp32 kernels.  Also the
+    addend form (prev_flags = LF_EPI_ADD): conv(x) * he + bias + addend, then the epilogue."""
+    from latentfusion_amd import ops
+    from latentfusion_amd._lib import LF_EPI_ADD, LF_EPI_LRELU, LF_EPI_PIXELNORM
+    g = torch.Generator().manual_seed(sum(shape))
+    flags = LF_EPI_LRELU | LF_EPI_PIXELNORM
+    x = ops.cl(torch.randn(*shape, generator=g).to(DEV))
+    w = torch.randn(16, 16, 3, 3, 3, generator=g).to(DEV)
+    b = (torch.randn(16, generator=g) * 0.1).to(DEV)
+    he = ops.he_constant(w)
+    up, upt = ops.pack_conv3d_c16_wino(w), ops.pack_conv3d_c16_wino(w, transpose=True)
+    ref, nref = ops._conv3x3_raw(x, ops.pack_conv3x3(w), b, 16, he, flags, True)
+    got, ngot = ops.conv3d_c16_wino(x, up, b, he, flags)
+    assert (got - ref).abs().max().item() < 5e-5
+    assert (ngot - nref).abs().max().item() < 5e-5
+    gs, _ = ops.conv3d_c16_wino_split(x, ops.pack_conv3d_c16_wino_split(w), b, he, flags)
+    assert (gs - ref).abs().max().item() < 5e-5
+    prev = (ref, nref, flags)
+    gref = ops.conv3x3_bwd_data(x, ops.pack_conv3x3(w, transpose=True), 16, he, prev)
+    gw, _ = ops.conv3d_c16_wino(x, upt, None, he, 0, prev=prev)
+    assert (gw - gref).abs().max().item() < 5e-5 * max(gref.abs().max().item(), 1.0)
+    # addend form: plain (no activation) and with the full epilogue
+    addend = ops.cl(torch.randn(*shape, generator=g).to(DEV))
+    raw, _ = ops._conv3x3_raw(x, ops.pack_conv3x3(w), b, 16, he, 0, False)
+    plain, _ = ops.conv3d_c16_wino(x, up, b, he, 0, prev=(addend, None, LF_EPI_ADD))
+    assert (plain - (raw + addend)).abs().max().item() < 5e-5
+    act = torch.nn.functional.leaky_relu(raw + addend, 0.2)
+    norm = torch.sqrt((act ** 2).mean(dim=1, keepdim=True) + 1e-8)
+    full, nfull = ops.conv3d_c16_wino(x, up, b, he, flags, prev=(addend, None, LF_EPI_ADD))
+    assert (full - act / norm).abs().max().item() < 5e-5
+    assert (nfull.view(norm.shape) - norm).abs().max().item() < 5e-5
