@@ -74,6 +74,14 @@ __device__ __forceinline__ Tap make_tap(float gx, float gy, float gz, int W, int
   return t;
 }
 
+// Workgroups are dispatched round-robin over the 8 XCDs (one L2 each): flat workgroup id b runs on XCD b % 8.
+// Giving XCD k the k-th contiguous eighth of the work list keeps neighbouring tiles -- whose gather footprints
+// overlap -- behind one L2 instead of eight.  (Measured neutral for these kernels: the gathered volume lives in the
+// 256 MB Infinity Cache either way; kept for the coefficient gradient, whose blocks are large.)
+__device__ __forceinline__ unsigned xcd_contiguous(unsigned b, unsigned nb) {
+  return (nb % 8 == 0) ? (b % 8) * (nb / 8) + b / 8 : b;
+}
+
 // VEC = 4: one thread per (voxel, 4-channel group), C % 4 == 0.  VEC = 1: one thread per (voxel, channel).
 // A block covers a compact 2^lx x 2^ly x 2^lz output tile (4x4x4 for C = 16), so that the 8-corner
 // footprints of its voxels overlap in L1; 32-bit index math only.
@@ -131,18 +139,29 @@ static int bwd_vox_per_block(long nvox, int N) {
   while (p < 4096 && p * 2 <= v) p <<= 1;
   return p;
 }
+// the block's voxels form a compact tile of 2^bx x 2^by x 2^bz voxels (4096 -> 16^3 ... 64 -> 4^3) walked in
+// 4x4x4 sub-tiles, so the 8-corner footprints overlap in L1 / L2 instead of spanning a whole plane
+struct BwdTile { int lx, ly, lz, ntx, nty, ntz; };
+static BwdTile bwd_tile(int vpb, int D, int H, int W) {
+  int lg = 0;
+  while ((1 << lg) < vpb) ++lg;                               // vpb = 2^lg, 6 <= lg <= 12
+  BwdTile t;
+  t.lx = (lg + 2) / 3; t.ly = (lg + 1) / 3; t.lz = lg / 3;
+  t.ntx = (W + (1 << t.lx) - 1) >> t.lx; t.nty = (H + (1 << t.ly) - 1) >> t.ly; t.ntz = (D + (1 << t.lz) - 1) >> t.lz;
+  return t;
+}
 
 template <int VEC>
 __global__ void __launch_bounds__(256) resample_bwd_coef_kernel(
     const float* __restrict__ gout, const float* __restrict__ vol, long vol_bstride,
-    const float* __restrict__ coef, float* __restrict__ partial, int nblk, int vpb,
+    const float* __restrict__ coef, float* __restrict__ partial, int nblk, int vpb, BwdTile bt,
     int N, int D, int H, int W, int C, int lpv, Steps st) {
   // lpv = lanes cooperating on one voxel: a power of two <= 64 with lpv * VEC >= C
-  const int n = blockIdx.y;
+  const unsigned fb = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int n = fb / nblk, blk = fb - n * nblk;
   const float* cf = coef + (long)n * LF_MAP_COEFS;
   const int nvox = D * H * W;                                  // < 2^31 (checked by the launcher)
-  const int v_begin = blockIdx.x * vpb;
-  const int v_end = min(v_begin + vpb, nvox);
+  const int tx = blk % bt.ntx, ty = (blk / bt.ntx) % bt.nty, tz = blk / (bt.ntx * bt.nty);
   const int q = threadIdx.x % lpv;
   const int vslot = threadIdx.x / lpv;
   const int vstep = blockDim.x / lpv;
@@ -150,14 +169,19 @@ __global__ void __launch_bounds__(256) resample_bwd_coef_kernel(
 #pragma unroll
   for (int i = 0; i < 18; ++i) acc[i] = 0.f;
   // all lanes of a wave iterate the same number of times so the shuffles below are convergent
-  const int iters = (v_end - v_begin + vstep - 1) / vstep;
+  const int iters = (vpb + vstep - 1) / vstep;
   for (int it = 0; it < iters; ++it) {
-    const int v = v_begin + it * vstep + vslot;
-    const bool live = v < v_end;
+    // i-th voxel of the tile: low 6 bits = position inside a 4x4x4 sub-tile, the rest = sub-tile, x fastest
+    const int i = it * vstep + vslot;
+    const int sub = i >> 6;
+    const int sbx = bt.lx - 2, sby = bt.ly - 2;                 // log2 sub-tiles along x, y
+    const int x = (tx << bt.lx) + ((sub & ((1 << sbx) - 1)) << 2) + (i & 3);
+    const int y = (ty << bt.ly) + (((sub >> sbx) & ((1 << sby) - 1)) << 2) + ((i >> 2) & 3);
+    const int z = (tz << bt.lz) + ((sub >> (sbx + sby)) << 2) + ((i >> 4) & 3);
+    const bool live = i < vpb && x < W && y < H && z < D;
+    const int v = (z * H + y) * W + x;
     float hx = 0.f, hy = 0.f, hz = 0.f, a = 0.f, b = 0.f, k = 0.f;
     if (live && q * VEC < C) {
-      const int zy = v / W, x = v - zy * W;
-      const int z = zy / H, y = zy - z * H;
       float gx, gy, gz;
       eval_grid<LF_MAP_O2C>(cf, x, y, z, W, H, D, st, gx, gy, gz, a, b, k);
       const Tap t = make_tap(gx, gy, gz, W, H, D);
@@ -210,7 +234,7 @@ __global__ void __launch_bounds__(256) resample_bwd_coef_kernel(
   __syncthreads();
   if (threadIdx.x < 18) {
     const float s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-    partial[((long)n * nblk + blockIdx.x) * 18 + threadIdx.x] = s;
+    partial[((long)n * nblk + blk) * 18 + threadIdx.x] = s;
   }
 }
 
@@ -309,7 +333,8 @@ extern "C" int lf_resample3d_fwd(const float* vol, int vol_n, const float* coef,
 extern "C" size_t lf_resample3d_bwd_coef_scratch_bytes(int N, int D, int H, int W) {
   const long nvox = (long)D * H * W;
   const int vpb = bwd_vox_per_block(nvox, N);
-  const long nblk = (nvox + vpb - 1) / vpb;
+  const BwdTile bt = bwd_tile(vpb, D, H, W);
+  const long nblk = (long)bt.ntx * bt.nty * bt.ntz;
   return (size_t)N * nblk * 18 * sizeof(float);
 }
 
@@ -323,10 +348,13 @@ extern "C" int lf_resample3d_bwd_coef(const float* gout, const float* vol, int v
   if ((long)D * H * W >= 0x7fffffffL) return LF_EINVAL;
   const long nvox = (long)D * H * W;
   const int vpb = bwd_vox_per_block(nvox, N);
-  const int nblk = (int)((nvox + vpb - 1) / vpb);
+  const BwdTile bt = bwd_tile(vpb, D, H, W);
+  const long nblk_l = (long)bt.ntx * bt.nty * bt.ntz;
+  if (nblk_l * N > 0x7fffffffL) return LF_EINVAL;
+  const int nblk = (int)nblk_l;
   const long bstride = vol_n == 1 ? 0 : nvox * C;
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid(nblk, N), block(256);
+  dim3 grid((unsigned)(nblk_l * N)), block(256);
   float* partial = (float*)scratch;
   // lanes per voxel: next power of two covering the channel groups (idle lanes contribute 0)
   const bool vec = (C % 4 == 0) && lf_aligned16(gout) && lf_aligned16(vol);
@@ -335,9 +363,9 @@ extern "C" int lf_resample3d_bwd_coef(const float* gout, const float* vol, int v
   while (lpv < groups) lpv <<= 1;
   if (lpv > 64) return LF_EINVAL;                       // C > 256 (vec) / C > 64 (scalar)
   if (vec)
-    hipLaunchKernelGGL((resample_bwd_coef_kernel<4>), grid, block, 0, s, gout, vol, bstride, coef, partial, nblk, vpb, N, D, H, W, C, lpv, make_steps(D, H, W));
+    hipLaunchKernelGGL((resample_bwd_coef_kernel<4>), grid, block, 0, s, gout, vol, bstride, coef, partial, nblk, vpb, bt, N, D, H, W, C, lpv, make_steps(D, H, W));
   else
-    hipLaunchKernelGGL((resample_bwd_coef_kernel<1>), grid, block, 0, s, gout, vol, bstride, coef, partial, nblk, vpb, N, D, H, W, C, lpv, make_steps(D, H, W));
+    hipLaunchKernelGGL((resample_bwd_coef_kernel<1>), grid, block, 0, s, gout, vol, bstride, coef, partial, nblk, vpb, bt, N, D, H, W, C, lpv, make_steps(D, H, W));
   int st = lf_launch_status();
   if (st) return st;
   hipLaunchKernelGGL(resample_bwd_coef_reduce, dim3(N), dim3(256), 0, s, partial, nblk, gcoef);
