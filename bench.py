@@ -216,6 +216,9 @@ def main():
                    'volume_MB': z_full.numel() * 4 / 1e6}
         del model0, obs0, z_sh, z_full
 
+    if world > 1:
+        barrier()
+        dist.destroy_process_group()
     if rank != 0:
         return
     value = world * a.steps / elapsed
