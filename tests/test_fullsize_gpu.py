@@ -62,13 +62,15 @@ def test_fullsize_hypotheses_are_independent():
     torch.testing.assert_close(g1[0] / 4.0, gall[2], atol=1e-7 * gall[2].abs().max().item() + 1e-12, rtol=1e-5)
 
 
-def test_midsize_end_to_end_vs_oracle():
-    """SYN(32,16), N=3: build + render + loss + camera gradients, HIP vs CPU oracle."""
+@pytest.mark.parametrize('S,N', [(32, 3), (64, 2)])
+def test_midsize_end_to_end_vs_oracle(S, N):
+    """SYN(32,16) N=3 and SYN(64,16) N=2 (the largest the oracle finishes in seconds; at 64^3 the Winograd
+    workgroups walk whole tile columns): build + render + loss + camera gradients, HIP vs CPU oracle."""
     import lf_oracle as O
     from lf_oracle import pose as opose
     from latentfusion_amd import synth
     from latentfusion_amd.engine import RenderLoopEngine
-    S, C, N = 32, 16, 3
+    C = 16
     model, cks = synth.build_model(S, C, 'gru', seed=11, device=DEV, bias_std=0.05)
     obs = synth.make_observation(4, seed=12, device=DEV)
     z_obj = model.build_latent_object(obs)
