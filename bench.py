@@ -73,12 +73,15 @@ def cpu_baseline(cks, z_obj_cpu, target_data, init, cfg, iters):
     c['args'] = dict(cfg['args'])
     c['args']['num_iters'] = 1
     c['args']['converge_patience'] = 10 ** 6
-    opose.gradient_estimate(model, z_obj_cpu, target, cam0, c)              # warm-up (page-in, thread pools)
+    _, first = opose.gradient_estimate(model, z_obj_cpu, target, cam0, c)   # warm-up (page-in, thread pools)
     c['args']['num_iters'] = iters
     t0 = time.perf_counter()
     opose.gradient_estimate(model, z_obj_cpu, target, cam0, c)
     dt = time.perf_counter() - t0
-    return iters / dt, torch.get_num_threads()
+    # iteration 0 of the oracle on the SAME latent volume / target / initial cameras: the full-size parity check
+    ref0 = {'rank_loss': first['rank_loss'][0],
+            'grad': torch.cat((first['grad_log_q'][0], first['grad_t'][0], first['grad_viewport'][0]), dim=1)}
+    return iters / dt, torch.get_num_threads(), ref0
 
 
 def main():
@@ -128,6 +131,10 @@ def main():
     init = pu.sample_cameras_with_estimate(N, target.camera.to('cpu'))
     init_rec = {'K': init.intrinsic.clone(), 'log_q': init.log_quaternion.clone(), 't': init.translation.clone()}
     st = est.start(z_obj, target, init.zoom(None, model.input_size, model.camera_dist).to(dev))
+    # losses and camera gradients of iteration 0 (before any optimiser step), for the parity line below
+    with torch.no_grad():
+        l0, g0 = st['engine'].forward_backward(st['cam'], need_grad=True)
+    hip0 = {'rank_loss': l0[:, 4].cpu(), 'grad': g0.cpu()}
 
     def barrier():
         torch.cuda.synchronize()
@@ -240,10 +247,21 @@ def main():
                      'note': roof_note},
     }
     if world == 1 and not a.no_cpu_baseline:
-        v, cores = cpu_baseline(cks[:3] + (cks[3],), z_obj.cpu(), tdata, init_rec, cfg, a.cpu_iters)
+        v, cores, ref0 = cpu_baseline(cks[:3] + (cks[3],), z_obj.cpu(), tdata, init_rec, cfg, a.cpu_iters)
+        gerr = (hip0['grad'] - ref0['grad']).norm(dim=1) / ref0['grad'].norm(dim=1).clamp_min(1e-30)
         out['cpu_baseline'] = {'value': v, 'unit': 'iters/s', 'cores': cores, 'kind': 'port',
                                'sample': f'{a.cpu_iters} timed iteration(s) of the same SYN({S},{C}) N={N} pose loop '
-                                         f'(oracle, after 1 warm-up iteration; latent volume taken from the GPU build)'}
+                                         f'(oracle, after 1 warm-up iteration; latent volume taken from the GPU build)',
+                               # HIP path vs the oracle on iteration 0 of this very workload (same volume, target,
+                               # initial cameras): per-hypothesis ranking loss and camera-parameter gradients
+                               'parity_at_full_size': {
+                                   'rank_loss_max_abs_diff': (hip0['rank_loss'] - ref0['rank_loss']).abs().max().item(),
+                                   'rank_loss_max_rel_diff': ((hip0['rank_loss'] - ref0['rank_loss']).abs()
+                                                              / ref0['rank_loss'].abs().clamp_min(1e-30)).max().item(),
+                                   'camera_grad_max_rel_l2_err': gerr.max().item(),
+                                   'argmin_equal': bool(torch.argmin(hip0['rank_loss']) == torch.argmin(ref0['rank_loss'])),
+                                   'ranking_equal': bool(torch.equal(torch.argsort(hip0['rank_loss']),
+                                                                     torch.argsort(ref0['rank_loss'])))}}
     if alt is not None:
         out['alt'] = alt
     if sharded is not None:
