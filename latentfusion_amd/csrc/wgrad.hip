@@ -74,7 +74,8 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
 // One 512-thread workgroup per CU walks 2 x 8 x 16-voxel tiles: the x halo (4 x 10 x 18 voxels) and the gpre
 // tile arrive by LDS-DMA (double-buffered, zero fill outside the volume), every wave owns two x-rows of the
 // tile and keeps all 27 tap accumulators (108 VGPRs) across its whole tile range; the per-wave partial sums
-// are written once at the end and summed by wgrad_reduce_kernel in a fixed order.
+// are combined through LDS at the end, one block per workgroup is written and wgrad_reduce_kernel sums the blocks
+// in a fixed order.
 constexpr int WTZ = 2, WTY = 8, WTX = 16, WHZ = 4, WHY = 10, WHX = 18;
 constexpr int WHALO = WHZ * WHY * WHX;                          // 720 voxels
 constexpr int WPH = (WHALO * 4 + 63) / 64;                      // 45 halo pieces (1 KiB)
@@ -162,12 +163,30 @@ __global__ void __launch_bounds__(512) wgrad3d_c16_kernel(
       __syncthreads();
     }
   }
-  // per-wave partials: block index = workgroup * 8 + wave (wgrad_reduce_kernel sums them in this order)
-  float* out = partial + ((long)(blockIdx.x * 8 + wave) * 27) * 256;
+  // the eight waves' partials are summed through LDS in a fixed tree (waves w+4 -> w, w+2 -> w, 1 -> 0), so a
+  // workgroup writes ONE 27 x 256 block (wgrad_reduce_kernel then sums `gridDim.x` blocks instead of 8x as many:
+  // 7 MB instead of 57 MB per launch, which dominated small launches)
+  f32x4* red = (f32x4*)smem;                                    // [wave slot][27][64 lanes]
 #pragma unroll
-  for (int tap = 0; tap < 27; ++tap)
+  for (int half = 4; half >= 1; half >>= 1) {
+    __syncthreads();                                            // previous round consumed / tile loop done with LDS
+    if (wave >= half && wave < 2 * half) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) out[tap * 256 + (4 * k + i) * 16 + m] = acc[tap][i];
+      for (int tap = 0; tap < 27; ++tap) red[((wave - half) * 27 + tap) * 64 + lane] = acc[tap];
+    }
+    __syncthreads();
+    if (wave < half) {
+#pragma unroll
+      for (int tap = 0; tap < 27; ++tap) acc[tap] += red[(wave * 27 + tap) * 64 + lane];
+    }
+  }
+  if (wave == 0) {
+    float* out = partial + (long)blockIdx.x * 27 * 256;
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) out[tap * 256 + (4 * k + i) * 16 + m] = acc[tap][i];
+  }
 }
 
 struct WgradPlan { int taps, nct, ncit, chunk, nblk; };
@@ -233,7 +252,7 @@ extern "C" int lf_conv_bwd_weight(const float* x, const float* gpre, float* gw, 
                        ptz, (int)pt);
     int st = lf_launch_status();
     if (st) return st;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(27, 1), dim3(256), 0, s, (const float*)scratch, gw, cus * 8, 27, 1, 1, 16, 16,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(27, 1), dim3(256), 0, s, (const float*)scratch, gw, cus, 27, 1, 1, 16, 16,
                        scale);
     return lf_launch_status();
   }

@@ -431,10 +431,10 @@ def _epilogue_bwd(gy, y, norm, flags):
     return gp
 
 
-def conv_bwd_weight(x, gp, dims, cin, he):
+def conv_bwd_weight(x, gp, dims, cin, he, want_bias=True):
     """Weight and bias gradients of y = conv(x, W) * he + b from the pre-activation gradient `gp`
     (lf_conv_bwd_weight).  x, gp: channels-last (N,C,[D,]H,W), or plain [rows][C] matrices for dims = 0.
-    Returns (gw [taps][Cout][Cin], gb [Cout])."""
+    Returns (gw [taps][Cout][Cin], gb [Cout] or None when want_bias is False)."""
     L = _lib.lib()
     if dims == 3 and gp.shape[1] == 16 and cin > 16:
         # the LDS-staged 16 -> 16 kernel is ~4x faster than the generic one even with the slice copies:
@@ -442,7 +442,16 @@ def conv_bwd_weight(x, gp, dims, cin, he):
         parts, gb = [], None
         for c0 in range(0, cin, 16):
             c1 = min(c0 + 16, cin)
-            gw_c, gb = conv_bwd_weight(cl(x[:, c0:c1]), gp, dims, c1 - c0, he)
+            if c1 - c0 < 16:
+                # ragged last chunk (the 3 coordinate channels of the 35-channel GRU gates): zero-pad it to 16 so it
+                # also takes the LDS-staged kernel (0.25 ms instead of 6.6 ms on the generic one at 128^3)
+                xc = empty_cl((x.shape[0], 16) + tuple(x.shape[2:]), x.device).zero_()
+                xc[:, :c1 - c0] = x[:, c0:c1]
+                gw_c, gb_c = conv_bwd_weight(xc, gp, dims, 16, he, want_bias and c0 == 0)
+                gw_c = gw_c[:, :, :c1 - c0]
+            else:
+                gw_c, gb_c = conv_bwd_weight(cl(x[:, c0:c1]), gp, dims, 16, he, want_bias and c0 == 0)
+            gb = gb_c if c0 == 0 else gb                       # the bias gradient (column sums of gp) once, not per chunk
             parts.append(gw_c)
         return torch.cat(parts, dim=2), gb
     if dims == 0:
@@ -453,12 +462,14 @@ def conv_bwd_weight(x, gp, dims, cin, he):
         D, H, W = (gp.shape[2:] if dims == 3 else (1,) + tuple(gp.shape[2:]))
     taps = {0: 1, 2: 9, 3: 27}[dims]
     gw = torch.empty(taps, cout, cin, device=gp.device, dtype=torch.float32)
-    gb = torch.empty(1, cout, 1, device=gp.device, dtype=torch.float32)
+    gb = torch.empty(1, cout, 1, device=gp.device, dtype=torch.float32) if want_bias else None
     nbytes = max(L.lf_conv_bwd_weight_scratch_bytes(dims, N, D, H, W, cin, cout),
                  L.lf_conv_bwd_weight_scratch_bytes(0, N, D, H, W, 0, cout))
     scratch = torch.empty(nbytes // 4 + 1, device=gp.device, dtype=torch.float32)
     check(L.lf_conv_bwd_weight(_ptr(x), _ptr(gp), _ptr(gw), _ptr(scratch), scratch.numel() * 4, dims, N, D, H, W, cin, cout,
                                he, _stream()), 'lf_conv_bwd_weight')
+    if not want_bias:
+        return gw, None
     check(L.lf_conv_bwd_weight(None, _ptr(gp), _ptr(gb), _ptr(scratch), scratch.numel() * 4, 0, N, D, H, W, 0, cout,
                                1.0, _stream()), 'lf_conv_bwd_weight')
     return gw, gb.reshape(cout)
