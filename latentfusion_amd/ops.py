@@ -533,6 +533,62 @@ def conv3x3(x, weight, bias, lrelu=True, pixelnorm=True):
     return _Conv3x3.apply(x, weight, bias, flags)
 
 
+class _Conv3x3Sum16(torch.autograd.Function):
+    """conv3d(cat(parts), W) * he + b for a 16-channel output, evaluated WITHOUT the concatenation as a sum of
+    16 -> 16 Winograd convolutions (the addend form of lf_conv3d_c16_wino), one per part.  `parts` are
+    channels-last (N,16,D,H,W) tensors; part p stands for `widths[p]` input channels of W (narrower parts -- the
+    3 coordinate channels of the ConvGRU gates -- are zero-padded to 16 by the caller).  Backward: per-part data
+    gradients on the same kernel, weight gradients on the LDS-staged 16 -> 16 kernel, no slice copies."""
+
+    @staticmethod
+    def forward(ctx, weight, bias, widths, *parts):
+        _req(weight, 'weight')
+        assert weight.dim() == 5 and weight.shape[0] == 16 and sum(widths) == weight.shape[1] and len(widths) == len(parts)
+        he = he_constant(weight)
+
+        def make():
+            wd, packs, c0 = weight.detach(), [], 0
+            for wdt in widths:
+                wp = wd.new_zeros(16, 16, 3, 3, 3)
+                wp[:, :wdt] = wd[:, c0:c0 + wdt]
+                packs.append((pack_conv3d_c16_wino(wp), pack_conv3d_c16_wino(wp, transpose=True)))
+                c0 += wdt
+            return packs
+        packs = _cached(weight, 'sum16_' + '_'.join(map(str, widths)), make)
+        y = None
+        for i, (p, (pf, _pt)) in enumerate(zip(parts, packs)):
+            _req(p, 'part')
+            prev = None if y is None else (y, None, _lib.LF_EPI_ADD)
+            y, _ = conv3d_c16_wino(cl(p), pf, bias.detach() if (bias is not None and i == 0) else None, he, 0, prev=prev)
+        ctx.he, ctx.widths, ctx.packs, ctx.weight = he, widths, packs, weight
+        need_w = weight.requires_grad or (bias is not None and bias.requires_grad)
+        ctx.parts = [cl(p) for p in parts] if need_w else None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        gy = cl(gy)
+        w = ctx.weight
+        gparts = []
+        for i, (_pf, pt) in enumerate(ctx.packs):
+            gparts.append(conv3d_c16_wino(gy, pt, None, ctx.he, 0)[0] if ctx.needs_input_grad[3 + i] else None)
+        gw = gb = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            cols = []
+            for i, (p, wdt) in enumerate(zip(ctx.parts, ctx.widths)):
+                g_i, gb_i = conv_bwd_weight(p, gy, 3, 16, ctx.he, want_bias=(i == 0))
+                gb = gb_i if i == 0 else gb
+                cols.append(g_i[:, :, :wdt])
+            gwt = torch.cat(cols, dim=2)                                   # [27][16][sum widths]
+            gw = gwt.reshape(3, 3, 3, 16, w.shape[1]).permute(3, 4, 0, 1, 2).contiguous()
+        return (gw if ctx.needs_input_grad[0] else None, gb if ctx.needs_input_grad[1] else None, None, *gparts)
+
+
+def conv3x3_sum16(weight, bias, widths, parts):
+    """See _Conv3x3Sum16."""
+    return _Conv3x3Sum16.apply(weight, bias, tuple(widths), *parts)
+
+
 def _conv1x1_raw(x_ptr_tensor, wpack, bias, N, P, cin, ksl, xbs, xss, cout, y2d, he, flags, yaddr=None):
     """y2d: output buffer; yaddr = (batch_stride, row_stride, slice_channels, slice_stride) or None
     for plain [N*P][cout] rows.  Returns norm or None."""

@@ -135,6 +135,24 @@ class ConvGRUCell(nn.Module):
         x_out = self.out_gate(torch.cat([x, h_cur * reset], dim=1))
         return h_cur * (1 - update) + x_out * update
 
+    def parts_ok(self, z, h):
+        """3-D, 16 state channels, 16 + 3 input channels, on the device: the gates can run as sums of 16 -> 16
+        Winograd convolutions over (view, coords, state) without building the 35-channel concatenation."""
+        w = self.update_gate.module.weight
+        return (z.is_cuda and z.dim() == 5 and w.dim() == 5 and self.hidden_dim == 16 and self.input_dim == 19
+                and z.shape[1] == 16 and h.shape[1] == 16 and z.shape[2] * z.shape[3] * z.shape[4] * 64 < 2 ** 31)
+
+    def forward_parts(self, z, c16, h_cur):
+        """forward(cat(z, coords), h_cur) with the coordinate channels given zero-padded to 16 (`c16`)."""
+        from .. import ops
+
+        def gate(g, state):
+            return ops.conv3x3_sum16(g.module.weight, g.bias, (16, 3, 16), (z, c16, state))
+        update = torch.sigmoid(gate(self.update_gate, h_cur))
+        reset = torch.sigmoid(gate(self.reset_gate, h_cur))
+        x_out = gate(self.out_gate, h_cur * reset)
+        return h_cur * (1 - update) + x_out * update
+
 
 class ConvLSTMCell(nn.Module):
     """reference modules/lstm.py:7-56."""
@@ -161,6 +179,7 @@ class GRUFuser(_ArgsFuser):
         self.in_channels, self.cube_size, self.conv_module = in_channels, cube_size, conv_module
         n_coord = 2 if conv_module == EqualizedConv2d else 3
         self.gru = ConvGRUCell(in_channels + n_coord, in_channels, kernel_size=3, bias=True, conv_module=conv_module)
+        self.split_gates = True        # False: always the concatenated 35-channel convolutions (tests compare the two)
 
     def _args(self):
         return {'in_channels': self.in_channels, 'cube_size': self.cube_size}
@@ -172,6 +191,13 @@ class GRUFuser(_ArgsFuser):
         h = z_obj[:, 0]
         coords = (utils.get_normalized_pixel_coords(h) if self.conv_module == EqualizedConv2d
                   else utils.get_normalized_voxel_coords(h))
+        if self.split_gates and self.gru.parts_ok(h, h):
+            from .. import ops
+            c16 = ops.empty_cl((h.shape[0], 16) + tuple(h.shape[2:]), h.device).zero_()
+            c16[:, :3] = coords
+            for i in range(1, z_obj.shape[1]):
+                h = self.gru.forward_parts(z_obj[:, i], c16, h)
+            return h.unsqueeze(1), {}
         for i in range(1, z_obj.shape[1]):
             h = self.gru(torch.cat((z_obj[:, i], coords), dim=1), h)
         return h.unsqueeze(1), {}

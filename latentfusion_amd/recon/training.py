@@ -28,26 +28,27 @@ class FlatParameters:
         if not self.params:
             raise ValueError('no parameters to train')
         dev = self.params[0].device
-        n = sum(p.numel() for p in self.params)
-        self.data = torch.empty(n, device=dev, dtype=torch.float32)
-        self.grad = torch.zeros(n, device=dev, dtype=torch.float32)
-        off = 0
+        # every parameter starts on a 64-byte boundary: the HIP kernels read weights and biases as 16-byte vectors
+        # (the 1- and 3-element biases of the output heads would otherwise shift everything behind them)
+        self.offsets, n = [], 0
         for p in self.params:
+            self.offsets.append(n)
+            n += (p.numel() + 15) // 16 * 16
+        self.data = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.grad = torch.zeros(n, device=dev, dtype=torch.float32)
+        for p, off in zip(self.params, self.offsets):
             k = p.numel()
             self.data[off:off + k].copy_(p.detach().reshape(-1))
             p.data = self.data[off:off + k].view(p.shape)
             p.requires_grad_(True)
             p.grad = self.grad[off:off + k].view(p.shape)          # autograd accumulates into the flat buffer
-            off += k
 
     def zero_grad(self):
         self.grad.zero_()
-        off = 0
-        for p in self.params:                                        # re-attach views a caller may have dropped
+        for p, off in zip(self.params, self.offsets):                # re-attach views a caller may have dropped
             k = p.numel()
             if p.grad is None or p.grad.data_ptr() != self.grad[off:off + k].data_ptr():
                 p.grad = self.grad[off:off + k].view(p.shape)
-            off += k
 
 
 class FlatAdam:

@@ -291,7 +291,7 @@ def test_generator_training_step(golden):
     fu = fusion.from_checkpoint(g['fuser']).to(DEV)
     ph = Photographer.from_checkpoint(pck).to(DEV)
     step = training.GeneratorStep(sc, fu, ph, **kw)
-    before = step.flat.data.clone()
+    before = [q.detach().clone() for q in step.flat.params]
     cam = prod_camera(oc)
     batch = {'in': {'camera': cam, 'image': o['color'].unsqueeze(0).to(DEV), 'mask': o['mask'].unsqueeze(0).to(DEV),
                     'depth': o['depth'].unsqueeze(0).to(DEV)},
@@ -300,7 +300,7 @@ def test_generator_training_step(golden):
     for k in ('depth_recon', 'mask_recon', 'mask_beta', 'total'):
         close(got[k], want[k], atol=1e-5, rtol=1e-4)
     # first Adam step with betas (0, 0.99): delta = -lr * g / (|g| + eps)
-    delta = (step.flat.data - before).cpu()
+    delta = torch.cat([(q.detach() - b).reshape(-1) for q, b in zip(step.flat.params, before)]).cpu()
     ograd = torch.cat([cks[key]['state_dict'][n].grad.reshape(-1)
                        for key, mod in (('s', sc), ('p', ph), ('f', fu)) for n, _ in mod.named_parameters()])
     assert delta.shape == ograd.shape
@@ -360,3 +360,34 @@ def test_gru_fuser_winograd_inference_path():
         slow, _ = fu(z.clone().requires_grad_(True), None, None, None)
     assert fast.shape == slow.shape == (1, 1, 16, 9, 12, 21)
     close(fast, slow, atol=2e-5, rtol=1e-4)
+
+
+def test_gru_fuser_split_gates_match_concatenated_gates_under_autograd():
+    """Training path of the 16-channel GRU fuser: gates as sums of 16 -> 16 convolutions over (view, coords, state)
+    (ops.conv3x3_sum16: Winograd forward / data gradients, LDS-staged weight gradients, no 35-channel
+    concatenation) against the concatenated 35-channel convolutions of the reference formulation
+    (modules/gru.py:37-43) -- output, gradients of every gate weight and bias, gradient of the per-view volumes."""
+    from latentfusion_amd.recon import fusion
+    torch.manual_seed(6)
+    fu = fusion.GRUFuser(16).to(DEV)
+    for p in fu.parameters():
+        p.requires_grad_(True)
+    with torch.no_grad():
+        for gate in (fu.gru.update_gate, fu.gru.reset_gate, fu.gru.out_gate):
+            gate.bias.normal_(0.0, 0.3)
+    gen = torch.Generator().manual_seed(23)
+    z0 = torch.randn(1, 3, 16, 10, 24, 33, generator=gen).to(DEV)
+    gout = torch.randn(1, 1, 16, 10, 24, 33, generator=gen).to(DEV)
+    res = {}
+    for split in (False, True):
+        fu.split_gates = split
+        fu.zero_grad()
+        z = z0.clone().requires_grad_(True)
+        out, _ = fu(z, None, None, None)
+        (out * gout).sum().backward()
+        res[split] = (out.detach(), z.grad.clone(), {k: p.grad.clone() for k, p in fu.named_parameters()})
+    close(res[True][0], res[False][0], atol=3e-5, rtol=1e-4)
+    scale = res[False][1].abs().max().item()
+    close(res[True][1], res[False][1], atol=2e-5 * scale, rtol=1e-3)
+    for k, g in res[False][2].items():
+        close(res[True][2][k], g, atol=2e-5 * max(g.abs().max().item(), 1e-3), rtol=1e-3)
