@@ -206,6 +206,14 @@ int lf_gru_stage_a(const float* upre, const float* rpre, int pre_stride, const f
                    long nvox, int Ch, int rec_stride, int rec_off, void* stream);
 int lf_gru_stage_b(const float* h, const float* u, const float* cand, float* h_out, float* rec, long nvox, int Ch,
                    int rec_stride, int rec_off, void* stream);
+/* Backward of the two stages for the training path (autograd of modules/gru.py:37-43), plain arrays of n floats
+ * (n % 4 == 0, 16-byte aligned):
+ *   stage B: gh = g (1 - u), gu = g (cand - h), gc = g u
+ *   stage A: gupre = gu u (1 - u), grpre = grh h r (1 - r), gh = grh r,  r = sigmoid(rpre) */
+int lf_gru_stage_b_bwd(const float* g, const float* h, const float* u, const float* cand, float* gh, float* gu, float* gc,
+                       long n, void* stream);
+int lf_gru_stage_a_bwd(const float* gu, const float* grh, const float* u, const float* rpre, const float* h, float* gupre,
+                       float* grpre, float* gh, long n, void* stream);
 
 /* 2-D grid sampling of planar images, F.grid_sample(align_corners=False) semantics: the crop / zoom
  * (geometry.py:20-44,287-354; zeros padding), Camera.uncrop (geometry.py:261-285; border padding) and the

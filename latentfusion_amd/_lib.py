@@ -55,6 +55,8 @@ SIGNATURES = {
     'lf_wino2d_output_transform': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint, c_float, c_float, P]),
     'lf_gru_stage_a': (c_int, [P, P, c_int, P, P, P, c_long, c_int, c_int, c_int, P]),
     'lf_gru_stage_b': (c_int, [P, P, P, P, P, c_long, c_int, c_int, c_int, P]),
+    'lf_gru_stage_b_bwd': (c_int, [P, P, P, P, P, P, P, c_long, P]),
+    'lf_gru_stage_a_bwd': (c_int, [P, P, P, P, P, P, P, P, c_long, P]),
     'lf_grid_sample2d_fwd': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     'lf_grid_sample2d_bwd': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     'lf_conv_bwd_weight_scratch_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),

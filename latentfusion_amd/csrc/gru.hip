@@ -40,7 +40,60 @@ __global__ void __launch_bounds__(256) gru_stage_b_kernel(const float* __restric
   if (rec != nullptr) rec[v * rec_stride + rec_off + c] = hn;
 }
 
+// ---- backward of the two stages (training path; plain [n] arrays, 4 elements per thread) ----
+//   stage B:  h' = h (1 - u) + c u          ->  gh = g (1 - u),  gu = g (c - h),  gc = g u
+//   stage A:  u = s(upre), rh = h s(rpre)   ->  gupre = gu u (1 - u),  grpre = grh h r (1 - r),  gh = grh r
+__global__ void __launch_bounds__(256) gru_stage_b_bwd_kernel(const f32x4* __restrict__ g, const f32x4* __restrict__ h,
+                                                              const f32x4* __restrict__ u, const f32x4* __restrict__ cand,
+                                                              f32x4* __restrict__ gh, f32x4* __restrict__ gu,
+                                                              f32x4* __restrict__ gc, long n4) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const f32x4 gg = g[i], uu = u[i];
+  gh[i] = gg * (1.f - uu);
+  gu[i] = gg * (cand[i] - h[i]);
+  gc[i] = gg * uu;
+}
+
+__global__ void __launch_bounds__(256) gru_stage_a_bwd_kernel(const f32x4* __restrict__ gu, const f32x4* __restrict__ grh,
+                                                              const f32x4* __restrict__ u, const f32x4* __restrict__ rpre,
+                                                              const f32x4* __restrict__ h, f32x4* __restrict__ gupre,
+                                                              f32x4* __restrict__ grpre, f32x4* __restrict__ gh, long n4) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const f32x4 uu = u[i], rp = rpre[i], hh = h[i], gr = grh[i];
+  f32x4 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) r[e] = sigmoidf_(rp[e]);
+  gupre[i] = gu[i] * uu * (1.f - uu);
+  grpre[i] = gr * hh * r * (1.f - r);
+  gh[i] = gr * r;
+}
+
 }  // namespace
+
+extern "C" int lf_gru_stage_b_bwd(const float* g, const float* h, const float* u, const float* cand, float* gh, float* gu,
+                                  float* gc, long n, void* stream) {
+  lf_clear_error();
+  if (n <= 0 || (n & 3)) return LF_EINVAL;
+  if (!lf_aligned16(g) || !lf_aligned16(h) || !lf_aligned16(u) || !lf_aligned16(cand) || !lf_aligned16(gh) || !lf_aligned16(gu) ||
+      !lf_aligned16(gc)) return LF_EALIGN;
+  hipLaunchKernelGGL(gru_stage_b_bwd_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const f32x4*)g, (const f32x4*)h, (const f32x4*)u, (const f32x4*)cand, (f32x4*)gh, (f32x4*)gu, (f32x4*)gc, n / 4);
+  return lf_launch_status();
+}
+
+extern "C" int lf_gru_stage_a_bwd(const float* gu, const float* grh, const float* u, const float* rpre, const float* h,
+                                  float* gupre, float* grpre, float* gh, long n, void* stream) {
+  lf_clear_error();
+  if (n <= 0 || (n & 3)) return LF_EINVAL;
+  if (!lf_aligned16(gu) || !lf_aligned16(grh) || !lf_aligned16(u) || !lf_aligned16(rpre) || !lf_aligned16(h) ||
+      !lf_aligned16(gupre) || !lf_aligned16(grpre) || !lf_aligned16(gh)) return LF_EALIGN;
+  hipLaunchKernelGGL(gru_stage_a_bwd_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const f32x4*)gu, (const f32x4*)grh, (const f32x4*)u, (const f32x4*)rpre, (const f32x4*)h, (f32x4*)gupre,
+                     (f32x4*)grpre, (f32x4*)gh, n / 4);
+  return lf_launch_status();
+}
 
 extern "C" int lf_gru_stage_a(const float* upre, const float* rpre, int pre_stride, const float* h, float* u, float* rec,
                               long nvox, int Ch, int rec_stride, int rec_off, void* stream) {

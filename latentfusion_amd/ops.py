@@ -584,6 +584,64 @@ class _Conv3x3Sum16(torch.autograd.Function):
         return (gw if ctx.needs_input_grad[0] else None, gb if ctx.needs_input_grad[1] else None, None, *gparts)
 
 
+class _GruGates(torch.autograd.Function):
+    """(upre, rpre, h) -> (u = sigmoid(upre), rh = h * sigmoid(rpre)); one kernel each way (lf_gru_stage_a[_bwd])
+    instead of five element-wise passes over the volume (modules/gru.py:37-40)."""
+
+    @staticmethod
+    def forward(ctx, upre, rpre, h):
+        L = _lib.lib()
+        upre, rpre, h = cl(upre), cl(rpre), cl(h)
+        u, rh = torch.empty_like(h), torch.empty_like(h)
+        C = h.shape[1]
+        nvox = h.numel() // C
+        check(L.lf_gru_stage_a(_ptr(upre), _ptr(rpre), C, _ptr(h), _ptr(u), _ptr(rh), nvox, C, C, 0, _stream()), 'lf_gru_stage_a')
+        ctx.save_for_backward(u, rpre, h)
+        return u, rh
+
+    @staticmethod
+    def backward(ctx, gu, grh):
+        L = _lib.lib()
+        u, rpre, h = ctx.saved_tensors
+        gu, grh = cl(gu), cl(grh)
+        gupre, grpre, gh = torch.empty_like(h), torch.empty_like(h), torch.empty_like(h)
+        check(L.lf_gru_stage_a_bwd(_ptr(gu), _ptr(grh), _ptr(u), _ptr(rpre), _ptr(h), _ptr(gupre), _ptr(grpre), _ptr(gh),
+                                   h.numel(), _stream()), 'lf_gru_stage_a_bwd')
+        return gupre, grpre, gh
+
+
+class _GruBlend(torch.autograd.Function):
+    """(h, u, cand) -> h (1 - u) + cand u  (modules/gru.py:42; lf_gru_stage_b[_bwd])."""
+
+    @staticmethod
+    def forward(ctx, h, u, cand):
+        L = _lib.lib()
+        h, u, cand = cl(h), cl(u), cl(cand)
+        out = torch.empty_like(h)
+        C = h.shape[1]
+        check(L.lf_gru_stage_b(_ptr(h), _ptr(u), _ptr(cand), _ptr(out), None, h.numel() // C, C, C, 0, _stream()), 'lf_gru_stage_b')
+        ctx.save_for_backward(h, u, cand)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        h, u, cand = ctx.saved_tensors
+        g = cl(g)
+        gh, gu, gc = torch.empty_like(h), torch.empty_like(h), torch.empty_like(h)
+        check(L.lf_gru_stage_b_bwd(_ptr(g), _ptr(h), _ptr(u), _ptr(cand), _ptr(gh), _ptr(gu), _ptr(gc), h.numel(), _stream()),
+              'lf_gru_stage_b_bwd')
+        return gh, gu, gc
+
+
+def gru_gates(upre, rpre, h):
+    return _GruGates.apply(upre, rpre, h)
+
+
+def gru_blend(h, u, cand):
+    return _GruBlend.apply(h, u, cand)
+
+
 def conv3x3_sum16(weight, bias, widths, parts):
     """See _Conv3x3Sum16."""
     return _Conv3x3Sum16.apply(weight, bias, tuple(widths), *parts)

@@ -148,10 +148,8 @@ class ConvGRUCell(nn.Module):
 
         def gate(g, state):
             return ops.conv3x3_sum16(g.module.weight, g.bias, (16, 3, 16), (z, c16, state))
-        update = torch.sigmoid(gate(self.update_gate, h_cur))
-        reset = torch.sigmoid(gate(self.reset_gate, h_cur))
-        x_out = gate(self.out_gate, h_cur * reset)
-        return h_cur * (1 - update) + x_out * update
+        update, rh = ops.gru_gates(gate(self.update_gate, h_cur), gate(self.reset_gate, h_cur), h_cur)
+        return ops.gru_blend(h_cur, update, gate(self.out_gate, rh))
 
 
 class ConvLSTMCell(nn.Module):
