@@ -189,6 +189,40 @@ __global__ void __launch_bounds__(512) wgrad3d_c16_kernel(
   }
 }
 
+// ---- bias gradient of a 16-channel layer: column sums of gpre [rows][16] ------------------------------
+// A streaming reduction (the generic path runs it as a GEMM against a vector of ones with at most 512 blocks,
+// 250 us for 134 MB; this takes ~40).  Fixed order: rows strided inside a block, blocks summed in fp64.
+__global__ void __launch_bounds__(256) colsum16_partial_kernel(const f32x4* __restrict__ gp, float* __restrict__ partial,
+                                                               long rows, int chunk) {
+  const int t = threadIdx.x, q = t & 3, slot = t >> 2;
+  const long r0 = (long)blockIdx.x * chunk, r1 = min(r0 + chunk, rows);
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (long r = r0 + slot; r < r1; r += 64) acc += __builtin_nontemporal_load(gp + r * 4 + q);
+  __shared__ f32x4 red[256];
+  red[t] = acc;
+  __syncthreads();
+  if (t < 16) {
+    float s = 0.f;
+    for (int i = 0; i < 64; ++i) s += red[i * 4 + (t >> 2)][t & 3];
+    partial[(long)blockIdx.x * 16 + t] = s;
+  }
+}
+
+__global__ void __launch_bounds__(256) colsum16_final_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ out,
+                                                             float scale) {
+  const int t = threadIdx.x, co = t & 15, grp = t >> 4;
+  double s = 0.0;
+  for (int b = grp; b < nblk; b += 16) s += (double)partial[(long)b * 16 + co];
+  __shared__ double red[256];
+  red[t] = s;
+  __syncthreads();
+  if (t < 16) {
+    double tot = 0.0;
+    for (int g = 0; g < 16; ++g) tot += red[g * 16 + t];
+    out[t] = (float)(tot * (double)scale);
+  }
+}
+
 struct WgradPlan { int taps, nct, ncit, chunk, nblk; };
 
 bool wgrad_plan(int dims, long total, int Cin, int Cout, bool ones, WgradPlan& p) {
@@ -233,6 +267,19 @@ extern "C" int lf_conv_bwd_weight(const float* x, const float* gpre, float* gw, 
   lf_clear_error();
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || gpre == nullptr || gw == nullptr) return LF_EINVAL;
   const bool ones = (x == nullptr);
+  if (ones && Cout == 16 && lf_aligned16(gpre)) {
+    const long rows = (long)N * D * H * W;
+    long chunk = (rows + 1023) / 1024;                            // ~1024 blocks: four per CU keep enough loads in flight
+    chunk = (chunk + 63) / 64 * 64;
+    const int nblk = (int)((rows + chunk - 1) / chunk);
+    if (scratch_bytes < (size_t)nblk * 16 * sizeof(float)) return LF_ENOSPC;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(colsum16_partial_kernel, dim3(nblk), dim3(256), 0, s, (const f32x4*)gpre, (float*)scratch, rows, (int)chunk);
+    int st = lf_launch_status();
+    if (st) return st;
+    hipLaunchKernelGGL(colsum16_final_kernel, dim3(1), dim3(256), 0, s, (const float*)scratch, nblk, gw, scale);
+    return lf_launch_status();
+  }
   if (!ones && wgrad_fast3d(dims, N, D, H, W, Cin, Cout) && lf_aligned16(x) && lf_aligned16(gpre)) {
     const int cus = wgrad_cus();
     if (scratch_bytes < (size_t)cus * 8 * 27 * 256 * sizeof(float)) return LF_ENOSPC;
