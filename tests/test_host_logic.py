@@ -527,3 +527,26 @@ def test_observation_save_load_roundtrip(tmp_path):
     assert cam.translation.shape == (3, 3) and float(cam.translation[:, 2].min()) > 0.5
     z = obs.zoom_estimate(1.5, 32)
     assert z.color.shape[-2:] == (32, 32)
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    """profiles/r01_bench_1gpu.json is the last bench.py line measured on an MI355X: every field the bench
+    contract names must be there, with the roofline / cpu_baseline objects of the hot-path tier."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'r01_bench_1gpu.json')
+    d = json.load(open(path))
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['higher_is_better'] is True and d['scaling'] == 'weak' and d['vs_baseline'] is None and d['n_gpus'] == 1
+    assert 'workload' in d['config'] and 'model' not in d['config']
+    r = d['roofline']
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        assert k in r, k
+    assert r['bound'] in ('hbm', 'mfma') and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
+    c = d['cpu_baseline']
+    for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+        assert k in c, k
+    assert c['kind'] in ('reference', 'port') and c['unit'] == d['unit']
+    assert abs(d['value'] - d['n_gpus'] * d['steps'] / (d['ms_per_step'] * 1e-3 * d['steps'])) < 1e-6 * d['value']
