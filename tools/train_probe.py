@@ -35,7 +35,7 @@ def main():
     step = training.GeneratorStep(model.sculptor, model.fuser, model.photographer, g_depth_recon_loss_k=S * S // 4)
     batch = {'in': {'camera': obs_in.camera, 'image': obs_in.color.unsqueeze(0), 'mask': obs_in.mask.unsqueeze(0)},
              'out_gt': {'camera': obs_out.camera, 'depth': obs_out.depth.unsqueeze(0), 'mask': obs_out.mask.unsqueeze(0)}}
-    out = {'params_M': step.flat.data.numel() / 1e6, 'views_in': a.views_in, 'views_out': a.views_out, 'size': S}
+    out = {'params_M': sum(q.numel() for q in step.flat.params) / 1e6, 'views_in': a.views_in, 'views_out': a.views_out, 'size': S}
     times, losses = [], []
     for i in range(a.steps + 1):
         torch.cuda.synchronize(); t0 = time.perf_counter()
