@@ -100,6 +100,8 @@ def main():
     from latentfusion_amd.pose import estimation, utils as pu
 
     S, C, V, N = a.size, a.channels, a.views, a.samples
+    if C != 16 and a.conv_mode != 'fp32':
+        a.conv_mode = 'fp32'                       # the Winograd / split kernels are written for the 16-channel blocks
     # every rank owns its own object: different weights seed -> different volume, same shapes
     model, cks = synth.build_model(S, C, a.fuser, seed=rank, device=dev)
     ref_obs = synth.make_observation(V, seed=100 + rank, device=dev)
@@ -230,7 +232,7 @@ def main():
         return
     value = world * a.steps / elapsed
     out = {
-        'metric': 'pose-optim iters/sec (reconstruct+render+backward), 16 views, 128^3 voxels',
+        'metric': f'pose-optim iters/sec (reconstruct+render+backward), {V} views, {S}^3 voxels',
         'value': value, 'unit': 'iters/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
         'ms_per_step': elapsed / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32' if a.conv_mode in ('fp32', 'winograd') else 'f32 (conv3d products split into 3 f16 MFMAs, fp32 accumulate)', 'data': 'synthetic (SYN(S,C) random-init weights, synthetic observations)',
