@@ -407,7 +407,8 @@ def test_conv3d_c16_kernels_on_random_shapes():
         assert (gotw - want).abs().max().item() < 1e-4 * max(want.abs().max().item(), 1e-3), (N, D, H, W)
 
 
-@pytest.mark.parametrize('shape', [(4, 16, 14, 48, 96), (3, 16, 22, 64, 64), (1, 16, 30, 40, 200), (8, 16, 32, 64, 64)])
+@pytest.mark.parametrize('shape', [(4, 16, 14, 48, 96), (3, 16, 22, 64, 64), (1, 16, 30, 40, 200), (8, 16, 32, 64, 64),
+                                   (2, 16, 2, 128, 256), (2, 16, 3, 96, 160)])
 def test_winograd_sliding_halo_and_addend(shape):
     """Volumes with more tiles than resident workgroups, so every workgroup walks several tiles of a column and
     the halo slides along z (LDS -> LDS move + two fetched planes), with tile ranges that start and end in the
