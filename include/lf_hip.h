@@ -215,6 +215,51 @@ int lf_gru_stage_b_bwd(const float* g, const float* h, const float* u, const flo
 int lf_gru_stage_a_bwd(const float* gu, const float* grh, const float* u, const float* rpre, const float* h, float* gupre,
                        float* grpre, float* gh, long n, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Depth-column composites of the renderer (channels-last volumes [N][D][H][W][C], P = H*W pixels).
+ * A depth column is strided by P*C floats: lanes run along the contiguous (pixel, channel) axis, the depth axis is
+ * split over the waves of a workgroup (and over 16-lane groups combined with wave shuffles for the single-channel
+ * softmax), partials meet in LDS in a fixed order -> deterministic, no atomics.
+ *   lf_column_reduce_sum_fwd   y[n][p][c] = sum_d x[n][d][p][c]        Photographer 'sum' projection,
+ *                                                                       recon/models.py:436-437
+ *   lf_column_reduce_sum_bwd   gx[n][d][p][c] = gy[n][p][c]
+ *   lf_column_softmax_fwd      w = softmax_d(logits[n][d][p]) ; zdepth[n][p] = sum_d w * linspace(-1,1,D)[d]
+ *                              (_compute_depth_weights + _depth_from_weight, recon/models.py:378-395);
+ *                              weights or zdepth may be NULL
+ *   lf_column_softmax_bwd      glogits = w * (t - sum_d w t),  t = gweights + gzdepth * linspace(-1,1,D)
+ *                              (either gradient may be NULL)
+ *   lf_column_scale_fwd/bwd    out[row][:] = z[row][:] * w[row]  (z * depth_weights_resized, models.py:427-430);
+ *                              bwd: gz = gout * w, gw[row] = sum_c gout * z  (gz or gw may be NULL); C % 4 == 0 */
+int lf_column_reduce_sum_fwd(const float* x, float* y, int N, int D, long P, int C, void* stream);
+int lf_column_reduce_sum_bwd(const float* gy, float* gx, int N, int D, long P, int C, void* stream);
+int lf_column_softmax_fwd(const float* logits, float* weights, float* zdepth, int N, int D, long P, void* stream);
+int lf_column_softmax_bwd(const float* weights, const float* gweights, const float* gzdepth, float* glogits,
+                          int N, int D, long P, void* stream);
+int lf_column_scale_fwd(const float* z, const float* w, float* out, long rows, int C, void* stream);
+int lf_column_scale_bwd(const float* gout, const float* z, const float* w, float* gz, float* gw, long rows, int C,
+                        void* stream);
+
+/* View reductions of the fusers: z holds V per-view volumes of n floats each, `view_stride` floats apart (any
+ * element order -- the output uses the same one).
+ *   lf_fuse_views_fwd  kind = LF_FUSE_MEAN | MAX | ABSMAX (signed value of largest magnitude) | MEDIAN (lower median,
+ *                      torch.median; V <= 64): PoolFuser / pool_tensor, recon/fusion.py:45-57, functional.py:47-49.
+ *                      idx (may be NULL; unused for MEAN) receives the selected view per element.
+ *   lf_fuse_views_bwd  gz[v][i] = g[i] / V (MEAN) or g[i] * (v == idx[i]).
+ *   lf_fuse_blend_fwd  BlendFuser.forward, recon/fusion.py:139-148: weights[v][row] = softmax_v(logits[v][row]),
+ *                      out[row][:] = sum_v z[v][row][:] * weights[v][row]  (rows voxels, C % 4 == 0 channels-last;
+ *                      logits / weights views `logit_view_stride` floats apart); weights may be NULL.
+ *   lf_fuse_blend_bwd  gz[v] = g * w_v ; glogits_v = w_v (a_v - sum_u w_u a_u), a_v = sum_c g z_v (either may be NULL). */
+#define LF_FUSE_MEAN   0
+#define LF_FUSE_MAX    1
+#define LF_FUSE_ABSMAX 2
+#define LF_FUSE_MEDIAN 3
+int lf_fuse_views_fwd(const float* z, float* out, int* idx, int kind, int V, long n, long view_stride, void* stream);
+int lf_fuse_views_bwd(const float* g, const int* idx, float* gz, int kind, int V, long n, long view_stride, void* stream);
+int lf_fuse_blend_fwd(const float* z, const float* logits, float* weights, float* out, int V, long rows, int C,
+                      long z_view_stride, long logit_view_stride, void* stream);
+int lf_fuse_blend_bwd(const float* g, const float* z, const float* weights, float* gz, float* glogits, int V, long rows,
+                      int C, long z_view_stride, long logit_view_stride, void* stream);
+
 /* 2-D grid sampling of planar images, F.grid_sample(align_corners=False) semantics: the crop / zoom
  * (geometry.py:20-44,287-354; zeros padding), Camera.uncrop (geometry.py:261-285; border padding) and the
  * image-based-rendering warps (ibr.py:52-93).  img [N][C][H][W], grid [N][Ho][Wo][2] = (x, y) in [-1,1],

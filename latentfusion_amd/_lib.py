@@ -16,6 +16,7 @@ LF_EPI_ADD = 4
 LF_MAP_O2C = 0
 LF_MAP_C2O = 1
 LF_MAP_COEFS = 20
+LF_FUSE_MEAN, LF_FUSE_MAX, LF_FUSE_ABSMAX, LF_FUSE_MEDIAN = 0, 1, 2, 3
 LF_AMAX_FLOATS = 2048          # floats of a max-abs side-channel buffer (include/lf_hip.h)
 
 P = c_void_p
@@ -57,6 +58,16 @@ SIGNATURES = {
     'lf_gru_stage_b': (c_int, [P, P, P, P, P, c_long, c_int, c_int, c_int, P]),
     'lf_gru_stage_b_bwd': (c_int, [P, P, P, P, P, P, P, c_long, P]),
     'lf_gru_stage_a_bwd': (c_int, [P, P, P, P, P, P, P, P, c_long, P]),
+    'lf_column_reduce_sum_fwd': (c_int, [P, P, c_int, c_int, c_long, c_int, P]),
+    'lf_column_reduce_sum_bwd': (c_int, [P, P, c_int, c_int, c_long, c_int, P]),
+    'lf_column_softmax_fwd': (c_int, [P, P, P, c_int, c_int, c_long, P]),
+    'lf_column_softmax_bwd': (c_int, [P, P, P, P, c_int, c_int, c_long, P]),
+    'lf_column_scale_fwd': (c_int, [P, P, P, c_long, c_int, P]),
+    'lf_column_scale_bwd': (c_int, [P, P, P, P, P, c_long, c_int, P]),
+    'lf_fuse_views_fwd': (c_int, [P, P, P, c_int, c_int, c_long, c_long, P]),
+    'lf_fuse_views_bwd': (c_int, [P, P, P, c_int, c_int, c_long, c_long, P]),
+    'lf_fuse_blend_fwd': (c_int, [P, P, P, P, c_int, c_long, c_int, c_long, c_long, P]),
+    'lf_fuse_blend_bwd': (c_int, [P, P, P, P, P, c_int, c_long, c_int, c_long, c_long, P]),
     'lf_grid_sample2d_fwd': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     'lf_grid_sample2d_bwd': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     'lf_conv_bwd_weight_scratch_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),

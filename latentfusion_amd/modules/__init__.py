@@ -39,8 +39,7 @@ class _Weight(nn.Module):
         super().__init__()
         self.out_channels, self.in_channels = out_channels, in_channels
         self.kernel_size = kernel_size
-        self.weight = nn.Parameter(torch.randn(out_channels, in_channels, *([kernel_size] * dims)),
-                                   requires_grad=False)
+        self.weight = nn.Parameter(torch.randn(out_channels, in_channels, *([kernel_size] * dims)))
 
 
 class Equalized(nn.Module):
@@ -59,7 +58,7 @@ class Equalized(nn.Module):
             raise NotImplementedError('supported: kernel 3 / padding 1 and kernel 1 / padding 0')
         self.kernel_size, self.padding = kernel_size, padding
         self.module = _Weight(out_channels, in_channels, kernel_size, self.dims)
-        self.bias = nn.Parameter(torch.zeros(out_channels), requires_grad=False) if bias else None
+        self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
 
     @property
     def weight(self):                       # He constant, like the reference attribute

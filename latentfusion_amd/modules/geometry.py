@@ -314,24 +314,28 @@ class Camera:
         return ((depth - zn) / (zf - zn)).clamp(0, 1) * 2.0 - 1.0
 
     # ---- viewport <-> frame resampling -----------------------------------------------------
-    def zoom_viewport(self, target_size, target_dist, target_fu=None, target_fv=None, image_scale=1.0):
-        """Viewport of the canonical 'zoomed' camera (reference :294-339)."""
-        zs = self.translation[:, 2]
+    def zoom_viewport(self, target_size, target_dist, target_fu=None, target_fv=None, image_scale=1.0, zs=None,
+                      centroid_uvs=None):
+        """Viewport of the canonical 'zoomed' camera (reference :294-339).  zs / centroid_uvs override the depth and
+        the projected centre of the object (default: the camera's own t_z and projected origin)."""
+        if zs is None:
+            zs = self.translation[:, 2]
         fu, fv = self.fu, self.fv
         tfu = fu if target_fu is None else target_fu
         tfv = fv if target_fv is None else target_fv
         bu = target_dist * (1.0 / zs) / fu * tfu * target_size / self.width * image_scale
         bv = target_dist * (1.0 / zs) / fv * tfv * target_size / self.height * image_scale
-        origin = torch.tensor((0.0, 0.0, 0.0, 1.0), device=self.device).view(1, 4, 1).expand(len(self), -1, -1)
-        uvw = self.intrinsic @ self.obj_to_cam @ origin
-        uv = (uvw[:, :2] / uvw[:, 2, None]).squeeze(2)
-        cu, cv = uv[:, 0] / self.width, uv[:, 1] / self.height
+        if centroid_uvs is None:
+            origin = torch.tensor((0.0, 0.0, 0.0, 1.0), device=self.device).view(1, 4, 1).expand(len(self), -1, -1)
+            uvw = self.intrinsic @ self.obj_to_cam @ origin
+            centroid_uvs = (uvw[:, :2] / uvw[:, 2, None]).squeeze(2).float()
+        cu, cv = centroid_uvs[:, 0] / self.width, centroid_uvs[:, 1] / self.height
         return torch.stack(((cu - bu / 2) * float(self.width), (cv - bv / 2) * float(self.height),
                             (cu + bu / 2) * float(self.width), (cv + bv / 2) * float(self.height)), dim=1)
 
-    def zoom(self, image, target_size, target_dist, target_fu=None, target_fv=None, image_scale=1.0,
-             scale_mode='bilinear'):
-        boxes = self.zoom_viewport(target_size, target_dist, target_fu, target_fv, image_scale)
+    def zoom(self, image, target_size, target_dist, target_fu=None, target_fv=None, image_scale=1.0, zs=None,
+             centroid_uvs=None, scale_mode='bilinear'):
+        boxes = self.zoom_viewport(target_size, target_dist, target_fu, target_fv, image_scale, zs, centroid_uvs)
         camera_new = self._like(viewport=boxes)
         if image is None:
             return camera_new
@@ -394,11 +398,14 @@ def c2o_coefficients(camera, cube_size):
     t = camera.translation.double()
     R = _rotation64(camera)
     M = torch.cat((R * (cube_size / 2.0), t.unsqueeze(2)), dim=2)          # (N,3,4): l -> p_cam
-    fu, fv, u0, v0 = K[:, 0, 0, None], K[:, 1, 1, None], K[:, 0, 2, None], K[:, 1, 2, None]
+    # pixel = K (3x4) @ [p_cam; 1]: the FULL intrinsic product of the reference (:634), so skew / off-diagonal entries
+    # and a non-trivial third row act exactly as they do there; rows as 4-vectors over (lx, ly, lz, 1)
+    Pm = K[:, :, :3] @ M
+    Pm = torch.cat((Pm[:, :, :3], Pm[:, :, 3:] + K[:, :, 3:]), dim=2)
     vw, vh = (vp[:, 2] - vp[:, 0])[:, None], (vp[:, 3] - vp[:, 1])[:, None]
-    X, Y, Z = M[:, 0], M[:, 1], M[:, 2]
-    a0 = 2.0 / vw * (fu * X + u0 * Z) - (2.0 * vp[:, 0, None] / vw + 1.0) * Z
-    a1 = 2.0 / vh * (fv * Y + v0 * Z) - (2.0 * vp[:, 1, None] / vh + 1.0) * Z
+    X, Y, Z = Pm[:, 0], Pm[:, 1], Pm[:, 2]
+    a0 = 2.0 / vw * X - (2.0 * vp[:, 0, None] / vw + 1.0) * Z
+    a1 = 2.0 / vh * Y - (2.0 * vp[:, 1, None] / vh + 1.0) * Z
     a2 = Z / (2.0 * camera.z_span)
     a2 = torch.cat((a2[:, :3], a2[:, 3:] - ((t[:, 2] - camera.z_span) / (2.0 * camera.z_span))[:, None]), dim=1)
     return torch.cat((a0, a1, a2, Z), dim=1).float()

@@ -96,14 +96,13 @@ class Observation:
         import numpy as np
         from PIL import Image
 
-        from .utils import MyEncoder
         path = Path(path)
         path.mkdir(exist_ok=True, parents=True)
         cam = self.camera.to('cpu')
         camera_json = cam.to_kwargs()
         camera_json['meta'] = self.meta
         with open(path / 'cameras.json', 'w') as f:
-            json.dump(camera_json, f, indent=2, cls=MyEncoder)
+            json.dump(camera_json, f, indent=2, default=lambda o: o.tolist() if torch.is_tensor(o) else str(o))
         color, depth, mask = self.color.cpu(), self.depth.cpu(), self.mask.cpu()
         for i in range(len(self)):
             Image.fromarray((255.0 * color[i].permute(1, 2, 0).numpy()).astype(np.uint8)).save(path / f'{i:04d}.color.png')

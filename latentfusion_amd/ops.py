@@ -499,18 +499,16 @@ class _Conv3x3(torch.autograd.Function):
             wpack = _cached(weight, 'c3f', lambda: pack_conv3x3(weight))
             y, norm = _conv3x3_raw(x, wpack, b, weight.shape[0], he, flags, True)
         ctx.flags, ctx.he = flags, he
-        ctx.weight = weight
-        ctx.x = x if (weight.requires_grad or (bias is not None and bias.requires_grad)) else None
-        ctx.save_for_backward(y, norm) if norm is not None else ctx.save_for_backward(y)
+        need_w = weight.requires_grad or (bias is not None and bias.requires_grad)
+        # everything the backward reads goes through save_for_backward (autograd's version check then catches
+        # in-place edits between forward and backward); None slots are allowed
+        ctx.save_for_backward(y, norm, weight, x if need_w else None)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        saved = ctx.saved_tensors
-        y = saved[0]
-        norm = saved[1] if len(saved) > 1 else None
+        y, norm, w, x_saved = ctx.saved_tensors
         gp = _epilogue_bwd(cl(gy), y, norm, ctx.flags)
-        w = ctx.weight
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             if _wino_ok(gp, w):
@@ -522,7 +520,7 @@ class _Conv3x3(torch.autograd.Function):
                 gx, _ = _conv3x3_raw(gp, wpack_t, None, w.shape[1], ctx.he, 0, False)
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             dims = w.dim() - 2
-            gwt, gb = conv_bwd_weight(ctx.x, gp, dims, w.shape[1], ctx.he)
+            gwt, gb = conv_bwd_weight(x_saved, gp, dims, w.shape[1], ctx.he)
             k = (3,) * dims
             gw = gwt.reshape(*k, w.shape[0], w.shape[1]).permute(dims, dims + 1, *range(dims)).contiguous()
         return gx, gw if ctx.needs_input_grad[1] else None, gb if ctx.needs_input_grad[2] else None, None
@@ -560,22 +558,22 @@ class _Conv3x3Sum16(torch.autograd.Function):
             _req(p, 'part')
             prev = None if y is None else (y, None, _lib.LF_EPI_ADD)
             y, _ = conv3d_c16_wino(cl(p), pf, bias.detach() if (bias is not None and i == 0) else None, he, 0, prev=prev)
-        ctx.he, ctx.widths, ctx.packs, ctx.weight = he, widths, packs, weight
+        ctx.he, ctx.widths, ctx.packs = he, widths, packs
         need_w = weight.requires_grad or (bias is not None and bias.requires_grad)
-        ctx.parts = [cl(p) for p in parts] if need_w else None
+        ctx.save_for_backward(weight, *([cl(p) for p in parts] if need_w else []))
         return y
 
     @staticmethod
     def backward(ctx, gy):
         gy = cl(gy)
-        w = ctx.weight
+        w, *saved_parts = ctx.saved_tensors
         gparts = []
         for i, (_pf, pt) in enumerate(ctx.packs):
             gparts.append(conv3d_c16_wino(gy, pt, None, ctx.he, 0)[0] if ctx.needs_input_grad[3 + i] else None)
         gw = gb = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             cols = []
-            for i, (p, wdt) in enumerate(zip(ctx.parts, ctx.widths)):
+            for i, (p, wdt) in enumerate(zip(saved_parts, ctx.widths)):
                 g_i, gb_i = conv_bwd_weight(p, gy, 3, 16, ctx.he, want_bias=(i == 0))
                 gb = gb_i if i == 0 else gb
                 cols.append(g_i[:, :, :wdt])
@@ -678,18 +676,15 @@ class _Conv1x1(torch.autograd.Function):
         wpack = _cached(weight, 'c1f', lambda: pack_conv1x1(weight.reshape(cout, cin)))
         y = empty_cl((N, cout) + tuple(x.shape[2:]), x.device)
         norm = _conv1x1_raw(x, wpack, bias.detach() if bias is not None else None, N, P, cin, 1, P * cin, 0, cout, y, he, flags)
-        ctx.flags, ctx.he, ctx.weight = flags, he, weight
-        ctx.x = x if (weight.requires_grad or (bias is not None and bias.requires_grad)) else None
-        ctx.save_for_backward(y, norm) if norm is not None else ctx.save_for_backward(y)
+        ctx.flags, ctx.he = flags, he
+        need_w = weight.requires_grad or (bias is not None and bias.requires_grad)
+        ctx.save_for_backward(y, norm, weight, x if need_w else None)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        saved = ctx.saved_tensors
-        y = saved[0]
-        norm = saved[1] if len(saved) > 1 else None
+        y, norm, w, x_saved = ctx.saved_tensors
         gp = _epilogue_bwd(cl(gy), y, norm, ctx.flags)
-        w = ctx.weight
         cout, cin = w.shape[0], w.shape[1]
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
@@ -700,7 +695,7 @@ class _Conv1x1(torch.autograd.Function):
             _conv1x1_raw(gp, wpack_t, None, N, P, cout, 1, P * cout, 0, cin, gx, ctx.he, 0)
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             rows = gp.numel() // cout                                       # channels-last: plain [rows][C] matrices
-            gwt, gb = conv_bwd_weight(ctx.x.permute(0, *range(2, ctx.x.dim()), 1).reshape(rows, cin),
+            gwt, gb = conv_bwd_weight(x_saved.permute(0, *range(2, x_saved.dim()), 1).reshape(rows, cin),
                                       gp.permute(0, *range(2, gp.dim()), 1).reshape(rows, cout), 0, cin, ctx.he)
             gw = gwt.reshape(w.shape)
         return gx, gw if ctx.needs_input_grad[1] else None, gb if ctx.needs_input_grad[2] else None, None
@@ -731,17 +726,16 @@ class _FactorProject(torch.autograd.Function):
             raise NotImplementedError('factor projection needs C % 4 == 0 on the HIP path')
         norm = _conv1x1_raw(x, wpack, bias.detach() if bias is not None else None, N, H * W, C, D,
                             D * H * W * C, H * W * C, cout, y, he, flags)
-        ctx.flags, ctx.he, ctx.weight, ctx.xshape = flags, he, weight, x.shape
-        ctx.x = x if (weight.requires_grad or (bias is not None and bias.requires_grad)) else None
-        ctx.save_for_backward(y, norm)
+        ctx.flags, ctx.he, ctx.xshape = flags, he, x.shape
+        need_w = weight.requires_grad or (bias is not None and bias.requires_grad)
+        ctx.save_for_backward(y, norm, weight, x if need_w else None)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        y, norm = ctx.saved_tensors
+        y, norm, w, x_saved = ctx.saved_tensors
         gp = _epilogue_bwd(cl(gy), y, norm, ctx.flags)
         N, C, D, H, W = ctx.xshape
-        w = ctx.weight
         cout = w.shape[0]
         # gx[n,d,p,c] = he * sum_co gp[n,p,co] * W[co, c*D+d]  == pointwise conv with Cout' = D*C
         wt = _cached(w, 'fpb', lambda: pack_conv1x1(w.reshape(cout, C, D).permute(2, 1, 0).reshape(D * C, cout)))
@@ -752,7 +746,7 @@ class _FactorProject(torch.autograd.Function):
         gw = gb = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             # rows = pixels, K = (c, d) in the reference's order c*D + d: one copy of the volume (training only)
-            xr = ctx.x.permute(0, 3, 4, 1, 2).reshape(N * H * W, C * D)
+            xr = x_saved.permute(0, 3, 4, 1, 2).reshape(N * H * W, C * D)
             gwt, gb = conv_bwd_weight(xr.contiguous(), gp.permute(0, 2, 3, 1).reshape(N * H * W, cout), 0, C * D, ctx.he)
             gw = gwt.reshape(w.shape)
         return gx, gw if ctx.needs_input_grad[1] else None, gb if ctx.needs_input_grad[2] else None
@@ -791,6 +785,210 @@ def lift(x, weight, bias, out_size):
     out = empty_cl((V, c0, out_size, H, W), x.device)
     check(L.lf_lift_unfold(_ptr(tmp), None, _ptr(out), V, P, c0, out_size, _stream()), 'lf_lift_unfold')
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# depth-column composites (renderer) and view reductions (fusers)
+# ---------------------------------------------------------------------------------------------
+class _ColumnSum(torch.autograd.Function):
+    """(N,C,D,H,W) -> (N,C,H,W), sum over the depth axis: the 'sum' projection (recon/models.py:436-437)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        L = _lib.lib()
+        x = cl(_req(x, 'x'))
+        N, C, D, H, W = x.shape
+        y = empty_cl((N, C, H, W), x.device)
+        with _timed('column_sum'):
+            check(L.lf_column_reduce_sum_fwd(_ptr(x), _ptr(y), N, D, H * W, C, _stream()), 'lf_column_reduce_sum_fwd')
+        ctx.xshape = tuple(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        L = _lib.lib()
+        N, C, D, H, W = ctx.xshape
+        g = cl(gy)
+        gx = empty_cl(ctx.xshape, g.device)
+        check(L.lf_column_reduce_sum_bwd(_ptr(g), _ptr(gx), N, D, H * W, C, _stream()), 'lf_column_reduce_sum_bwd')
+        return gx
+
+
+def column_sum(x):
+    return _ColumnSum.apply(x)
+
+
+class _ColumnSoftmax(torch.autograd.Function):
+    """Single-channel logits (N,1,D,H,W) -> (softmax over D (N,1,D,H,W), expected depth sum_d w * linspace(-1,1,D)
+    (N,1,H,W)): Photographer._compute_depth_weights / _depth_from_weight (recon/models.py:378-395)."""
+
+    @staticmethod
+    def forward(ctx, logits):
+        L = _lib.lib()
+        lg = _req(logits, 'logits').contiguous()
+        N, one, D, H, W = lg.shape
+        if one != 1:
+            raise ValueError('column_softmax expects single-channel logits')
+        w = torch.empty_like(lg)
+        zd = torch.empty(N, 1, H, W, device=lg.device, dtype=torch.float32)
+        with _timed('column_softmax'):
+            check(L.lf_column_softmax_fwd(_ptr(lg), _ptr(w), _ptr(zd), N, D, H * W, _stream()), 'lf_column_softmax_fwd')
+        ctx.save_for_backward(w)
+        ctx.set_materialize_grads(False)
+        return w, zd
+
+    @staticmethod
+    def backward(ctx, gw, gzd):
+        L = _lib.lib()
+        w, = ctx.saved_tensors
+        N, _, D, H, W = w.shape
+        if gw is None and gzd is None:
+            return None
+        gw = gw.contiguous() if gw is not None else None
+        gzd = gzd.contiguous() if gzd is not None else None
+        gl = torch.empty_like(w)
+        check(L.lf_column_softmax_bwd(_ptr(w), _ptr(gw) if gw is not None else None, _ptr(gzd) if gzd is not None else None,
+                                      _ptr(gl), N, D, H * W, _stream()), 'lf_column_softmax_bwd')
+        return gl
+
+
+def column_softmax(logits):
+    return _ColumnSoftmax.apply(logits)
+
+
+class _ColumnScale(torch.autograd.Function):
+    """z (N,C,D,H,W) * w (N,1,D,H,W): the occlusion weighting z * depth_weights_resized (recon/models.py:427-430)."""
+
+    @staticmethod
+    def forward(ctx, z, w):
+        L = _lib.lib()
+        z = cl(_req(z, 'z'))
+        w = _req(w, 'w').contiguous()
+        N, C, D, H, W = z.shape
+        if tuple(w.shape) != (N, 1, D, H, W) or C % 4:
+            raise ValueError('column_scale: w must be (N,1,D,H,W) and C a multiple of 4')
+        out = empty_cl(z.shape, z.device)
+        check(L.lf_column_scale_fwd(_ptr(z), _ptr(w), _ptr(out), N * D * H * W, C, _stream()), 'lf_column_scale_fwd')
+        ctx.save_for_backward(z, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        L = _lib.lib()
+        z, w = ctx.saved_tensors
+        N, C, D, H, W = z.shape
+        g = cl(gout)
+        gz = empty_cl(z.shape, z.device) if ctx.needs_input_grad[0] else None
+        gw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
+        if gz is None and gw is None:
+            return None, None
+        check(L.lf_column_scale_bwd(_ptr(g), _ptr(z), _ptr(w), _ptr(gz) if gz is not None else None,
+                                    _ptr(gw) if gw is not None else None, N * D * H * W, C, _stream()), 'lf_column_scale_bwd')
+        return gz, gw
+
+
+def column_scale(z, w):
+    return _ColumnScale.apply(z, w)
+
+
+def _dense_views(z):
+    """(B,V,...) -> (B*V,...) with every view dense in ONE common element order (channels-last when the per-view
+    tensors are 4-/5-D, which is what the encoder produces: no copy then)."""
+    zz = z.reshape(z.shape[0] * z.shape[1], *z.shape[2:])
+    return cl(zz) if zz.dim() in (4, 5) else zz.contiguous()
+
+
+FUSE_KINDS = {'mean': _lib.LF_FUSE_MEAN, 'max': _lib.LF_FUSE_MAX, 'abs_max': _lib.LF_FUSE_ABSMAX, 'median': _lib.LF_FUSE_MEDIAN}
+
+
+class _FuseViews(torch.autograd.Function):
+    """PoolFuser reductions over the view axis: z (B,V,...) -> (B,1,...)  (recon/fusion.py:45-57)."""
+
+    @staticmethod
+    def forward(ctx, z, kind):
+        L = _lib.lib()
+        _req(z, 'z')
+        B, V = z.shape[0], z.shape[1]
+        zz = _dense_views(z)
+        n = zz[0].numel()
+        out = torch.empty_like(zz[:B])
+        need_idx = kind != _lib.LF_FUSE_MEAN and ctx.needs_input_grad[0]
+        idx = torch.empty(B, n, device=z.device, dtype=torch.int32) if need_idx else None
+        with _timed('fuse_views'):
+            for b in range(B):
+                check(L.lf_fuse_views_fwd(_ptr(zz[b * V]), _ptr(out[b]), _ptr(idx[b]) if idx is not None else None, kind, V, n, n,
+                                          _stream()), 'lf_fuse_views_fwd')
+        ctx.meta = (kind, B, V, n, tuple(zz.shape), tuple(z.shape))
+        if idx is not None:
+            ctx.save_for_backward(idx)
+        return out.unsqueeze(1)
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        kind, B, V, n, zshape, orig = ctx.meta
+        idx = ctx.saved_tensors[0] if ctx.saved_tensors else None
+        g = g.squeeze(1)
+        g = cl(g) if g.dim() in (4, 5) else g.contiguous()
+        gz = torch.empty(zshape, device=g.device, dtype=torch.float32,
+                         memory_format=(torch.channels_last_3d if len(zshape) == 5 else torch.channels_last if len(zshape) == 4
+                                        else torch.contiguous_format))
+        for b in range(B):
+            check(L.lf_fuse_views_bwd(_ptr(g[b]), _ptr(idx[b]) if idx is not None else None, _ptr(gz[b * V]), kind, V, n, n,
+                                      _stream()), 'lf_fuse_views_bwd')
+        return gz.view(orig), None
+
+
+def fuse_views(z, pool_type):
+    if pool_type not in FUSE_KINDS:
+        raise ValueError(f'Unknown pool_type value {pool_type}')
+    return _FuseViews.apply(z, FUSE_KINDS[pool_type])
+
+
+class _FuseBlend(torch.autograd.Function):
+    """BlendFuser.forward (recon/fusion.py:139-148): z (B,V,C,D,H,W), logits (B,V,1,D,H,W) ->
+    (sum_v z * softmax_v(logits) (B,1,C,D,H,W), weights (B,V,1,D,H,W))."""
+
+    @staticmethod
+    def forward(ctx, z, logits):
+        L = _lib.lib()
+        _req(z, 'z'), _req(logits, 'logits')
+        B, V, C = z.shape[:3]
+        zz = _dense_views(z)                                    # (B*V,C,D,H,W) channels-last
+        lg = logits.reshape(B * V, -1).contiguous()             # (B*V, rows)
+        rows = lg.shape[1]
+        if zz[0].numel() != rows * C or C % 4:
+            raise ValueError('fuse_blend: shapes of z and logits do not match / C % 4 != 0')
+        w = torch.empty_like(lg)
+        out = torch.empty_like(zz[:B])
+        with _timed('fuse_blend'):
+            for b in range(B):
+                check(L.lf_fuse_blend_fwd(_ptr(zz[b * V]), _ptr(lg[b * V]), _ptr(w[b * V]), _ptr(out[b]), V, rows, C, rows * C, rows,
+                                          _stream()), 'lf_fuse_blend_fwd')
+        ctx.save_for_backward(zz, w)
+        ctx.meta = (B, V, C, rows, tuple(z.shape), tuple(logits.shape))
+        ctx.mark_non_differentiable(w)
+        return out.unsqueeze(1), w.view(logits.shape)
+
+    @staticmethod
+    def backward(ctx, g, _gw):
+        L = _lib.lib()
+        zz, w = ctx.saved_tensors
+        B, V, C, rows, zshape, lshape = ctx.meta
+        g = cl(g.squeeze(1))
+        gz = torch.empty_like(zz) if ctx.needs_input_grad[0] else None
+        gl = torch.empty_like(w) if ctx.needs_input_grad[1] else None
+        if gz is None and gl is None:
+            return None, None
+        for b in range(B):
+            check(L.lf_fuse_blend_bwd(_ptr(g[b]), _ptr(zz[b * V]), _ptr(w[b * V]), _ptr(gz[b * V]) if gz is not None else None,
+                                      _ptr(gl[b * V]) if gl is not None else None, V, rows, C, rows * C, rows, _stream()),
+                  'lf_fuse_blend_bwd')
+        return (gz.view(zshape) if gz is not None else None), (gl.view(lshape) if gl is not None else None)
+
+
+def fuse_blend(z, logits):
+    return _FuseBlend.apply(z, logits)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -118,30 +118,48 @@ class MetropolisPoseEstimator(PoseEstimator):
         super().__init__(**kwargs)
         self.num_samples, self.num_iters = num_samples, num_iters
         self.translation_std, self.quaternion_std = translation_std, quaternion_std
+        self.replay_draws = None        # tests: list of recorded draws consumed in order (randn t, randn q, rand)
+
+    def _draw(self, kind, like):
+        """The three random draws of one step, in the reference's order: randn_like(translation),
+        randn_like(log_quaternion) (pu.perturb_camera, pose/utils.py:13-17), rand_like(loss) (:288)."""
+        if self.replay_draws is not None:
+            return self.replay_draws.pop(0).to(like.device)
+        return torch.randn_like(like) if kind == 'randn' else torch.rand_like(like)
 
     def _estimate(self, z_obj, target_obs, **kwargs):
-        camera_init = kwargs['camera'] if 'camera' in kwargs else self.initial_pose(target_obs)
-        camera = pu.sample_cameras_with_estimate(self.num_samples, camera_init).to(self.device)
-        error = torch.full((self.num_samples,), 100.0, device=self.device)
+        if kwargs.get('cameras', None) is not None:             # given sample cameras (the reference always samples)
+            camera_init = camera = kwargs['cameras']
+            camera = camera.to(self.device)
+        else:
+            camera_init = kwargs['camera'] if 'camera' in kwargs else self.initial_pose(target_obs)
+            camera = pu.sample_cameras_with_estimate(self.num_samples, camera_init).to(self.device)
+        error = torch.full((len(camera),), 100.0, device=self.device)
         temp_weight = 1.0 / camera_init.translation[:, -1].mean().item()
         sched = ExponentialScheduler(temp_weight * 0.1, temp_weight * 0.005, num_steps=self.num_iters)
         target_obs = target_obs.to(self.device)
         ranking, history = [], []
+        self.accept_history = []
         for step in range(self.num_iters):
-            camera, error, _ = self._refine_pose(z_obj, camera.clone(), error.clone(), target_obs, sched.get(step))
+            camera, error, n_acc = self._refine_pose(z_obj, camera.clone(), error.clone(), target_obs, sched.get(step))
+            self.accept_history.append(n_acc)
             if self._track_best_items(ranking, step, list(camera), error.tolist()) > 0:
                 history.append((error, camera.clone().to('cpu')))
         cameras = Camera.cat([c for c, _, _ in ranking])
         return (cameras, history) if self.return_camera_history else cameras
 
     def _refine_pose(self, z_obj, prev_camera, prev_error, target_obs, temperature=1.0):
-        camera = pu.perturb_camera(prev_camera, self.translation_std, self.quaternion_std)
+        camera = prev_camera.clone()
+        camera.translation = camera.translation + self._draw('randn', camera.translation) * self.translation_std
+        camera.log_quaternion = camera.log_quaternion + self._draw('randn', camera.log_quaternion) * self.quaternion_std
         with torch.no_grad():
+            # the reference evaluates the latent term unconditionally, the target code under the perturbed,
+            # un-zoomed cameras (estimation.py:279)
             z_target_latent = self.model.compute_latent_code(target_obs, camera)
             zd, zl, z_lat, z_camera = self._render_observation(z_obj, camera)
             ld = self.loss_func(target_obs, zd, zl, z_camera, z_pred_latent=z_lat, z_target_latent=z_target_latent)
             loss = sum(weigh_losses(ld, self.loss_weights).values())
-        accept = torch.exp((prev_error - loss) / temperature) > torch.rand_like(loss)
+        accept = torch.exp((prev_error - loss) / temperature) > self._draw('rand', loss)
         camera[~accept] = prev_camera[~accept]
         loss[~accept] = prev_error[~accept]
         return camera, loss, int(accept.sum().item())
@@ -392,6 +410,10 @@ class GradientPoseEstimator(PoseEstimator):
         from ..engine import RenderLoopEngine
         ph = getattr(self.model, 'photographer', None)
         if ph is None or not RenderLoopEngine.supports(ph, self.loss_weights):
+            return None
+        # a scheduled term the fused loss does not evaluate (e.g. [loss_schedules.latent] with loss_weights.latent = 0)
+        # must not be dropped silently: the reference applies every scheduled weight (estimation.py:612-617)
+        if any(k not in RenderLoopEngine.LOSS_KEYS for k in self.loss_schedules):
             return None
         return RenderLoopEngine(ph, z_obj, target_obs, self.loss_weights, conv_mode=self.conv_mode)
 

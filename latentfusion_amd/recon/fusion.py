@@ -39,6 +39,12 @@ def absolute_max_pool(tensor, dim):
 
 
 def pool_tensor(tensor, pool_type, dim=0):
+    """Device tensors pooled over the view axis of a (B,V,...) stack go through lf_fuse_views_fwd (no ATen on the
+    product path).  Host tensors -- only the world-size-2 gloo tests of the sharding logic (tests/test_parallel.py)
+    ever pass them -- and other axes use the expressions below."""
+    if tensor.is_cuda and dim == 1 and tensor.dim() >= 3:
+        from .. import ops
+        return ops.fuse_views(tensor, pool_type)
     if pool_type == 'max':
         return tensor.max(dim=dim, keepdim=True)[0]
     if pool_type == 'abs_max':
@@ -100,16 +106,20 @@ class BlendFuser(_ArgsFuser):
     def _args(self):
         return {'block_config': self.block_config, 'in_channels': self.in_channels, 'cube_size': self.cube_size}
 
-    def compute_blend_weights(self, z_cam, camera):
+    def compute_blend_logits(self, z_cam, camera):
         V = z_cam.shape[1]
         z_cam = bv2b(z_cam)
         w = self.unet(torch.cat((z_cam, utils.get_normalized_voxel_depth(z_cam)), dim=1))
-        w = b2bv(self.transform_block(w, camera), V)
-        return torch.softmax(w, dim=1)
+        return b2bv(self.transform_block(w, camera), V)
+
+    def compute_blend_weights(self, z_cam, camera):
+        return torch.softmax(self.compute_blend_logits(z_cam, camera), dim=1)
 
     def forward(self, z_obj, z_cam_mid, z_obj_mid, camera):
-        w = self.compute_blend_weights(z_cam_mid[-1], camera)
-        return torch.sum(z_obj * w, dim=1, keepdim=True), {'blend_weights': w.squeeze(2)}
+        # softmax over the views and the weighted sum in one pass over the V volumes (lf_fuse_blend_fwd)
+        from .. import ops
+        out, w = ops.fuse_blend(z_obj, self.compute_blend_logits(z_cam_mid[-1], camera))
+        return out, {'blend_weights': w.squeeze(2)}
 
 
 class ConvGRUCell(nn.Module):

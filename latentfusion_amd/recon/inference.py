@@ -28,9 +28,13 @@ class LatentFusionModel:
         return self.train(False)
 
     def train(self, train):
+        """eval() also freezes the parameters (requires_grad False): the pose estimators differentiate w.r.t. the
+        camera only, and the reference's backward through this facade accumulates weight gradients nobody reads
+         -- here those kernels are simply not launched.  train(True) re-enables them."""
         for m in (self.sculptor, self.photographer, self.fuser, self.generator):
             if m is not None:
                 m.train(train)
+                m.requires_grad_(bool(train))
         return self
 
     def zoom_observation(self, observation):

@@ -12,6 +12,7 @@ from ..modules.blocks import OutputBlock2d, OutputBlock3d, create_blocks
 from ..modules.geometry import (Camera, CameraToObjectTransform, FactorProjection2d3d, FactorProjection3d2d,
                                 ObjectToCameraTransform, TileProjection2d3d)
 from ..three.batchview import b2bv, bv2b
+from .. import ops
 from . import fusion
 from .utils import get_normalized_voxel_depth
 
@@ -31,8 +32,8 @@ def _get_activation(kind, relu_slope=0.2):
 
 def load_models(checkpoint, kwargs=None, device=None, return_generator=False):
     """Rebuilds (sculptor, fuser, photographer, discriminator[, generator]) from a training
-    checkpoint (reference :32-70).  The discriminator / IBR generator are training-only and are
-    returned as None."""
+    checkpoint (reference :32-70).  The discriminator is training-only (its module is out of scope) and is
+    returned as None; the IBR generator (a UNet2d) is rebuilt when the checkpoint carries one."""
     if kwargs is None:
         kwargs = checkpoint['args']
     sck = checkpoint['modules']['sculptor']
@@ -47,7 +48,10 @@ def load_models(checkpoint, kwargs=None, device=None, return_generator=False):
     photographer = Photographer.from_checkpoint(pck).to(device)
     fuser = fusion.from_checkpoint(checkpoint['modules']['fuser']).to(device)
     if return_generator:
-        return sculptor, fuser, photographer, None, None
+        generator = None
+        if 'generator' in checkpoint.get('modules', {}):                    # reference :63-66
+            generator = unet.UNet2d.from_checkpoint(checkpoint['modules']['generator']).to(device)
+        return sculptor, fuser, photographer, None, generator
     return sculptor, fuser, photographer, None
 
 
@@ -152,8 +156,6 @@ class Photographer(_Checkpointed):
                  occlusion_config=False, in_views=1, skip_connections=False, relu_slope=0.2, cube_size=1.0,
                  predict_color=False, predict_depth=True, predict_mask=True, scale_mode='bilinear', **kwargs):
         super().__init__()
-        if skip_connections:
-            raise NotImplementedError('skip_connections are not used by any shipped recipe')
         self.image_config, self.camera_config, self.object_config = image_config, camera_config, object_config
         self.occlusion_config, self.projection_type = occlusion_config, projection_type
         self.predict_color, self.predict_depth, self.predict_mask = predict_color, predict_depth, predict_mask
@@ -166,11 +168,19 @@ class Photographer(_Checkpointed):
                                skip_connections=skip_connections, cube_size=cube_size, predict_color=predict_color,
                                predict_depth=predict_depth, predict_mask=predict_mask, scale_mode=scale_mode)
 
-        self.object_blocks = (create_blocks(object_config, EqualizedConv3d, 2.0, in_views=in_views, scale_mode=scale_mode)
+        # skip_connections (reference :296-313): object blocks from the second one and "all" camera blocks take the
+        # matching encoder activations as extra input channels.  Quirk Q20: the camera blocks are created with
+        # skip_connect_start=True (== 1), so camera block 0 gets NO extra channels allocated although forward
+        # concatenates them for every camera block -- the reference cannot run forward() with skip_connections=True
+        # (no shipped recipe sets it).  Construction / state_dict are reproduced exactly; forward concatenates like
+        # the reference and fails on the same channel mismatch.
+        self.object_blocks = (create_blocks(object_config, EqualizedConv3d, 2.0, in_views=in_views,
+                                            skip_connections=skip_connections, scale_mode=scale_mode)
                               if object_config else nn.ModuleList())
         self.transform_block = ObjectToCameraTransform(cube_size)
         self.occlusion_module = (unet.UNet3d(object_config[-1] + 1, 1, occlusion_config) if occlusion_config else None)
-        self.camera_blocks = create_blocks(camera_config, EqualizedConv3d, 2.0, scale_mode=scale_mode)
+        self.camera_blocks = create_blocks(camera_config, EqualizedConv3d, 2.0, skip_connections=skip_connections,
+                                           skip_connect_start=True, skip_connection_views=in_views, scale_mode=scale_mode)
         self.projection_block = (FactorProjection3d2d(camera_config[-1], image_config[0][0], out_size=self.camera_out_size)
                                  if projection_type == 'factor' else None)
         self.image_decoder = unet.UNet2d(None, None, image_config)
@@ -195,26 +205,44 @@ class Photographer(_Checkpointed):
     def forward(self, z_obj, camera, z_cam_mid=None, z_obj_mid=None, return_latent=False):
         if z_obj.shape[0] != len(camera):
             raise ValueError(f'batch dimension of z_obj and camera much match. ({z_obj.shape[0]} != {len(camera)})')
+        if self.skip_connections and (z_cam_mid is None or z_obj_mid is None):
+            raise ValueError('z_cam_intermediate / z_obj_intermediate required for skip connections.')
+        if self.skip_connections:                                     # reference :407-409
+            z_cam_mid = [self.transform_block(zc, camera) for zc in z_cam_mid]
         z = z_obj
-        for block in self.object_blocks:
-            z = block(z)
+        for block_id, block in enumerate(self.object_blocks):
+            if self.skip_connections and block_id >= 1:
+                z = torch.cat((z, z_obj_mid[-block_id - 1]), dim=1)
+            z = self._checked(block, z)
         z = self.transform_block(z, camera)
-        for block in self.camera_blocks:
-            z = block(z)
+        for block_id, block in enumerate(self.camera_blocks):
+            if self.skip_connections:
+                z = torch.cat((z, z_cam_mid[-block_id - 1]), dim=1)
+            z = self._checked(block, z)
         z_depth = None
         if self.occlusion_module is not None:                 # reference :378-395,427-430
             logits = self.occlusion_module(torch.cat((z, get_normalized_voxel_depth(z)), dim=1))
-            w = torch.softmax(logits, dim=2)
-            w_resized = torch.softmax(nn.functional.interpolate(logits, z.size(-1)), dim=2)
-            z_depth = (get_normalized_voxel_depth(w) * w).sum(dim=2)
-            z = z * w_resized
+            # softmax over the depth column + expected depth in one pass (lf_column_softmax_fwd)
+            w, z_depth = ops.column_softmax(logits)
+            if tuple(logits.shape[-3:]) != tuple(z.shape[-3:]):
+                # occlusion U-Net at another resolution: nearest resize of the logits first (reference :385)
+                w = ops.column_softmax(nn.functional.interpolate(logits, z.size(-1)))[0]
+            z = ops.column_scale(z, w)
         if self.projection_type == 'sum':
-            z = z.sum(dim=2)
+            z = ops.column_sum(z)
         elif self.projection_type == 'factor':
             z = self.projection_block(z)
         y = self.image_decoder(z)
         y = torch.cat([ob(y) for ob in self.output_blocks], dim=1)
         return y, (z if return_latent else None), z_depth
+
+    @staticmethod
+    def _checked(block, z):
+        want = block.conv1.module.weight.shape[1]
+        if z.shape[1] != want:          # the message F.conv3d gives in the reference (Q20)
+            raise RuntimeError(f'Given groups=1, weight of size {list(block.conv1.module.weight.shape)}, expected input'
+                               f'{list(z.shape)} to have {want} channels, but got {z.shape[1]} channels instead')
+        return block(z)
 
     def interpret_logits(self, logits, apply_mask=False):
         """logits -> {'depth','mask',(+'color'), '*_logits'} (reference :455-484)."""

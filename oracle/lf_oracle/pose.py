@@ -3,6 +3,7 @@
   default_pose_loss            pose/estimation.py:70-118, pose/utils.py:81-117
   GradientPoseEstimator loop   pose/estimation.py:500-713
   CrossEntropy refine step     pose/estimation.py:376-410 (GMM sampling is injected, not restated)
+  Metropolis refine / loop     pose/estimation.py:219-295 (random draws are injected, not restated)
   camera sampling              pose/utils.py:28-45
 """
 import copy
@@ -211,6 +212,52 @@ def ce_refine(model, z_obj, target, cams, loss_weights, num_elites, sample_flipp
         loss = weigh(ld, loss_weights)
     order = torch.argsort(loss)
     return loss, order, order[:num_elites], cams
+
+
+def metropolis_refine(model, z_obj, target, prev_cam, prev_error, noise_t, noise_q, thresholds, temperature,
+                      loss_weights, translation_std, quaternion_std):
+    """MetropolisPoseEstimator._refine_pose (estimation.py:277-295) with its three random draws injected:
+    noise_t / noise_q are the randn_like draws of pu.perturb_camera (pose/utils.py:13-17, translation first),
+    thresholds the rand_like draw of the acceptance test.  The latent term is always evaluated: the target code is
+    computed under the PERTURBED, un-zoomed cameras (estimation.py:279), the prediction under their zoom (base
+    _render_observation :207-216).  Returns (cameras, errors, accept mask, raw losses before accept/reject)."""
+    cam = prev_cam.like(t=prev_cam.t + noise_t * translation_std, log_q=prev_cam.log_q + noise_q * quaternion_std)
+    with torch.no_grad():
+        z_target_latent = model.compute_latent_code(target, cam)
+        zc = cam.zoom(None, model.input_size, model.camera_dist)
+        y, lat = model.render_latent_object(z_obj, zc, apply_mask=True)
+        z_depth = cam.denormalize_depth(y['depth'].squeeze(0)) * y['mask'].squeeze(0)
+        ld = pose_loss(target, z_depth, y['mask_logits'].squeeze(0), zc)
+        ld['latent'] = latent_loss(lat, z_target_latent)
+        raw = weigh(ld, loss_weights)
+    accept = torch.exp((prev_error - raw) / temperature) > thresholds
+    keep = ~accept
+    loss = torch.where(keep, prev_error, raw)
+    out = cam.like(t=torch.where(keep[:, None], prev_cam.t, cam.t), log_q=torch.where(keep[:, None], prev_cam.log_q, cam.log_q),
+                   viewport=torch.where(keep[:, None], prev_cam.viewport, cam.viewport))
+    return out, loss, accept, raw
+
+
+def metropolis_estimate(model, z_obj, target, init_cams, draws, num_iters, ranking_size, loss_weights,
+                        translation_std, quaternion_std):
+    """MetropolisPoseEstimator._estimate (estimation.py:237-275) from given initial sample cameras; `draws[k]` =
+    (noise_t, noise_q, thresholds) of step k.  Temperature: ExponentialScheduler(0.1 w, 0.005 w), w = 1 / mean t_z."""
+    cam = init_cams.clone()
+    error = torch.full((len(cam),), 100.0)
+    w = 1.0 / init_cams.t[:, -1].mean().item()
+    sched = ExponentialScheduler(w * 0.1, w * 0.005, num_steps=num_iters)
+    ranking, trace = [], []
+    for step in range(num_iters):
+        T = sched.get(step)
+        nt, nq, th = draws[step]
+        cam, error, accept, raw = metropolis_refine(model, z_obj, target, cam, error, nt, nq, th, T, loss_weights,
+                                                    translation_std, quaternion_std)
+        ranking.extend((cam[i], error[i].item(), step) for i in range(len(cam)))
+        ranking.sort(key=lambda r: r[1])
+        del ranking[ranking_size:]
+        trace.append({'temperature': T, 'error': error.clone(), 'accept': accept.clone(), 'raw': raw.clone(),
+                      't': cam.t.clone(), 'log_q': cam.log_q.clone()})
+    return camlib.cat([r[0] for r in ranking]), trace, ranking
 
 
 class ExponentialScheduler:

@@ -667,12 +667,244 @@ def g18_training_prep(lf):
     save('g18_training_prep', {'batch_views': one, 'out': res, 'samplers': samp})
 
 
+def g19_metropolis(lf):
+    """MetropolisPoseEstimator (pose/estimation.py:219-295): four steps of the loop of `_estimate` driven through the
+    reference's own `_refine_pose` / `_track_best_items`, with every random draw (the two randn_like of
+    pu.perturb_camera, the rand_like of the acceptance test) recorded so that the oracle and the HIP path can replay
+    them.  `_estimate` itself is not callable here (`initial_pose` needs skimage), so its loop body (:257-270) is
+    driven from given sample cameras.  Model / object / target (with its colour frame: the latent term needs it) are those of g12_latent_code (same seeds)."""
+    from latentfusion.pose import estimation, utils as pu
+    from latentfusion.utils import ExponentialScheduler
+    S, C, V, N, K = 16, 8, 4, 5, 6
+    model, cks, dist = _model(lf, S, C, 'gru', seed=60)
+    ref_obs = synth_obs(lf, V, seed=61)
+    target = synth_obs(lf, 1, seed=62)
+    target.color = torch.round(target.color * 255.0) / 255.0          # 8-bit colours, as stored by g12
+    z_obj = model.build_latent_object(ref_obs)
+    g12 = torch.load(os.path.join(OUT, 'g12_latent_code.pt'), weights_only=False)
+    assert torch.equal(g12['z_obj'], z_obj), 'g19 must share the model / object / target of g12_latent_code'
+    weights = {'depth': 1.0, 'ov_depth': 0.3, 'iou': 0.1, 'mask': 0.2, 'latent': 0.5}
+    est = estimation.MetropolisPoseEstimator(model=model, num_samples=N, num_iters=K, ranking_size=3, loss_weights=weights,
+                                             translation_std=0.004, quaternion_std=3.0 / 180.0 * math.pi)
+    torch.manual_seed(25)
+    camera = pu.sample_cameras_with_estimate(N, target.camera)
+    init = cam_dict(camera)
+    error = torch.full((N,), 100.0)
+    temp_weight = 1.0 / target.camera.translation[:, -1].mean().item()
+    sched = ExponentialScheduler(temp_weight * 0.1, temp_weight * 0.005, num_steps=K)
+    log = []
+    real_randn, real_rand = torch.randn_like, torch.rand_like
+
+    def randn_like(t, *a, **k):
+        r = real_randn(t, *a, **k)
+        log.append(('randn', r.clone()))
+        return r
+
+    def rand_like(t, *a, **k):
+        r = real_rand(t, *a, **k)
+        log.append(('rand', r.clone()))
+        return r
+    steps, ranking = [], []
+    torch.manual_seed(26)
+    torch.randn_like, torch.rand_like = randn_like, rand_like
+    try:
+        for step in range(K):
+            T = sched.get(step)
+            del log[:]
+            with torch.no_grad():
+                camera, error, n_acc = est._refine_pose(z_obj, camera.clone(), error.clone(), target_obs=target, temperature=T)
+            kinds = [k for k, _ in log]
+            assert kinds == ['randn', 'randn', 'rand'], kinds
+            est._track_best_items(ranking, step, camera, error)
+            steps.append({'temperature': T, 'noise_t': log[0][1], 'noise_q': log[1][1], 'thresholds': log[2][1],
+                          'error': error.clone(), 'num_accepted': n_acc, 't': camera.translation.clone(),
+                          'log_q': camera.log_quaternion.clone()})
+    finally:
+        torch.randn_like, torch.rand_like = real_randn, real_rand
+    print('g19 accepted per step:', [s_['num_accepted'] for s_ in steps])
+    save('g19_metropolis', {'model_fixture': 'g12_latent_code', 'weights': weights, 'num_samples': N, 'num_iters': K,
+                            'ranking_size': 3, 'translation_std': 0.004, 'quaternion_std': 3.0 / 180.0 * math.pi,
+                            'init': init, 'steps': steps,
+                            'ranking_error': torch.tensor([float(e) for _, e, _ in ranking]),
+                            'ranking_step': torch.tensor([s_ for _, _, s_ in ranking]),
+                            'ranking_t': torch.cat([c.translation for c, _, _ in ranking]),
+                            'ranking_log_q': torch.cat([c.log_quaternion for c, _, _ in ranking])})
+
+
+def g20_released_width(lf):
+    """BASELINE cfg 3 at released WIDTH: the structure of tools/train/train.sh:28-66 with the resolution scaled down
+    (64^2 images, 16^3 volume) but 64-96 channel 2-D and 3-D blocks, i.e. the layers that take the wide
+    (Winograd-GEMM) kernels on the HIP path.  Pins: encode, decode + camera gradients, the pose loss + its camera
+    gradients (what RenderLoopEngine computes), and one cross-entropy evaluation (flip augmentation, loss order).
+    The target frame is g7_adam_trace's (same generator and seed), not stored again."""
+    from latentfusion.recon.models import Sculptor, Photographer
+    from latentfusion.recon import fusion
+    from latentfusion.recon.inference import LatentFusionModel
+    from latentfusion.pose import estimation, utils as pu
+    from latentfusion.modules.geometry import Camera
+    torch.manual_seed(130)
+    S_in = 64
+    sc = Sculptor(in_size=S_in, image_config=[[64, 'D', 64, 'D', 96], [96, 64]], camera_config=[8, 64],
+                  object_config=[64, 64], projection_type='factor', input_color=True, input_depth=False, input_mask=True,
+                  scale_mode='nearest').eval()
+    S = sc.out_size
+    ph = Photographer(in_size=S, image_config=[[64, 'D', 96], [96, 'U', 64, 'U', 64, 'U', 64]], camera_config=[64, 64],
+                      object_config=[], projection_type='factor', predict_depth=True, predict_mask=True,
+                      scale_mode='nearest').eval()
+    fu = fusion.get_fuser('pool:mean', 64, 1.0).eval()
+    for m in (sc, ph):
+        for k, p in m.named_parameters():
+            if k.endswith('bias'):
+                p.data.normal_(0, 0.1)
+    assert S == 16 and ph.out_size == S_in, (S, ph.out_size)
+    dist = lf.recon.utils.optimal_camera_dist(615.4991, S_in, 0.5, slack=0.5)
+    model = LatentFusionModel(sc, fu, ph, dist, 'cpu')
+    ref_obs = synth_obs(lf, 3, seed=131)
+    pre = model.preprocess_observation(ref_obs)
+    z_obj = model.build_latent_object(ref_obs)
+    # decode + camera gradients of random functionals of the logits
+    cam = rand_cameras(lf, 3, zoomed_size=S_in, dist=dist, seed=132)
+    for name in ('log_quaternion', 'translation', 'viewport'):
+        setattr(cam, name, getattr(cam, name).detach().requires_grad_(True))
+    y, lat, _ = ph.decode(z_obj, cam, return_latent=True, apply_mask=True)
+    g = torch.Generator().manual_seed(133)
+    wd = torch.randn(y['depth_logits'].shape, generator=g)
+    wm = torch.randn(y['mask_logits'].shape, generator=g)
+    ((y['depth_logits'] * wd).sum() + (y['mask_logits'] * wm).sum()).backward()
+    out = {'sculptor': ck(sc), 'fuser': ck(fu), 'photographer': ck(ph), 'camera_dist': dist,
+           'obs_pre': {'color': pre.color.clone(), 'depth': pre.depth.clone(), 'mask': pre.mask.clone(), 'cam': cam_dict(pre.camera)},
+           'z_obj': z_obj.clone(), 'cam': cam_dict(cam), 'wd': wd, 'wm': wm,
+           'y': {k: v.detach().clone() for k, v in y.items()}, 'latent': lat.detach().clone(),
+           'g_log_q': cam.log_quaternion.grad.clone(), 'g_t': cam.translation.grad.clone(), 'g_viewport': cam.viewport.grad.clone()}
+    # pose loss of N samples around the target pose + gradients of the mean weighted loss (estimation.py:596-617)
+    target = synth_obs(lf, 1, seed=22)
+    g7 = torch.load(os.path.join(OUT, 'g7_adam_trace.pt'), weights_only=False)
+    assert torch.equal(g7['target']['depth'], target.depth), 'g20 reuses the target frame of g7_adam_trace'
+    torch.manual_seed(134)
+    init = pu.sample_cameras_with_estimate(4, target.camera)
+    zc = init.zoom(None, model.input_size, model.camera_dist)
+    for name in ('log_quaternion', 'translation', 'viewport'):
+        setattr(zc, name, getattr(zc, name).detach().requires_grad_(True))
+    weights = {'depth': 1.0, 'ov_depth': 0.3, 'iou': 0.1, 'mask': 0.2}
+    pred, _ = model.render_latent_object(z_obj, zc, return_latent=True)
+    ld = estimation.default_pose_loss(target, zc.denormalize_depth(pred['depth'].squeeze(0)), pred['mask_logits'].squeeze(0), zc)
+    total = sum(weights[k] * v for k, v in ld.items())
+    total.mean().backward()
+    out['loss'] = {'init': cam_dict(init), 'zoomed': cam_dict(zc), 'weights': weights,
+                   'components': {k: v.detach().clone() for k, v in ld.items()}, 'total': total.detach().clone(),
+                   'g_log_q': zc.log_quaternion.grad.clone(), 'g_t': zc.translation.grad.clone(),
+                   'g_viewport': zc.viewport.grad.clone()}
+    # one cross-entropy evaluation with the linemod preset's weights (configs/cross_entropy_linemod.toml) + a mask term
+    torch.manual_seed(135)
+    cams = pu.sample_cameras_with_estimate(6, target.camera, hemisphere=True, upright=True)
+    ce = estimation.CrossEntropyPoseEstimator(
+        model=model, num_samples=24, num_elites=8, num_iters=1, num_gmm_components=2, learning_rate=0.9, sample_flipped=True,
+        ranking_size=4, loss_weights={'depth': 1.0, 'ov_depth': 0.0, 'iou': 0.0, 'mask': 0.0})
+    allc = Camera.cat([cams, pu.flip_camera(cams, axis=(0.0, 0.0, 1.0)), pu.flip_camera(cams, axis=(0.0, 1.0, 0.0)),
+                       pu.flip_camera(cams, axis=(1.0, 0.0, 0.0))])
+    with torch.no_grad():                                   # the body of _refine_pose (estimation.py:382-400)
+        zd, zl, _, zcam = ce._render_observation(z_obj, allc)
+        ld2 = ce.loss_func(target, zd, zl, zcam)
+        loss = sum(estimation.weigh_losses(ld2, ce.loss_weights).values())
+    # ... and through _refine_pose itself with the sampler stubbed: elites come back sorted by the same losses
+    ce._sample_poses = lambda gmm, n: torch.cat([cams.translation, cams.log_quaternion], dim=-1)
+    with torch.no_grad():
+        elite_cams, elite_loss = ce._refine_pose(z_obj, target, None, None, 8, cams[0])
+    assert torch.allclose(elite_loss, torch.sort(loss)[0][:8])
+    out['ce'] = {'cams': cam_dict(cams), 'all_cams': cam_dict(allc), 'loss': loss.clone(), 'order': torch.argsort(loss),
+                 'weights': dict(ce.loss_weights), 'elite_loss': elite_loss.clone(),
+                 'elite_log_q': elite_cams.log_quaternion.clone()}
+    save('g20_released_width', out)
+
+
+def g21_bop_scene(lf):
+    """The committed BOP-layout fixture scene through the reference's own flow (tools/poserbpf_comparison.py:195-215,
+    111-124): BOPDataset -> Observation.from_dataset(sample_evenly views) -> preprocess -> build_latent_object, then one
+    cross-entropy evaluation (estimation.py:382-400) of injected sample cameras against a held-out frame of the
+    scene.  Network = g7_adam_trace's SYN(16,8) checkpoints (same seeds)."""
+    import numpy as np
+    from pathlib import Path
+    from latentfusion.observation import Observation
+    from latentfusion.pose import estimation, utils as pu
+    from latentfusion.modules.geometry import Camera
+    root = os.path.join(OUT, 'bop_fixture')
+    had = hasattr(np, 'bool')
+    if not had:
+        np.bool = bool
+    try:
+        from latentfusion.datasets.bop import BOPDataset
+        model, cks, dist = _model(lf, 16, 8, 'gru', seed=20)
+        g7 = torch.load(os.path.join(OUT, 'g7_adam_trace.pt'), weights_only=False)
+        assert all(torch.equal(v, g7['photographer']['state_dict'][k]) for k, v in cks[2]['state_dict'].items())
+        ds = BOPDataset(Path(root) / 'lm', Path(root) / 'lm' / 'test' / '000002', object_id=2, center_object=True)
+        inds = ds.sample_evenly(3)
+        input_obs = Observation.from_dataset(ds, inds=inds)
+        held = [i for i in range(len(ds)) if i not in inds.tolist()]
+        target_obs = Observation.from_dataset(ds, inds=torch.tensor(held[:1]))
+        pre = model.preprocess_observation(input_obs)
+        with torch.no_grad():
+            z_obj = model.build_latent_object(input_obs)
+        torch.manual_seed(140)
+        cams = pu.sample_cameras_with_estimate(4, target_obs.camera, hemisphere=True, upright=True)
+        ce = estimation.CrossEntropyPoseEstimator(
+            model=model, num_samples=16, num_elites=5, num_iters=1, num_gmm_components=2, learning_rate=0.9, sample_flipped=True,
+            ranking_size=4, loss_weights={'depth': 1.0, 'ov_depth': 0.2, 'iou': 0.1, 'mask': 0.3})
+        allc = Camera.cat([cams, pu.flip_camera(cams, axis=(0.0, 0.0, 1.0)), pu.flip_camera(cams, axis=(0.0, 1.0, 0.0)),
+                           pu.flip_camera(cams, axis=(1.0, 0.0, 0.0))])
+        with torch.no_grad():
+            zd, zl, _, zcam = ce._render_observation(z_obj, allc)
+            ld = ce.loss_func(target_obs, zd, zl, zcam)
+            loss = sum(estimation.weigh_losses(ld, ce.loss_weights).values())
+        save('g21_bop_scene', {
+            'model_fixture': 'g7_adam_trace', 'object_id': 2, 'input_inds': inds.clone(), 'target_ind': held[0],
+            'input': obs_dict(input_obs), 'target': obs_dict(target_obs),
+            'pre': {'color': pre.color.clone(), 'depth': pre.depth.clone(), 'mask': pre.mask.clone(), 'cam': cam_dict(pre.camera)},
+            'z_obj': z_obj.clone(), 'cams': cam_dict(cams), 'all_cams': cam_dict(allc),
+            'weights': dict(ce.loss_weights), 'components': {k: v.clone() for k, v in ld.items()}, 'loss': loss.clone(),
+            'order': torch.argsort(loss)})
+        print('g21 losses', loss)
+    finally:
+        if not had:
+            del np.bool
+
+
+def g22_photographer_skip(lf):
+    """Photographer(skip_connections=True) (recon/models.py:296-313,400-425): parameter names / shapes the reference
+    allocates, and the fact that its forward cannot run (quirk Q20: camera block 0 is concatenated with a skip
+    tensor it has no channels for -- create_blocks(skip_connect_start=True))."""
+    from latentfusion.recon.models import Sculptor, Photographer
+    S, C = 8, 4
+    img = [[8, 16], [16, 8]]
+    out = {}
+    for name, oc, cc in (('a', [C, C], [C, C]), ('b', [C, 8, C], [C, 8, C]), ('c', [], [C, C])):
+        torch.manual_seed(150)
+        sc = Sculptor(in_size=S, image_config=img, camera_config=cc, object_config=oc if oc else [C, C],
+                      projection_type='factor', scale_mode='nearest').eval()
+        ph = Photographer(in_size=S, image_config=img, camera_config=cc, object_config=oc, projection_type='factor',
+                          skip_connections=True, scale_mode='nearest').eval()
+        cam = rand_cameras(lf, 2, zoomed_size=S, dist=2.0, seed=151)
+        x = torch.randn(2, 4, S, S)
+        err = None
+        with torch.no_grad():
+            z, zc, zo = sc(x, cam)
+            try:
+                ph(z, cam, z_cam_mid=zc, z_obj_mid=zo)
+            except Exception as e:                                  # noqa: BLE001
+                err = (type(e).__name__, str(e)[:160])
+        out[name] = {'object_config': oc, 'camera_config': cc, 'shapes': {k: tuple(v.shape) for k, v in ph.state_dict().items()},
+                     'error': err}
+        print('g22', name, err)
+    save('g22_photographer_skip', {'in_size': S, 'image_config': img, 'cases': out})
+
+
 def main():
     lf = refharness.load_reference()
     import latentfusion.recon.utils  # noqa
     torch.set_num_threads(8)
     gens = [g0_preprocess, g1_camera, g2_resample, g3_block, g4_fusers, g5_decode, g6_loss, g7_g10_loop, g9_ibr,
-            g11_released_like, g12_latent_code, g13_metrics, g14_initial_pose, g15_losses, g16_bop_reader, g17_api_helpers, g18_training_prep]
+            g11_released_like, g12_latent_code, g13_metrics, g14_initial_pose, g15_losses, g16_bop_reader, g17_api_helpers, g18_training_prep,
+            g19_metropolis, g20_released_width, g21_bop_scene,
+            g22_photographer_skip]
     only = sys.argv[1:]                                  # e.g. `python oracle/make_golden.py g13` regenerates one group
     for fn in gens:
         if not only or any(fn.__name__.startswith(o + '_') or fn.__name__ == o for o in only):

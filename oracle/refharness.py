@@ -105,6 +105,13 @@ def load_reference():
                 super().__init__(*a, **k)
         lr_scheduler.ReduceLROnPlateau = _Plateau
 
+    # torch >= 2.x: Sampler.__init__ takes no data_source any more; the reference's samplers still pass one
+    # (torchutils.py:181,199 -- used by Observation.from_dataset through IndexedDataLoader).
+    from torch.utils.data import Sampler
+    if not getattr(Sampler, '_lf_compat', False):
+        Sampler.__init__ = lambda self, *a, **k: None
+        Sampler._lf_compat = True
+
     import warnings
     warnings.filterwarnings('ignore')
     sys.path.insert(0, REFERENCE_ROOT)

@@ -170,6 +170,47 @@ def test_g12_latent_code_on_hip(golden):
     close(ld['latent'], g['latent_loss'], atol=1e-4, rtol=1e-3)
 
 
+def test_g19_metropolis_on_hip(golden):
+    """MetropolisPoseEstimator on the HIP path, replaying the random draws the reference consumed (two randn_like of
+    pu.perturb_camera + the rand_like of the acceptance test per step): identical accept / reject decisions at
+    every step, per-sample errors within the north-star tolerance, identical final ranking (steps and cameras)."""
+    from latentfusion_amd.observation import Observation
+    from latentfusion_amd.pose import estimation
+    from latentfusion_amd.recon import fusion
+    from latentfusion_amd.recon.inference import LatentFusionModel
+    from latentfusion_amd.recon.models import Photographer, Sculptor
+    g, m = golden('g19_metropolis'), golden('g12_latent_code')
+    model = LatentFusionModel(Sculptor.from_checkpoint(m['sculptor']), fusion.from_checkpoint(m['fuser']),
+                              Photographer.from_checkpoint(m['photographer']), m['camera_dist'], DEV)
+    tg = m['target']
+    target = Observation(tg['color_u8'].float() / 255.0, tg['depth'], tg['mask'].float(), prod_camera(tg['cam'], 'cpu'))
+    est = estimation.MetropolisPoseEstimator(model=model, num_samples=g['num_samples'], num_iters=g['num_iters'],
+                                             ranking_size=g['ranking_size'], loss_weights=g['weights'],
+                                             translation_std=g['translation_std'], quaternion_std=g['quaternion_std'],
+                                             return_camera_history=True)
+    est.replay_draws = [d for s in g['steps'] for d in (s['noise_t'], s['noise_q'], s['thresholds'])]
+    # step by step (the loop body of _estimate), so that every intermediate state is compared
+    camera = prod_camera(g['init'])
+    error = torch.full((g['num_samples'],), 100.0, device=DEV)
+    z_obj = m['z_obj'].to(DEV)
+    tdev = target.to(DEV)
+    prev_t = g['init']['t']
+    for s in g['steps']:
+        camera, error, n_acc = est._refine_pose(z_obj, camera.clone(), error.clone(), tdev, s['temperature'])
+        assert n_acc == s['num_accepted']
+        assert torch.equal((camera.translation.cpu() != prev_t).any(dim=1), (s['t'] != prev_t).any(dim=1))
+        close(error, s['error'], atol=1e-4, rtol=1e-3)
+        close(camera.translation, s['t'], atol=1e-6)
+        close(camera.log_quaternion, s['log_q'], atol=1e-6)
+        prev_t = s['t']
+    # and the whole estimator from the same sample cameras
+    est.replay_draws = [d for s in g['steps'] for d in (s['noise_t'], s['noise_q'], s['thresholds'])]
+    best, hist = est.estimate(z_obj, target, cameras=prod_camera(g['init'], 'cpu'))
+    assert est.accept_history == [s['num_accepted'] for s in g['steps']]
+    close(best.translation, g['ranking_t'], atol=1e-6)
+    close(best.log_quaternion, g['ranking_log_q'], atol=1e-6)
+
+
 @pytest.mark.parametrize('variant', ['factor', 'sum'])
 def test_photographer_parameter_gradients(golden, variant):
     """Training-step side: d(loss)/d(every Photographer weight and bias) through the HIP
@@ -391,3 +432,24 @@ def test_gru_fuser_split_gates_match_concatenated_gates_under_autograd():
     close(res[True][1], res[False][1], atol=2e-5 * scale, rtol=1e-3)
     for k, g in res[False][2].items():
         close(res[True][2][k], g, atol=2e-5 * max(g.abs().max().item(), 1e-3), rtol=1e-3)
+
+
+def test_skip_connections_quirk(golden):
+    """Quirk Q20: the reference's Photographer(skip_connections=True) concatenates a skip tensor in front of camera
+    block 0, which was allocated without skip channels (create_blocks(skip_connect_start=True)), so its forward raises
+    a channel-mismatch RuntimeError for every configuration (golden g22).  The HIP path builds the same modules,
+    performs the same O2C resamples / concatenations and stops at the same point."""
+    from latentfusion_amd.recon.models import Photographer, Sculptor
+    g = golden('g22_photographer_skip')
+    case = g['cases']['b']
+    torch.manual_seed(0)
+    sc = Sculptor(in_size=g['in_size'], image_config=g['image_config'], camera_config=case['camera_config'],
+                  object_config=case['object_config'], projection_type='factor', scale_mode='nearest').to(DEV)
+    ph = Photographer(in_size=g['in_size'], image_config=g['image_config'], camera_config=case['camera_config'],
+                      object_config=case['object_config'], projection_type='factor', skip_connections=True,
+                      scale_mode='nearest').to(DEV)
+    cam = prod_camera(golden('g2_resample')['cam'])[:2]
+    with torch.no_grad():
+        z, zc, zo = sc(torch.randn(2, 4, g['in_size'], g['in_size'], device=DEV), cam)
+        with pytest.raises(RuntimeError, match='channels'):
+            ph(z, cam, z_cam_mid=zc, z_obj_mid=zo)

@@ -116,6 +116,24 @@ def test_coefficient_blocks_reproduce_reference_grids(golden):
     num = torch.einsum('nrc,zyxc->nzyxr', A, l)
     g2 = torch.stack((num[..., 0] / num[..., 3], num[..., 1] / num[..., 3], num[..., 2]), -1)
     close(g2.float(), nets.c2o_grid(ocam, S), atol=2e-5)
+    # skewed intrinsics (K[0,1] != 0, K[1,0] != 0): the C2O map is the FULL product K @ p_cam of the reference
+    # (modules/geometry.py:634), not just (fu, fv, u0, v0)
+    d2 = dict(d)
+    d2['K'] = d['K'].clone()
+    d2['K'][:, 0, 1] = 7.5
+    d2['K'][:, 1, 0] = -3.25
+    cam2, ocam2 = prod_camera(d2), O.cam_from_dict(d2)
+    A = c2o_coefficients(cam2, 1.0).double().view(-1, 4, 4)
+    num = torch.einsum('nrc,zyxc->nzyxr', A, l)
+    g3 = torch.stack((num[..., 0] / num[..., 3], num[..., 1] / num[..., 3], num[..., 2]), -1)
+    close(g3.float(), nets.c2o_grid(ocam2, S), atol=2e-5)
+    assert (g3 - g2).abs().max() > 1e-3
+    # zoom(zs=, centroid_uvs=) (reference :287-339): explicit depth / centre override the camera's own
+    z0 = cam.zoom(None, 16, 2.0)
+    z1 = cam.zoom(None, 16, 2.0, zs=cam.translation[:, 2] * 2.0)
+    close((z1.viewport[:, 2] - z1.viewport[:, 0]) * 2.0, z0.viewport[:, 2] - z0.viewport[:, 0], atol=1e-3)
+    z2 = cam.zoom(None, 16, 2.0, centroid_uvs=torch.tensor([[100.0, 50.0]]).expand(len(cam), -1))
+    close((z2.viewport[:, 0] + z2.viewport[:, 2]) / 2, torch.full((len(cam),), 100.0), atol=1e-3)
 
 
 def test_observation_preprocessing_golden(golden):
@@ -441,7 +459,7 @@ def test_api_helpers_golden(golden):
     """The small host-side helpers that complete the reference's API surface (Camera lattices and
     back-projection, object lattice, point statistics, spherical helpers, rigid edits, batch/view concat,
     distances, functional) against the reference's own output (golden g17)."""
-    from latentfusion_amd import distances, functional as LF, three, utils
+    from latentfusion_amd import distances, functional as LF, three
     from latentfusion_amd.modules.geometry import CameraToObjectTransform
     g = golden('g17_api_helpers')
     cam = prod_camera(g['cam'])
@@ -476,13 +494,7 @@ def test_api_helpers_golden(golden):
     close(distances.distance(a, b, dim=1), g['dist_c']); close(distances.distance(a, b, metric='euclidean', dim=1), g['dist_e'])
     for m, want in g['outer'].items():
         close(distances.outer_distance(a, b, metric=m), want, atol=1e-6)
-    close(LF.normalize(t4, (0.1, 0.2, 0.3), (0.5, 0.6, 0.7)), g['norm']); close(LF.denormalize(t4, (0.1, 0.2, 0.3), (0.5, 0.6, 0.7)), g['denorm'])
-    close(LF.unit_normalize(t4, 1), g['unit']); close(LF.absolute_max_pool(t4, 0), g['amp'], atol=0, rtol=0)
-    assert utils.list_arg(int)('1,2,3') == [1, 2, 3] and utils.list_arg()('') == []
-    assert utils.block_config_arg()('16,D,32:32,U,16') == [[16, 'D', 32], [32, 'U', 16]]
-    assert utils.flatten_list([[1], [2, 3]]) == [1, 2, 3]
-    with pytest.raises(ValueError):
-        utils.list_choices_arg(['a'])('a,b')
+    close(LF.absolute_max_pool(t4, 0), g['amp'], atol=0, rtol=0)
 
 
 def test_training_prep_golden(golden):
@@ -550,3 +562,20 @@ def test_committed_bench_line_has_the_contract_fields():
         assert k in c, k
     assert c['kind'] in ('reference', 'port') and c['unit'] == d['unit']
     assert abs(d['value'] - d['n_gpus'] * d['steps'] / (d['ms_per_step'] * 1e-3 * d['steps'])) < 1e-6 * d['value']
+
+
+def test_photographer_skip_connections_allocation(golden):
+    """Photographer(skip_connections=True): same parameter names and shapes as the reference allocates
+    (recon/models.py:296-313).  Its forward cannot run in the reference (quirk Q20, pinned by g22 and reproduced on
+    the GPU in tests/test_decode_gpu.py::test_skip_connections_quirk)."""
+    from latentfusion_amd.recon.models import Photographer
+    g = golden('g22_photographer_skip')
+    for name, case in g['cases'].items():
+        ph = Photographer(in_size=g['in_size'], image_config=g['image_config'], camera_config=case['camera_config'],
+                          object_config=case['object_config'], projection_type='factor', skip_connections=True,
+                          scale_mode='nearest')
+        assert {k: tuple(v.shape) for k, v in ph.state_dict().items()} == case['shapes'], name
+        assert case['error'][0] == 'RuntimeError' and 'channels' in case['error'][1]
+        assert ph.create_checkpoint()['args']['skip_connections'] is True
+    with pytest.raises(ValueError):
+        ph(torch.zeros(1, 4, 8, 8, 8), type('C', (), {'__len__': lambda self: 1})())

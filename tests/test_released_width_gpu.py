@@ -1,0 +1,178 @@
+"""BASELINE cfg 3 at released WIDTH on the HIP path (golden g20 from the real reference): the 64-96 channel 2-D and
+3-D blocks run on the wide Winograd kernels (input transform -> per-frequency fp32-MFMA GEMM -> output transform),
+through the autograd modules AND through RenderLoopEngine's wide branch; plus the committed BOP-layout fixture scene
+taken through Observation.from_dataset -> build_latent_object -> CrossEntropyPoseEstimator.evaluate_samples.
+
+North-star bar: rendered logits / depth / mask within 1e-3 relative of the reference, identical loss ORDER."""
+import os
+
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def close(a, b, atol=1e-4, rtol=1e-3):
+    torch.testing.assert_close(a.detach().cpu().contiguous(), b.detach().cpu().contiguous(), atol=atol, rtol=rtol)
+
+
+def prod_camera(d, device=DEV):
+    from latentfusion_amd.modules.geometry import Camera
+    return Camera(d['K'].to(device), None, d['z_span'], d['viewport'].to(device), width=d['width'],
+                  height=d['height'], log_quaternion=d['log_q'].to(device), translation=d['t'].to(device))
+
+
+def _model(g):
+    from latentfusion_amd.recon import fusion
+    from latentfusion_amd.recon.inference import LatentFusionModel
+    from latentfusion_amd.recon.models import Photographer, Sculptor
+    return LatentFusionModel(Sculptor.from_checkpoint(g['sculptor']), fusion.from_checkpoint(g['fuser']),
+                             Photographer.from_checkpoint(g['photographer']), g['camera_dist'], DEV)
+
+
+def _target(t7, device=DEV):
+    from latentfusion_amd.observation import Observation
+    tg = t7['target']
+    return Observation(None, tg['depth'], tg['mask'].float(), prod_camera(tg['cam'], 'cpu')).to(device)
+
+
+def _wide_kernels_used(fn):
+    """Runs fn() with the per-kernel timer on and returns the set of kernel tags that were launched."""
+    from latentfusion_amd import ops
+    ops.KERNEL_TIMER = []
+    try:
+        out = fn()
+        torch.cuda.synchronize()
+        tags = {n for n, _, _ in ops.KERNEL_TIMER}
+    finally:
+        ops.KERNEL_TIMER = None
+    return out, tags
+
+
+def test_g20_encode_decode_modules(golden):
+    g = golden('g20_released_width')
+    model = _model(g)
+    o = g['obs_pre']
+    with torch.no_grad():
+        (z, _), tags = _wide_kernels_used(lambda: model.sculptor.encode(
+            model.fuser, prod_camera(o['cam']), o['color'].unsqueeze(0).to(DEV), o['depth'].unsqueeze(0).to(DEV),
+            o['mask'].unsqueeze(0).to(DEV)))
+    assert any(t.startswith('wino3d') for t in tags) and any(t.startswith('wino2d') for t in tags), tags
+    close(z, g['z_obj'], atol=2e-4, rtol=1e-3)
+    cam = prod_camera(g['cam'])
+    for p in (cam.log_quaternion, cam.translation, cam.viewport):
+        p.requires_grad_(True)
+    (y, lat, _), tags = _wide_kernels_used(lambda: model.photographer.decode(g['z_obj'].to(DEV), cam, return_latent=True,
+                                                                            apply_mask=True))
+    assert any(t.startswith('wino3d') for t in tags) and any(t.startswith('wino2d') for t in tags), tags
+    for k in ('depth_logits', 'mask_logits', 'depth', 'mask'):
+        close(y[k], g['y'][k], atol=2e-4, rtol=1e-3)
+    close(lat, g['latent'], atol=2e-4, rtol=1e-3)
+    ((y['depth_logits'] * g['wd'].to(DEV)).sum() + (y['mask_logits'] * g['wm'].to(DEV)).sum()).backward()
+    got = torch.cat((cam.log_quaternion.grad, cam.translation.grad, cam.viewport.grad), dim=1).cpu()
+    want = torch.cat((g['g_log_q'], g['g_t'], g['g_viewport']), dim=1)
+    rel = ((got - want).norm(dim=1) / want.norm(dim=1)).max().item()
+    assert rel < 1e-2, rel
+
+
+def test_g20_engine_wide_branch(golden):
+    """RenderLoopEngine on 64-channel camera blocks: the wide Winograd branch of the fused forward + backward
+    against the reference's default_pose_loss components and d(mean weighted loss)/d(camera parameters)."""
+    from latentfusion_amd.engine import RenderLoopEngine
+    g, t7 = golden('g20_released_width'), golden('g7_adam_trace')
+    model = _model(g)
+    L = g['loss']
+    target = _target(t7)
+    assert RenderLoopEngine.supports(model.photographer, L['weights'])
+    eng = RenderLoopEngine(model.photographer, g['z_obj'].to(DEV), target, L['weights'])
+    assert eng.conv_mode == 'winograd' and eng.wgemm is not None, 'the wide Winograd branch should drive 64-channel camera blocks'
+    zc = prod_camera(L['zoomed'])
+    (losses, gparams), tags = _wide_kernels_used(lambda: eng.forward_backward(zc))
+    assert any(t.startswith('wino3d') for t in tags), tags
+    for i, k in enumerate(eng.LOSS_KEYS):
+        close(losses[:, i], L['components'][k], atol=2e-5, rtol=1e-3)
+    close(losses[:, 4], L['total'], atol=2e-5, rtol=1e-3)
+    want = torch.cat((L['g_log_q'], L['g_t'], L['g_viewport']), dim=1)
+    rel = ((gparams.cpu() - want).norm(dim=1) / want.norm(dim=1)).max().item()
+    assert rel < 1e-2, rel
+    assert torch.equal(torch.argsort(losses[:, 4].cpu()), torch.argsort(L['total']))
+
+
+def test_g20_gradient_estimator_takes_the_wide_engine(golden):
+    """GradientPoseEstimator picks the fused engine for this architecture and its first iteration reproduces the
+    reference's losses; the module path (use_engine=False) agrees with it."""
+    from latentfusion_amd.pose import estimation
+    g, t7 = golden('g20_released_width'), golden('g7_adam_trace')
+    model = _model(g)
+    L = g['loss']
+    for use_engine in (True, False):
+        est = estimation.GradientPoseEstimator(model=model, learning_rate=0.01, num_samples=4, num_iters=2, ranking_size=4,
+                                               converge_threshold=1e-6, converge_patience=10, optimizer='adam',
+                                               loss_weights=L['weights'], use_engine=use_engine, track_stats=True)
+        best, stats = est.estimate(g['z_obj'].to(DEV), _target(t7, 'cpu'), camera=prod_camera(L['init'], 'cpu'))
+        close(stats['rank_loss'][0], L['total'], atol=2e-5, rtol=1e-3)
+        assert int(torch.argmin(stats['rank_loss'][0])) == int(torch.argmin(L['total']))
+
+
+def test_g20_cross_entropy_evaluation(golden):
+    """CrossEntropyPoseEstimator.evaluate_samples (flip augmentation, zoom, render, loss) at released width:
+    per-sample losses and their ORDER equal the reference's (estimation.py:382-400)."""
+    from latentfusion_amd.pose import estimation
+    g, t7 = golden('g20_released_width'), golden('g7_adam_trace')
+    model = _model(g)
+    ce = g['ce']
+    est = estimation.CrossEntropyPoseEstimator(model=model, num_samples=24, num_elites=8, num_iters=1, num_gmm_components=2,
+                                               learning_rate=0.9, sample_flipped=True, ranking_size=4,
+                                               loss_weights=ce['weights'])
+    cams, loss = est.evaluate_samples(g['z_obj'].to(DEV), _target(t7), prod_camera(ce['cams']))
+    close(cams.log_quaternion, ce['all_cams']['log_q'], atol=1e-5)
+    close(loss, ce['loss'], atol=2e-5, rtol=1e-3)
+    assert same_order_up_to_ties(loss, ce['loss'], 2e-5) and int(torch.argmin(loss)) == int(ce['order'][0])
+    close(torch.sort(loss)[0][:8], ce['elite_loss'], atol=2e-5, rtol=1e-3)
+
+
+def same_order_up_to_ties(loss, ref_loss, tol):
+    """The HIP losses sort like the reference's wherever the reference separates two samples by more than tol."""
+    loss, ref_loss = loss.detach().cpu(), ref_loss.detach().cpu()
+    order = torch.argsort(ref_loss)
+    for a, b in zip(order[:-1].tolist(), order[1:].tolist()):
+        if ref_loss[b] - ref_loss[a] > tol and not loss[a] < loss[b]:
+            return False
+    return True
+
+
+def test_g21_bop_scene_on_hip(golden):
+    """BASELINE cfg 3's data path on the GPU: the committed BOP-layout fixture scene is read by the product's
+    BOPDataset, batched by Observation.from_dataset (evenly spread reference views), reconstructed by
+    build_latent_object and scored by CrossEntropyPoseEstimator.evaluate_samples against a held-out frame of the
+    scene -- compared with what the reference produced from the same files (tools/poserbpf_comparison.py:195-215,
+    pose/estimation.py:382-400, datasets/bop.py:49-236)."""
+    from pathlib import Path
+    from latentfusion_amd.datasets.bop import BOPDataset
+    from latentfusion_amd.observation import Observation
+    from latentfusion_amd.pose import estimation
+    g, t7 = golden('g21_bop_scene'), golden('g7_adam_trace')
+    model = _model(t7)
+    root = Path(GOLDEN) / 'bop_fixture' / 'lm'
+    ds = BOPDataset(root, root / 'test' / '000002', object_id=g['object_id'], center_object=True)
+    inds = ds.sample_evenly(3)
+    assert inds.tolist() == g['input_inds'].tolist()
+    input_obs = Observation.from_dataset(ds, inds=inds)
+    close(input_obs.depth, g['input']['depth'], atol=1e-6, rtol=1e-6)
+    pre = model.preprocess_observation(input_obs.to(DEV))
+    close(pre.color, g['pre']['color'], atol=1e-5)
+    close(pre.depth, g['pre']['depth'], atol=1e-5)
+    close(pre.camera.viewport, g['pre']['cam']['viewport'], atol=1e-3)
+    z_obj = model.build_latent_object(input_obs)
+    close(z_obj, g['z_obj'], atol=2e-4, rtol=1e-3)
+    target_obs = Observation.from_dataset(ds, inds=[g['target_ind']])
+    est = estimation.CrossEntropyPoseEstimator(model=model, num_samples=16, num_elites=5, num_iters=1, num_gmm_components=2,
+                                               learning_rate=0.9, sample_flipped=True, ranking_size=4, loss_weights=g['weights'])
+    cams, loss = est.evaluate_samples(z_obj, target_obs.to(DEV), prod_camera(g['cams']))
+    close(cams.log_quaternion, g['all_cams']['log_q'], atol=1e-5)
+    close(loss, g['loss'], atol=1e-4, rtol=1e-3)
+    assert same_order_up_to_ties(loss, g['loss'], 5e-4)
+    assert int(torch.argmin(loss)) == int(torch.argmin(g['loss']))
