@@ -44,11 +44,13 @@ def parse():
     ap.add_argument('--samples', type=int, default=8)
     ap.add_argument('--fuser', default='gru')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-iters', type=int, default=1)
+    ap.add_argument('--cpu-iters', type=int, default=3, help='timed oracle iterations of the CPU baseline (after 1 warm-up)')
     ap.add_argument('--no-alt', action='store_true', help='skip the secondary f16x3 measurement')
     ap.add_argument('--sharded-build', action='store_true',
-                    help='(opt-in, N > 1) also reconstruct ONE object with its reference views sharded over the ranks and '
-                         'fused by an RCCL collective (parallel.build_latent_object_sharded); reported as `sharded_build`')
+                    help='reconstruct ONE pool:mean object with its reference views sharded over the ranks and fused by the '
+                         'RCCL all-reduce of the latent volume (parallel.build_latent_object_sharded); reported as '
+                         '`sharded_build`.  ON by default when N > 1 (the north-star collective); this flag forces it at N = 1')
+    ap.add_argument('--no-sharded-build', action='store_true', help='skip the view-sharded build at N > 1')
     ap.add_argument('--conv-mode', default='winograd', choices=['fp32', 'winograd', 'f16x3', 'winograd_f16x3'],
                     help="conv3d kernels of the engine: 'winograd' (default; F(2^3,3^3) minimal filtering, all-fp32 "
                          "arithmetic), 'fp32' (direct implicit GEMM on the fp32 MFMA) or 'f16x3' (split precision)")
@@ -81,7 +83,7 @@ def cpu_baseline(cks, z_obj_cpu, target_data, init, cfg, iters):
     # iteration 0 of the oracle on the SAME latent volume / target / initial cameras: the full-size parity check
     ref0 = {'rank_loss': first['rank_loss'][0],
             'grad': torch.cat((first['grad_log_q'][0], first['grad_t'][0], first['grad_viewport'][0]), dim=1)}
-    return iters / dt, torch.get_num_threads(), ref0
+    return iters / dt, torch.get_num_threads(), ref0, dt
 
 
 def main():
@@ -177,41 +179,76 @@ def main():
                'value': world * a.steps / el2, 'unit': 'iters/s', 'ms_per_step': el2 / a.steps * 1e3,
                'conv_avg_launch_ms': sum(d2) / max(len(d2), 1)}
 
-    # roofline of the dominant kernel: conv3d_c16_persistent_kernel (fused conv3d C->C block; 2 forward +
-    # 2 data-gradient launches per iteration), HIP events recorded on the launch stream in the timed region
+    # ---- roofline of the dominant kernel (fused conv3d 16->16 block step; 2 forward + 2 data-gradient launches per
+    # iteration), from HIP events recorded on the launch stream inside the timed region -------------------------------
     name = {'fp32': f'conv3x3_3d_{C}x{C}', 'winograd': 'conv3d_c16_wino', 'f16x3': 'conv3d_c16_split',
             'winograd_f16x3': 'conv3d_c16_wino_split'}[a.conv_mode]
-    durs = [e0.elapsed_time(e1) for n_, e0, e1 in timer if n_ == name]
-    conv_ms = sum(durs) / max(len(durs), 1)
-    flops = 2.0 * 27 * C * C * (S ** 3) * N                        # algorithmic flops per launch
-    achieved = flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-    # f16x3 issues 3 f16 MFMA products per algorithmic product: price it against dense-f16 peak / 3
-    peak = FP32_MFMA_PEAK_TFLOPS if a.conv_mode in ('fp32', 'winograd') else F16_MFMA_PEAK_TFLOPS / 3.0
     kname = {'fp32': 'conv3d_c16_persistent_kernel', 'winograd': 'conv3d_c16_wino_kernel',
              'f16x3': 'conv3d_c16_f16x3_kernel', 'winograd_f16x3': 'conv3d_c16_wino_f16x3_kernel'}[a.conv_mode]
-    # Winograd F(2^3,3^3) executes 64 multiplies per 2x2x2 outputs instead of 216: `achieved` stays the
-    # ALGORITHMIC (direct-convolution) flops per launch / time, so it may exceed the fp32 MFMA peak
-    roof_note = None
-    if a.conv_mode == 'winograd':
-        ex = flops * 64.0 / 216.0
-        roof_note = {'algorithm': 'Winograd F(2x2x2,3x3x3), all-fp32', 'executed_mfma_flops_per_launch': ex,
-                     'executed_mfma_tflops': ex / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
-                     'algorithmic_bytes_per_launch': 2 * N * C * S ** 3 * 4 + N * S ** 3 * 4,
-                     'hbm_frac_of_8TBps': (2 * N * C * S ** 3 * 4 + N * S ** 3 * 4) / (conv_ms * 1e-3) / 8e12 if conv_ms > 0 else 0.0}
-    traffic = None
-    tpath = os.path.join(ROOT, 'profiles', 'r01_conv3d_hbm_bytes.json')          # PMC passes, tools/hbm_summary.py
-    if os.path.exists(tpath) and S == 128 and C == 16 and N == 8:
+
+    def avg_ms(tag):
+        d = [e0.elapsed_time(e1) for n_, e0, e1 in timer if n_ == tag]
+        return (sum(d) / len(d) if d else 0.0), len(d)
+    conv_ms, conv_launches = avg_ms(name)
+    nvox = N * S ** 3
+    alg_flops = 2.0 * 27 * C * C * nvox                            # direct-convolution count
+    alg_bytes = (2 * C + 1) * nvox * 4                             # read x, write y and one norm float per voxel
+    wino = a.conv_mode in ('winograd', 'winograd_f16x3')
+    exec_flops = alg_flops * (64.0 / 216.0 if wino else 1.0) * (1.0 if a.conv_mode in ('fp32', 'winograd') else 3.0)
+    # price against the pipe the products run on: fp32 MFMA for the all-fp32 kernels, dense f16 MFMA for the split ones
+    peak = FP32_MFMA_PEAK_TFLOPS if a.conv_mode in ('fp32', 'winograd') else F16_MFMA_PEAK_TFLOPS
+    sec = conv_ms * 1e-3
+    exec_tflops = exec_flops / sec / 1e12 if sec > 0 else 0.0
+    hbm_gbs = alg_bytes / sec / 1e9 if sec > 0 else 0.0
+    floor_ms = max(exec_flops / (peak * 1e12), alg_bytes / (HBM_PEAK_GBS * 1e9)) * 1e3
+    # measured HBM bytes per launch of this kernel (PMC passes, tools/pmc_collect.sh + tools/pmc_summary.py); refused when
+    # the kernel sources changed since the counters were collected
+    traffic, traffic_src = None, None
+    import glob
+    import hashlib
+    for tpath in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_hbm_bytes.json')), reverse=True):
         try:
-            traffic = json.load(open(tpath)).get('kernels', {}).get(kname, {}).get('bytes_per_launch')
+            tj = json.load(open(tpath))
+            stamp = tj.get('source_sha256', {})
+            fresh = bool(stamp) and all(
+                hashlib.sha256(open(os.path.join(ROOT, 'latentfusion_amd', 'csrc', f), 'rb').read()).hexdigest() == h
+                for f, h in stamp.items())
+            if fresh and S == 128 and C == 16 and N == 8 and kname in tj.get('kernels', {}):
+                traffic, traffic_src = tj['kernels'][kname]['bytes_per_launch'], os.path.basename(tpath)
+                break
         except Exception:                                           # noqa: BLE001
-            traffic = None
+            continue
+    roofline = {
+        'bound': 'mfma', 'kernel': kname + ' (fused conv3d 16->16 + He + bias + LeakyReLU + PixelNorm; forward and data-gradient forms)',
+        'achieved': exec_tflops, 'peak': peak, 'unit': 'TFLOP/s', 'frac': exec_tflops / peak,
+        'traffic': traffic, 'traffic_source': traffic_src,
+        'avg_launch_ms': conv_ms, 'launches_timed': conv_launches, 'floor_ms': floor_ms, 'floor_over_measured': floor_ms / conv_ms if conv_ms else 0.0,
+        'executed_flops_per_launch': exec_flops, 'algorithmic_flops_per_launch': alg_flops,
+        'algorithmic_bytes_per_launch': alg_bytes, 'hbm_achieved_GBps': hbm_gbs, 'hbm_frac': hbm_gbs / HBM_PEAK_GBS,
+        'note': ('achieved = flops EXECUTED on the matrix pipe / launch time (Winograd F(2x2x2,3x3x3) executes 64/216 of the '
+                 'direct-convolution multiplies: algorithmic rate = %.1f TFLOP/s, a 3.375x algorithmic speed-up that is not '
+                 'counted in frac); hbm_frac = algorithmic bytes / time / 8 TB/s; floor_ms = max(MFMA, HBM) time of this launch'
+                 % (alg_flops / sec / 1e12 if sec > 0 else 0.0))}
+    # the other heavy kernels of the iteration (HBM-bound): algorithmic bytes / measured time vs the 8 TB/s peak
+    others = {}
+    vol_b = C * nvox * 4
+    for tag, nbytes in (('resample_fwd', vol_b + C * S ** 3 * 4), ('resample_bwd_coef', vol_b + C * S ** 3 * 4),
+                        ('factor_project_fwd', vol_b), ('factor_project_bwd', 2 * vol_b)):
+        ms_, cnt_ = avg_ms(tag)
+        if cnt_:
+            others[tag] = {'avg_launch_ms': ms_, 'launches_timed': cnt_, 'algorithmic_bytes': nbytes,
+                           'hbm_frac': nbytes / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    # whole iteration vs its HBM floor (~2.2 GB per pose sample forward + backward)
+    iter_bytes = 2.2e9 * N * (S / 128.0) ** 3 * (C / 16.0)
+    iter_floor_ms = iter_bytes / (HBM_PEAK_GBS * 1e9) * 1e3
 
     sharded = None
-    if a.sharded_build:
-        # every rank builds the SAME model and observation; views are split over the ranks and the per-view
-        # volumes meet in one collective (all-reduce for pool fusers, ordered all-gather for GRU/LSTM)
+    if a.sharded_build or (world > 1 and not a.no_sharded_build):
+        # the north-star collective: every rank builds the SAME pool:mean model and observation; the reference views are
+        # split over the ranks and the per-view volumes meet in ONE RCCL all-reduce of the C*S^3 latent volume
         from latentfusion_amd import parallel
-        model0, _ = synth.build_model(S, C, a.fuser, seed=12345, device=dev)
+        sh_fuser = 'pool:mean'
+        model0, _ = synth.build_model(S, C, sh_fuser, seed=12345, device=dev)
         obs0 = synth.make_observation(V, seed=54321, device=dev)
         for rep in range(2):                                       # second pass = warm
             barrier()
@@ -221,8 +258,19 @@ def main():
             t_sh = time.perf_counter() - t0
         z_full = model0.build_latent_object(obs0)                  # local full build for comparison
         err = (z_sh - z_full).abs().max().item()
-        sharded = {'t_s': t_sh, 'fuser': a.fuser, 'views': V, 'ranks': world, 'max_abs_diff_vs_local_build': err,
-                   'volume_MB': z_full.numel() * 4 / 1e6}
+        # the collective alone: all-reduce of one latent volume, timed with barriers on both sides
+        ar_ms = None
+        if world > 1:
+            buf = torch.empty_like(z_full)
+            for rep in range(3):
+                barrier()
+                t0 = time.perf_counter()
+                dist.all_reduce(buf)
+                barrier()
+                ar_ms = (time.perf_counter() - t0) * 1e3
+        sharded = {'t_s': t_sh, 'fuser': sh_fuser, 'views': V, 'ranks': world, 'max_abs_diff_vs_local_build': err,
+                   'volume_MB': z_full.numel() * 4 / 1e6, 'allreduce_ms': ar_ms,
+                   'allreduce_algbw_GBps': (z_full.numel() * 4 / 1e9) / (ar_ms * 1e-3) if ar_ms else None}
         del model0, obs0, z_sh, z_full
 
     if world > 1:
@@ -242,18 +290,18 @@ def main():
                    'parallelism': f'objects x{world} (no data-path collective in the loop)'},
         't_build_s': t_build, 't_build_warm_s': t_build_warm,
         'e2e_100_iters_per_s': 100.0 / (t_build_warm + 100.0 * elapsed / a.steps),
-        'roofline': {'bound': 'mfma', 'kernel': kname + ' (fused conv3d 16->16 + He + bias + LeakyReLU + PixelNorm; fwd and data-grad)',
-                     'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
-                     'frac': achieved / peak, 'traffic': traffic,
-                     'avg_launch_ms': conv_ms, 'launches_timed': len(durs), 'flops_per_launch': flops,
-                     'note': roof_note},
+        'roofline': roofline,
+        'roofline_iter': {'hbm_floor_ms': iter_floor_ms, 'algorithmic_bytes_per_iteration': iter_bytes,
+                          'frac': iter_floor_ms / (elapsed / a.steps * 1e3), 'kernels': others},
     }
     if world == 1 and not a.no_cpu_baseline:
-        v, cores, ref0 = cpu_baseline(cks[:3] + (cks[3],), z_obj.cpu(), tdata, init_rec, cfg, a.cpu_iters)
+        v, cores, ref0, cpu_dt = cpu_baseline(cks[:3] + (cks[3],), z_obj.cpu(), tdata, init_rec, cfg, a.cpu_iters)
         gerr = (hip0['grad'] - ref0['grad']).norm(dim=1) / ref0['grad'].norm(dim=1).clamp_min(1e-30)
-        out['cpu_baseline'] = {'value': v, 'unit': 'iters/s', 'cores': cores, 'kind': 'port',
-                               'sample': f'{a.cpu_iters} timed iteration(s) of the same SYN({S},{C}) N={N} pose loop '
-                                         f'(oracle, after 1 warm-up iteration; latent volume taken from the GPU build)',
+        out['cpu_baseline'] = {'value': v, 'unit': 'iters/s', 'cores': cores, 'host_cores': os.cpu_count(), 'kind': 'port',
+                               'timed_s': cpu_dt,
+                               'sample': f'{a.cpu_iters} timed iteration(s) of the same SYN({S},{C}) N={N} pose loop (oracle = CPU restatement '
+                                         f'of the reference, after 1 warm-up iteration; latent volume taken from the GPU build; '
+                                         f'{cores} ATen threads of the {os.cpu_count()} host cores: more threads measured slower)',
                                # HIP path vs the oracle on iteration 0 of this very workload (same volume, target,
                                # initial cameras): per-hypothesis ranking loss and camera-parameter gradients
                                'parity_at_full_size': {

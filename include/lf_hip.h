@@ -47,6 +47,13 @@ int lf_abi_version(void);
 /* Name of the device the library is running on (for logs); returns 0 / hip error. */
 int lf_device_name(char* buf, int buflen);
 
+/* Kernel-variant switch for in-process A/B measurements (tools/, profiles/); results are equivalent within the test
+ * tolerances for every value.  key 1: 3-D resampler kernels, 1 = generic (64-bit addressing, any C), 2 = lean
+ * (default: 32-bit buffer addressing, C % 4 == 0, volumes < 4 GB per sample; other shapes take the generic ones),
+ * 3 = lean + the 16-channel specialisation of the gather.
+ * Returns the previous value or LF_EINVAL. */
+int lf_set_tuning(int key, int value);
+
 /* ------------------------------------------------------------------------------------------
  * 3-D resampling: out[n,z,y,x,:] = trilinear(vol[n or 0], g(n; x,y,z)), padding=border,
  * align_corners=False, i.e. F.grid_sample as used by

@@ -24,6 +24,7 @@ P = c_void_p
 SIGNATURES = {
     'lf_abi_version': (c_int, []),
     'lf_device_name': (c_int, [c_char_p, c_int]),
+    'lf_set_tuning': (c_int, [c_int, c_int]),
     'lf_resample3d_fwd': (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
     'lf_resample3d_bwd_coef_scratch_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
     'lf_resample3d_bwd_coef': (c_int, [P, P, c_int, P, P, P, c_size_t, c_int, c_int, c_int, c_int, c_int, P]),

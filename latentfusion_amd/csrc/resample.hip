@@ -8,6 +8,8 @@
 
 namespace {
 
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
 struct Tap {
   int x0, y0, z0, x1, y1, z1;   // clamped integer corners
   float tx, ty, tz;             // fractional offsets
@@ -290,6 +292,209 @@ __global__ void __launch_bounds__(256) resample_bwd_vol_kernel(
   }
 }
 
+
+// ================================================================================================================
+// Lean variants (default): the same arithmetic for the sampling position, but
+//   * every address is a 32-bit byte offset into a buffer resource of ONE sample (scalar base + vector offset; the
+//     generic kernels above spend a third of their VALU on 64-bit multiply-adds per tap) -- needs D*H*W*C*4 < 2^32;
+//   * the second corner along an axis is the first + a conditional stride (no second multiply);
+//   * the coefficient gradient first contracts the 4 channels of a lane with the gradient for each of the 8 corners
+//     (32 FMAs), sums those 8 scalars over the voxel's lanes with DPP row shuffles, and only then forms the three
+//     spatial derivatives -- instead of 3 x 4 difference-products per channel (144 ops);
+//   * the tile walk of the gradient kernel is wave-uniform (scalar unit) except for a per-thread constant.
+// Both are bound by the vector-memory path (8 x 64-byte gathers per output voxel through L1) once the VALU is lean.
+typedef unsigned u32;
+
+struct Tap32 {
+  u32 o000, o001, o010, o011, o100, o101, o110, o111;          // byte offsets of the 8 corners (record start)
+  float tx, ty, tz, mx, my, mz;
+};
+
+__device__ __forceinline__ void axis_tap(float g, int size, u32 stride, u32& o0, u32& d1, float& t, float& m) {
+  float p;
+  unnormalize_clip(g, size, p, m);
+  if (!(p == p)) p = 0.f;                                        // NaN samples voxel 0 (ATen clip semantics)
+  const float f = floorf(p);
+  t = p - f;
+  const int i0 = (int)f;
+  o0 = (u32)i0 * stride;
+  d1 = (i0 + 1 <= size - 1) ? stride : 0u;                       // clamped upper corner = same record
+}
+
+__device__ __forceinline__ Tap32 make_tap32(float gx, float gy, float gz, int W, int H, int D, u32 rec_bytes) {
+  Tap32 t;
+  u32 x0, dx, y0, dy, z0, dz;
+  axis_tap(gx, W, rec_bytes, x0, dx, t.tx, t.mx);
+  axis_tap(gy, H, rec_bytes * (u32)W, y0, dy, t.ty, t.my);
+  axis_tap(gz, D, rec_bytes * (u32)W * (u32)H, z0, dz, t.tz, t.mz);
+  const u32 b00 = z0 + y0, b01 = b00 + dy, b10 = b00 + dz, b11 = b01 + dz;
+  t.o000 = b00 + x0; t.o001 = t.o000 + dx;
+  t.o010 = b01 + x0; t.o011 = t.o010 + dx;
+  t.o100 = b10 + x0; t.o101 = t.o100 + dx;
+  t.o110 = b11 + x0; t.o111 = t.o110 + dx;
+  return t;
+}
+
+__device__ __forceinline__ f32x4 ldrec(__amdgpu_buffer_rsrc_t rs, u32 off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
+}
+
+// one thread per (voxel, 4-channel group); block = compact 2^lx x 2^ly x 2^lz tile; C % 4 == 0
+template <int KIND>
+__global__ void __launch_bounds__(256) resample_fwd_lean_kernel(
+    const float* __restrict__ vol, long vol_bstride, const float* __restrict__ coef,
+    float* __restrict__ out, int D, int H, int W, int C, int lpt, int lx, int ly, int lz, int nbz, Steps st) {
+  const int lpv = C >> 2;
+  const int n = blockIdx.z / nbz, bz = blockIdx.z - n * nbz;
+  const int slot = threadIdx.x / lpt, q0 = threadIdx.x - slot * lpt;
+  if (slot >= (1 << (lx + ly + lz))) return;
+  const int x = (blockIdx.x << lx) + (slot & ((1 << lx) - 1));
+  const int y = (blockIdx.y << ly) + ((slot >> lx) & ((1 << ly) - 1));
+  const int z = (bz << lz) + (slot >> (lx + ly));
+  if (x >= W || y >= H || z >= D) return;
+  const u32 rec = (u32)C * 4u;
+  const u32 sample_bytes = (u32)D * (u32)H * (u32)W * rec;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(vol + (long)n * vol_bstride), 0, sample_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (long)n * D * H * W * C), 0, sample_bytes, 0x00020000);
+  const float* cf = coef + n * LF_MAP_COEFS;
+  float gx, gy, gz, a, b, k;
+  eval_grid<KIND>(cf, x, y, z, W, H, D, st, gx, gy, gz, a, b, k);
+  const Tap32 t = make_tap32(gx, gy, gz, W, H, D, rec);
+  const float wx1 = t.tx, wx0 = 1.f - t.tx, wy1 = t.ty, wy0 = 1.f - t.ty, wz1 = t.tz, wz0 = 1.f - t.tz;
+  const float w000 = wx0 * wy0 * wz0, w001 = wx1 * wy0 * wz0, w010 = wx0 * wy1 * wz0, w011 = wx1 * wy1 * wz0;
+  const float w100 = wx0 * wy0 * wz1, w101 = wx1 * wy0 * wz1, w110 = wx0 * wy1 * wz1, w111 = wx1 * wy1 * wz1;
+  const u32 orow = (u32)((z * H + y) * W + x) * rec;
+  for (int q = q0; q < lpv; q += lpt) {
+    const u32 co = (u32)q * 16u;
+    const f32x4 v000 = ldrec(rs, t.o000 + co), v001 = ldrec(rs, t.o001 + co), v010 = ldrec(rs, t.o010 + co), v011 = ldrec(rs, t.o011 + co);
+    const f32x4 v100 = ldrec(rs, t.o100 + co), v101 = ldrec(rs, t.o101 + co), v110 = ldrec(rs, t.o110 + co), v111 = ldrec(rs, t.o111 + co);
+    const f32x4 r = v000 * w000 + v001 * w001 + v010 * w010 + v011 * w011 + v100 * w100 + v101 * w101 + v110 * w110 + v111 * w111;
+    // streamed output (nt): keep L2 for the gathered volume
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, r), ro, (int)(orow + co), 0, 2);
+  }
+}
+
+// C == 16 specialisation of the lean gather (variant 3): fixed 4x4x4 tile, no integer division, no channel loop, one
+// scalar-weight FMA per channel and corner (the generic form lets the compiler pack the FMAs in pairs, which costs
+// a register move per weight to build the pairs).
+template <int KIND>
+__global__ void __launch_bounds__(256) resample_fwd_c16_kernel(
+    const float* __restrict__ vol, long vol_bstride, const float* __restrict__ coef,
+    float* __restrict__ out, int D, int H, int W, int nbz, Steps st) {
+  const int n = blockIdx.z / nbz, bz = blockIdx.z - n * nbz;
+  const int q = threadIdx.x & 3, vs = threadIdx.x >> 2;
+  const int x = (blockIdx.x << 2) + (vs & 3), y = (blockIdx.y << 2) + ((vs >> 2) & 3), z = (bz << 2) + (vs >> 4);
+  if (x >= W || y >= H || z >= D) return;
+  const u32 sample_bytes = (u32)D * (u32)H * (u32)W * 64u;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(vol + (long)n * vol_bstride), 0, sample_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (long)n * D * H * W * 16), 0, sample_bytes, 0x00020000);
+  const float* cf = coef + n * LF_MAP_COEFS;
+  float gx, gy, gz, a, b, k;
+  eval_grid<KIND>(cf, x, y, z, W, H, D, st, gx, gy, gz, a, b, k);
+  const Tap32 t = make_tap32(gx, gy, gz, W, H, D, 64u);
+  const u32 co = (u32)q * 16u;
+  const f32x4 v000 = ldrec(rs, t.o000 + co), v001 = ldrec(rs, t.o001 + co), v010 = ldrec(rs, t.o010 + co), v011 = ldrec(rs, t.o011 + co);
+  const f32x4 v100 = ldrec(rs, t.o100 + co), v101 = ldrec(rs, t.o101 + co), v110 = ldrec(rs, t.o110 + co), v111 = ldrec(rs, t.o111 + co);
+  const float wx1 = t.tx, wx0 = 1.f - t.tx, wy1 = t.ty, wy0 = 1.f - t.ty, wz1 = t.tz, wz0 = 1.f - t.tz;
+  const float w000 = wx0 * wy0 * wz0, w001 = wx1 * wy0 * wz0, w010 = wx0 * wy1 * wz0, w011 = wx1 * wy1 * wz0;
+  const float w100 = wx0 * wy0 * wz1, w101 = wx1 * wy0 * wz1, w110 = wx0 * wy1 * wz1, w111 = wx1 * wy1 * wz1;
+  f32x4 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float acc = v000[e] * w000;
+    // (inline asm keeps these as v_fmac_f32 with the weight as a plain operand)
+    asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "v"(v001[e]), "v"(w001));
+    asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "v"(v010[e]), "v"(w010));
+    asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "v"(v011[e]), "v"(w011));
+    asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "v"(v100[e]), "v"(w100));
+    asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "v"(v101[e]), "v"(w101));
+    asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "v"(v110[e]), "v"(w110));
+    asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "v"(v111[e]), "v"(w111));
+    r[e] = acc;
+  }
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, r), ro, (int)((u32)((z * H + y) * W + x) * 64u + co), 0, 2);
+}
+
+// sum over the 4 lanes of a quad (all four receive it)
+__device__ __forceinline__ float quad_sum4(float v) {
+  const float a = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));   // [1,0,3,2]
+  return a + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x4E, 0xF, 0xF, true));            // [2,3,0,1]
+}
+
+// coefficient gradient, C == 16 (4 lanes per voxel, 64 voxels per block-iteration): block = 2^lg-voxel tile walked in
+// 4x4x4 sub-tiles; thread (v = tid >> 2, q = tid & 3) keeps its position inside the sub-tile, the sub-tile index is
+// wave-uniform
+__global__ void __launch_bounds__(256) resample_bwd_coef_c16_kernel(
+    const float* __restrict__ gout, const float* __restrict__ vol, long vol_bstride,
+    const float* __restrict__ coef, float* __restrict__ partial, int nblk, int vpb, BwdTile bt,
+    int D, int H, int W, Steps st) {
+  const unsigned fb = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int n = fb / nblk, blk = fb - n * nblk;
+  const float* cf = coef + n * LF_MAP_COEFS;
+  const u32 rec = 64u;
+  const u32 sample_bytes = (u32)D * (u32)H * (u32)W * rec;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(vol + (long)n * vol_bstride), 0, sample_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)(gout + (long)n * D * H * W * 16), 0, sample_bytes, 0x00020000);
+  const int tx = blk % bt.ntx, ty = (blk / bt.ntx) % bt.nty, tz = blk / (bt.ntx * bt.nty);
+  const int q = threadIdx.x & 3, vs = threadIdx.x >> 2;          // vs = position inside a 4x4x4 sub-tile
+  const int px = vs & 3, py = (vs >> 2) & 3, pz = vs >> 4;
+  const int sbx = bt.lx - 2, sby = bt.ly - 2;
+  float acc[18];
+#pragma unroll
+  for (int i = 0; i < 18; ++i) acc[i] = 0.f;
+  const float qsel = (q == 0) ? 1.f : 0.f;                       // one lane of the quad feeds the sums
+  const int nsub = vpb >> 6;
+  for (int sub = 0; sub < nsub; ++sub) {                         // wave-uniform
+    const int x = (tx << bt.lx) + ((sub & ((1 << sbx) - 1)) << 2) + px;
+    const int y = (ty << bt.ly) + (((sub >> sbx) & ((1 << sby) - 1)) << 2) + py;
+    const int z = (tz << bt.lz) + ((sub >> (sbx + sby)) << 2) + pz;
+    const bool live = x < W && y < H && z < D;
+    float hx = 0.f, hy = 0.f, hz = 0.f, a = 0.f, b = 0.f, k = 0.f;
+    float gx, gy, gz;
+    eval_grid<LF_MAP_O2C>(cf, live ? x : 0, live ? y : 0, live ? z : 0, W, H, D, st, gx, gy, gz, a, b, k);
+    const Tap32 t = make_tap32(gx, gy, gz, W, H, D, rec);
+    const u32 co = (u32)q * 16u;
+    // out-of-tile lanes read offset 0xffffffff: outside the descriptor's range -> zeros, no branch
+    const u32 dead = live ? 0u : 0xffffffffu;
+    const f32x4 go = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+        rg, (int)(((u32)((z * H + y) * W + x) * rec + co) | dead), 0, 2));      // streamed once (nt)
+    const f32x4 v000 = ldrec(rs, (t.o000 + co) | dead), v001 = ldrec(rs, (t.o001 + co) | dead);
+    const f32x4 v010 = ldrec(rs, (t.o010 + co) | dead), v011 = ldrec(rs, (t.o011 + co) | dead);
+    const f32x4 v100 = ldrec(rs, (t.o100 + co) | dead), v101 = ldrec(rs, (t.o101 + co) | dead);
+    const f32x4 v110 = ldrec(rs, (t.o110 + co) | dead), v111 = ldrec(rs, (t.o111 + co) | dead);
+#define DOT4(v) ((go[0] * (v)[0] + go[1] * (v)[1]) + (go[2] * (v)[2] + go[3] * (v)[3]))
+    const float p000 = quad_sum4(DOT4(v000)), p001 = quad_sum4(DOT4(v001)), p010 = quad_sum4(DOT4(v010)), p011 = quad_sum4(DOT4(v011));
+    const float p100 = quad_sum4(DOT4(v100)), p101 = quad_sum4(DOT4(v101)), p110 = quad_sum4(DOT4(v110)), p111 = quad_sum4(DOT4(v111));
+#undef DOT4
+    const float wx1 = t.tx, wx0 = 1.f - t.tx, wy1 = t.ty, wy0 = 1.f - t.ty, wz1 = t.tz, wz0 = 1.f - t.tz;
+    const float dxv = (p001 - p000) * (wy0 * wz0) + (p011 - p010) * (wy1 * wz0) + (p101 - p100) * (wy0 * wz1) + (p111 - p110) * (wy1 * wz1);
+    const float dyv = (p010 - p000) * (wx0 * wz0) + (p011 - p001) * (wx1 * wz0) + (p110 - p100) * (wx0 * wz1) + (p111 - p101) * (wx1 * wz1);
+    const float dzv = (p100 - p000) * (wx0 * wy0) + (p101 - p001) * (wx1 * wy0) + (p110 - p010) * (wx0 * wy1) + (p111 - p011) * (wx1 * wy1);
+    hx = dxv * t.mx * qsel; hy = dyv * t.my * qsel; hz = dzv * t.mz * qsel;
+    const float ak = a * k, bk = b * k;
+    acc[0] += hx;       acc[1] += hy;       acc[2] += hz;
+    acc[3] += hx * a;   acc[4] += hy * a;   acc[5] += hz * a;
+    acc[6] += hx * b;   acc[7] += hy * b;   acc[8] += hz * b;
+    acc[9] += hx * k;   acc[10] += hy * k;  acc[11] += hz * k;
+    acc[12] += hx * ak; acc[13] += hy * ak; acc[14] += hz * ak;
+    acc[15] += hx * bk; acc[16] += hy * bk; acc[17] += hz * bk;
+  }
+  __shared__ float red[4][18];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < 18; ++i) {
+    const float s = lf_wave_sum(acc[i]);
+    if (lane == 0) red[wave][i] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 18) {
+    const float s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    partial[((long)n * nblk + blk) * 18 + threadIdx.x] = s;
+  }
+}
+
+int g_resample_variant = 2;                                    // 1 = generic kernels, 2 = lean kernels (lf_set_tuning)
+
 bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 Steps make_steps(int D, int H, int W) {
@@ -323,6 +528,23 @@ extern "C" int lf_resample3d_fwd(const float* vol, int vol_n, const float* coef,
   dim3 grid((unsigned)((W + (1 << tlx) - 1) >> tlx), (unsigned)((H + (1 << tly) - 1) >> tly), (unsigned)(nbz * N)), block(256);
   const Steps st = make_steps(D, H, W);
   hipStream_t s = (hipStream_t)stream;
+  if (g_resample_variant == 3 && vec && C == 16 && (long)D * H * W * 64 < 0xffffffffL) {
+    const int nbz4 = (D + 3) >> 2;
+    if ((long)nbz4 * N > 65535 || ((H + 3) >> 2) > 65535) return LF_EINVAL;
+    dim3 g4((unsigned)((W + 3) >> 2), (unsigned)((H + 3) >> 2), (unsigned)(nbz4 * N));
+    if (kind == LF_MAP_O2C)
+      hipLaunchKernelGGL((resample_fwd_c16_kernel<LF_MAP_O2C>), g4, block, 0, s, vol, bstride, coef, out, D, H, W, nbz4, st);
+    else
+      hipLaunchKernelGGL((resample_fwd_c16_kernel<LF_MAP_C2O>), g4, block, 0, s, vol, bstride, coef, out, D, H, W, nbz4, st);
+    return lf_launch_status();
+  }
+  if (g_resample_variant >= 2 && vec && (long)D * H * W * C * 4 < 0xffffffffL) {
+    if (kind == LF_MAP_O2C)
+      hipLaunchKernelGGL((resample_fwd_lean_kernel<LF_MAP_O2C>), grid, block, 0, s, vol, bstride, coef, out, D, H, W, C, lpt, tlx, tly, tlz, nbz, st);
+    else
+      hipLaunchKernelGGL((resample_fwd_lean_kernel<LF_MAP_C2O>), grid, block, 0, s, vol, bstride, coef, out, D, H, W, C, lpt, tlx, tly, tlz, nbz, st);
+    return lf_launch_status();
+  }
 #define LAUNCH(K, V) hipLaunchKernelGGL((resample_fwd_kernel<K, V>), grid, block, 0, s, vol, bstride, coef, out, N, D, H, W, C, lpt, tlx, tly, tlz, nbz, st)
   if (kind == LF_MAP_O2C) { if (vec) LAUNCH(LF_MAP_O2C, 4); else LAUNCH(LF_MAP_O2C, 1); }
   else                    { if (vec) LAUNCH(LF_MAP_C2O, 4); else LAUNCH(LF_MAP_C2O, 1); }
@@ -362,6 +584,13 @@ extern "C" int lf_resample3d_bwd_coef(const float* gout, const float* vol, int v
   int lpv = 1;
   while (lpv < groups) lpv <<= 1;
   if (lpv > 64) return LF_EINVAL;                       // C > 256 (vec) / C > 64 (scalar)
+  if (g_resample_variant >= 2 && vec && C == 16 && vpb >= 64 && nvox * 64 < 0xffffffffL) {
+    hipLaunchKernelGGL(resample_bwd_coef_c16_kernel, grid, block, 0, s, gout, vol, bstride, coef, partial, nblk, vpb, bt, D, H, W, make_steps(D, H, W));
+    int st2 = lf_launch_status();
+    if (st2) return st2;
+    hipLaunchKernelGGL(resample_bwd_coef_reduce, dim3(N), dim3(256), 0, s, partial, nblk, gcoef);
+    return lf_launch_status();
+  }
   if (vec)
     hipLaunchKernelGGL((resample_bwd_coef_kernel<4>), grid, block, 0, s, gout, vol, bstride, coef, partial, nblk, vpb, bt, N, D, H, W, C, lpv, make_steps(D, H, W));
   else
@@ -388,4 +617,15 @@ extern "C" int lf_resample3d_bwd_vol(const float* gout, const float* coef, int k
   else
     return LF_EINVAL;
   return lf_launch_status();
+}
+
+// Tuning / A-B switch (not part of the functional interface): key 1 = resampler variant (1 generic, 2 lean, 3 lean + 16-channel gather).
+// Returns the previous value, or LF_EINVAL for an unknown key.
+extern "C" int lf_set_tuning(int key, int value) {
+  if (key == 1) {
+    const int prev = g_resample_variant;
+    if (value >= 1 && value <= 3) g_resample_variant = value;
+    return prev;
+  }
+  return LF_EINVAL;
 }

@@ -202,8 +202,9 @@ class RenderLoopEngine:
 
         # ---- 3-D forward ----
         x0 = ops.empty_cl((n, self.C, S, S, S), dev)
-        check(L.lf_resample3d_fwd(self.z.data_ptr(), 1, cf20.data_ptr(), LF_MAP_O2C, x0.data_ptr(), n, S, S, S, self.C, s),
-              'lf_resample3d_fwd')
+        with ops._timed('resample_fwd'):
+            check(L.lf_resample3d_fwd(self.z.data_ptr(), 1, cf20.data_ptr(), LF_MAP_O2C, x0.data_ptr(), n, S, S, S, self.C, s),
+                  'lf_resample3d_fwd')
         acts, norms = [x0], []
         flags = LF_EPI_LRELU | LF_EPI_PIXELNORM
         for li_, (w, b, he, wp, _wt) in enumerate(self.convs):
@@ -224,7 +225,8 @@ class RenderLoopEngine:
         cout = pw.shape[0]
         Cl = acts[-1].shape[1]
         zp = ops.empty_cl((n, cout, S, S), dev)
-        pnorm = ops._conv1x1_raw(acts[-1], ppack, pb, n, S * S, Cl, S, S * S * S * Cl, S * S * Cl, cout, zp, phe, flags)
+        with ops._timed('factor_project_fwd'):
+            pnorm = ops._conv1x1_raw(acts[-1], ppack, pb, n, S * S, Cl, S, S * S * S * Cl, S * S * Cl, cout, zp, phe, flags)
 
         # ---- 2-D decoder + heads + fused loss (autograd over small maps) ----
         zp_leaf = zp.detach().requires_grad_(need_grad)
@@ -249,10 +251,11 @@ class RenderLoopEngine:
             # max-abs of each gradient volume (order-independent atomic max inside the producing kernel):
             # lets the split kernels pre-scale tiny gradients by an exact power of two
             amax = ops.amax_buffer(None, dev, rows=nconv + 1) if self.split is not None else None
-            check(L.lf_conv1x1_bwd_data(gp.data_ptr(), ppack_t.data_ptr(), g.data_ptr(), n, S * S, cout, S * Cl,
-                                        S * S * S * Cl, Cl, Cl, S * S * Cl, phe, acts[nconv].data_ptr(),
-                                        norms[nconv - 1].data_ptr(), flags, ops.SLOPE,
-                                        amax[nconv].data_ptr() if amax is not None else None, s), 'lf_conv1x1_bwd_data')
+            with ops._timed('factor_project_bwd'):
+                check(L.lf_conv1x1_bwd_data(gp.data_ptr(), ppack_t.data_ptr(), g.data_ptr(), n, S * S, cout, S * Cl,
+                                            S * S * S * Cl, Cl, Cl, S * S * Cl, phe, acts[nconv].data_ptr(),
+                                            norms[nconv - 1].data_ptr(), flags, ops.SLOPE,
+                                            amax[nconv].data_ptr() if amax is not None else None, s), 'lf_conv1x1_bwd_data')
             for i in range(nconv - 1, -1, -1):
                 w, b, he, _wp, wt = self.convs[i]
                 prev = (acts[i], norms[i - 1], flags) if i > 0 else None
@@ -279,8 +282,9 @@ class RenderLoopEngine:
         gcoef18 = torch.empty(n, 18, device=dev, dtype=torch.float32)
         nbytes = L.lf_resample3d_bwd_coef_scratch_bytes(n, S, S, S)
         scratch = torch.empty(nbytes // 4 + 1, device=dev, dtype=torch.float32)
-        check(L.lf_resample3d_bwd_coef(g.data_ptr(), self.z.data_ptr(), 1, cf20.data_ptr(), gcoef18.data_ptr(),
-                                       scratch.data_ptr(), scratch.numel() * 4, n, S, S, S, self.C, s), 'lf_resample3d_bwd_coef')
+        with ops._timed('resample_bwd_coef'):
+            check(L.lf_resample3d_bwd_coef(g.data_ptr(), self.z.data_ptr(), 1, cf20.data_ptr(), gcoef18.data_ptr(),
+                                           scratch.data_ptr(), scratch.numel() * 4, n, S, S, S, self.C, s), 'lf_resample3d_bwd_coef')
         gcoefs = g_cf.contiguous()
         gcoefs[:, :18] = gcoef18
         gparams = torch.empty(n, NPAR, device=dev, dtype=torch.float32)

@@ -6,8 +6,8 @@ The hot path shards on three independent axes and needs NO collectiv
 loop:
   objects      one object per rank (bench.py --gpus N, BASELINE cfg 4): zero communication;
   views        reference views of one object are encoded V/G per rank, then fused with ONE
-               collective over the C*S^3 latent volume (all-reduce for pool:mean / pool:max,
-               all-gather + replicated ordered recurrence for the order-dependent GRU/LSTM fusers);
+               collective over the C*S^3 latent volume (all-reduce forms for pool:mean / pool:max / pool:abs_max /
+               blend, all-gather + replicated ordered recurrence for the order-dependent GRU/LSTM fusers);
   hypotheses   pose samples are split across ranks; N loss scalars are all-gathered per iteration.
 
 xGMI note: a ring all-reduce is bound by one ~153 GB/s link (134 MB volume at SYN(128,16): ~1.5 ms);
@@ -39,43 +39,79 @@ def shard_views(observation, rank=None, size=None):
     return observation[b:e], (b, e)
 
 
-def fuse_sharded(fuser, z_local, num_views_total, group=None):
+def _pool(z, kind):
+    """Pool over the view axis of (1, V, ...) -- lf_fuse_views_fwd for device tensors (recon/fusion.pool_tensor)."""
+    from .recon.fusion import pool_tensor
+    return pool_tensor(z, kind, dim=1)
+
+
+def fuse_sharded(fuser, z_local, num_views_total, group=None, z_cam_mid_local=None, camera_local=None):
     """Fuses per-view latent volumes that are sharded over ranks.
 
     z_local: (1, V_local, C, S, S, S) volumes of this rank's views (V_local may be 0).
     Returns the fused (1, 1, C, S, S, S) volume, identical on every rank.
 
-    pool:mean   local sum -> all-reduce(SUM) -> / V          (one collective of C*S^3 floats)
-    pool:max    local max -> all-reduce(MAX)
-    others      all-gather of the per-view volumes in rank (= view) order, then the fuser runs
-                replicated on the full, ordered view list: GRU/LSTM fusion is an order-dependent
-                recurrence (reference recon/fusion.py:180-201) and abs_max/median are
-                not reducible with a single all-reduce.
+    pool:mean     local sum -> all-reduce(SUM) -> / V          (ONE collective of C*S^3 floats)
+    pool:max      local max -> all-reduce(MAX)
+    pool:abs_max  local signed abs-max a -> m = all-reduce(MAX, |a|) -> all-reduce(MAX, where(|a| == m, a, -m)):
+                  +m if any rank holds +m, else -m (an exact +/- tie across ranks, a measure-zero event, resolves
+                  to + instead of to the earlier view)
+    blend         per-view logits l (BlendFuser.compute_blend_logits on the local views): g = all-reduce(MAX, max_v l);
+                  e = exp(l - g); ONE all-reduce(SUM) of [sum_v z e | sum_v e] ((C+1)*S^3 floats); out = num / den --
+                  the same max-subtracted softmax as the single-process fuser (recon/fusion.py:139-148)
+    others        all-gather of the per-view volumes in rank (= view) order, then the fuser runs replicated on the
+                  full, ordered view list: GRU/LSTM fusion is an order-dependent recurrence (reference
+                  recon/fusion.py:180-201), and the median needs every view.
     """
     rank, size = world()
     kind = type(fuser).__name__
     pool = getattr(fuser, 'pool_type', None)
     if size == 1:
-        return fuser(z_local, None, None, None)[0]
-    if kind == 'PoolFuser' and pool in ('mean', 'max'):
-        shape = (1, 1) + tuple(z_local.shape[2:])
-        if pool == 'mean':
-            acc = z_local.sum(dim=1, keepdim=True) if z_local.shape[1] else z_local.new_zeros(shape)
-            acc = acc.contiguous()
-            dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
-            return acc / float(num_views_total)
-        acc = (z_local.max(dim=1, keepdim=True)[0] if z_local.shape[1]
-               else z_local.new_full(shape, float('-inf'))).contiguous()
+        mids = [z_cam_mid_local] if z_cam_mid_local is not None else None
+        return fuser(z_local, mids, None, camera_local)[0]
+    shape = (1, 1) + tuple(z_local.shape[2:])
+    have = z_local.shape[1] > 0
+    if kind == 'PoolFuser' and pool == 'mean':
+        acc = (_pool(z_local, 'mean') * float(z_local.shape[1]) if have else z_local.new_zeros(shape)).contiguous()
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
+        return acc / float(num_views_total)
+    if kind == 'PoolFuser' and pool == 'max':
+        acc = (_pool(z_local, 'max') if have else z_local.new_full(shape, float('-inf'))).contiguous()
         dist.all_reduce(acc, op=dist.ReduceOp.MAX, group=group)
         return acc
+    if kind == 'PoolFuser' and pool == 'abs_max':
+        a = (_pool(z_local, 'abs_max') if have else z_local.new_zeros(shape)).contiguous()
+        m = a.abs()
+        dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
+        cand = torch.where(a.abs() == m, a, -m).contiguous()
+        dist.all_reduce(cand, op=dist.ReduceOp.MAX, group=group)
+        return cand
+    if kind == 'BlendFuser' and z_cam_mid_local is not None:
+        C = z_local.shape[2]
+        if have:
+            logits = fuser.compute_blend_logits(z_cam_mid_local, camera_local)          # (1, V_local, 1, S, S, S)
+            gmax = logits.max(dim=1, keepdim=True)[0].contiguous()
+        else:
+            gmax = z_local.new_full((1, 1, 1) + tuple(z_local.shape[3:]), float('-inf'))
+        dist.all_reduce(gmax, op=dist.ReduceOp.MAX, group=group)
+        buf = z_local.new_zeros((1, 1, C + 1) + tuple(z_local.shape[3:]))
+        if have:
+            e = torch.exp(logits - gmax)
+            buf[:, :, :C] = (z_local * e).sum(dim=1, keepdim=True)
+            buf[:, :, C:] = e.sum(dim=1, keepdim=True)
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+        return (buf[:, :, :C] / buf[:, :, C:]).contiguous()
     # ordered all-gather (ragged: ranks may hold different numbers of views)
     counts = [shard_range(num_views_total, r, size) for r in range(size)]
     vmax = max(e - b for b, e in counts)
-    pad = z_local.new_zeros((1, vmax) + tuple(z_local.shape[2:]))
-    pad[:, :z_local.shape[1]] = z_local
-    parts = [torch.empty_like(pad) for _ in range(size)]
-    dist.all_gather(parts, pad.contiguous(), group=group)
-    z_all = torch.cat([p[:, :e - b] for p, (b, e) in zip(parts, counts)], dim=1)
+
+    def gather_views(t):
+        pad = t.new_zeros((1, vmax) + tuple(t.shape[2:]))
+        pad[:, :t.shape[1]] = t
+        parts = [torch.empty_like(pad) for _ in range(size)]
+        dist.all_gather(parts, pad.contiguous(), group=group)
+        return torch.cat([p[:, :e - b] for p, (b, e) in zip(parts, counts)], dim=1)
+    z_all = gather_views(z_local)
     return fuser(z_all, None, None, None)[0]
 
 
@@ -87,20 +123,28 @@ def build_latent_object_sharded(model, observation, group=None):
     total = len(obs)
     local, (b, e) = shard_views(obs, rank, size)
     with torch.no_grad():
+        cap = _Capture()
         if e > b:
-            z_local, _ = model.sculptor.encode(_Identity(), camera=local.camera, color=local.color.unsqueeze(0),
+            z_local, _ = model.sculptor.encode(cap, camera=local.camera, color=local.color.unsqueeze(0),
                                                depth=local.depth.unsqueeze(0), mask=local.mask.unsqueeze(0))
         else:
             c, s = model.sculptor.out_channels, model.sculptor.out_size
             z_local = torch.zeros(1, 0, c, s, s, s, device=model.device)
-        return fuse_sharded(model.fuser, z_local, total, group)
+        return fuse_sharded(model.fuser, z_local, total, group, z_cam_mid_local=cap.z_cam_mid, camera_local=cap.camera)
 
 
-class _Identity:
-    """Stand-in fuser that returns the un-fused per-view volumes."""
+class _Capture:
+    """Stand-in fuser: returns the un-fused per-view volumes and keeps what a BlendFuser needs for its logits."""
+
+    z_cam_mid = camera = None
 
     def __call__(self, z_obj, z_cam_mid, z_obj_mid, camera):
+        self.z_cam_mid = z_cam_mid[-1] if z_cam_mid else None
+        self.camera = camera
         return z_obj, {}
+
+
+_Identity = _Capture
 
 
 def shard_hypotheses(camera, rank=None, size=None):
@@ -110,18 +154,33 @@ def shard_hypotheses(camera, rank=None, size=None):
     return camera[b:e], (b, e)
 
 
-def gather_losses(local_losses, n_total, group=None):
-    """All-gather of per-hypothesis loss scalars (ragged) -> (n_total,) on every rank, in order."""
+def gather_rows(local_rows, n_total, group=None):
+    """All-gather of per-hypothesis rows (ragged over ranks) -> (n_total, ...) on every rank, in hypothesis order.
+    One small collective per pose iteration: N loss scalars (+ 10 camera parameters when the ranking needs them)."""
     rank, size = world()
     if size == 1:
-        return local_losses
+        return local_rows
     counts = [shard_range(n_total, r, size) for r in range(size)]
     nmax = max(e - b for b, e in counts)
-    pad = local_losses.new_zeros(nmax)
-    pad[:local_losses.shape[0]] = local_losses
+    pad = local_rows.new_zeros((nmax,) + tuple(local_rows.shape[1:]))
+    pad[:local_rows.shape[0]] = local_rows
     parts = [torch.empty_like(pad) for _ in range(size)]
-    dist.all_gather(parts, pad, group=group)
+    dist.all_gather(parts, pad.contiguous(), group=group)
     return torch.cat([p[:e - b] for p, (b, e) in zip(parts, counts)])
+
+
+def gather_losses(local_losses, n_total, group=None):
+    """All-gather of per-hypothesis loss scalars (ragged) -> (n_total,) on every rank, in order."""
+    return gather_rows(local_losses, n_total, group)
+
+
+def broadcast_(tensor, src=0, group=None):
+    """In-place broadcast from `src` (no-op in a single process).  Used for the few host-random quantities of the
+    estimators (GMM samples, initial hypotheses) so that every rank ranks the SAME hypotheses."""
+    rank, size = world()
+    if size > 1:
+        dist.broadcast(tensor, src=src, group=group)
+    return tensor
 
 
 # ---------------------------------------------------------------------------------------------

@@ -64,8 +64,14 @@ def load_schedules_from_config(config):
 
 class PoseEstimator:
     def __init__(self, *, model, ranking_size, loss_weights, loss_func=None, return_camera_history=False,
-                 verbose=False):
+                 verbose=False, shard_hypotheses=False):
+        """shard_hypotheses (an addition; the reference is single-process): under torch.distributed every rank
+        renders and scores only its contiguous slice of the pose hypotheses; the per-hypothesis rows (loss
+        [+ camera parameters]) are all-gathered once per iteration (parallel.gather_rows) and every rank ranks the
+        full set, so the returned ranking is identical on all ranks and to a one-rank run.  Host-random draws
+        (initial hypotheses, GMM samples) are taken from rank 0."""
         self.model = model
+        self.shard_hypotheses = bool(shard_hypotheses)
         self.ranking_size = ranking_size
         self.loss_func = default_pose_loss if loss_func is None else loss_func
         self.loss_weights = defaultdict(float)
@@ -88,6 +94,22 @@ class PoseEstimator:
         if len(target_obs) > 1:
             raise ValueError('The pose can only be estiamted for one observation at a time.')
         return self._estimate(z_obj, target_obs, **kwargs)
+
+    def _sharding(self):
+        """(rank, size) when hypothesis sharding is active, else (0, 1)."""
+        if not self.shard_hypotheses:
+            return 0, 1
+        from .. import parallel
+        return parallel.world()
+
+    def _sync_cameras_from_rank0(self, camera):
+        """Every rank must rank the SAME hypotheses: take rank 0's (they come from host RNGs)."""
+        if self._sharding()[1] == 1:
+            return camera
+        from .. import parallel
+        blk = torch.cat((camera.log_quaternion, camera.translation, camera.viewport), dim=1).detach().clone().contiguous()
+        parallel.broadcast_(blk)
+        return camera._like(log_quaternion=blk[:, 0:3].clone(), translation=blk[:, 3:6].clone(), viewport=blk[:, 6:10].clone())
 
     def _track_best_items(self, ranking, step, items, loss):
         """Merge this step's (camera, loss) pairs into the top-`ranking_size` list; returns the
@@ -189,6 +211,7 @@ class CrossEntropyPoseEstimator(PoseEstimator):
             cameras = pu.sample_cameras_with_estimate(n=self.num_gmm_components * self.num_samples,
                                                       camera_est=camera_init, upright=self.init_upright,
                                                       hemisphere=self.init_hemisphere)
+        cameras = self._sync_cameras_from_rank0(cameras.to(self.device)) if self._sharding()[1] > 1 else cameras
         gmm = self._create_gmm(self._camera_to_params(cameras).cpu())
         target_obs = target_obs.to(self.device)
         prev_gmm, ranking, history = None, [], []
@@ -212,10 +235,21 @@ class CrossEntropyPoseEstimator(PoseEstimator):
         if self.loss_weights.get('latent', 0.0) > 0.0:
             with torch.no_grad():
                 z_target_latent = self.model.compute_latent_code(target_obs, cameras[0])
+        rank, size = self._sharding()
+        local = cameras
+        if size > 1:                                               # this rank's contiguous slice of the hypotheses
+            from .. import parallel
+            b, e = parallel.shard_range(len(cameras), rank, size)
+            local = cameras[b:e]
         with torch.no_grad():
-            zd, zl, z_lat, z_camera = self._render_observation(z_obj, cameras)
-            ld = self.loss_func(target_obs, zd, zl, z_camera, z_pred_latent=z_lat, z_target_latent=z_target_latent)
-            loss = sum(weigh_losses(ld, self.loss_weights).values())
+            if len(local):
+                zd, zl, z_lat, z_camera = self._render_observation(z_obj, local)
+                ld = self.loss_func(target_obs, zd, zl, z_camera, z_pred_latent=z_lat, z_target_latent=z_target_latent)
+                loss = sum(weigh_losses(ld, self.loss_weights).values())
+            else:
+                loss = torch.zeros(0, device=cameras.device)
+            if size > 1:
+                loss = parallel.gather_rows(loss.contiguous(), len(cameras))     # N scalars per iteration
         return cameras, loss
 
     def _refine_pose(self, z_obj, target_obs, prev_gmm, gmm, num_elites, camera_init):
@@ -231,6 +265,9 @@ class CrossEntropyPoseEstimator(PoseEstimator):
         params = torch.tensor(params, dtype=torch.float32, device=self.device)
         params[:, :3] += torch.randn_like(params[:, :3]) * self.translation_std
         params[:, 3:] += torch.randn_like(params[:, 3:]) * self.quaternion_std
+        if self._sharding()[1] > 1:                                # numpy / torch host RNGs differ per rank
+            from .. import parallel
+            parallel.broadcast_(params)
         return params
 
     def _create_gmm(self, params=None):
@@ -379,6 +416,7 @@ class GradientPoseEstimator(PoseEstimator):
             camera = pu.sample_cameras_with_estimate(n=self.num_samples, camera_est=self.initial_pose(target_obs))
         target_obs = target_obs.to(self.device)
         camera = camera.zoom(None, self.model.input_size, self.model.camera_dist).to(self.device)
+        camera = self._sync_cameras_from_rank0(camera)
         ranking = []
         stats, history = self._optimize_camera(z_obj, target_obs, camera, iters=self.num_iters, ranking=ranking)
         best = Camera.cat([c for c, _, _ in ranking])
@@ -430,6 +468,22 @@ class GradientPoseEstimator(PoseEstimator):
     def start(self, z_obj, target_obs, cameras, ranking=None):
         """Creates the per-run loop state (parameters, optimiser, schedulers); `cameras` must
         already be zoomed and on the device.  Exposed so that bench.py can time `iterate`."""
+        rank, size = self._sharding()
+        shard, full_cpu = None, None
+        if size > 1:
+            # this rank optimises its contiguous slice of the hypotheses (own optimiser / plateau state); the ranking
+            # sees all of them through one all-gather of (loss, parameters) rows per iteration
+            from .. import parallel
+            b, e = parallel.shard_range(len(cameras), rank, size)
+            if e <= b:
+                raise ValueError(f'shard_hypotheses: {len(cameras)} hypotheses cannot be split over {size} ranks')
+            shard, full_cpu = (b, e, len(cameras)), cameras.to('cpu')
+            cameras = cameras[b:e]
+        st = self._start_local(z_obj, target_obs, cameras, ranking)
+        st['shard'], st['template_full_cpu'] = shard, full_cpu
+        return st
+
+    def _start_local(self, z_obj, target_obs, cameras, ranking):
         engine = self._engine_for(z_obj, target_obs)
         if engine is not None:
             from ..engine import camera_params
@@ -470,11 +524,25 @@ class GradientPoseEstimator(PoseEstimator):
                 z_target_latent = self.model.compute_latent_code(target_obs, cam)
         loss_dict, optim_loss, rank_loss, optim_weights = self.loss_and_grad(st['z_obj'], target_obs, cam, step,
                                                                            z_target_latent)
-        rank_host = rank_loss.tolist()                                # the one D2H sync per iteration
-        detached = cam.uncrop().detach().clone()
-        if self.return_camera_history:
-            st['camera_history'].append((rank_loss.cpu(), detached.to('cpu')))
-        delta = self._track_best_items(st['ranking'], step, list(detached.to('cpu')), rank_host)
+        shard = st.get('shard')
+        if shard is not None:
+            from .. import parallel
+            rows = torch.cat((rank_loss.unsqueeze(1), cam.log_quaternion.detach(), cam.translation.detach()), dim=1)
+            rows = parallel.gather_rows(rows.contiguous(), shard[2]).cpu()
+            rank_all = rows[:, 0].tolist()                            # the one D2H sync per iteration
+            rank_host = rank_all[shard[0]:shard[1]]
+            detached_all = st['template_full_cpu']._like(log_quaternion=rows[:, 1:4].clone(), translation=rows[:, 4:7].clone(),
+                                                         viewport=None)
+            if self.return_camera_history:
+                st['camera_history'].append((rows[:, 0].clone(), detached_all))
+            delta = self._track_best_items(st['ranking'], step, list(detached_all), rank_all)
+            detached = cam.uncrop().detach().clone()
+        else:
+            rank_host = rank_loss.tolist()                            # the one D2H sync per iteration
+            detached = cam.uncrop().detach().clone()
+            if self.return_camera_history:
+                st['camera_history'].append((rank_loss.cpu(), detached.to('cpu')))
+            delta = self._track_best_items(st['ranking'], step, list(detached.to('cpu')), rank_host)
         if self.track_stats:
             angle = three.quaternion.angular_distance(detached.quaternion, st['target_q']).squeeze()
             trans = torch.norm(detached.translation - target_obs.camera.translation, dim=1).squeeze()
@@ -507,6 +575,9 @@ class GradientPoseEstimator(PoseEstimator):
         with torch.no_grad():
             losses, gparams = eng.forward_backward(st['cam'], need_grad=True)
             dev = torch.cat((losses[:, :5], P.detach()), dim=1)
+            if st.get('shard') is not None:                           # (N_local,15) -> (N,15) over the ranks
+                from .. import parallel
+                dev = parallel.gather_rows(dev.contiguous(), st['shard'][2])
         slot = st.setdefault('pinned', {})
         key = step & 1
         if key not in slot or slot[key].shape != dev.shape:
@@ -537,7 +608,8 @@ class GradientPoseEstimator(PoseEstimator):
         comp = {k: host[:, i] for i, k in enumerate(eng.LOSS_KEYS)}
         rank = sum(self.loss_weights.get(k, 0.0) * comp[k] for k in eng.LOSS_KEYS)
         rank_host = rank.tolist()
-        tpl = st['template_cpu']
+        shard = st.get('shard')
+        tpl = st['template_cpu'] if shard is None else st['template_full_cpu']
         detached = tpl._like(log_quaternion=host[:, 5:8].clone(), translation=host[:, 8:11].clone(), viewport=None)
         if self.return_camera_history:
             st['camera_history'].append((rank.clone(), detached))
@@ -549,7 +621,7 @@ class GradientPoseEstimator(PoseEstimator):
                 **{f'{k}_loss': v for k, v in comp.items()}, **{f'{k}_weight': v for k, v in optim_weights.items()},
                 'delta': delta, 'converge_count': st['converge_count'], 'angle_dist': angle, 'trans_dist': trans,
                 'optim_loss': host[:, 4].clone(), 'rank_loss': rank.clone()})
-        st['sched'].step(rank_host)
+        st['sched'].step(rank_host if shard is None else rank_host[shard[0]:shard[1]])
         if delta < self.converge_threshold:
             st['converge_count'] += 1
         elif delta > self.converge_threshold:

@@ -1,6 +1,7 @@
 """world_size-2 gloo tests (CPU) of the multi-GPU layer: view-sharded fusion equals the
-single-process result (all-reduce path for pool fusers, ordered all-gather path for the GRU),
-hypothesis sharding + loss gather preserve order.  The per-view encoder is irrelevant here
+single-process result (all-reduce forms for mean / max / abs_max / blend, ordered all-gather path for the GRU and
+the median), hypothesis sharding + loss gather preserve order, and the estimators run with shard_hypotheses=True
+return the ranking of a one-rank run.  The per-view encoder is irrelevant here
 (views are independent up to the fuser), so random per-view volumes stand in for it; the GRU
 fuser's gate convolutions are evaluated by the oracle."""
 import os
@@ -43,9 +44,22 @@ def _worker(rank, size, port, case, q):
         V, C, S = 5, 4, 6                       # 5 views over 2 ranks: ragged 3 + 2
         z = torch.randn(1, V, C, S, S, S, generator=g)
         b, e = parallel.shard_range(V, rank, size)
-        if case in ('mean', 'max', 'median'):
+        mids = cams = None
+        if case in ('mean', 'max', 'median', 'abs_max'):
             fuser = PoolFuser(case)
             want = fuser(z, None, None, None)[0]
+        elif case == 'blend':
+            mids = torch.randn(1, V, C, S, S, S, generator=g)
+
+            class BlendFuser:                     # the sharded path only needs the logits hook and the call signature
+                def compute_blend_logits(self, z_cam, camera):
+                    return (z_cam * torch.arange(1.0, C + 1.0).view(1, 1, C, 1, 1, 1)).sum(dim=2, keepdim=True)
+
+                def __call__(self, z_obj, z_cam_mid, z_obj_mid, camera):      # recon/fusion.py:139-148
+                    w = torch.softmax(self.compute_blend_logits(z_cam_mid[-1], camera), dim=1)
+                    return torch.sum(z_obj * w, dim=1, keepdim=True), {}
+            fuser = BlendFuser()
+            want = fuser(z, [mids], None, None)[0]
         else:
             gen = torch.Generator().manual_seed(1)
             sd = {}
@@ -54,7 +68,8 @@ def _worker(rank, size, port, case, q):
                 sd[f'gru.{gate}.bias'] = torch.randn(C, generator=gen) * 0.1
             fuser = OracleGRUFuser({'type': 'GRUFuser', 'state_dict': sd})
             want = fuser(z, None, None, None)[0]
-        got = parallel.fuse_sharded(fuser, z[:, b:e].contiguous(), V)
+        got = parallel.fuse_sharded(fuser, z[:, b:e].contiguous(), V,
+                                    z_cam_mid_local=mids[:, b:e].contiguous() if mids is not None else None)
         err = (got - want).abs().max().item()
         # hypotheses
         losses = torch.arange(7, dtype=torch.float32) * 1.5
@@ -65,7 +80,7 @@ def _worker(rank, size, port, case, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('case', ['mean', 'max', 'median', 'gru'])
+@pytest.mark.parametrize('case', ['mean', 'max', 'abs_max', 'blend', 'median', 'gru'])
 def test_view_sharded_fusion_world2(case):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
@@ -79,7 +94,7 @@ def test_view_sharded_fusion_world2(case):
         assert p.exitcode == 0
     for rank, err, order_ok in results:
         # mean: (a+b)+(c+d+e) vs sequential mean -> fp32 re-association only; others bit-identical
-        assert err <= (1e-6 if case == 'mean' else 0.0), (case, rank, err)
+        assert err <= (1e-6 if case in ('mean', 'blend') else 0.0), (case, rank, err)
         assert order_ok
 
 
@@ -119,3 +134,93 @@ def test_flat_gradient_allreduce_world2():
     want = torch.arange(1000, dtype=torch.float32) * 1.5
     for r in (0, 1):
         assert torch.equal(got[r], want)
+
+
+# ---- hypothesis sharding inside the estimators -------------------------------------------------------------
+class _StubModel:
+    """Stands where LatentFusionModel stands: a differentiable, pure-torch 'renderer' of the camera parameters, so the
+    sharding logic of the estimators (slicing, gathers, broadcasts, ranking) runs on CPU ranks."""
+    device, input_size, camera_dist = 'cpu', 16, 2.0
+
+    def render_latent_object(self, z_obj, camera, return_latent=True, apply_mask=True):
+        n, h = len(camera), 16
+        base = torch.linspace(-1, 1, h).view(1, 1, h, 1) + torch.linspace(-1, 1, h).view(1, 1, 1, h)
+        q, t = camera.log_quaternion, camera.translation
+        col = lambda v: v.reshape(n, 1, 1, 1)                                     # noqa: E731
+        dl = base * col(q[:, 0]) + col(t[:, 2]) - 1.0 + 0.3 * col(q[:, 1])
+        ml = base * 3.0 + col(q[:, 2]) + col(t[:, 0]) * 5.0
+        y = {'depth_logits': dl.unsqueeze(0), 'mask_logits': ml.unsqueeze(0), 'depth': torch.tanh(dl).unsqueeze(0),
+             'mask': torch.sigmoid(ml).unsqueeze(0)}
+        return y, torch.zeros(n, 1, 2, 2)
+
+
+def _stub_case():
+    from latentfusion_amd import synth
+    from latentfusion_amd.modules.geometry import Camera
+    from latentfusion_amd.observation import Observation
+    from latentfusion_amd.pose import utils as pu
+    td = synth.make_observation_data(1, seed=2)
+    target = Observation(None, td['depth'][:, :, ::8, ::8].contiguous(), td['mask'][:, :, ::8, ::8].contiguous(),
+                         Camera(td['intrinsic'] * torch.tensor([[0.125], [0.125], [1.0]]), td['extrinsic'], width=80, height=60))
+    torch.manual_seed(3)
+    init = pu.sample_cameras_with_estimate(5, target.camera)                     # 5 hypotheses over 2 ranks: 3 + 2
+    return _StubModel(), target, init
+
+
+def _ranking_of(cams):
+    return torch.cat((cams.log_quaternion, cams.translation), dim=1)
+
+
+def _estimator_worker(rank, size, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=size)
+    try:
+        import numpy as np
+        from latentfusion_amd.pose import estimation
+        model, target, init = _stub_case()
+        z_obj = torch.zeros(1)
+        w = {'depth': 1.0, 'ov_depth': 0.3, 'iou': 0.1, 'mask': 0.2}
+        out = {}
+        for sharded in (False, True):
+            g = estimation.GradientPoseEstimator(model=model, learning_rate=0.01, num_samples=5, num_iters=6, ranking_size=4,
+                                                 converge_threshold=1e-9, converge_patience=100, optimizer='adam',
+                                                 loss_weights=w, shard_hypotheses=sharded, return_camera_history=True)
+            best, hist = g.estimate(z_obj, target, camera=init)
+            out[('grad', sharded)] = (_ranking_of(best), torch.stack([h[0] for h in hist]))
+            ce = estimation.CrossEntropyPoseEstimator(model=model, num_samples=12, num_elites=4, num_iters=3, num_gmm_components=2,
+                                                      learning_rate=0.9, sample_flipped=True, ranking_size=3, loss_weights=w,
+                                                      shard_hypotheses=sharded)
+            _, loss = ce.evaluate_samples(z_obj, target, init)
+            out[('ce_eval', sharded)] = loss
+            torch.manual_seed(7 + (0 if not sharded else rank))      # rank 1's own RNG must not matter when sharded
+            np.random.seed(7 + (0 if not sharded else rank))
+            out[('ce', sharded)] = (_ranking_of(ce.estimate(z_obj, target, cameras=init)),)
+        q.put((rank, {k: tuple(t.clone() for t in v) if isinstance(v, tuple) else v.clone() for k, v in out.items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_estimators_with_sharded_hypotheses_world2():
+    """GradientPoseEstimator.iterate and CrossEntropyPoseEstimator.evaluate_samples / estimate with
+    shard_hypotheses=True on 2 gloo ranks: every rank returns the ranking of the one-rank run (same losses per
+    iteration, same best cameras), although each rendered only its slice of the hypotheses."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_estimator_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        best1, hist1 = res[r][('grad', False)]
+        best2, hist2 = res[r][('grad', True)]
+        torch.testing.assert_close(hist2, hist1, atol=1e-6, rtol=1e-6)           # per-iteration losses of all 5 hypotheses
+        torch.testing.assert_close(best2, best1, atol=1e-6, rtol=1e-6)
+        torch.testing.assert_close(res[r][('ce_eval', True)], res[r][('ce_eval', False)], atol=1e-6, rtol=1e-6)
+        assert res[r][('ce_eval', True)].shape[0] == 20                         # 5 hypotheses x 4 flips, gathered
+    # the sharded cross-entropy search: both ranks end with rank 0's ranking, which is the one-rank result for rank 0's seed
+    torch.testing.assert_close(res[1][('ce', True)][0], res[0][('ce', True)][0], atol=0, rtol=0)
+    torch.testing.assert_close(res[0][('ce', True)][0], res[0][('ce', False)][0], atol=1e-6, rtol=1e-6)

@@ -1,0 +1,111 @@
+#!/usr/bin/env python
+"""Condenses the passes of tools/pmc_collect.sh into the two files kept under profiles/:
+
+    python tools/pmc_summary.py gpurun_out/<tag> profiles/r02
+
+  profiles/r02_kernels_pmc.txt   per kernel: mean SQ / TCC counters per launch and the derived figures the roofline
+                                 discussion uses (VALU per MFMA, MFMA-pipe busy, LDS conflict share, L2 hit rate)
+  profiles/r02_hbm_bytes.json    per kernel: HBM bytes per launch = FETCH_SIZE (x2: gfx950 counts 128-B requests at 64 B;
+                                 the factor is calibrated on a 1 GiB copy of the same run) + WRITE_SIZE, next to the
+                                 algorithmic bytes, stamped with the sha256 of the kernel sources so that bench.py can
+                                 refuse a stale file (MI355X_MICROARCH.md, HBM / rocprofv3 section).
+"""
+import collections
+import csv
+import glob
+import hashlib
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNELS = collections.OrderedDict([
+    # key -> (substring of the kernel name, algorithmic bytes per launch at N=8, C=16, S=128)
+    ('conv3d_c16_wino_kernel', ('conv3d_c16_wino_kernel', 2 * 8 * 16 * 128 ** 3 * 4 + 8 * 128 ** 3 * 4)),
+    ('conv3d_c16_persistent_kernel', ('conv3d_c16_persistent_kernel', 2 * 8 * 16 * 128 ** 3 * 4 + 8 * 128 ** 3 * 4)),
+    ('resample_fwd_kernel', ('resample_fwd_kernel', 8 * 16 * 128 ** 3 * 4 + 16 * 128 ** 3 * 4)),
+    ('resample_bwd_coef_kernel', ('resample_bwd_coef_kernel', 8 * 16 * 128 ** 3 * 4 + 16 * 128 ** 3 * 4)),
+    ('conv1x1_kernel', ('conv1x1_kernel', 8 * 16 * 128 ** 3 * 4)),
+    ('conv1x1_bwd', ('conv1x1_bwd', 2 * 8 * 16 * 128 ** 3 * 4)),
+    ('column_sum_fwd_kernel', ('column_sum_fwd_kernel', 8 * 16 * 128 ** 3 * 4)),
+])
+SOURCES = ['conv_wino.hip', 'conv.hip', 'resample.hip', 'pointwise.hip', 'reduce.hip']
+
+
+def source_hashes():
+    out = {}
+    for f in SOURCES:
+        p = os.path.join(ROOT, 'latentfusion_amd', 'csrc', f)
+        if os.path.exists(p):
+            out[f] = hashlib.sha256(open(p, 'rb').read()).hexdigest()
+    return out
+
+
+def load(dirname):
+    """{kernel name: {counter: [values per dispatch]}} over every *_counter_collection.csv of the directory;
+    rocprofv3 writes one row per (dispatch, counter[, dimension]): rows of one dispatch are summed."""
+    per = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(float)))
+    for path in sorted(glob.glob(os.path.join(dirname, '*counter_collection.csv'))):
+        tag = os.path.basename(path).split('_')[0]
+        for r in csv.DictReader(open(path)):
+            per[r['Kernel_Name']][r['Counter_Name']][(tag, r['Dispatch_Id'])] += float(r['Counter_Value'])
+    return {k: {c: list(v.values()) for c, v in cs.items()} for k, cs in per.items()}
+
+
+def mean(v):
+    return sum(v) / len(v) if v else None
+
+
+def find(data, sub, floor_counter=None, floor=0.0):
+    hits = [k for k in data if sub in k]
+    if not hits:
+        return None
+    # several template instances may match: take the one with the most work
+    return max(hits, key=lambda k: mean(data[k].get('SQ_WAVE_CYCLES', data[k].get('FETCH_SIZE', [0]))) or 0)
+
+
+def main(dirname, prefix):
+    data = load(dirname)
+    GiB = 1024.0 ** 3
+    cal = find(data, 'copyBuffer') or find(data, 'direct_copy_kernel')
+    calf = [v for v in data.get(cal, {}).get('FETCH_SIZE', []) if v > 1e5] if cal else []
+    calw = [v for v in data.get(cal, {}).get('WRITE_SIZE', []) if v > 1e5] if cal else []
+    corr = (GiB / 1024.0) / mean(calf) if calf else 2.0
+    wcorr = (GiB / 1024.0) / mean(calw) if calw else 1.0
+    lines = [f'# PMC counters per launch (means over the dispatches of tools/hbm_probe.py), from {dirname}',
+             '# bench shape SYN(128,16), N = 8: 8 x 128^3 voxels x 16 channels fp32 per volume',
+             f'# FETCH_SIZE correction (1 GiB copy in the same run): x{corr:.4f};  WRITE_SIZE: x{wcorr:.4f}', '']
+    hbm = {'shape': 'N=8, C=16, S=128 (SYN(128,16) bench shape), fp32', 'collected': 'tools/pmc_collect.sh (separate --pmc passes)',
+           'fetch_correction': corr, 'write_correction': wcorr, 'source_sha256': source_hashes(), 'kernels': {}}
+    for key, (sub, alg) in KERNELS.items():
+        k = find(data, sub)
+        if k is None:
+            continue
+        c = {n: mean(v) for n, v in data[k].items()}
+        lines.append(f'## {key}   ({k[:110]})')
+        for n in sorted(c):
+            lines.append(f'{n:32s} {c[n]:14.4e}')
+        d = []
+        if c.get('SQ_INSTS_MFMA') and c.get('SQ_INSTS_VALU'):
+            d.append(f"VALU per MFMA = {c['SQ_INSTS_VALU'] / c['SQ_INSTS_MFMA']:.2f}")
+        if c.get('SQ_VALU_MFMA_BUSY_CYCLES') and c.get('GRBM_GUI_ACTIVE'):
+            d.append('MFMA pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs) = '
+                     f"{c['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024.0 * c['GRBM_GUI_ACTIVE'] / 8.0):.3f}")
+        if c.get('SQ_LDS_IDX_ACTIVE'):
+            d.append(f"LDS conflict share = {c.get('SQ_LDS_BANK_CONFLICT', 0.0) / c['SQ_LDS_IDX_ACTIVE']:.3f}")
+        if c.get('TCC_HIT_sum') is not None and c.get('TCC_MISS_sum') is not None and c['TCC_HIT_sum'] + c['TCC_MISS_sum'] > 0:
+            d.append(f"L2 hit rate = {c['TCC_HIT_sum'] / (c['TCC_HIT_sum'] + c['TCC_MISS_sum']):.3f}")
+        if c.get('FETCH_SIZE') is not None and c.get('WRITE_SIZE') is not None:
+            rb, wb = c['FETCH_SIZE'] * 1024 * corr, c['WRITE_SIZE'] * 1024 * wcorr
+            d.append(f'HBM bytes per launch = {rb / 1e9:.3f} GB read + {wb / 1e9:.3f} GB written = {(rb + wb) / 1e9:.3f} GB '
+                     f'({(rb + wb) / alg:.2f}x the algorithmic {alg / 1e9:.3f} GB)')
+            hbm['kernels'][key] = {'kernel_name': k[:160], 'read_bytes': rb, 'write_bytes': wb, 'bytes_per_launch': rb + wb,
+                                   'algorithmic_bytes_per_launch': alg}
+        lines += ['   ' + x for x in d] + ['']
+    open(prefix + '_kernels_pmc.txt', 'w').write('\n'.join(lines) + '\n')
+    json.dump(hbm, open(prefix + '_hbm_bytes.json', 'w'), indent=1)
+    print('\n'.join(lines))
+
+
+if __name__ == '__main__':
+    main(sys.argv[1], sys.argv[2])

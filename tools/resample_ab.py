@@ -5,6 +5,8 @@ gradient (lf_resample3d_bwd_coef) at the bench shape (N = 8, 128^3 x 16), checke
     hipcc -x hip --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -shared -Ilatentfusion_amd/csrc -Iinclude \
           latentfusion_amd/csrc/resample.hip -o scratch/rs_a.so
     python tools/resample_ab.py scratch/rs_a.so scratch/rs_b.so
+    python tools/resample_ab.py latentfusion_amd/csrc/liblf_hip.so@1 latentfusion_amd/csrc/liblf_hip.so@2
+(`path@v` selects kernel variant v of that library through lf_set_tuning(1, v) before every call)
 """
 import ctypes
 import os
@@ -37,8 +39,13 @@ cf20[:, :18] = coefs[:, :18]
 st = torch.cuda.current_stream().cuda_stream
 
 
-def bind(path):
+def bind(spec):
+    path, _, var = spec.partition('@')
     L = ctypes.CDLL(os.path.abspath(path))
+    L._variant = int(var) if var else None
+    if L._variant is not None:
+        L.lf_set_tuning.restype = I
+        L.lf_set_tuning.argtypes = [I, I]
     L.lf_resample3d_fwd.restype = I
     L.lf_resample3d_fwd.argtypes = [P, I, P, I, P, I, I, I, I, I, P]
     L.lf_resample3d_bwd_coef_scratch_bytes.restype = ctypes.c_size_t
@@ -48,9 +55,15 @@ def bind(path):
     return L
 
 
+def select(L):
+    if L._variant is not None:
+        L.lf_set_tuning(1, L._variant)
+
+
 libs = [bind(p) for p in sys.argv[1:]]
 state = []
 for L in libs:
+    select(L)
     out = torch.empty_like(gout)
     nb = L.lf_resample3d_bwd_coef_scratch_bytes(N, S, S, S)
     scratch = torch.empty(nb // 4 + 1, device=dev)
@@ -69,6 +82,7 @@ for r in range(ROUNDS):
     for i in range(len(libs)):
         for fn, acc in ((state[i][2], tf), (state[i][3], tb)):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            select(libs[i])
             e0.record()
             for _ in range(5):
                 fn()
