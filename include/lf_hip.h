@@ -49,8 +49,9 @@ int lf_device_name(char* buf, int buflen);
 
 /* Kernel-variant switch for in-process A/B measurements (tools/, profiles/); results are equivalent within the test
  * tolerances for every value.  key 1: 3-D resampler kernels, 1 = generic (64-bit addressing, any C), 2 = lean
- * (default: 32-bit buffer addressing, C % 4 == 0, volumes < 4 GB per sample; other shapes take the generic ones),
- * 3 = lean + the 16-channel specialisation of the gather.
+ * (32-bit buffer addressing, C % 4 == 0, volumes < 4 GB per sample; other shapes take the generic ones),
+ * 3 = lean + the 16-channel specialisation of the gather (default).  key 2: lean coefficient-gradient kernel, sub-tiles in
+ * flight per workgroup iteration: 1 = one, 2 = two, 3 = two at 4 waves per SIMD (default).
  * Returns the previous value or LF_EINVAL. */
 int lf_set_tuning(int key, int value);
 
@@ -195,6 +196,25 @@ long lf_wino3d_tiles(int N, int D, int H, int W);
 int lf_wino3d_input_transform(const float* x, float* V, int N, int D, int H, int W, int C, void* stream);
 int lf_wino3d_output_transform(const float* M, const float* bias, float* y, float* norm_out, int N, int D, int H, int W,
                                int C, float he, unsigned flags, float slope, float eps, void* stream);
+
+/* Stages 2 + 3 of the wide Winograd convolution in ONE launch, on this library's own fp32-MFMA GEMM (no library GEMM on
+ * the hot path): for every frequency f the product V[f] (T x Cin) . U2[f]^T is accumulated on v_mfma_f32_16x16x4_f32 and
+ * folded straight into the 2^dims outputs of each tile (output transform A^T M A), then He scale, bias and LeakyReLU are
+ * applied in the store -- M (8x / 4x the output) never reaches memory.  dims = 3: V [64][T][Cin] from
+ * lf_wino3d_input_transform; dims = 2 (D = 1): V [16][T][Cin] from lf_wino2d_input_transform.
+ * U2: [F][CoutP][Cin], CoutP = lf_wino_fused_cout_padded(Cout) (zero padded), U2[f][co][ci] = ((G (x) ..) w)[co][ci][f]
+ * -- output-channel major so that both GEMM operands stream along the contraction axis.  Cin, Cout multiples of 4.
+ * flags: LF_EPI_LRELU only; for PixelNorm run lf_pixelnorm_fwd on y afterwards (y is 1/8 resp. 1/4 of V).
+ * Also the data gradient of the same convolution (transposed / flipped U2, flags = 0, bias = NULL).
+ * Replaces Equalized.forward + LeakyReLU of modules/equalized.py:57-64, blocks.py:152-158 for >= 64-channel layers.
+ * Problems with few tile / channel blocks are split over the frequencies (more workgroups): each part writes its raw
+ * partial outputs to `scratch` (lf_wino_fused_scratch_bytes(...) bytes, 0 when no split is used) and a second launch
+ * adds them in a fixed order and applies the epilogue -- deterministic, no atomics. */
+int lf_wino_fused_cout_padded(int Cout);
+size_t lf_wino_fused_scratch_bytes(int dims, int N, int D, int H, int W, int Cout);
+int lf_wino_fused_gemm(const float* V, const float* U2, const float* bias, float* y, void* scratch, size_t scratch_bytes,
+                       int dims, int N, int D, int H, int W, int Cin, int Cout, float he, unsigned flags, float slope,
+                       void* stream);
 
 /* 2-D counterpart, F(2x2,3x3): V [16][T][Cin], M [16][T][Cout], T = lf_wino2d_tiles(N, H, W), f = b*4 + c (y, x). */
 long lf_wino2d_tiles(int N, int H, int W);

@@ -52,6 +52,9 @@ SIGNATURES = {
     'lf_wino3d_tiles': (c_long, [c_int, c_int, c_int, c_int]),
     'lf_wino3d_input_transform': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'lf_wino3d_output_transform': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_uint, c_float, c_float, P]),
+    'lf_wino_fused_cout_padded': (c_int, [c_int]),
+    'lf_wino_fused_scratch_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    'lf_wino_fused_gemm': (c_int, [P, P, P, P, P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_uint, c_float, P]),
     'lf_wino2d_tiles': (c_long, [c_int, c_int, c_int]),
     'lf_wino2d_input_transform': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     'lf_wino2d_output_transform': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint, c_float, c_float, P]),

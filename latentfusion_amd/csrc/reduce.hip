@@ -20,6 +20,7 @@ namespace {
 // i-th point of torch.linspace(-1, 1, n): start + step*i in the first half, end - step*(n-1-i) in the second
 // (ATen's symmetric formula; step = 2/(n-1) rounded to fp32 on the host)
 __device__ __forceinline__ float depth_coord(int i, int n, float step) {
+  if (n == 1) return -1.f;                                       // linspace(-1, 1, 1) = [start]
   return (i < n / 2) ? -1.f + step * (float)i : 1.f - step * (float)(n - 1 - i);
 }
 
@@ -207,23 +208,37 @@ __global__ void __launch_bounds__(256) fuse_views_fwd_kernel(const T* __restrict
   if (i >= nvec) return;
   T r;
   int sel[O::W];
+  // views are read four at a time (independent streamed loads: every view is a separate stream `vstride` apart, one
+  // load in flight per lane would leave the kernel latency-bound) and combined in view order
   if (kind == LF_FUSE_MEAN) {
-    T acc = z[i];
-    for (int v = 1; v < V; ++v) acc += z[i + v * vstride_vec];
+    T acc = __builtin_nontemporal_load(z + i);
+    int v = 1;
+    for (; v + 3 < V; v += 4) {
+      const T c0 = __builtin_nontemporal_load(z + i + (long)v * vstride_vec), c1 = __builtin_nontemporal_load(z + i + (long)(v + 1) * vstride_vec);
+      const T c2 = __builtin_nontemporal_load(z + i + (long)(v + 2) * vstride_vec), c3 = __builtin_nontemporal_load(z + i + (long)(v + 3) * vstride_vec);
+      acc += c0; acc += c1; acc += c2; acc += c3;
+    }
+    for (; v < V; ++v) acc += __builtin_nontemporal_load(z + i + (long)v * vstride_vec);
     r = acc / (float)V;
   } else if (kind == LF_FUSE_MAX || kind == LF_FUSE_ABSMAX) {
-    r = z[i];
+    r = __builtin_nontemporal_load(z + i);
 #pragma unroll
     for (int e = 0; e < O::W; ++e) sel[e] = 0;
-    for (int v = 1; v < V; ++v) {
-      const T c = z[i + v * vstride_vec];
+    auto consider = [&](const T& c, int v) {
 #pragma unroll
       for (int e = 0; e < O::W; ++e) {
         const float a = O::get(c, e), b = O::get(r, e);
         const bool take = (kind == LF_FUSE_MAX) ? (a > b) : (fabsf(a) > fabsf(b));   // first maximum wins ties
         if (take) { O::set(r, e, a); sel[e] = v; }
       }
+    };
+    int v = 1;
+    for (; v + 3 < V; v += 4) {
+      const T c0 = __builtin_nontemporal_load(z + i + (long)v * vstride_vec), c1 = __builtin_nontemporal_load(z + i + (long)(v + 1) * vstride_vec);
+      const T c2 = __builtin_nontemporal_load(z + i + (long)(v + 2) * vstride_vec), c3 = __builtin_nontemporal_load(z + i + (long)(v + 3) * vstride_vec);
+      consider(c0, v); consider(c1, v + 1); consider(c2, v + 2); consider(c3, v + 3);
     }
+    for (; v < V; ++v) consider(__builtin_nontemporal_load(z + i + (long)v * vstride_vec), v);
   } else {
     // lower median = element of rank (V-1)/2 (torch.median); rank by counting, ties by view index
     const int want = (V - 1) / 2;

@@ -424,7 +424,8 @@ __device__ __forceinline__ float quad_sum4(float v) {
 // coefficient gradient, C == 16 (4 lanes per voxel, 64 voxels per block-iteration): block = 2^lg-voxel tile walked in
 // 4x4x4 sub-tiles; thread (v = tid >> 2, q = tid & 3) keeps its position inside the sub-tile, the sub-tile index is
 // wave-uniform
-__global__ void __launch_bounds__(256) resample_bwd_coef_c16_kernel(
+template <int MINW, int UNR>
+__global__ void __launch_bounds__(256, MINW) resample_bwd_coef_c16_kernel(
     const float* __restrict__ gout, const float* __restrict__ vol, long vol_bstride,
     const float* __restrict__ coef, float* __restrict__ partial, int nblk, int vpb, BwdTile bt,
     int D, int H, int W, Steps st) {
@@ -444,40 +445,53 @@ __global__ void __launch_bounds__(256) resample_bwd_coef_c16_kernel(
   for (int i = 0; i < 18; ++i) acc[i] = 0.f;
   const float qsel = (q == 0) ? 1.f : 0.f;                       // one lane of the quad feeds the sums
   const int nsub = vpb >> 6;
-  for (int sub = 0; sub < nsub; ++sub) {                         // wave-uniform
-    const int x = (tx << bt.lx) + ((sub & ((1 << sbx) - 1)) << 2) + px;
-    const int y = (ty << bt.ly) + (((sub >> sbx) & ((1 << sby) - 1)) << 2) + py;
-    const int z = (tz << bt.lz) + ((sub >> (sbx + sby)) << 2) + pz;
-    const bool live = x < W && y < H && z < D;
-    float hx = 0.f, hy = 0.f, hz = 0.f, a = 0.f, b = 0.f, k = 0.f;
-    float gx, gy, gz;
-    eval_grid<LF_MAP_O2C>(cf, live ? x : 0, live ? y : 0, live ? z : 0, W, H, D, st, gx, gy, gz, a, b, k);
-    const Tap32 t = make_tap32(gx, gy, gz, W, H, D, rec);
-    const u32 co = (u32)q * 16u;
-    // out-of-tile lanes read offset 0xffffffff: outside the descriptor's range -> zeros, no branch
-    const u32 dead = live ? 0u : 0xffffffffu;
-    const f32x4 go = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-        rg, (int)(((u32)((z * H + y) * W + x) * rec + co) | dead), 0, 2));      // streamed once (nt)
-    const f32x4 v000 = ldrec(rs, (t.o000 + co) | dead), v001 = ldrec(rs, (t.o001 + co) | dead);
-    const f32x4 v010 = ldrec(rs, (t.o010 + co) | dead), v011 = ldrec(rs, (t.o011 + co) | dead);
-    const f32x4 v100 = ldrec(rs, (t.o100 + co) | dead), v101 = ldrec(rs, (t.o101 + co) | dead);
-    const f32x4 v110 = ldrec(rs, (t.o110 + co) | dead), v111 = ldrec(rs, (t.o111 + co) | dead);
-#define DOT4(v) ((go[0] * (v)[0] + go[1] * (v)[1]) + (go[2] * (v)[2] + go[3] * (v)[3]))
-    const float p000 = quad_sum4(DOT4(v000)), p001 = quad_sum4(DOT4(v001)), p010 = quad_sum4(DOT4(v010)), p011 = quad_sum4(DOT4(v011));
-    const float p100 = quad_sum4(DOT4(v100)), p101 = quad_sum4(DOT4(v101)), p110 = quad_sum4(DOT4(v110)), p111 = quad_sum4(DOT4(v111));
-#undef DOT4
-    const float wx1 = t.tx, wx0 = 1.f - t.tx, wy1 = t.ty, wy0 = 1.f - t.ty, wz1 = t.tz, wz0 = 1.f - t.tz;
-    const float dxv = (p001 - p000) * (wy0 * wz0) + (p011 - p010) * (wy1 * wz0) + (p101 - p100) * (wy0 * wz1) + (p111 - p110) * (wy1 * wz1);
-    const float dyv = (p010 - p000) * (wx0 * wz0) + (p011 - p001) * (wx1 * wz0) + (p110 - p100) * (wx0 * wz1) + (p111 - p101) * (wx1 * wz1);
-    const float dzv = (p100 - p000) * (wx0 * wy0) + (p101 - p001) * (wx1 * wy0) + (p110 - p010) * (wx0 * wy1) + (p111 - p011) * (wx1 * wy1);
-    hx = dxv * t.mx * qsel; hy = dyv * t.my * qsel; hz = dzv * t.mz * qsel;
-    const float ak = a * k, bk = b * k;
-    acc[0] += hx;       acc[1] += hy;       acc[2] += hz;
-    acc[3] += hx * a;   acc[4] += hy * a;   acc[5] += hz * a;
-    acc[6] += hx * b;   acc[7] += hy * b;   acc[8] += hz * b;
-    acc[9] += hx * k;   acc[10] += hy * k;  acc[11] += hz * k;
-    acc[12] += hx * ak; acc[13] += hy * ak; acc[14] += hz * ak;
-    acc[15] += hx * bk; acc[16] += hy * bk; acc[17] += hz * bk;
+  const u32 co = (u32)q * 16u;
+  // UNR sub-tiles are in flight per iteration: the 9 loads of a voxel have nothing to overlap with inside one
+  // sub-tile (a block walks its tile serially), so with one sub-tile at a time the kernel is bound by memory latency,
+  // not by bandwidth (measured: 0.64 ms at 4 waves/SIMD; the loads alone need ~0.3 ms of the L1 path)
+  for (int sub0 = 0; sub0 < nsub; sub0 += UNR) {                 // wave-uniform
+    Tap32 t[UNR];
+    float a[UNR], b[UNR], k[UNR];
+    f32x4 go[UNR], v[UNR][8];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int sub = sub0 + u;
+      const int x = (tx << bt.lx) + ((sub & ((1 << sbx) - 1)) << 2) + px;
+      const int y = (ty << bt.ly) + (((sub >> sbx) & ((1 << sby) - 1)) << 2) + py;
+      const int z = (tz << bt.lz) + ((sub >> (sbx + sby)) << 2) + pz;
+      const bool live = sub < nsub && x < W && y < H && z < D;
+      float gx, gy, gz;
+      eval_grid<LF_MAP_O2C>(cf, live ? x : 0, live ? y : 0, live ? z : 0, W, H, D, st, gx, gy, gz, a[u], b[u], k[u]);
+      t[u] = make_tap32(gx, gy, gz, W, H, D, rec);
+      // out-of-tile lanes read offset 0xffffffff: outside the descriptor's range -> zeros, no branch
+      const u32 dead = live ? 0u : 0xffffffffu;
+      go[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+          rg, (int)(((u32)((z * H + y) * W + x) * rec + co) | dead), 0, 2));      // streamed once (nt)
+      v[u][0] = ldrec(rs, (t[u].o000 + co) | dead); v[u][1] = ldrec(rs, (t[u].o001 + co) | dead);
+      v[u][2] = ldrec(rs, (t[u].o010 + co) | dead); v[u][3] = ldrec(rs, (t[u].o011 + co) | dead);
+      v[u][4] = ldrec(rs, (t[u].o100 + co) | dead); v[u][5] = ldrec(rs, (t[u].o101 + co) | dead);
+      v[u][6] = ldrec(rs, (t[u].o110 + co) | dead); v[u][7] = ldrec(rs, (t[u].o111 + co) | dead);
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      float p[8];
+#pragma unroll
+      for (int c8 = 0; c8 < 8; ++c8)
+        p[c8] = quad_sum4((go[u][0] * v[u][c8][0] + go[u][1] * v[u][c8][1]) + (go[u][2] * v[u][c8][2] + go[u][3] * v[u][c8][3]));
+      const float wx1 = t[u].tx, wx0 = 1.f - wx1, wy1 = t[u].ty, wy0 = 1.f - wy1, wz1 = t[u].tz, wz0 = 1.f - wz1;
+      // p index = z*4 + y*2 + x
+      const float dxv = (p[1] - p[0]) * (wy0 * wz0) + (p[3] - p[2]) * (wy1 * wz0) + (p[5] - p[4]) * (wy0 * wz1) + (p[7] - p[6]) * (wy1 * wz1);
+      const float dyv = (p[2] - p[0]) * (wx0 * wz0) + (p[3] - p[1]) * (wx1 * wz0) + (p[6] - p[4]) * (wx0 * wz1) + (p[7] - p[5]) * (wx1 * wz1);
+      const float dzv = (p[4] - p[0]) * (wx0 * wy0) + (p[5] - p[1]) * (wx1 * wy0) + (p[6] - p[2]) * (wx0 * wy1) + (p[7] - p[3]) * (wx1 * wy1);
+      const float hx = dxv * t[u].mx * qsel, hy = dyv * t[u].my * qsel, hz = dzv * t[u].mz * qsel;
+      const float ak = a[u] * k[u], bk = b[u] * k[u];
+      acc[0] += hx;          acc[1] += hy;          acc[2] += hz;
+      acc[3] += hx * a[u];   acc[4] += hy * a[u];   acc[5] += hz * a[u];
+      acc[6] += hx * b[u];   acc[7] += hy * b[u];   acc[8] += hz * b[u];
+      acc[9] += hx * k[u];   acc[10] += hy * k[u];  acc[11] += hz * k[u];
+      acc[12] += hx * ak;    acc[13] += hy * ak;    acc[14] += hz * ak;
+      acc[15] += hx * bk;    acc[16] += hy * bk;    acc[17] += hz * bk;
+    }
   }
   __shared__ float red[4][18];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -493,7 +507,8 @@ __global__ void __launch_bounds__(256) resample_bwd_coef_c16_kernel(
   }
 }
 
-int g_resample_variant = 2;                                    // 1 = generic kernels, 2 = lean kernels (lf_set_tuning)
+int g_bwd_coef_variant = 3;   // lean coefficient gradient: 1 = one sub-tile in flight, 2 = two, 3 = two at 4 waves/SIMD
+int g_resample_variant = 3;   // 1 = generic kernels, 2 = lean kernels, 3 = lean + 16-channel gather (lf_set_tuning)
 
 bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
@@ -585,7 +600,13 @@ extern "C" int lf_resample3d_bwd_coef(const float* gout, const float* vol, int v
   while (lpv < groups) lpv <<= 1;
   if (lpv > 64) return LF_EINVAL;                       // C > 256 (vec) / C > 64 (scalar)
   if (g_resample_variant >= 2 && vec && C == 16 && vpb >= 64 && nvox * 64 < 0xffffffffL) {
-    hipLaunchKernelGGL(resample_bwd_coef_c16_kernel, grid, block, 0, s, gout, vol, bstride, coef, partial, nblk, vpb, bt, D, H, W, make_steps(D, H, W));
+    const Steps stp = make_steps(D, H, W);
+    if (g_bwd_coef_variant == 1)
+      hipLaunchKernelGGL((resample_bwd_coef_c16_kernel<1, 1>), grid, block, 0, s, gout, vol, bstride, coef, partial, nblk, vpb, bt, D, H, W, stp);
+    else if (g_bwd_coef_variant == 2)
+      hipLaunchKernelGGL((resample_bwd_coef_c16_kernel<1, 2>), grid, block, 0, s, gout, vol, bstride, coef, partial, nblk, vpb, bt, D, H, W, stp);
+    else
+      hipLaunchKernelGGL((resample_bwd_coef_c16_kernel<4, 2>), grid, block, 0, s, gout, vol, bstride, coef, partial, nblk, vpb, bt, D, H, W, stp);
     int st2 = lf_launch_status();
     if (st2) return st2;
     hipLaunchKernelGGL(resample_bwd_coef_reduce, dim3(N), dim3(256), 0, s, partial, nblk, gcoef);
@@ -625,6 +646,11 @@ extern "C" int lf_set_tuning(int key, int value) {
   if (key == 1) {
     const int prev = g_resample_variant;
     if (value >= 1 && value <= 3) g_resample_variant = value;
+    return prev;
+  }
+  if (key == 2) {
+    const int prev = g_bwd_coef_variant;
+    if (value >= 1 && value <= 3) g_bwd_coef_variant = value;
     return prev;
   }
   return LF_EINVAL;

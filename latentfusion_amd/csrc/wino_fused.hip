@@ -1,0 +1,290 @@
+// Wide Winograd convolutions, stage 2 + 3 in one kernel (gfx950): the per-frequency products
+//   M[f] = V[f] (tiles x Cin) . U[f] (Cin x Cout),   f = 0 .. F-1   (F = 64 for F(2x2x2,3x3x3), 16 for F(2x2,3x3))
+// on the fp32 MFMA (v_mfma_f32_16x16x4_f32, exact fp32 products and accumulation) with the OUTPUT TRANSFORM
+// Y = A^T M A (x, y[, z]) folded into the frequency loop and the conv epilogue (He scale, bias, LeakyReLU) into the
+// store -- the Winograd-domain products M (8x / 4x the size of the output) never exist in memory, and no library GEMM
+// sits on the hot path of the released-width model (latentfusion/modules/blocks.py:152-158 at 64-512 channels,
+// tools/train/train.sh:28-66; the same kernel evaluates the data gradients with transposed / flipped weight packs).
+//
+// Work split: a 256-thread workgroup owns 64 output channels x 64 Winograd tiles for ALL frequencies; wave (wr, wc)
+// owns the 32 x 32 block (couts wr*32.., tiles wc*32..) as 2 x 2 MFMA tiles.  MFMA roles are swapped w.r.t. a textbook
+// GEMM -- A = weights [16 couts][k], B = inputs [k][16 tiles] -- so a lane ends up with 4 CONSECUTIVE output channels
+// of one tile and the channels-last store is a float4 per lane (64 B contiguous per 4 lanes).
+// The (f, k) loop is flattened into stages of KC = 32 input channels: the A (64 x 32) and B (64 x 32) chunks of a
+// stage are DMA'd global -> LDS (buffer_load_dwordx4 ... lds) into a ring of 4 stages, three stages ahead of the one
+// that feeds the 32 MFMAs per wave, with ONE workgroup barrier per stage (measured: with a register-staged double
+// buffer, one stage ahead, the kernel ran at ~15 % of the fp32 MFMA peak -- bound by the latency of each stage's
+// loads); LDS rows are 128 B with the eight 16-byte chunks XOR-swizzled by (row >> 1) & 7, which makes the hardware's
+// 16-lane ds_read_b128 groups hit distinct banks.  Within a 16-wide k-group a
+// lane group kg = lane >> 4 takes k = kg*4 + i in MFMA step i (the contraction index may be permuted freely as long as
+// A and B agree), so one ds_read_b128 feeds four MFMA steps.
+// After the last chunk of a frequency the 2 x 2 accumulators are folded into the 2^dims output accumulators with the
+// (wave-uniform) coefficients A^T[o][f] in {-1, 0, 1}.
+#include "lf_common.h"
+
+namespace {
+
+constexpr int MT = 64;      // Winograd tiles per workgroup   (B rows)
+constexpr int NT = 64;      // output channels per workgroup  (A rows)
+constexpr int KC = 32;      // input channels per stage
+constexpr int TILE_BYTES = 64 * KC * 4;                          // 8 KiB per operand chunk
+constexpr int NSTAGE = 4;                                        // LDS ring depth (stages of A + B chunks)
+constexpr int WF_LDS = NSTAGE * 2 * TILE_BYTES;                  // 64 KiB: two workgroups per CU
+
+typedef unsigned u32;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// byte offset of 16-byte chunk c (0..7) of row r in a 64 x 32-float LDS tile
+__device__ __forceinline__ int lds_chunk(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
+
+// A^T = [[1, 1, 1, 0], [0, 1, -1, -1]]: coefficient of frequency component a in output o
+__device__ __forceinline__ float at_coef(int o, int a) {
+  return o == 0 ? (a < 3 ? 1.f : 0.f) : (a == 0 ? 0.f : (a == 1 ? 1.f : -1.f));
+}
+
+template <int DIMS>
+__global__ void __launch_bounds__(256, 2) wino_fused_kernel(
+    const float* __restrict__ V, const float* __restrict__ U2, const float* __restrict__ bias, float* __restrict__ y,
+    long T, int tz, int ty, int tx, int D, int H, int W, int Cin, int Cout, int CoutP, float he, unsigned flags, float slope,
+    float* __restrict__ partial, long ysize) {
+  constexpr int F = DIMS == 3 ? 64 : 16;
+  constexpr int NO = DIMS == 3 ? 8 : 4;                          // outputs per tile
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wr = w >> 1, wc = w & 1;
+  const int lr = lane & 15, kg = lane >> 4;
+  const long m0 = (long)blockIdx.x * MT;                         // first tile of this workgroup
+  const int n0 = blockIdx.y * NT;                                // first output channel
+
+  // ---- global -> LDS staging by LDS-DMA (buffer_load_dwordx4 ... lds): a wave-instruction deposits 64 x 16 B = 1 KiB
+  // linearly at a wave-uniform LDS address, so the swizzle is applied on the GLOBAL side: the lane that lands on
+  // LDS position pos = piece*64 + lane (row r = pos >> 3, slot pos & 7) fetches logical chunk c = slot ^ ((r >> 1) & 7)
+  // of that row.  A stage = 8 pieces of A + 8 of B; wave w issues pieces 2w, 2w+1 of each.  No staging registers,
+  // no ds_write; out-of-range chunks (k >= Cin, tile >= T) get an out-of-range offset and the DMA writes zeros. ----
+  const u32 slabV = (u32)((long)T * Cin * 4 <= 0xffffffffL ? (long)T * Cin * 4 : 0xffffffffL);
+  const u32 slabU = (u32)((long)CoutP * Cin * 4);
+  u32 offA[2], offB[2];
+  int kch[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int pos = (w * 2 + i) * 64 + lane, r = pos >> 3, c = (pos & 7) ^ ((r >> 1) & 7);
+    kch[i] = c * 4;
+    offA[i] = (u32)(n0 + r) * (u32)Cin * 4u + (u32)c * 16u;      // U2[f][n0 + r][k0 + 4c ..]
+    const long row = m0 + r;
+    offB[i] = row < T ? (u32)row * (u32)Cin * 4u + (u32)c * 16u : 0xffffffffu;
+  }
+  const int nk = (Cin + KC - 1) / KC;
+  // frequency split (small problems: few tile / channel blocks): workgroup z handles frequencies
+  // [z * F / gridDim.z, (z + 1) * F / gridDim.z) and writes its un-scaled partial outputs; lf's finish kernel adds the
+  // partials in a fixed order and applies the epilogue
+  const int fper = F / gridDim.z, f_first = blockIdx.z * fper;
+  const int S = fper * nk;
+  auto issue = [&](int s) {
+    const int fl = s / nk, k0 = (s - fl * nk) * KC, f = f_first + fl;      // wave-uniform
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(V + (long)f * T * Cin), 0, slabV, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void*)(U2 + (long)f * CoutP * Cin), 0, slabU, 0x00020000);
+    unsigned char* slot = smem + (s % NSTAGE) * 2 * TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool kok = k0 + kch[i] < Cin;                        // (Cin % 4 == 0: whole chunks are in or out)
+      const int va = kok ? (int)(offA[i] + (u32)k0 * 4u) : 0x7fffffff;
+      const int vb = (kok && offB[i] != 0xffffffffu) ? (int)(offB[i] + (u32)k0 * 4u) : 0x7fffffff;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (__attribute__((address_space(3))) void*)(slot + (w * 2 + i) * 1024), 16, va, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(slot + TILE_BYTES + (w * 2 + i) * 1024), 16, vb, 0, 0, 0);
+    }
+  };
+
+  // ---- MFMA operand addressing: row of this lane in A (cout) and B (tile) for the two 16-row tiles of the wave ----
+  int rdA[2][2], rdB[2][2];                                      // [row tile][k-group j]
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int ra_ = wr * 32 + t * 16 + lr, rb_ = wc * 32 + t * 16 + lr;
+      rdA[t][j] = lds_chunk(ra_, j * 4 + kg);
+      rdB[t][j] = TILE_BYTES + lds_chunk(rb_, j * 4 + kg);
+    }
+
+  f32x4 Y[NO][2][2];
+#pragma unroll
+  for (int o = 0; o < NO; ++o)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) Y[o][a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // ring of NSTAGE stages: stages s+1 .. s+NSTAGE-1 are in flight while stage s feeds the MFMAs
+  for (int s0 = 0; s0 < NSTAGE - 1 && s0 < S; ++s0) issue(s0);
+  int kc = 0, f = f_first;
+  for (int s = 0; s < S; ++s) {
+    // this wave's pieces of stage s have landed when at most the pieces of the later stages it issued are outstanding
+    // (4 DMA instructions per stage and wave); then the workgroup barrier makes every wave's pieces visible AND
+    // certifies that everybody is done reading stage s-1, whose ring slot the next issue overwrites
+    const int ahead = min(NSTAGE - 2, S - 1 - s);
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (s + NSTAGE - 1 < S) issue(s + NSTAGE - 1);
+    const unsigned char* base = smem + (s % NSTAGE) * 2 * TILE_BYTES;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      f32x4 fa[2], fb[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        fa[t] = *(const f32x4*)(base + rdA[t][j]);
+        fb[t] = *(const f32x4*)(base + rdB[t][j]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a][i], fb[b][i], acc[a][b], 0, 0, 0);
+    }
+    if (++kc == nk) {
+      // frequency f complete: fold it into the outputs, Y[o] += A^T[o][f] * M[f]
+      kc = 0;
+      const int fc = f & 3, fb_ = (f >> 2) & 3, fa_ = (f >> 4) & 3;      // x, y, z frequency (DIMS == 2: fa_ unused)
+#pragma unroll
+      for (int o = 0; o < NO; ++o) {
+        float cf = at_coef(o & 1, fc) * at_coef((o >> 1) & 1, fb_);
+        if (DIMS == 3) cf *= at_coef((o >> 2) & 1, fa_);
+        if (cf != 0.f) {                                         // wave-uniform
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) Y[o][a][b] += acc[a][b] * cf;
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      ++f;
+    }
+  }
+
+  // ---- epilogue: He scale, bias, LeakyReLU; lane holds couts n0 + wr*32 + a*16 + kg*4 .. +3 of tile column lr ----
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const long tile = m0 + wc * 32 + b * 16 + lr;
+    if (tile >= T) continue;
+    long r = tile;
+    const int bx = (int)(r % tx); r /= tx;
+    const int by = (int)(r % ty); r /= ty;
+    const int bz = DIMS == 3 ? (int)(r % tz) : 0;
+    const long n = DIMS == 3 ? r / tz : r;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int co = n0 + wr * 32 + a * 16 + kg * 4;
+      if (co >= Cout) continue;
+      f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (bias != nullptr) bv = *(const f32x4*)(bias + co);
+#pragma unroll
+      for (int o = 0; o < NO; ++o) {
+        const int gx = 2 * bx + (o & 1), gy = 2 * by + ((o >> 1) & 1), gz = 2 * bz + (DIMS == 3 ? ((o >> 2) & 1) : 0);
+        if (gx >= W || gy >= H || gz >= D) continue;
+        const long vox = ((n * D + gz) * H + gy) * W + gx;
+        if (partial != nullptr) {                                // frequency-split launch: raw partial sums
+          *(f32x4*)(partial + (long)blockIdx.z * ysize + vox * Cout + co) = Y[o][a][b];
+          continue;
+        }
+        f32x4 v = Y[o][a][b] * he + bv;
+        if (flags & LF_EPI_LRELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * slope);
+        }
+        *(f32x4*)(y + vox * Cout + co) = v;
+      }
+    }
+  }
+}
+
+// y = epilogue(he * sum_z partial[z] + bias): fixed-order sum of the frequency-split partial outputs
+__global__ void __launch_bounds__(256) wino_fused_finish_kernel(const f32x4* __restrict__ partial, const float* __restrict__ bias,
+                                                               f32x4* __restrict__ y, long n4, long ysize4, int zs, int c4,
+                                                               float he, unsigned flags, float slope) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  f32x4 acc = partial[i];
+  for (int z = 1; z < zs; ++z) acc += partial[i + z * ysize4];
+  f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (bias != nullptr) bv = *(const f32x4*)(bias + (i % c4) * 4);
+  f32x4 v = acc * he + bv;
+  if (flags & LF_EPI_LRELU) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * slope);
+  }
+  y[i] = v;
+}
+
+// frequency split of a launch with gx x gy tile / channel blocks: enough workgroups to fill the chip
+int fused_zsplit(int dims, long gx, int gy) {
+  const int F = dims == 3 ? 64 : 16;
+  int zs = 1;
+  while (zs < F && gx * gy * zs < 256) zs <<= 1;
+  return zs;
+}
+
+}  // namespace
+
+extern "C" int lf_wino_fused_cout_padded(int Cout) { return (Cout + NT - 1) / NT * NT; }
+
+// bytes of scratch lf_wino_fused_gemm needs for this shape (0: none)
+extern "C" size_t lf_wino_fused_scratch_bytes(int dims, int N, int D, int H, int W, int Cout) {
+  if ((dims != 2 && dims != 3) || N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
+  const int tz = dims == 3 ? (D + 1) / 2 : 1, ty = (H + 1) / 2, tx = (W + 1) / 2;
+  const long T = (long)N * tz * ty * tx;
+  const int zs = fused_zsplit(dims, (T + MT - 1) / MT, lf_wino_fused_cout_padded(Cout) / NT);
+  return zs > 1 ? (size_t)zs * N * D * H * W * Cout * sizeof(float) : 0;
+}
+
+// y = epilogue(output_transform(V[f] . U2[f]^T)):  V [F][T][Cin] from lf_wino{2,3}d_input_transform;
+// scratch: lf_wino_fused_scratch_bytes(...) bytes (small problems are split over the frequencies);
+// U2 [F][CoutP][Cin] (output-channel major, CoutP = lf_wino_fused_cout_padded(Cout), zero padded);
+// y channels-last [N][D][H][W][Cout].  flags: LF_EPI_LRELU (PixelNorm: run lf_pixelnorm_fwd on y afterwards).
+extern "C" int lf_wino_fused_gemm(const float* V, const float* U2, const float* bias, float* y, void* scratch,
+                                  size_t scratch_bytes, int dims, int N, int D, int H, int W, int Cin, int Cout, float he,
+                                  unsigned flags, float slope, void* stream) {
+  lf_clear_error();
+  if ((dims != 2 && dims != 3) || N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return LF_EINVAL;
+  if ((Cin & 3) || (Cout & 3) || (dims == 2 && D != 1) || (flags & ~LF_EPI_LRELU)) return LF_EINVAL;
+  if (!lf_aligned16(V) || !lf_aligned16(U2) || !lf_aligned16(y) || (bias && !lf_aligned16(bias))) return LF_EALIGN;
+  const int tz = dims == 3 ? (D + 1) / 2 : 1, ty = (H + 1) / 2, tx = (W + 1) / 2;
+  const long T = (long)N * tz * ty * tx;
+  const int CoutP = lf_wino_fused_cout_padded(Cout);
+  // 32-bit byte offsets inside one frequency slab
+  if (T * Cin * 4 > 0xffffffffL || (long)CoutP * Cin * 4 > 0xffffffffL) return LF_EINVAL;
+  const long gx = (T + MT - 1) / MT;
+  if (gx > 0x7fffffffL || CoutP / NT > 65535) return LF_EINVAL;
+  const int zs = fused_zsplit(dims, gx, CoutP / NT);
+  const long ysize = (long)N * D * H * W * Cout;
+  if (zs > 1 && (scratch == nullptr || scratch_bytes < (size_t)zs * ysize * sizeof(float) || !lf_aligned16(scratch))) return LF_ENOSPC;
+  float* partial = zs > 1 ? (float*)scratch : nullptr;
+  dim3 grid((unsigned)gx, (unsigned)(CoutP / NT), (unsigned)zs), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  static bool attr_set = false;
+  if (!attr_set) {                                               // 64 KiB of dynamic LDS
+    hipError_t e = hipFuncSetAttribute((const void*)wino_fused_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wino_fused_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  if (dims == 3)
+    hipLaunchKernelGGL((wino_fused_kernel<3>), grid, block, WF_LDS, s, V, U2, bias, y, T, tz, ty, tx, D, H, W, Cin, Cout, CoutP, he, flags, slope, partial, ysize);
+  else
+    hipLaunchKernelGGL((wino_fused_kernel<2>), grid, block, WF_LDS, s, V, U2, bias, y, T, tz, ty, tx, D, H, W, Cin, Cout, CoutP, he, flags, slope, partial, ysize);
+  int st = lf_launch_status();
+  if (st || zs == 1) return st;
+  const long n4 = ysize / 4;
+  hipLaunchKernelGGL(wino_fused_finish_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (const f32x4*)partial, bias, (f32x4*)y,
+                     n4, n4, zs, Cout / 4, he, flags, slope);
+  return lf_launch_status();
+}

@@ -162,8 +162,9 @@ class RenderLoopEngine:
         self.conv_mode = conv_mode
         self.split = self.wino = self.wgemm = None
         if conv_mode == 'winograd' and not c16:
-            # wide blocks (released model: 256 -> 256 on 16^3): three-stage Winograd over library GEMMs
-            self.wgemm = [(ops.pack_conv3d_wino_gemm(w), ops.pack_conv3d_wino_gemm(w, transpose=True)) for w, *_ in self.convs]
+            # wide blocks (released model: 256 -> 256 on 16^3): Winograd input transform + the fused fp32-MFMA GEMM /
+            # output transform / epilogue kernel (lf_wino_fused_gemm)
+            self.wgemm = [w for w, *_ in self.convs]            # packs are cached on the parameters (ops.wide_conv)
         if conv_mode == 'f16x3':
             self.split = [(ops.pack_conv3d_c16_split(w), ops.pack_conv3d_c16_split(w, transpose=True)) for w, *_ in self.convs]
         elif conv_mode == 'winograd_f16x3':
@@ -216,7 +217,7 @@ class RenderLoopEngine:
             elif self.wino is not None:
                 y, nrm = ops.conv3d_c16_wino(acts[-1], self.wino[li_][0], b, he, flags)
             elif self.wgemm is not None:
-                y, nrm = ops.conv3d_wino_gemm(acts[-1], self.wgemm[li_][0], b, he, flags)
+                y, nrm = ops.wide_conv(acts[-1], self.wgemm[li_], b, he, flags)
             else:
                 y, nrm = ops._conv3x3_raw(acts[-1], wp, b, w.shape[0], he, flags, True)
             acts.append(y)
@@ -276,7 +277,7 @@ class RenderLoopEngine:
                 w, b, he, _wp, wt = self.convs[i]
                 gpre = ops._epilogue_bwd(g, acts[i + 1], norms[i], flags)
                 if self.wgemm is not None:
-                    g, _ = ops.conv3d_wino_gemm(gpre, self.wgemm[i][1], None, he, 0)
+                    g, _ = ops.wide_conv(gpre, self.wgemm[i], None, he, 0, transpose=True)
                 else:
                     g, _ = ops._conv3x3_raw(gpre, wt, None, w.shape[1], he, 0, False)
         gcoef18 = torch.empty(n, 18, device=dev, dtype=torch.float32)

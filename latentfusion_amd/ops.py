@@ -251,9 +251,77 @@ def pack_conv3d_wino_gemm(weight, transpose=False):
     return U.reshape(16, w.shape[1], w.shape[0]).float().contiguous()
 
 
+# 'fused' (default): input transform -> lf_wino_fused_gemm (this library's fp32-MFMA GEMM with the output transform and
+# the epilogue folded in; the Winograd-domain products never reach memory).  'bmm': the three-stage form with the
+# per-frequency products on the library GEMM (torch.bmm -> rocBLAS), kept for A/B measurements (tools/rel_probe.py).
+WIDE_CONV_MODE = 'fused'
+
+
+def pack_conv_wino_fused(weight, transpose=False):
+    """[Cout,Cin,3,3(,3)] -> U2 [64 | 16 f][CoutP][Cin] (output-channel major, CoutP = lf_wino_fused_cout_padded(Cout),
+    zero padded) for lf_wino_fused_gemm: U2[f][co][ci] = ((G x ..) w)[co][ci][f], evaluated in fp64."""
+    L = _lib.lib()
+    w = weight.detach()
+    if transpose:
+        w = w.transpose(0, 1).flip(dims=tuple(range(2, w.dim())))
+    G = torch.tensor(_WINO_G, dtype=torch.float64, device=w.device)
+    cout, cin = w.shape[0], w.shape[1]
+    if w.dim() == 5:
+        U = torch.einsum('ai,bj,ck,omijk->abcom', G, G, G, w.double()).reshape(64, cout, cin)
+    else:
+        U = torch.einsum('bj,ck,omjk->bcom', G, G, w.double()).reshape(16, cout, cin)
+    out = torch.zeros(U.shape[0], L.lf_wino_fused_cout_padded(cout), cin, device=w.device, dtype=torch.float32)
+    out[:, :cout] = U.float()
+    return out.contiguous()
+
+
+def conv_wino_fused(x, U2, cout, bias, he, flags):
+    """Wide 2-D / 3-D conv: Winograd input transform, then ONE launch for the per-frequency fp32-MFMA products, the
+    output transform, He scale, bias and LeakyReLU (lf_wino_fused_gemm); PixelNorm as a pass over the (small) output.
+    Returns (y, norm or None)."""
+    L = _lib.lib()
+    dims = x.dim() - 2
+    N, cin = x.shape[0], x.shape[1]
+    D, H, W = (x.shape[2:] if dims == 3 else (1,) + tuple(x.shape[2:]))
+    if dims == 3:
+        T = L.lf_wino3d_tiles(N, D, H, W)
+        V = torch.empty(64, T, cin, device=x.device, dtype=torch.float32)
+        with _timed('wino3d_input'):
+            check(L.lf_wino3d_input_transform(_ptr(x), _ptr(V), N, D, H, W, cin, _stream()), 'lf_wino3d_input_transform')
+    else:
+        T = L.lf_wino2d_tiles(N, H, W)
+        V = torch.empty(16, T, cin, device=x.device, dtype=torch.float32)
+        with _timed('wino2d_input'):
+            check(L.lf_wino2d_input_transform(_ptr(x), _ptr(V), N, H, W, cin, _stream()), 'lf_wino2d_input_transform')
+    y = empty_cl((N, cout) + tuple(x.shape[2:]), x.device)
+    nscr = L.lf_wino_fused_scratch_bytes(dims, N, D, H, W, cout)
+    scr = torch.empty(nscr // 4, device=x.device, dtype=torch.float32) if nscr else None
+    with _timed(f'wino{dims}d_fused'):
+        check(L.lf_wino_fused_gemm(_ptr(V), _ptr(U2), _ptr(bias) if bias is not None else None, _ptr(y),
+                                   _ptr(scr) if scr is not None else None, nscr, dims, N, D, H, W, cin,
+                                   cout, he, flags & LF_EPI_LRELU, SLOPE, _stream()), 'lf_wino_fused_gemm')
+    del V
+    norm = None
+    if flags & LF_EPI_PIXELNORM:
+        norm = torch.empty(N * D * H * W, device=x.device, dtype=torch.float32)
+        check(L.lf_pixelnorm_fwd(_ptr(y), _ptr(y), _ptr(norm), N * D * H * W, cout, PN_EPS, _stream()), 'lf_pixelnorm_fwd')
+    return y, norm
+
+
+def wide_conv(x, weight, bias, he, flags, transpose=False):
+    """Dispatch of a wide (>= 64-channel) 3x3(x3) convolution or its data gradient (transpose=True) by WIDE_CONV_MODE."""
+    cout = weight.shape[1] if transpose else weight.shape[0]
+    if WIDE_CONV_MODE == 'fused':
+        U2 = _cached(weight, 'wfb' if transpose else 'wff', lambda: pack_conv_wino_fused(weight, transpose=transpose))
+        return conv_wino_fused(x, U2, cout, bias, he, flags)
+    U = _cached(weight, 'g3b' if transpose else 'g3f', lambda: pack_conv3d_wino_gemm(weight, transpose=transpose))
+    return conv3d_wino_gemm(x, U, bias, he, flags)
+
+
 def conv3d_wino_gemm(x, U, bias, he, flags):
     """Wide 3-D conv as Winograd F(2x2x2,3x3x3): input transform (HIP) -> 64 batched fp32 GEMMs (rocBLAS via
-    torch.bmm) -> output transform with the fused epilogue (HIP).  Returns (y, norm or None)."""
+    torch.bmm) -> output transform with the fused epilogue (HIP).  Returns (y, norm or None).  (A/B reference of the
+    fused path: WIDE_CONV_MODE = 'bmm'.)"""
     L = _lib.lib()
     if x.dim() == 4:
         return _conv2d_wino_gemm(x, U, bias, he, flags)
@@ -493,8 +561,8 @@ class _Conv3x3(torch.autograd.Function):
         b = bias.detach() if bias is not None else None
         if _wino_ok(x, weight):                               # 3-D 16 -> 16: the all-fp32 Winograd kernel
             y, norm = conv3d_c16_wino(x, _cached(weight, 'w3f', lambda: pack_conv3d_c16_wino(weight)), b, he, flags)
-        elif _wino_gemm_ok(x, weight):                        # wide 3-D: three-stage Winograd over library GEMMs
-            y, norm = conv3d_wino_gemm(x, _cached(weight, 'g3f', lambda: pack_conv3d_wino_gemm(weight)), b, he, flags)
+        elif _wino_gemm_ok(x, weight):                        # wide 2-D / 3-D: Winograd with the fused fp32-MFMA GEMM
+            y, norm = wide_conv(x, weight, b, he, flags)
         else:
             wpack = _cached(weight, 'c3f', lambda: pack_conv3x3(weight))
             y, norm = _conv3x3_raw(x, wpack, b, weight.shape[0], he, flags, True)
@@ -514,7 +582,7 @@ class _Conv3x3(torch.autograd.Function):
             if _wino_ok(gp, w):
                 gx, _ = conv3d_c16_wino(gp, _cached(w, 'w3b', lambda: pack_conv3d_c16_wino(w, transpose=True)), None, ctx.he, 0)
             elif _wino_gemm_ok(gp, w):
-                gx, _ = conv3d_wino_gemm(gp, _cached(w, 'g3b', lambda: pack_conv3d_wino_gemm(w, transpose=True)), None, ctx.he, 0)
+                gx, _ = wide_conv(gp, w, None, ctx.he, 0, transpose=True)
             else:
                 wpack_t = _cached(w, 'c3b', lambda: pack_conv3x3(w, transpose=True))
                 gx, _ = _conv3x3_raw(gp, wpack_t, None, w.shape[1], ctx.he, 0, False)

@@ -157,6 +157,48 @@ def test_conv3x3_vs_torch(dims, cin, cout, S):
     close(bd.grad, b.grad, atol=2e-4 * b.grad.abs().max().item(), rtol=1e-3)
 
 
+@pytest.mark.parametrize('dims,cin,cout,S,N', [(3, 64, 64, 8, 2), (3, 72, 132, 6, 1), (3, 260, 64, 5, 3), (2, 64, 64, 13, 2),
+                                               (2, 196, 128, 9, 1), (2, 68, 320, 6, 2), (3, 256, 256, 16, 2), (2, 512, 256, 32, 1)])
+def test_wide_conv_fused_gemm(dims, cin, cout, S, N):
+    """lf_wino_fused_gemm (own fp32-MFMA GEMM + output transform + epilogue in one launch) against (a) the three-stage
+    form on the library GEMM (WIDE_CONV_MODE = 'bmm') and (b) an fp64 evaluation of the same layer: ragged channel
+    counts (Cin / Cout not multiples of the 32 / 64 blocking), tile counts that do not fill a workgroup, odd extents,
+    the released 256 -> 256 width; forward and data-gradient forms."""
+    from latentfusion_amd import ops
+    from latentfusion_amd._lib import LF_EPI_LRELU, LF_EPI_PIXELNORM
+    g = torch.Generator().manual_seed(dims * 1000 + cin * 10 + cout)
+    x = torch.randn((N, cin) + (S,) * dims, generator=g)
+    w = torch.randn((cout, cin) + (3,) * dims, generator=g)
+    b = torch.randn(cout, generator=g) * 0.1
+    xd, wd, bd = ops.cl(x.to(DEV)), w.to(DEV), b.to(DEV)
+    he = ops.he_constant(w)
+    flags = LF_EPI_LRELU | LF_EPI_PIXELNORM
+    conv = torch.nn.functional.conv3d if dims == 3 else torch.nn.functional.conv2d
+    convt = torch.nn.functional.conv_transpose3d if dims == 3 else torch.nn.functional.conv_transpose2d
+    pre = conv(x.double(), w.double(), None, 1, 1) * he + b.double().view(1, -1, *([1] * dims))
+    act = torch.nn.functional.leaky_relu(pre, 0.2)
+    want = act / torch.sqrt((act ** 2).mean(dim=1, keepdim=True) + 1e-8)
+    got = {}
+    for mode in ('fused', 'bmm'):
+        ops.WIDE_CONV_MODE = mode
+        try:
+            y, nrm = ops.wide_conv(xd, wd, bd, he, flags)
+            gin = ops.cl(torch.randn((N, cout) + (S,) * dims, generator=torch.Generator().manual_seed(1)).to(DEV))
+            gx, _ = ops.wide_conv(gin, wd, None, he, 0, transpose=True)
+        finally:
+            ops.WIDE_CONV_MODE = 'fused'
+        got[mode] = (y, nrm, gx, gin)
+    y, nrm, gx, gin = got['fused']
+    scale = want.abs().max().item()
+    assert (y.double().cpu() - want).abs().max().item() < 2e-5 * max(1.0, scale)
+    assert (got['bmm'][0].double().cpu() - want).abs().max().item() < 2e-5 * max(1.0, scale)
+    close(nrm.view(want.shape[0], *want.shape[2:]), torch.sqrt((act ** 2).mean(dim=1) + 1e-8).float(), atol=1e-5, rtol=1e-5)
+    gwant = convt(gin.double().cpu(), w.double(), None, 1, 1) * he
+    err = (gx.double().cpu() - gwant).abs().max().item()
+    assert err < 3e-5 * max(1.0, gwant.abs().max().item()), err
+    close(gx, got['bmm'][2], atol=3e-5 * max(1.0, gwant.abs().max().item()), rtol=1e-4)
+
+
 @pytest.mark.parametrize('cin,cout,act,norm', [(16, 2, False, False), (4, 16, True, False), (35, 16, True, True),
                                                (16, 128, True, True), (20, 200, True, True)])
 def test_conv1x1_vs_torch(cin, cout, act, norm):

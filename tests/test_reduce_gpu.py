@@ -145,7 +145,8 @@ def test_column_and_view_reduce_bandwidth_at_headline_size():
     (>= 3 TB/s asserted; the measured figure is printed for profiles/)."""
     from latentfusion_amd import ops
     x = torch.randn(8, 16, 128, 128, 128, device=DEV).contiguous(memory_format=torch.channels_last_3d)
-    z = torch.randn(1, 16, 16, 128, 128, 128, device=DEV)
+    # 16 per-view volumes as the encoder leaves them: (B*V, C, D, H, W) channels-last, viewed as (B, V, ...) -- no copy
+    z = torch.randn(16, 16, 128, 128, 128, device=DEV).contiguous(memory_format=torch.channels_last_3d).unsqueeze(0)
     res = {}
     for name, fn, nbytes in (('column_sum', lambda: ops.column_sum(x), x.numel() * 4 + x.numel() // 128 * 4),
                              ('fuse_views_mean', lambda: ops.fuse_views(z, 'mean'), z.numel() * 4 + z.numel() // 16 * 4),

@@ -23,12 +23,15 @@ KERNELS = collections.OrderedDict([
     # key -> (substring of the kernel name, algorithmic bytes per launch at N=8, C=16, S=128)
     ('conv3d_c16_wino_kernel', ('conv3d_c16_wino_kernel', 2 * 8 * 16 * 128 ** 3 * 4 + 8 * 128 ** 3 * 4)),
     ('conv3d_c16_persistent_kernel', ('conv3d_c16_persistent_kernel', 2 * 8 * 16 * 128 ** 3 * 4 + 8 * 128 ** 3 * 4)),
-    ('resample_fwd_kernel', ('resample_fwd_kernel', 8 * 16 * 128 ** 3 * 4 + 16 * 128 ** 3 * 4)),
-    ('resample_bwd_coef_kernel', ('resample_bwd_coef_kernel', 8 * 16 * 128 ** 3 * 4 + 16 * 128 ** 3 * 4)),
+    ('resample_fwd', ('resample_fwd', 8 * 16 * 128 ** 3 * 4 + 16 * 128 ** 3 * 4)),
+    ('resample_bwd_coef', ('resample_bwd_coef_', 8 * 16 * 128 ** 3 * 4 + 16 * 128 ** 3 * 4)),
     ('conv1x1_kernel', ('conv1x1_kernel', 8 * 16 * 128 ** 3 * 4)),
-    ('conv1x1_bwd', ('conv1x1_bwd', 2 * 8 * 16 * 128 ** 3 * 4)),
     ('column_sum_fwd_kernel', ('column_sum_fwd_kernel', 8 * 16 * 128 ** 3 * 4)),
 ])
+# hbm_probe.py launches the Winograd kernel REP times in its forward form, then REP times as a data gradient with the
+# producer's epilogue backward fused (reads the saved activation and norm as well): reported separately
+SPLIT = {'conv3d_c16_wino_kernel': (('forward form', 2 * 8 * 16 * 128 ** 3 * 4 + 8 * 128 ** 3 * 4),
+                                    ('data-gradient form + fused previous-layer backward', 3 * 8 * 16 * 128 ** 3 * 4 + 8 * 128 ** 3 * 4))}
 SOURCES = ['conv_wino.hip', 'conv.hip', 'resample.hip', 'pointwise.hip', 'reduce.hip']
 
 
@@ -49,7 +52,7 @@ def load(dirname):
         tag = os.path.basename(path).split('_')[0]
         for r in csv.DictReader(open(path)):
             per[r['Kernel_Name']][r['Counter_Name']][(tag, r['Dispatch_Id'])] += float(r['Counter_Value'])
-    return {k: {c: list(v.values()) for c, v in cs.items()} for k, cs in per.items()}
+    return {k: {c: [v[d] for d in sorted(v, key=lambda td: (td[0], int(td[1])))] for c, v in cs.items()} for k, cs in per.items()}
 
 
 def mean(v):
@@ -57,7 +60,7 @@ def mean(v):
 
 
 def find(data, sub, floor_counter=None, floor=0.0):
-    hits = [k for k in data if sub in k]
+    hits = [k for k in data if sub in k and 'coef_reduce' not in k]
     if not hits:
         return None
     # several template instances may match: take the one with the most work
@@ -81,8 +84,22 @@ def main(dirname, prefix):
         k = find(data, sub)
         if k is None:
             continue
-        c = {n: mean(v) for n, v in data[k].items()}
-        lines.append(f'## {key}   ({k[:110]})')
+        variants = [(key, alg, {n: mean(v) for n, v in data[k].items()})]
+        if key in SPLIT:
+            (na, alga), (nb, algb) = SPLIT[key]
+            half = {n: len(v) // 2 for n, v in data[k].items()}
+            variants = [(f'{key} [{na}]', alga, {n: mean(v[:half[n]]) for n, v in data[k].items() if half[n]}),
+                        (f'{key} [{nb}]', algb, {n: mean(v[half[n]:]) for n, v in data[k].items() if half[n]})]
+        for vi, (vkey, alg, c) in enumerate(variants):
+            summarise(lines, hbm, key if vi == 0 else key + '_bwd', vkey, k, alg, c, corr, wcorr)
+    open(prefix + '_kernels_pmc.txt', 'w').write('\n'.join(lines) + '\n')
+    json.dump(hbm, open(prefix + '_hbm_bytes.json', 'w'), indent=1)
+    print('\n'.join(lines))
+
+
+def summarise(lines, hbm, key, vkey, k, alg, c, corr, wcorr):
+    if True:
+        lines.append(f'## {vkey}   ({k[:110]})')
         for n in sorted(c):
             lines.append(f'{n:32s} {c[n]:14.4e}')
         d = []
@@ -102,9 +119,6 @@ def main(dirname, prefix):
             hbm['kernels'][key] = {'kernel_name': k[:160], 'read_bytes': rb, 'write_bytes': wb, 'bytes_per_launch': rb + wb,
                                    'algorithmic_bytes_per_launch': alg}
         lines += ['   ' + x for x in d] + ['']
-    open(prefix + '_kernels_pmc.txt', 'w').write('\n'.join(lines) + '\n')
-    json.dump(hbm, open(prefix + '_hbm_bytes.json', 'w'), indent=1)
-    print('\n'.join(lines))
 
 
 if __name__ == '__main__':

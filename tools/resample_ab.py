@@ -42,7 +42,9 @@ st = torch.cuda.current_stream().cuda_stream
 def bind(spec):
     path, _, var = spec.partition('@')
     L = ctypes.CDLL(os.path.abspath(path))
+    var, _, var2 = var.partition('.')                      # path@<resampler variant>[.<coefficient-gradient variant>]
     L._variant = int(var) if var else None
+    L._variant2 = int(var2) if var2 else None
     if L._variant is not None:
         L.lf_set_tuning.restype = I
         L.lf_set_tuning.argtypes = [I, I]
@@ -58,6 +60,8 @@ def bind(spec):
 def select(L):
     if L._variant is not None:
         L.lf_set_tuning(1, L._variant)
+    if L._variant2 is not None:
+        L.lf_set_tuning(2, L._variant2)
 
 
 libs = [bind(p) for p in sys.argv[1:]]
