@@ -507,7 +507,7 @@ __global__ void __launch_bounds__(256, MINW) resample_bwd_coef_c16_kernel(
   }
 }
 
-int g_bwd_coef_variant = 3;   // lean coefficient gradient: 1 = one sub-tile in flight, 2 = two, 3 = two at 4 waves/SIMD
+int g_bwd_coef_variant = 1;   // lean coefficient gradient: 1 = one sub-tile in flight, 2 = two, 3 = two at 4 waves/SIMD, 4 / 5 = one at 6 / 8 waves/SIMD
 int g_resample_variant = 3;   // 1 = generic kernels, 2 = lean kernels, 3 = lean + 16-channel gather (lf_set_tuning)
 
 bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
@@ -605,8 +605,12 @@ extern "C" int lf_resample3d_bwd_coef(const float* gout, const float* vol, int v
       hipLaunchKernelGGL((resample_bwd_coef_c16_kernel<1, 1>), grid, block, 0, s, gout, vol, bstride, coef, partial, nblk, vpb, bt, D, H, W, stp);
     else if (g_bwd_coef_variant == 2)
       hipLaunchKernelGGL((resample_bwd_coef_c16_kernel<1, 2>), grid, block, 0, s, gout, vol, bstride, coef, partial, nblk, vpb, bt, D, H, W, stp);
-    else
+    else if (g_bwd_coef_variant == 3)
       hipLaunchKernelGGL((resample_bwd_coef_c16_kernel<4, 2>), grid, block, 0, s, gout, vol, bstride, coef, partial, nblk, vpb, bt, D, H, W, stp);
+    else if (g_bwd_coef_variant == 4)
+      hipLaunchKernelGGL((resample_bwd_coef_c16_kernel<6, 1>), grid, block, 0, s, gout, vol, bstride, coef, partial, nblk, vpb, bt, D, H, W, stp);
+    else
+      hipLaunchKernelGGL((resample_bwd_coef_c16_kernel<8, 1>), grid, block, 0, s, gout, vol, bstride, coef, partial, nblk, vpb, bt, D, H, W, stp);
     int st2 = lf_launch_status();
     if (st2) return st2;
     hipLaunchKernelGGL(resample_bwd_coef_reduce, dim3(N), dim3(256), 0, s, partial, nblk, gcoef);
@@ -650,7 +654,7 @@ extern "C" int lf_set_tuning(int key, int value) {
   }
   if (key == 2) {
     const int prev = g_bwd_coef_variant;
-    if (value >= 1 && value <= 3) g_bwd_coef_variant = value;
+    if (value >= 1 && value <= 5) g_bwd_coef_variant = value;
     return prev;
   }
   return LF_EINVAL;

@@ -28,7 +28,7 @@ constexpr int MT = 64;      // Winograd tiles per workgroup   (B rows)
 constexpr int NT = 64;      // output channels per workgroup  (A rows)
 constexpr int KC = 32;      // input channels per stage
 constexpr int TILE_BYTES = 64 * KC * 4;                          // 8 KiB per operand chunk
-constexpr int NSTAGE = 4;                                        // LDS ring depth (stages of A + B chunks)
+constexpr int NSTAGE = 4;                                        // LDS ring depth (stages of A + B chunks); a power of two
 constexpr int WF_LDS = NSTAGE * 2 * TILE_BYTES;                  // 64 KiB: two workgroups per CU
 
 typedef unsigned u32;
@@ -79,18 +79,45 @@ __global__ void __launch_bounds__(256, 2) wino_fused_kernel(
   // partials in a fixed order and applies the epilogue
   const int fper = F / gridDim.z, f_first = blockIdx.z * fper;
   const int S = fper * nk;
-  auto issue = [&](int s) {
-    const int fl = s / nk, k0 = (s - fl * nk) * KC, f = f_first + fl;      // wave-uniform
-    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(V + (long)f * T * Cin), 0, slabV, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void*)(U2 + (long)f * CoutP * Cin), 0, slabU, 0x00020000);
-    unsigned char* slot = smem + (s % NSTAGE) * 2 * TILE_BYTES;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const bool kok = k0 + kch[i] < Cin;                        // (Cin % 4 == 0: whole chunks are in or out)
-      const int va = kok ? (int)(offA[i] + (u32)k0 * 4u) : 0x7fffffff;
-      const int vb = (kok && offB[i] != 0xffffffffu) ? (int)(offB[i] + (u32)k0 * 4u) : 0x7fffffff;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (__attribute__((address_space(3))) void*)(slot + (w * 2 + i) * 1024), 16, va, 0, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(slot + TILE_BYTES + (w * 2 + i) * 1024), 16, vb, 0, 0, 0);
+  // The issue side keeps its own cursor (frequency, k-chunk, ring slot) three stages ahead of the compute side, so a
+  // piece costs one LDS-DMA instruction and no address arithmetic: the per-lane byte offset inside the frequency slab
+  // is a loop invariant (voffset), the k-chunk advances through the instruction's SCALAR offset, and the two buffer
+  // descriptors are rebuilt only when the cursor enters the next frequency.  (First version: stage index -> (f, k) by
+  // division and fresh descriptors per piece = 4.6 scalar instructions per MFMA, MFMA pipe 54 % busy.)
+  const long strideU = (long)CoutP * Cin, strideV = (long)T * Cin;
+  const float* pU = U2 + (long)f_first * strideU;
+  const float* pV = V + (long)f_first * strideV;
+  __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void*)pU, 0, slabU, 0x00020000);
+  __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)pV, 0, slabV, 0x00020000);
+  int ik = 0, islot = 0, issued = 0;                             // cursor: k-chunk of the stage being issued, its ring slot
+  const bool ktail = (Cin % KC) != 0;
+  const int vA[2] = {(int)offA[0], (int)offA[1]};
+  const int vB[2] = {offB[0] != 0xffffffffu ? (int)offB[0] : 0x7fffffff, offB[1] != 0xffffffffu ? (int)offB[1] : 0x7fffffff};
+  // piece q (0..3) of the cursor's stage for this wave: q = 2*i + (0: weights A, 1: inputs B)
+  auto issue_piece = [&](int q) {
+    unsigned char* slot = smem + islot * 2 * TILE_BYTES;
+    const int i = q >> 1;
+    const int k0b = ik * KC * 4;                                 // scalar byte offset of the k-chunk
+    int va = vA[i], vb = vB[i];
+    if (ktail && ik == nk - 1) {                                 // (wave-uniform) ragged last chunk: lanes beyond Cin read zeros
+      const bool kok = ik * KC + kch[i] < Cin;
+      va = kok ? va : 0x7fffffff;
+      vb = kok ? vb : 0x7fffffff;
+    }
+    if ((q & 1) == 0)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (__attribute__((address_space(3))) void*)(slot + (w * 2 + i) * 1024), 16, va, k0b, 0, 0);
+    else
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(slot + TILE_BYTES + (w * 2 + i) * 1024), 16, vb, k0b, 0, 0);
+    if (q == 3) {                                                // stage complete: advance the cursor
+      ++issued;
+      islot = (islot + 1) & (NSTAGE - 1);
+      if (++ik == nk) {
+        ik = 0;
+        pU += strideU;
+        pV += strideV;
+        ru = __builtin_amdgcn_make_buffer_rsrc((void*)pU, 0, slabU, 0x00020000);
+        rv = __builtin_amdgcn_make_buffer_rsrc((void*)pV, 0, slabV, 0x00020000);
+      }
     }
   };
 
@@ -119,7 +146,9 @@ __global__ void __launch_bounds__(256, 2) wino_fused_kernel(
     for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // ring of NSTAGE stages: stages s+1 .. s+NSTAGE-1 are in flight while stage s feeds the MFMAs
-  for (int s0 = 0; s0 < NSTAGE - 1 && s0 < S; ++s0) issue(s0);
+  for (int s0 = 0; s0 < NSTAGE - 1 && s0 < S; ++s0)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) issue_piece(q);
   int kc = 0, f = f_first;
   for (int s = 0; s < S; ++s) {
     // this wave's pieces of stage s have landed when at most the pieces of the later stages it issued are outstanding
@@ -130,24 +159,33 @@ __global__ void __launch_bounds__(256, 2) wino_fused_kernel(
     else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (s + NSTAGE - 1 < S) issue(s + NSTAGE - 1);
+    const bool more = issued < S;                                // wave-uniform
     const unsigned char* base = smem + (s % NSTAGE) * 2 * TILE_BYTES;
+    f32x4 fa[2][2], fb[2][2];                                    // [k-group j][row tile]
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      f32x4 fa[2], fb[2];
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        fa[t] = *(const f32x4*)(base + rdA[t][j]);
-        fb[t] = *(const f32x4*)(base + rdB[t][j]);
+        fa[j][t] = *(const f32x4*)(base + rdA[t][j]);
+        fb[j][t] = *(const f32x4*)(base + rdB[t][j]);
       }
+    // the four DMA pieces of stage s+3 are issued BETWEEN groups of eight MFMAs: an LDS-DMA instruction holds the
+    // issuing (in-order) wave for ~60-180 cycles, which the 8 x 32 cycles of matrix work already queued ahead of it cover
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+      for (int i2 = 0; i2 < 2; ++i2) {
 #pragma unroll
-          for (int b = 0; b < 2; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a][i], fb[b][i], acc[a][b], 0, 0, 0);
-    }
+        for (int i = i2 * 2; i < i2 * 2 + 2; ++i)
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j][a][i], fb[j][b][i], acc[a][b], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) issue_piece(j * 2 + i2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     if (++kc == nk) {
       // frequency f complete: fold it into the outputs, Y[o] += A^T[o][f] * M[f]
       kc = 0;
@@ -229,7 +267,7 @@ __global__ void __launch_bounds__(256) wino_fused_finish_kernel(const f32x4* __r
 int fused_zsplit(int dims, long gx, int gy) {
   const int F = dims == 3 ? 64 : 16;
   int zs = 1;
-  while (zs < F && gx * gy * zs < 256) zs <<= 1;
+  while (zs < F && gx * gy * zs < 512) zs <<= 1;                 // >= two resident workgroups per CU (256 CUs)
   return zs;
 }
 

@@ -1,0 +1,56 @@
+#!/usr/bin/env python
+"""A/B timing of the wide (>= 64-channel) 3x3(x3) convolution paths at the released model's layer shapes
+(tools/train/train.sh:28-66): 'fused' = Winograd input transform + lf_wino_fused_gemm (own fp32-MFMA GEMM with the
+output transform / epilogue folded in), 'bmm' = three-stage form with the per-frequency products on the library GEMM.
+Prints per shape: total ms of the conv (+ PixelNorm), ms of the GEMM stage alone (HIP events on the launch stream), the
+executed fp32-MFMA rate of that stage and the max abs difference between the two paths.
+
+    python tools/wide_conv_probe.py [N]
+"""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from latentfusion_amd import ops  # noqa: E402
+from latentfusion_amd._lib import LF_EPI_LRELU, LF_EPI_PIXELNORM  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+SHAPES = [(3, 256, 256, 16), (2, 64, 64, 256), (2, 128, 64, 256), (2, 196, 128, 128), (2, 256, 196, 64), (2, 512, 256, 32),
+          (2, 1024, 512, 16), (2, 1024, 512, 8), (2, 512, 512, 4)]
+flags = LF_EPI_LRELU | LF_EPI_PIXELNORM
+out = []
+for dims, cin, cout, S in SHAPES:
+    g = torch.Generator().manual_seed(cin + cout + S)
+    x = ops.cl(torch.randn((N, cin) + (S,) * dims, generator=g).cuda())
+    w = torch.randn((cout, cin) + (3,) * dims, generator=g).cuda()
+    b = torch.zeros(cout).cuda()
+    he = ops.he_constant(w)
+    F = 64 if dims == 3 else 16
+    tiles = N * (S // 2) ** dims
+    flops = 2.0 * F * tiles * cin * cout
+    rec = {'dims': dims, 'cin': cin, 'cout': cout, 'S': S, 'N': N, 'executed_GFLOP': flops / 1e9}
+    ys = {}
+    for mode in ('fused', 'bmm'):
+        ops.WIDE_CONV_MODE = mode
+        for _ in range(3):
+            y, _n = ops.wide_conv(x, w, b, he, flags)
+        torch.cuda.synchronize()
+        ops.KERNEL_TIMER = []
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            y, _n = ops.wide_conv(x, w, b, he, flags)
+        e1.record()
+        torch.cuda.synchronize()
+        tm, ops.KERNEL_TIMER = ops.KERNEL_TIMER, None
+        gemm = [a.elapsed_time(c) for n_, a, c in tm if n_.endswith('_fused') or n_.endswith('_gemm')]
+        rec[mode] = {'conv_ms': e0.elapsed_time(e1) / 10, 'gemm_stage_ms': sum(gemm) / len(gemm),
+                     'gemm_stage_TFLOPs': flops / (sum(gemm) / len(gemm) * 1e-3) / 1e12}
+        ys[mode] = y
+    ops.WIDE_CONV_MODE = 'fused'
+    rec['max_abs_diff'] = (ys['fused'] - ys['bmm']).abs().max().item()
+    out.append(rec)
+    print(json.dumps(rec))
