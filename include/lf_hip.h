@@ -86,6 +86,15 @@ int lf_resample3d_bwd_coef(const float* gout, const float* vol, int vol_n, const
 int lf_resample3d_bwd_vol(const float* gout, const float* coef, int kind, float* gvol, int vol_n,
                           int N, int D, int H, int W, int C, void* stream);
 
+/* The same gradient, DETERMINISTIC: contributions are accumulated as round(value * 2^K) with 64-bit integer atomics
+ * (integer addition is associative, so the result does not depend on the order the hardware retires them) and
+ * converted back in a second pass; K follows max|gout| (found by an order-independent atomic max) so that 2^24
+ * contributions to one voxel cannot overflow -- the quantum is 2^-38 of the largest gradient.  gvol is overwritten.
+ * scratch: lf_resample3d_bwd_vol_det_scratch_bytes(vol_n, D, H, W, C) bytes, 8-byte aligned. */
+size_t lf_resample3d_bwd_vol_det_scratch_bytes(int vol_n, int D, int H, int W, int C);
+int lf_resample3d_bwd_vol_det(const float* gout, const float* coef, int kind, float* gvol, int vol_n, void* scratch,
+                              size_t scratch_bytes, int N, int D, int H, int W, int C, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * He-equalised 3x3(x3) convolution with fused epilogue, stride 1, zero padding 1:
  *   y = conv(x, W) * he + bias ; [LeakyReLU(slope)] ; [PixelNorm over channels (eps)]

@@ -29,6 +29,8 @@ SIGNATURES = {
     'lf_resample3d_bwd_coef_scratch_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
     'lf_resample3d_bwd_coef': (c_int, [P, P, c_int, P, P, P, c_size_t, c_int, c_int, c_int, c_int, c_int, P]),
     'lf_resample3d_bwd_vol': (c_int, [P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    'lf_resample3d_bwd_vol_det_scratch_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    'lf_resample3d_bwd_vol_det': (c_int, [P, P, c_int, P, c_int, P, c_size_t, c_int, c_int, c_int, c_int, c_int, P]),
     'lf_conv3x3_cout_padded': (c_int, [c_int]),
     'lf_conv1x1_cout_padded': (c_int, [c_int]),
     'lf_conv3x3_fwd': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

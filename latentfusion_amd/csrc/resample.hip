@@ -510,6 +510,65 @@ __global__ void __launch_bounds__(256, MINW) resample_bwd_coef_c16_kernel(
 int g_bwd_coef_variant = 1;   // lean coefficient gradient: 1 = one sub-tile in flight, 2 = two, 3 = two at 4 waves/SIMD, 4 / 5 = one at 6 / 8 waves/SIMD
 int g_resample_variant = 3;   // 1 = generic kernels, 2 = lean kernels, 3 = lean + 16-channel gather (lf_set_tuning)
 
+// ---- deterministic splat: the same scatter, accumulated in 64-bit fixed point ----------------------------------
+// Float atomics make the result depend on the order in which the hardware retires them.  Integer addition is
+// associative, so accumulating round(contribution * 2^K) with 64-bit integer atomics gives bit-identical results
+// for every execution order; K is chosen from max|gout| so that 2^24 contributions (every output voxel of every
+// sample landing on ONE source voxel -- border clamping can do that) cannot overflow: the quantum is 2^-38 of the
+// largest gradient, finer than fp32's own resolution of any sum it could be added to.
+__global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ out) {
+  float m = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0.f && m < 3.0e38f) atomicMax(out, __float_as_uint(m));   // max is order-independent
+}
+
+__device__ __forceinline__ float fixed_scale(const unsigned* amax) {
+  const float am = __uint_as_float(*amax);
+  if (!(am > 0.f)) return 1.f;
+  int ex;
+  frexpf(am, &ex);                                               // am = m * 2^ex, m in [0.5, 1)
+  return ldexpf(1.f, 38 - ex);                                   // |contribution| * scale < 2^38
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(256) resample_bwd_vol_fixed_kernel(
+    const float* __restrict__ gout, const float* __restrict__ coef, unsigned long long* __restrict__ acc,
+    long acc_bstride, const unsigned* __restrict__ amax, int N, int D, int H, int W, int C, Steps st) {
+  const long per_sample = (long)D * H * W * C;
+  const int n = blockIdx.y;
+  const float* cf = coef + (long)n * LF_MAP_COEFS;
+  const float scale = fixed_scale(amax);
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < per_sample; idx += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % C);
+    long v = idx / C;
+    const int x = (int)(v % W); v /= W;
+    const int y = (int)(v % H);
+    const int z = (int)(v / H);
+    float gx, gy, gz, a, b, k;
+    eval_grid<KIND>(cf, x, y, z, W, H, D, st, gx, gy, gz, a, b, k);
+    const Tap t = make_tap(gx, gy, gz, W, H, D);
+    const float go = gout[(long)n * per_sample + idx] * scale;   // exact: power-of-two scale
+    unsigned long long* base = acc + (long)n * acc_bstride + c;
+    const long sW = C, sH = (long)W * C, sD = (long)H * W * C;
+    const float wx1 = t.tx, wx0 = 1.f - t.tx, wy1 = t.ty, wy0 = 1.f - t.ty, wz1 = t.tz, wz0 = 1.f - t.tz;
+#define SPLAT(Z, Y, X, WGT) atomicAdd(base + (Z) * sD + (Y) * sH + (X) * sW, (unsigned long long)__float2ll_rn(go * (WGT)))
+    SPLAT(t.z0, t.y0, t.x0, wx0 * wy0 * wz0); SPLAT(t.z0, t.y0, t.x1, wx1 * wy0 * wz0);
+    SPLAT(t.z0, t.y1, t.x0, wx0 * wy1 * wz0); SPLAT(t.z0, t.y1, t.x1, wx1 * wy1 * wz0);
+    SPLAT(t.z1, t.y0, t.x0, wx0 * wy0 * wz1); SPLAT(t.z1, t.y0, t.x1, wx1 * wy0 * wz1);
+    SPLAT(t.z1, t.y1, t.x0, wx0 * wy1 * wz1); SPLAT(t.z1, t.y1, t.x1, wx1 * wy1 * wz1);
+#undef SPLAT
+  }
+}
+
+__global__ void __launch_bounds__(256) fixed_to_float_kernel(const long long* __restrict__ acc, const unsigned* __restrict__ amax,
+                                                            float* __restrict__ out, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  out[i] = (float)((double)acc[i] / (double)fixed_scale(amax));
+}
+
 bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 Steps make_steps(int D, int H, int W) {
@@ -658,4 +717,40 @@ extern "C" int lf_set_tuning(int key, int value) {
     return prev;
   }
   return LF_EINVAL;
+}
+
+// Deterministic form of lf_resample3d_bwd_vol (no float atomics): see resample_bwd_vol_fixed_kernel.  gvol is
+// overwritten (no zero-initialisation needed).  scratch: lf_resample3d_bwd_vol_det_scratch_bytes(...) bytes.
+extern "C" size_t lf_resample3d_bwd_vol_det_scratch_bytes(int vol_n, int D, int H, int W, int C) {
+  if (vol_n <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
+  return (size_t)vol_n * D * H * W * C * sizeof(long long) + 256;
+}
+
+extern "C" int lf_resample3d_bwd_vol_det(const float* gout, const float* coef, int kind, float* gvol, int vol_n, void* scratch,
+                                         size_t scratch_bytes, int N, int D, int H, int W, int C, void* stream) {
+  lf_clear_error();
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0) return LF_EINVAL;
+  if ((vol_n != 1 && vol_n != N) || (kind != LF_MAP_O2C && kind != LF_MAP_C2O)) return LF_EINVAL;
+  const long items = (long)D * H * W * C, total = items * vol_n;
+  if (scratch == nullptr || scratch_bytes < lf_resample3d_bwd_vol_det_scratch_bytes(vol_n, D, H, W, C)) return LF_ENOSPC;
+  if ((((uintptr_t)scratch) & 7u) != 0) return LF_EALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  unsigned long long* acc = (unsigned long long*)scratch;
+  unsigned* amax = (unsigned*)((char*)scratch + (size_t)total * sizeof(long long));
+  hipError_t e = hipMemsetAsync(scratch, 0, (size_t)total * sizeof(long long) + 256, s);
+  if (e != hipSuccess) return (int)e;
+  const long ng = items * N;
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)min((ng + 255) / 256, 4096L)), dim3(256), 0, s, gout, ng, amax);
+  int st = lf_launch_status();
+  if (st) return st;
+  const long bstride = vol_n == 1 ? 0 : items;
+  dim3 grid((unsigned)min((items + 255) / 256, (long)65535 * 16), N), block(256);
+  if (kind == LF_MAP_O2C)
+    hipLaunchKernelGGL((resample_bwd_vol_fixed_kernel<LF_MAP_O2C>), grid, block, 0, s, gout, coef, acc, bstride, amax, N, D, H, W, C, make_steps(D, H, W));
+  else
+    hipLaunchKernelGGL((resample_bwd_vol_fixed_kernel<LF_MAP_C2O>), grid, block, 0, s, gout, coef, acc, bstride, amax, N, D, H, W, C, make_steps(D, H, W));
+  st = lf_launch_status();
+  if (st) return st;
+  hipLaunchKernelGGL(fixed_to_float_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const long long*)acc, amax, gvol, total);
+  return lf_launch_status();
 }

@@ -16,6 +16,9 @@ from ._lib import LF_EPI_LRELU, LF_EPI_PIXELNORM, LF_MAP_C2O, LF_MAP_COEFS, LF_M
 
 SLOPE = 0.2
 PN_EPS = 1e-8
+# d(loss)/d(sampled volume) of the 3-D resamplers (training / encoder backward): True = fixed-point accumulation,
+# bit-reproducible (lf_resample3d_bwd_vol_det); False = fp32 atomics (lf_resample3d_bwd_vol, order-dependent rounding)
+DETERMINISTIC_SPLAT = True
 
 # Optional per-kernel timing with HIP events on the launch stream (used by bench.py for the
 # roofline of the dominant kernel).  Set to a list to collect (name, start_event, end_event).
@@ -425,9 +428,16 @@ class _Resample(torch.autograd.Function):
             check(L.lf_resample3d_bwd_coef(_ptr(g), _ptr(v), ctx.vol_n, _ptr(cf), _ptr(gcoef), _ptr(scratch),
                                            scratch.numel() * 4, n, D, H, W, C, _stream()), 'lf_resample3d_bwd_coef')
         if ctx.needs_input_grad[0]:
-            gv = empty_cl((ctx.vol_n, C, D, H, W), g.device).zero_()
-            check(L.lf_resample3d_bwd_vol(_ptr(g), _ptr(cf), ctx.kind, _ptr(gv), ctx.vol_n, n, D, H, W, C, _stream()),
-                  'lf_resample3d_bwd_vol')
+            if DETERMINISTIC_SPLAT:
+                gv = empty_cl((ctx.vol_n, C, D, H, W), g.device)
+                nb = L.lf_resample3d_bwd_vol_det_scratch_bytes(ctx.vol_n, D, H, W, C)
+                scr = torch.empty(nb // 8 + 1, device=g.device, dtype=torch.int64)
+                check(L.lf_resample3d_bwd_vol_det(_ptr(g), _ptr(cf), ctx.kind, _ptr(gv), ctx.vol_n, _ptr(scr), scr.numel() * 8,
+                                                  n, D, H, W, C, _stream()), 'lf_resample3d_bwd_vol_det')
+            else:
+                gv = empty_cl((ctx.vol_n, C, D, H, W), g.device).zero_()
+                check(L.lf_resample3d_bwd_vol(_ptr(g), _ptr(cf), ctx.kind, _ptr(gv), ctx.vol_n, n, D, H, W, C, _stream()),
+                      'lf_resample3d_bwd_vol')
             if gv.shape[0] == ctx.vol_shape[0]:
                 gvol = gv
             else:
