@@ -196,6 +196,21 @@ int lf_conv3d_c16_wino_split(const float* x, const void* upack, const float* bia
                              const float* prev_y, const float* prev_norm, unsigned prev_flags,
                              const float* amax_in, float* amax_out, void* stream);
 
+/* bf16-autocast form of the fused 16 -> 16 conv3d block step, for the training step (BASELINE cfg 5; the reference wraps
+ * Sculptor / Photographer.forward in `autocast(enabled=self.training)`, recon/models.py:199,405):
+ * operands rounded to bf16 (RNE) while the halo is staged, products on v_mfma_f32_16x16x16_bf16 with fp32 accumulation,
+ * DIRECT convolution (a Winograd transform of bf16 data is not bf16-exact).  round_out: 0 = fp32 epilogue on the fp32
+ * accumulator; 1 = autocast forward, y = epilogue(bf16(bf16(acc) * he) + bias) -- the convolution returns a half tensor and
+ * `* he` stays in half, the fp32 bias promotes the rest (modules/equalized.py:57-64); 2 = autocast data gradient
+ * (transposed / flipped pack, flags = 0, bias = NULL): the result is additionally rounded to bf16.
+ * wpack: lf_conv3d_c16_bf16_wpack_elems() bf16 values, [27 taps][64 lanes l][4]: W[cout = l & 15][cin = (l >> 4)*4 + i][tap].
+ * lf_round_bf16: y = bf16(x) kept in fp32 containers (the autocast cast of an operand of the other, fp32-MFMA kernels:
+ * bf16 x bf16 products are exact in fp32, so those kernels then compute what a bf16 MFMA would). */
+int lf_round_bf16(const float* x, float* y, long n, void* stream);
+size_t lf_conv3d_c16_bf16_wpack_elems(void);
+int lf_conv3d_c16_bf16(const float* x, const void* wpack, const float* bias, float* y, float* norm_out, int N, int D, int H,
+                       int W, float he, unsigned flags, float slope, float eps, int round_out, void* stream);
+
 /* Winograd F(2x2x2,3x3x3) for wide 3-D convolutions in three stages (input transform, 64 library GEMMs
  * M[f] = V[f] @ U[f] on the host side, output transform with the fused epilogue).  x, y channels-last;
  * V [64][T][Cin], M [64][T][Cout], T = lf_wino3d_tiles(N, D, H, W), frequency f = (a*4 + b)*4 + c (z, y, x);

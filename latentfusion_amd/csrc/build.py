@@ -5,7 +5,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ['resample.hip', 'conv.hip', 'pointwise.hip', 'image.hip', 'optim.hip', 'resize.hip', 'conv_split.hip', 'conv_wino.hip', 'wgrad.hip', 'sample2d.hip', 'gru.hip', 'wino_gemm.hip', 'reduce.hip', 'wino_fused.hip']
+SOURCES = ['resample.hip', 'conv.hip', 'pointwise.hip', 'image.hip', 'optim.hip', 'resize.hip', 'conv_split.hip', 'conv_wino.hip', 'wgrad.hip', 'sample2d.hip', 'gru.hip', 'wino_gemm.hip', 'reduce.hip', 'wino_fused.hip', 'conv_bf16.hip']
 LIB = os.path.join(HERE, 'liblf_hip.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function']
 

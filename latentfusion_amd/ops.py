@@ -20,6 +20,48 @@ PN_EPS = 1e-8
 # bit-reproducible (lf_resample3d_bwd_vol_det); False = fp32 atomics (lf_resample3d_bwd_vol, order-dependent rounding)
 DETERMINISTIC_SPLAT = True
 
+# bf16 autocast policy of the training step (reference: `autocast(enabled=self.training)` around Sculptor / Photographer
+# .forward, recon/models.py:199,405; tools/train/train_reconstruct.py:455).  Inside `with ops.autocast():` every
+# convolution (3x3(x3), 1x1, factor projections, GRU gates) sees bf16-rounded inputs and weights with fp32 accumulation,
+# its data / weight gradients likewise and rounded to bf16, exactly the tensors torch autocast hands to / takes from the
+# convolution; everything else (bias, LeakyReLU, PixelNorm, resampling, losses, master weights, Adam) stays fp32.
+# The 3-D 16 -> 16 blocks run on the bf16 MFMA (lf_conv3d_c16_bf16, forward and data gradient); the other layers round
+# their operands (lf_round_bf16) and keep the fp32-MFMA kernels, which then compute what a bf16 MFMA would (bf16 x bf16
+# products are exact in fp32).
+AUTOCAST = None
+
+
+class autocast:
+    def __init__(self, enabled=True):
+        self.enabled = enabled
+
+    def __enter__(self):
+        global AUTOCAST
+        self.prev = AUTOCAST
+        AUTOCAST = 'bf16' if self.enabled else None
+        return self
+
+    def __exit__(self, *exc):
+        global AUTOCAST
+        AUTOCAST = self.prev
+        return False
+
+
+def round_bf16(t):
+    """bf16(t) in an fp32 container of the same layout (lf_round_bf16)."""
+    L = _lib.lib()
+    _req(t, 'tensor')
+    src = t if (t.is_contiguous() or t.is_contiguous(memory_format=torch.channels_last)
+                or (t.dim() == 5 and t.is_contiguous(memory_format=torch.channels_last_3d))) else t.contiguous()
+    out = torch.empty_like(src, memory_format=torch.preserve_format)
+    check(L.lf_round_bf16(_ptr(src), _ptr(out), src.numel(), _stream()), 'lf_round_bf16')
+    return out
+
+
+def _ac_in(t):
+    """An operand as the convolution sees it under the active policy."""
+    return round_bf16(t) if AUTOCAST is not None else t
+
 # Optional per-kernel timing with HIP events on the launch stream (used by bench.py for the
 # roofline of the dominant kernel).  Set to a list to collect (name, start_event, end_event).
 KERNEL_TIMER = None
@@ -100,6 +142,18 @@ def _cached(key_tensor, tag, fn):
     return hit[1]
 
 
+def _wsrc(weight):
+    """The weight tensor the kernels should see: the parameter itself, or its bf16 rounding under autocast."""
+    if AUTOCAST is None:
+        return weight
+    return _cached(weight, 'ac_round', lambda: round_bf16(weight.detach()))
+
+
+def _pk(weight, tag, fn):
+    """Cached packed layout of `weight` (of its bf16 rounding under autocast) -- fn(tensor) builds it."""
+    return _cached(weight, tag + ('@ac' if AUTOCAST is not None else ''), lambda: fn(_wsrc(weight)))
+
+
 def _pad16(v):
     return (v + 15) // 16 * 16
 
@@ -173,6 +227,29 @@ def conv3d_c16_split(x, wsplit, bias, he, flags, prev=None, amax_in=None, amax_o
                                     _ptr(py) if py is not None else None, _ptr(pn) if pn is not None else None, pf,
                                     _ptr(amax_in) if amax_in is not None else None,
                                     _ptr(amax_out) if amax_out is not None else None, _stream()), 'lf_conv3d_c16_split')
+    return y, norm
+
+
+def pack_conv3d_c16_bf16(weight, transpose=False):
+    """[16,16,3,3,3] -> bf16 [27 taps][64 lanes][4] for lf_conv3d_c16_bf16: lane = (cin // 4) * 16 + cout."""
+    w = weight.detach()
+    if transpose:
+        w = w.transpose(0, 1).flip(dims=(2, 3, 4))
+    assert tuple(w.shape) == (16, 16, 3, 3, 3)
+    u = w.reshape(16, 4, 4, 27).permute(3, 1, 0, 2).reshape(27, 64, 4)      # [tap][kg][cout][i] -> [tap][lane][i]
+    return u.contiguous().to(torch.bfloat16)
+
+
+def conv3d_c16_bf16(x, wpack, bias, he, flags, round_out):
+    """Launch lf_conv3d_c16_bf16 on a channels-last (N,16,D,H,W) tensor."""
+    L = _lib.lib()
+    N, _, D, H, W = x.shape
+    y = empty_cl((N, 16, D, H, W), x.device)
+    norm = torch.empty(N * D * H * W, device=x.device, dtype=torch.float32) if (flags & LF_EPI_PIXELNORM) else None
+    with _timed('conv3d_c16_bf16'):
+        check(L.lf_conv3d_c16_bf16(_ptr(x), _ptr(wpack), _ptr(bias) if bias is not None else None, _ptr(y),
+                                   _ptr(norm) if norm is not None else None, N, D, H, W, he, flags, SLOPE, PN_EPS, round_out,
+                                   _stream()), 'lf_conv3d_c16_bf16')
     return y, norm
 
 
@@ -315,9 +392,9 @@ def wide_conv(x, weight, bias, he, flags, transpose=False):
     """Dispatch of a wide (>= 64-channel) 3x3(x3) convolution or its data gradient (transpose=True) by WIDE_CONV_MODE."""
     cout = weight.shape[1] if transpose else weight.shape[0]
     if WIDE_CONV_MODE == 'fused':
-        U2 = _cached(weight, 'wfb' if transpose else 'wff', lambda: pack_conv_wino_fused(weight, transpose=transpose))
+        U2 = _pk(weight, 'wfb' if transpose else 'wff', lambda w: pack_conv_wino_fused(w, transpose=transpose))
         return conv_wino_fused(x, U2, cout, bias, he, flags)
-    U = _cached(weight, 'g3b' if transpose else 'g3f', lambda: pack_conv3d_wino_gemm(weight, transpose=transpose))
+    U = _pk(weight, 'g3b' if transpose else 'g3f', lambda w: pack_conv3d_wino_gemm(w, transpose=transpose))
     return conv3d_wino_gemm(x, U, bias, he, flags)
 
 
@@ -509,6 +586,24 @@ def _epilogue_bwd(gy, y, norm, flags):
     return gp
 
 
+def bias_grad(gp, dims):
+    """Column sums of the pre-activation gradient = d(loss)/d(bias) (lf_conv_bwd_weight with x == NULL).
+    gp: channels-last (N,C,[D,]H,W), or a plain [rows][C] matrix for dims = 0."""
+    L = _lib.lib()
+    if dims == 0:
+        rows, cout = gp.shape[0], gp.shape[1]
+        N, D, H, W = 1, 1, 1, rows
+    else:
+        N, cout = gp.shape[0], gp.shape[1]
+        D, H, W = (gp.shape[2:] if dims == 3 else (1,) + tuple(gp.shape[2:]))
+    gb = torch.empty(1, cout, 1, device=gp.device, dtype=torch.float32)
+    nbytes = L.lf_conv_bwd_weight_scratch_bytes(0, N, D, H, W, 0, cout)
+    scratch = torch.empty(nbytes // 4 + 1, device=gp.device, dtype=torch.float32)
+    check(L.lf_conv_bwd_weight(None, _ptr(gp), _ptr(gb), _ptr(scratch), scratch.numel() * 4, 0, N, D, H, W, 0, cout,
+                               1.0, _stream()), 'lf_conv_bwd_weight')
+    return gb.reshape(cout)
+
+
 def conv_bwd_weight(x, gp, dims, cin, he, want_bias=True):
     """Weight and bias gradients of y = conv(x, W) * he + b from the pre-activation gradient `gp`
     (lf_conv_bwd_weight).  x, gp: channels-last (N,C,[D,]H,W), or plain [rows][C] matrices for dims = 0.
@@ -569,13 +664,19 @@ class _Conv3x3(torch.autograd.Function):
         x = cl(x)
         he = he_constant(weight)
         b = bias.detach() if bias is not None else None
-        if _wino_ok(x, weight):                               # 3-D 16 -> 16: the all-fp32 Winograd kernel
-            y, norm = conv3d_c16_wino(x, _cached(weight, 'w3f', lambda: pack_conv3d_c16_wino(weight)), b, he, flags)
-        elif _wino_gemm_ok(x, weight):                        # wide 2-D / 3-D: Winograd with the fused fp32-MFMA GEMM
-            y, norm = wide_conv(x, weight, b, he, flags)
+        ctx.ac = AUTOCAST is not None
+        if ctx.ac and _wino_ok(x, weight):                    # autocast, 3-D 16 -> 16: direct conv on the bf16 MFMA
+            y, norm = conv3d_c16_bf16(x, _pk(weight, 'b3f', pack_conv3d_c16_bf16), b, he, flags, 1)
+            x = round_bf16(x) if (weight.requires_grad or (bias is not None and bias.requires_grad)) else x
         else:
-            wpack = _cached(weight, 'c3f', lambda: pack_conv3x3(weight))
-            y, norm = _conv3x3_raw(x, wpack, b, weight.shape[0], he, flags, True)
+            x = _ac_in(x)
+            if _wino_ok(x, weight):                           # 3-D 16 -> 16: the all-fp32 Winograd kernel
+                y, norm = conv3d_c16_wino(x, _pk(weight, 'w3f', pack_conv3d_c16_wino), b, he, flags)
+            elif _wino_gemm_ok(x, weight):                    # wide 2-D / 3-D: Winograd with the fused fp32-MFMA GEMM
+                y, norm = wide_conv(x, weight, b, he, flags)
+            else:
+                wpack = _pk(weight, 'c3f', pack_conv3x3)
+                y, norm = _conv3x3_raw(x, wpack, b, weight.shape[0], he, flags, True)
         ctx.flags, ctx.he = flags, he
         need_w = weight.requires_grad or (bias is not None and bias.requires_grad)
         # everything the backward reads goes through save_for_backward (autograd's version check then catches
@@ -588,19 +689,29 @@ class _Conv3x3(torch.autograd.Function):
         y, norm, w, x_saved = ctx.saved_tensors
         gp = _epilogue_bwd(cl(gy), y, norm, ctx.flags)
         gx = gw = gb = None
-        if ctx.needs_input_grad[0]:
-            if _wino_ok(gp, w):
-                gx, _ = conv3d_c16_wino(gp, _cached(w, 'w3b', lambda: pack_conv3d_c16_wino(w, transpose=True)), None, ctx.he, 0)
-            elif _wino_gemm_ok(gp, w):
-                gx, _ = wide_conv(gp, w, None, ctx.he, 0, transpose=True)
-            else:
-                wpack_t = _cached(w, 'c3b', lambda: pack_conv3x3(w, transpose=True))
-                gx, _ = _conv3x3_raw(gp, wpack_t, None, w.shape[1], ctx.he, 0, False)
-        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            dims = w.dim() - 2
-            gwt, gb = conv_bwd_weight(x_saved, gp, dims, w.shape[1], ctx.he)
-            k = (3,) * dims
-            gw = gwt.reshape(*k, w.shape[0], w.shape[1]).permute(dims, dims + 1, *range(dims)).contiguous()
+        with autocast(ctx.ac):                                # the backward runs under the policy of its forward
+            if ctx.needs_input_grad[0]:
+                if ctx.ac and _wino_ok(gp, w):
+                    gx, _ = conv3d_c16_bf16(gp, _pk(w, 'b3b', lambda t: pack_conv3d_c16_bf16(t, transpose=True)), None, ctx.he, 0, 2)
+                else:
+                    gpc = _ac_in(gp)
+                    if _wino_ok(gpc, w):
+                        gx, _ = conv3d_c16_wino(gpc, _pk(w, 'w3b', lambda t: pack_conv3d_c16_wino(t, transpose=True)), None, ctx.he, 0)
+                    elif _wino_gemm_ok(gpc, w):
+                        gx, _ = wide_conv(gpc, w, None, ctx.he, 0, transpose=True)
+                    else:
+                        wpack_t = _pk(w, 'c3b', lambda t: pack_conv3x3(t, transpose=True))
+                        gx, _ = _conv3x3_raw(gpc, wpack_t, None, w.shape[1], ctx.he, 0, False)
+                    gx = _ac_in(gx)
+            if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+                dims = w.dim() - 2
+                # (autocast: the weight gradient sees the half-precision gradient; the bias is added in fp32, so its
+                # gradient is the column sum of the un-rounded one)
+                gwt, gb = conv_bwd_weight(x_saved, _ac_in(gp), dims, w.shape[1], ctx.he, want_bias=not ctx.ac)
+                if ctx.ac and ctx.needs_input_grad[2]:
+                    gb = bias_grad(gp, dims)
+                k = (3,) * dims
+                gw = _ac_in(gwt.reshape(*k, w.shape[0], w.shape[1]).permute(dims, dims + 1, *range(dims)).contiguous())
         return gx, gw if ctx.needs_input_grad[1] else None, gb if ctx.needs_input_grad[2] else None, None
 
 
@@ -622,15 +733,18 @@ class _Conv3x3Sum16(torch.autograd.Function):
         assert weight.dim() == 5 and weight.shape[0] == 16 and sum(widths) == weight.shape[1] and len(widths) == len(parts)
         he = he_constant(weight)
 
+        ctx.ac = AUTOCAST is not None
+        parts = tuple(_ac_in(cl(p)) for p in parts)
+
         def make():
-            wd, packs, c0 = weight.detach(), [], 0
+            wd, packs, c0 = _wsrc(weight).detach(), [], 0
             for wdt in widths:
                 wp = wd.new_zeros(16, 16, 3, 3, 3)
                 wp[:, :wdt] = wd[:, c0:c0 + wdt]
                 packs.append((pack_conv3d_c16_wino(wp), pack_conv3d_c16_wino(wp, transpose=True)))
                 c0 += wdt
             return packs
-        packs = _cached(weight, 'sum16_' + '_'.join(map(str, widths)), make)
+        packs = _cached(weight, 'sum16_' + '_'.join(map(str, widths)) + ('@ac' if ctx.ac else ''), make)
         y = None
         for i, (p, (pf, _pt)) in enumerate(zip(parts, packs)):
             _req(p, 'part')
@@ -644,10 +758,14 @@ class _Conv3x3Sum16(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         gy = cl(gy)
+        gy_full = gy
         w, *saved_parts = ctx.saved_tensors
+        if ctx.ac:
+            gy = round_bf16(gy)
         gparts = []
         for i, (_pf, pt) in enumerate(ctx.packs):
-            gparts.append(conv3d_c16_wino(gy, pt, None, ctx.he, 0)[0] if ctx.needs_input_grad[3 + i] else None)
+            gpart = conv3d_c16_wino(gy, pt, None, ctx.he, 0)[0] if ctx.needs_input_grad[3 + i] else None
+            gparts.append(round_bf16(gpart) if (ctx.ac and gpart is not None) else gpart)
         gw = gb = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             cols = []
@@ -657,6 +775,10 @@ class _Conv3x3Sum16(torch.autograd.Function):
                 cols.append(g_i[:, :, :wdt])
             gwt = torch.cat(cols, dim=2)                                   # [27][16][sum widths]
             gw = gwt.reshape(3, 3, 3, 16, w.shape[1]).permute(3, 4, 0, 1, 2).contiguous()
+            if ctx.ac:
+                gw = round_bf16(gw)
+                if ctx.needs_input_grad[1]:
+                    gb = bias_grad(gy_full, 3)
         return (gw if ctx.needs_input_grad[0] else None, gb if ctx.needs_input_grad[1] else None, None, *gparts)
 
 
@@ -746,12 +868,13 @@ class _Conv1x1(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, flags):
         _req(x, 'x'), _req(weight, 'weight')
-        x = cl(x)
+        ctx.ac = AUTOCAST is not None
+        x = _ac_in(cl(x))
         N, cin = x.shape[0], x.shape[1]
         P = x[0, 0].numel()
         cout = weight.shape[0]
         he = he_constant(weight)
-        wpack = _cached(weight, 'c1f', lambda: pack_conv1x1(weight.reshape(cout, cin)))
+        wpack = _pk(weight, 'c1f', lambda w: pack_conv1x1(w.reshape(cout, cin)))
         y = empty_cl((N, cout) + tuple(x.shape[2:]), x.device)
         norm = _conv1x1_raw(x, wpack, bias.detach() if bias is not None else None, N, P, cin, 1, P * cin, 0, cout, y, he, flags)
         ctx.flags, ctx.he = flags, he
@@ -765,17 +888,23 @@ class _Conv1x1(torch.autograd.Function):
         gp = _epilogue_bwd(cl(gy), y, norm, ctx.flags)
         cout, cin = w.shape[0], w.shape[1]
         gx = gw = gb = None
-        if ctx.needs_input_grad[0]:
-            wpack_t = _cached(w, 'c1b', lambda: pack_conv1x1(w.reshape(cout, cin).t()))
-            N = gp.shape[0]
-            P = gp[0, 0].numel()
-            gx = empty_cl((N, cin) + tuple(gp.shape[2:]), gp.device)
-            _conv1x1_raw(gp, wpack_t, None, N, P, cout, 1, P * cout, 0, cin, gx, ctx.he, 0)
-        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            rows = gp.numel() // cout                                       # channels-last: plain [rows][C] matrices
-            gwt, gb = conv_bwd_weight(x_saved.permute(0, *range(2, x_saved.dim()), 1).reshape(rows, cin),
-                                      gp.permute(0, *range(2, gp.dim()), 1).reshape(rows, cout), 0, cin, ctx.he)
-            gw = gwt.reshape(w.shape)
+        with autocast(ctx.ac):
+            gp_full, gp = gp, _ac_in(gp)
+            if ctx.needs_input_grad[0]:
+                wpack_t = _pk(w, 'c1b', lambda t: pack_conv1x1(t.reshape(cout, cin).t()))
+                N = gp.shape[0]
+                P = gp[0, 0].numel()
+                gx = empty_cl((N, cin) + tuple(gp.shape[2:]), gp.device)
+                _conv1x1_raw(gp, wpack_t, None, N, P, cout, 1, P * cout, 0, cin, gx, ctx.he, 0)
+                gx = _ac_in(gx)
+            if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+                rows = gp.numel() // cout                                   # channels-last: plain [rows][C] matrices
+                gwt, gb = conv_bwd_weight(x_saved.permute(0, *range(2, x_saved.dim()), 1).reshape(rows, cin),
+                                          gp.permute(0, *range(2, gp.dim()), 1).reshape(rows, cout), 0, cin, ctx.he,
+                                          want_bias=not ctx.ac)
+                if ctx.ac and ctx.needs_input_grad[2]:
+                    gb = bias_grad(gp_full.permute(0, *range(2, gp_full.dim()), 1).reshape(rows, cout), 0)
+                gw = _ac_in(gwt.reshape(w.shape))
         return gx, gw if ctx.needs_input_grad[1] else None, gb if ctx.needs_input_grad[2] else None, None
 
 
@@ -791,13 +920,13 @@ class _FactorProject(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         _req(x, 'x'), _req(weight, 'weight')
-        x = cl(x)
+        ctx.ac = AUTOCAST is not None
+        x = _ac_in(cl(x))
         N, C, D, H, W = x.shape
         cout = weight.shape[0]
         he = he_constant(weight)                      # fan_in = C*D
         # reference K index = c*D + d; kernel K index = d*C + c
-        w2 = weight.reshape(cout, C, D)
-        wpack = _cached(weight, 'fpf', lambda: pack_conv1x1(w2.permute(0, 2, 1).reshape(cout, D * C)))
+        wpack = _pk(weight, 'fpf', lambda w: pack_conv1x1(w.reshape(cout, C, D).permute(0, 2, 1).reshape(cout, D * C)))
         y = empty_cl((N, cout, H, W), x.device)
         flags = LF_EPI_LRELU | LF_EPI_PIXELNORM
         if C % 4:
@@ -815,18 +944,24 @@ class _FactorProject(torch.autograd.Function):
         gp = _epilogue_bwd(cl(gy), y, norm, ctx.flags)
         N, C, D, H, W = ctx.xshape
         cout = w.shape[0]
-        # gx[n,d,p,c] = he * sum_co gp[n,p,co] * W[co, c*D+d]  == pointwise conv with Cout' = D*C
-        wt = _cached(w, 'fpb', lambda: pack_conv1x1(w.reshape(cout, C, D).permute(2, 1, 0).reshape(D * C, cout)))
-        # output channel d*C + c of pixel p goes straight to gx[n][d][p][c] (channels-last volume)
-        gx = empty_cl((N, C, D, H, W), gp.device)
-        _conv1x1_raw(gp, wt, None, N, H * W, cout, 1, H * W * cout, 0, D * C, gx, ctx.he, 0,
-                     yaddr=(D * H * W * C, C, C, H * W * C))
         gw = gb = None
-        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            # rows = pixels, K = (c, d) in the reference's order c*D + d: one copy of the volume (training only)
-            xr = x_saved.permute(0, 3, 4, 1, 2).reshape(N * H * W, C * D)
-            gwt, gb = conv_bwd_weight(xr.contiguous(), gp.permute(0, 2, 3, 1).reshape(N * H * W, cout), 0, C * D, ctx.he)
-            gw = gwt.reshape(w.shape)
+        with autocast(ctx.ac):
+            gp_full, gp = gp, _ac_in(gp)
+            # gx[n,d,p,c] = he * sum_co gp[n,p,co] * W[co, c*D+d]  == pointwise conv with Cout' = D*C
+            wt = _pk(w, 'fpb', lambda t: pack_conv1x1(t.reshape(cout, C, D).permute(2, 1, 0).reshape(D * C, cout)))
+            # output channel d*C + c of pixel p goes straight to gx[n][d][p][c] (channels-last volume)
+            gx = empty_cl((N, C, D, H, W), gp.device)
+            _conv1x1_raw(gp, wt, None, N, H * W, cout, 1, H * W * cout, 0, D * C, gx, ctx.he, 0,
+                         yaddr=(D * H * W * C, C, C, H * W * C))
+            gx = _ac_in(gx)
+            if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+                # rows = pixels, K = (c, d) in the reference's order c*D + d: one copy of the volume (training only)
+                xr = x_saved.permute(0, 3, 4, 1, 2).reshape(N * H * W, C * D)
+                gwt, gb = conv_bwd_weight(xr.contiguous(), gp.permute(0, 2, 3, 1).reshape(N * H * W, cout), 0, C * D, ctx.he,
+                                          want_bias=not ctx.ac)
+                if ctx.ac and ctx.needs_input_grad[2]:
+                    gb = bias_grad(gp_full.permute(0, 2, 3, 1).reshape(N * H * W, cout), 0)
+                gw = _ac_in(gwt.reshape(w.shape))
         return gx, gw if ctx.needs_input_grad[1] else None, gb if ctx.needs_input_grad[2] else None
 
 

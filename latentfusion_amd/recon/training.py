@@ -5,8 +5,8 @@ kernel (weight-gradient, data-gradient, volume splat), optimiser step.
 What is reproduced: the loss composition and weighting (`loss_g`, :510-516 incl. the division by
 `batch_groups`), the criterion and optimiser factories (Adam with betas (0, 0.99)), the depth noise clamp
 for `generator_input_depth`, `crop_predicted_mask`.  What is not: the discriminator branch (disabled in the
-released recipe, train.sh:59), dataset / augmentation / logging plumbing, and bf16 autocast -- the kernels
-are fp32.  Data parallelism replaces `MyDataParallel` by one process per GPU with a bucketed gradient
+released recipe, train.sh:59) and dataset / augmentation / logging plumbing.  `use_amp=True` runs the generator under
+the bf16 autocast policy (ops.autocast; the 3-D 16 -> 16 blocks on the bf16 MFMA).  Data parallelism replaces `MyDataParallel` by one process per GPU with a bucketed gradient
 all-reduce over RCCL (`parallel.allreduce_flat_`).
 
 Parameters live in ONE flat fp32 buffer (the modules' tensors are views into it) and so do the gradients:
@@ -86,7 +86,11 @@ class GeneratorStep:
                  g_depth_recon_loss_type='hard_smooth_l1', g_depth_recon_loss_weight=25.0, g_depth_recon_loss_k=16384,
                  g_mask_recon_loss_type='binary_cross_entropy', g_mask_recon_loss_weight=25.0, g_mask_recon_loss_k=2000,
                  g_mask_beta_loss_weight=0.0, g_mask_beta_loss_param=0.01, batch_groups=1, generator_input_depth=False,
-                 depth_noise_std=0.0, process_group=None):
+                 depth_noise_std=0.0, process_group=None, use_amp=False):
+        """use_amp: the reference's `--use-amp` (trainutils.py:41,243-246; train_reconstruct.py:455,524-532): the generator's
+        forward runs under autocast.  Here the policy is bf16 (ops.autocast): same exponent range as fp32, so the
+        reference's GradScaler has nothing to do and is not reproduced; master weights, gradients' accumulation, losses and
+        Adam stay fp32."""
         if optimizer not in ('adam', 'adamw'):
             raise ValueError(f'Unknown optimizer {optimizer!r}')
         self.sculptor, self.fuser, self.photographer = sculptor, fuser, photographer
@@ -102,6 +106,7 @@ class GeneratorStep:
         self.beta_param, self.batch_groups = g_mask_beta_loss_param, batch_groups
         self.generator_input_depth, self.depth_noise_std = generator_input_depth, depth_noise_std
         self.group = process_group
+        self.use_amp = bool(use_amp)
 
     def losses(self, batch):
         """Forward of the generator and the loss terms of train_reconstruct.py:456-516."""
@@ -109,8 +114,9 @@ class GeneratorStep:
         depth_in = None
         if self.generator_input_depth:
             depth_in = (b_in['depth'] + self.depth_noise_std * torch.randn_like(b_in['depth'])).clamp(-1, 1)
-        z_obj, _ = self.sculptor.encode(self.fuser, b_in['camera'], b_in['image'], depth_in, b_in['mask'])
-        y, _, _ = self.photographer.decode(z_obj, b_out['camera'], return_latent=True, apply_mask=False)
+        with ops.autocast(self.use_amp):
+            z_obj, _ = self.sculptor.encode(self.fuser, b_in['camera'], b_in['image'], depth_in, b_in['mask'])
+            y, _, _ = self.photographer.decode(z_obj, b_out['camera'], return_latent=True, apply_mask=False)
         out = {}
         dev = z_obj.device
         zero = torch.zeros((), device=dev)

@@ -1,0 +1,136 @@
+"""bf16 autocast policy of the training step (BASELINE cfg 5): the bf16-MFMA conv3d kernel against an emulation of what
+torch autocast makes of Equalized.forward + LeakyReLU + PixelNorm (modules/equalized.py:57-64 under
+recon/models.py:199,405), and one generator step under `use_amp` against the CPU oracle run under
+torch.autocast(bfloat16).  Tolerances are bf16's: a value sitting on a rounding boundary may land one bf16 ulp (2^-8
+relative) away when the fp32 accumulation order differs."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import lf_oracle as O
+from lf_oracle import nets
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def bf(t):
+    return t.to(torch.bfloat16).float()
+
+
+@pytest.mark.parametrize('shape', [(2, 16, 8, 8, 16), (1, 16, 5, 9, 21), (3, 16, 4, 16, 32)])
+def test_conv3d_c16_bf16_kernel(shape):
+    from latentfusion_amd import ops
+    from latentfusion_amd._lib import LF_EPI_LRELU, LF_EPI_PIXELNORM
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(shape, generator=g)
+    w = torch.randn(16, 16, 3, 3, 3, generator=g)
+    b = torch.randn(16, generator=g) * 0.1
+    he = ops.he_constant(w)
+    xd = ops.cl(x.to(DEV))
+    acc = F.conv3d(bf(x).double(), bf(w).double(), None, 1, 1)              # exact products of the bf16 operands
+    # round_out = 0: fp32 epilogue on the accumulator
+    y0, n0 = ops.conv3d_c16_bf16(xd, ops.pack_conv3d_c16_bf16(w.to(DEV)), b.to(DEV), he, LF_EPI_LRELU | LF_EPI_PIXELNORM, 0)
+    pre = F.leaky_relu(acc * he + b.double().view(1, -1, 1, 1, 1), 0.2)
+    nrm = torch.sqrt((pre ** 2).mean(dim=1, keepdim=True) + 1e-8)
+    torch.testing.assert_close(y0.cpu().double(), pre / nrm, atol=2e-5, rtol=1e-5)
+    torch.testing.assert_close(n0.view(shape[0], *shape[2:]).cpu().double(), nrm.squeeze(1), atol=1e-5, rtol=1e-5)
+    # round_out = 1: the autocast forward -- bf16(bf16(acc) * he) + bias
+    y1, _ = ops.conv3d_c16_bf16(xd, ops.pack_conv3d_c16_bf16(w.to(DEV)), b.to(DEV), he, LF_EPI_LRELU, 1)
+    want = F.leaky_relu(bf(bf(acc.float()) * he) + b.view(1, -1, 1, 1, 1), 0.2)
+    err = (y1.cpu() - want).abs()
+    assert float(err.max()) <= 2 ** -7 * float(want.abs().max()), float(err.max())       # at most bf16 ulps on ties
+    assert float((err > 1e-6).float().mean()) < 5e-3                                     # ... and rarely
+    # round_out = 2: data gradient (transposed / flipped pack), result rounded to bf16
+    gy = torch.randn(shape, generator=g) * 1e-3
+    gx, _ = ops.conv3d_c16_bf16(ops.cl(gy.to(DEV)), ops.pack_conv3d_c16_bf16(w.to(DEV), transpose=True), None, he, 0, 2)
+    gwant = bf(bf(bf(F.conv_transpose3d(bf(gy).double(), bf(w).double(), None, 1, 1).float()) * he))
+    err = (gx.cpu() - gwant).abs()
+    assert float(err.max()) <= 2 ** -7 * float(gwant.abs().max())
+    assert float((err > 1e-9).float().mean()) < 5e-3
+
+
+def test_round_bf16():
+    from latentfusion_amd import ops
+    x = torch.randn(3, 5, 7, generator=torch.Generator().manual_seed(0)) * 100
+    assert torch.equal(ops.round_bf16(x.to(DEV)).cpu(), bf(x))
+    xc = torch.randn(2, 16, 4, 4, 4).to(DEV).contiguous(memory_format=torch.channels_last_3d)
+    assert torch.equal(ops.round_bf16(xc).cpu(), bf(xc.cpu()))
+
+
+def test_generator_step_under_bf16_autocast():
+    """GeneratorStep(use_amp=True) on SYN(16,16) (GRU fuser: the 16-channel gate convolutions and the 16 -> 16 blocks take
+    the bf16 paths): loss terms within bf16 tolerance of the oracle evaluated under torch.autocast(cpu, bfloat16), every
+    parameter gradient as close to the fp32 gradient as the oracle's bf16 gradient is (cosine similarity), and a decreasing
+    loss over repeated steps."""
+    from latentfusion_amd import losses as L, ops, synth
+    from latentfusion_amd.modules.geometry import Camera
+    from latentfusion_amd.observation import Observation
+    from latentfusion_amd.recon import training
+    S, C = 16, 16
+    model, (sck, fck, pck, dist) = synth.build_model(S, C, 'gru', seed=0, device=DEV, bias_std=0.1)
+    d = synth.make_observation_data(3, seed=7)
+    obs = model.preprocess_observation(Observation(d['color'], d['depth'], d['mask'], Camera(d['intrinsic'], d['extrinsic'])).to(DEV))
+    gen = torch.Generator().manual_seed(5)
+    tgt_depth = torch.rand(1, 3, 1, S, S, generator=gen) * 2 - 1
+    tgt_mask = (torch.rand(1, 3, 1, S, S, generator=gen) > 0.5).float()
+    kw = dict(g_depth_recon_loss_type='l1', g_depth_recon_loss_weight=25.0, g_mask_recon_loss_weight=25.0, generator_lr=1e-3)
+
+    # oracle under CPU autocast(bf16)
+    cks = {k: {**ck, 'state_dict': {n: v.clone().requires_grad_(True) for n, v in ck.get('state_dict', {}).items()}}
+           for k, ck in (('s', sck), ('f', fck), ('p', pck))}
+    cam = obs.camera.to('cpu')
+    ocam = O.Cam(cam.intrinsic, cam.log_quaternion, cam.translation, viewport=cam.viewport, z_span=cam.z_span, width=cam.width,
+                 height=cam.height)
+
+    def oracle_loss(autocast):
+        for ck in cks.values():
+            for v in ck['state_dict'].values():
+                v.grad = None
+        with torch.autocast('cpu', dtype=torch.bfloat16, enabled=autocast):
+            z = nets.encode(cks['s'], cks['f'], ocam, obs.color.cpu(), obs.depth.cpu(), obs.mask.cpu())
+            y, _, _ = nets.decode(cks['p'], z, ocam, apply_mask=False)
+        tot = 25.0 * L.reduce_loss(L.get_recon_criterion('l1')(y['depth'].float(), tgt_depth)) + \
+            25.0 * L.reduce_loss(L.get_recon_criterion('binary_cross_entropy')(y['mask_logits'].float(), tgt_mask))
+        tot.backward()
+        return float(tot), {(k, n): v.grad.clone() for k, ck in cks.items() for n, v in ck['state_dict'].items() if v.grad is not None}
+    want32, g32 = oracle_loss(False)
+    want16, g16 = oracle_loss(True)
+    assert abs(want16 - want32) / want32 > 1e-6, 'autocast had no effect on the oracle'
+
+    step = training.GeneratorStep(model.sculptor, model.fuser, model.photographer, use_amp=True, **kw)
+    batch = {'in': {'camera': obs.camera, 'image': obs.color.unsqueeze(0), 'mask': obs.mask.unsqueeze(0)},
+             'out_gt': {'camera': obs.camera, 'depth': tgt_depth.to(DEV), 'mask': tgt_mask.to(DEV)}}
+    ops.KERNEL_TIMER = []
+    try:
+        got = step.run_iteration(batch, is_step=False)
+        tags = {n for n, _, _ in ops.KERNEL_TIMER}
+    finally:
+        ops.KERNEL_TIMER = None
+    assert 'conv3d_c16_bf16' in tags, tags
+    tot = float(got['total'])
+    # within bf16 noise of the autocast oracle, and the deviation from fp32 is of the same order as the oracle's own
+    assert abs(tot - want16) / want16 < 2e-2, (tot, want16, want32)
+    # bf16 rounding noise on the gradients of this small random network is large (the oracle's own bf16 and fp32
+    # gradients of the first encoder layers agree only to cos ~0.85), and two bf16 evaluations with different
+    # accumulation orders are independent samples of it: the yardstick is the fp32 gradient -- the HIP bf16 step must be
+    # as close to it as the oracle's bf16 step is, over the whole parameter vector and (loosely: small tensors make the
+    # statistic itself noisy) per parameter
+    hip_all, orc_all, ref_all = [], [], []
+    for (k, n), gw in g16.items():
+        mod = {'s': model.sculptor, 'f': model.fuser, 'p': model.photographer}[k]
+        p = dict(mod.named_parameters())[n]
+        ref = g32[(k, n)].reshape(1, -1).double()
+        hip_all.append(p.grad.reshape(-1).cpu().double()); orc_all.append(gw.reshape(-1).double()); ref_all.append(ref.reshape(-1))
+        if gw.abs().max() < 1e-6 * max(v.abs().max() for v in g16.values()):
+            continue
+        cos_hip = F.cosine_similarity(p.grad.reshape(1, -1).cpu().double(), ref).item()
+        cos_orc = F.cosine_similarity(gw.reshape(1, -1).double(), ref).item()
+        assert cos_hip > min(0.99, cos_orc - 0.15) and cos_hip > 0.5, (k, n, cos_hip, cos_orc)
+    hip_all, orc_all, ref_all = torch.cat(hip_all), torch.cat(orc_all), torch.cat(ref_all)
+    cos_hip = F.cosine_similarity(hip_all, ref_all, dim=0).item()
+    cos_orc = F.cosine_similarity(orc_all, ref_all, dim=0).item()
+    print(f'bf16 autocast: cos(grad, fp32 grad) HIP {cos_hip:.4f}, oracle {cos_orc:.4f}; loss HIP {tot:.5f} oracle bf16 {want16:.5f} fp32 {want32:.5f}')
+    assert cos_hip > cos_orc - 0.03, (cos_hip, cos_orc)
+    losses = [float(step.run_iteration(batch)['total']) for _ in range(6)]
+    assert losses[-1] < losses[0]
