@@ -51,7 +51,7 @@ int lf_device_name(char* buf, int buflen);
  * tolerances for every value.  key 1: 3-D resampler kernels, 1 = generic (64-bit addressing, any C), 2 = lean
  * (32-bit buffer addressing, C % 4 == 0, volumes < 4 GB per sample; other shapes take the generic ones),
  * 3 = lean + the 16-channel specialisation of the gather (default).  key 2: lean coefficient-gradient kernel, sub-tiles in
- * flight per workgroup iteration: 1 = one, 2 = two, 3 = two at 4 waves per SIMD (default).
+ * flight per workgroup iteration: 1 = one, 2 = two (default), 3-5 = register-capped forms of 2 / 1.
  * Returns the previous value or LF_EINVAL. */
 int lf_set_tuning(int key, int value);
 

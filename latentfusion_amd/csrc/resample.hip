@@ -440,10 +440,12 @@ __global__ void __launch_bounds__(256, MINW) resample_bwd_coef_c16_kernel(
   const int q = threadIdx.x & 3, vs = threadIdx.x >> 2;          // vs = position inside a 4x4x4 sub-tile
   const int px = vs & 3, py = (vs >> 2) & 3, pz = vs >> 4;
   const int sbx = bt.lx - 2, sby = bt.ly - 2;
-  float acc[18];
+  // the 18 sums (hx, hy, hz) x (1, a, b, k, ak, bk) are split over the voxel's four lanes -- after the quad sums every
+  // lane holds the same (hx, hy, hz) -- so a lane carries 6 accumulators instead of 18: lane q owns basis functions
+  // 2q and 2q+1 (lane 3 idles)
+  float acc[6];
 #pragma unroll
-  for (int i = 0; i < 18; ++i) acc[i] = 0.f;
-  const float qsel = (q == 0) ? 1.f : 0.f;                       // one lane of the quad feeds the sums
+  for (int i = 0; i < 6; ++i) acc[i] = 0.f;
   const int nsub = vpb >> 6;
   const u32 co = (u32)q * 16u;
   // UNR sub-tiles are in flight per iteration: the 9 loads of a voxel have nothing to overlap with inside one
@@ -483,31 +485,35 @@ __global__ void __launch_bounds__(256, MINW) resample_bwd_coef_c16_kernel(
       const float dxv = (p[1] - p[0]) * (wy0 * wz0) + (p[3] - p[2]) * (wy1 * wz0) + (p[5] - p[4]) * (wy0 * wz1) + (p[7] - p[6]) * (wy1 * wz1);
       const float dyv = (p[2] - p[0]) * (wx0 * wz0) + (p[3] - p[1]) * (wx1 * wz0) + (p[6] - p[4]) * (wx0 * wz1) + (p[7] - p[5]) * (wx1 * wz1);
       const float dzv = (p[4] - p[0]) * (wx0 * wy0) + (p[5] - p[1]) * (wx1 * wy0) + (p[6] - p[2]) * (wx0 * wy1) + (p[7] - p[3]) * (wx1 * wy1);
-      const float hx = dxv * t[u].mx * qsel, hy = dyv * t[u].my * qsel, hz = dzv * t[u].mz * qsel;
-      const float ak = a[u] * k[u], bk = b[u] * k[u];
-      acc[0] += hx;          acc[1] += hy;          acc[2] += hz;
-      acc[3] += hx * a[u];   acc[4] += hy * a[u];   acc[5] += hz * a[u];
-      acc[6] += hx * b[u];   acc[7] += hy * b[u];   acc[8] += hz * b[u];
-      acc[9] += hx * k[u];   acc[10] += hy * k[u];  acc[11] += hz * k[u];
-      acc[12] += hx * ak;    acc[13] += hy * ak;    acc[14] += hz * ak;
-      acc[15] += hx * bk;    acc[16] += hy * bk;    acc[17] += hz * bk;
+      const float hx = dxv * t[u].mx, hy = dyv * t[u].my, hz = dzv * t[u].mz;
+      const float B0 = q == 0 ? 1.f : (q == 1 ? b[u] : (q == 2 ? a[u] * k[u] : 0.f));
+      const float B1 = q == 0 ? a[u] : (q == 1 ? k[u] : (q == 2 ? b[u] * k[u] : 0.f));
+      acc[0] += hx * B0; acc[1] += hy * B0; acc[2] += hz * B0;
+      acc[3] += hx * B1; acc[4] += hy * B1; acc[5] += hz * B1;
     }
   }
-  __shared__ float red[4][18];
+  // workgroup reduction in fp64: a thread's fp32 sum runs over its 64 voxels only; from there on (64 lanes x 4 waves,
+  // then the blocks in the finish kernel) nothing is rounded until the final conversion -- the 18 sums cancel to a
+  // small fraction of their terms' magnitude, so summation rounding would otherwise show in the camera gradients
+  __shared__ double red[4][18];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
-  for (int i = 0; i < 18; ++i) {
-    const float s = lf_wave_sum(acc[i]);
-    if (lane == 0) red[wave][i] = s;
+  for (int i = 0; i < 6; ++i) {
+    double s = (double)acc[i];
+#pragma unroll
+    for (int o = 32; o >= 4; o >>= 1) s += __shfl_xor(s, o, 64);     // over the 16 lanes that share this q
+    // lane q (0..2) of the first quad: basis 2q + i/3, component i%3 -> output index basis*3 + component
+    if (lane < 3) red[wave][(2 * lane + i / 3) * 3 + (i % 3)] = s;
   }
   __syncthreads();
   if (threadIdx.x < 18) {
-    const float s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-    partial[((long)n * nblk + blk) * 18 + threadIdx.x] = s;
+    const double s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    partial[((long)n * nblk + blk) * 18 + threadIdx.x] = (float)s;
   }
 }
 
-int g_bwd_coef_variant = 1;   // lean coefficient gradient: 1 = one sub-tile in flight, 2 = two, 3 = two at 4 waves/SIMD, 4 / 5 = one at 6 / 8 waves/SIMD
+int g_bwd_coef_variant = 2;   // lean coefficient gradient: 1 = one sub-tile in flight (6 waves/SIMD), 2 = two (4 waves/SIMD; default),
+                              // 3 = as 2 with a 128-register cap, 4 / 5 = one in flight capped at 6 / 8 waves/SIMD
 int g_resample_variant = 3;   // 1 = generic kernels, 2 = lean kernels, 3 = lean + 16-channel gather (lf_set_tuning)
 
 // ---- deterministic splat: the same scatter, accumulated in 64-bit fixed point ----------------------------------
