@@ -311,6 +311,14 @@ int lf_fuse_blend_fwd(const float* z, const float* logits, float* weights, float
 int lf_fuse_blend_bwd(const float* g, const float* z, const float* weights, float* gz, float* glogits, int V, long rows,
                       int C, long z_view_stride, long logit_view_stride, void* stream);
 
+/* Cell arithmetic of the convolutional LSTM fuser (modules/lstm.py:41-56): cc = conv([x, h]) holds the gate
+ * pre-activations of a voxel as channel blocks [i | f | o | g] (channels-last record of 4*Ch floats);
+ *   c' = sigmoid(f) c + sigmoid(i) tanh(g);  h' = sigmoid(o) tanh(c').
+ * bwd: given gh = dL/dh' and gcn = dL/dc' (either may be NULL) -> gcc [nvox][4*Ch] and gc = dL/dc. */
+int lf_lstm_cell_fwd(const float* cc, const float* c_cur, float* h_next, float* c_next, long nvox, int Ch, void* stream);
+int lf_lstm_cell_bwd(const float* cc, const float* c_cur, const float* gh, const float* gcn, float* gcc, float* gc,
+                     long nvox, int Ch, void* stream);
+
 /* 2-D grid sampling of planar images, F.grid_sample(align_corners=False) semantics: the crop / zoom
  * (geometry.py:20-44,287-354; zeros padding), Camera.uncrop (geometry.py:261-285; border padding) and the
  * image-based-rendering warps (ibr.py:52-93).  img [N][C][H][W], grid [N][Ho][Wo][2] = (x, y) in [-1,1],

@@ -65,6 +65,8 @@ SIGNATURES = {
     'lf_wino2d_output_transform': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint, c_float, c_float, P]),
     'lf_gru_stage_a': (c_int, [P, P, c_int, P, P, P, c_long, c_int, c_int, c_int, P]),
     'lf_gru_stage_b': (c_int, [P, P, P, P, P, c_long, c_int, c_int, c_int, P]),
+    'lf_lstm_cell_fwd': (c_int, [P, P, P, P, c_long, c_int, P]),
+    'lf_lstm_cell_bwd': (c_int, [P, P, P, P, P, P, c_long, c_int, P]),
     'lf_gru_stage_b_bwd': (c_int, [P, P, P, P, P, P, P, c_long, P]),
     'lf_gru_stage_a_bwd': (c_int, [P, P, P, P, P, P, P, P, c_long, P]),
     'lf_column_reduce_sum_fwd': (c_int, [P, P, c_int, c_int, c_long, c_int, P]),

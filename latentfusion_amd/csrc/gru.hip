@@ -70,7 +70,64 @@ __global__ void __launch_bounds__(256) gru_stage_a_bwd_kernel(const f32x4* __res
   gh[i] = gr * r;
 }
 
+// ---- ConvLSTM cell arithmetic (latentfusion/modules/lstm.py:41-56): cc = conv([x, h]) holds the four gate
+// pre-activations of a voxel as channel blocks [i | f | o | g] of Ch channels each (channels-last record of 4*Ch floats)
+//   c' = sigmoid(f) c + sigmoid(i) tanh(g);   h' = sigmoid(o) tanh(c')
+// one thread per (voxel, channel); backward recomputes the gates from cc.
+__global__ void __launch_bounds__(256) lstm_cell_fwd_kernel(const float* __restrict__ cc, const float* __restrict__ c_cur,
+                                                            float* __restrict__ h_next, float* __restrict__ c_next, long nvox, int Ch) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= nvox * Ch) return;
+  const long v = idx / Ch;
+  const int c = (int)(idx - v * Ch);
+  const float* r = cc + v * 4 * Ch + c;
+  const float i = sigmoidf_(r[0]), f = sigmoidf_(r[Ch]), o = sigmoidf_(r[2 * Ch]), g = tanhf(r[3 * Ch]);
+  const float cn = __fadd_rn(__fmul_rn(f, c_cur[idx]), __fmul_rn(i, g));
+  c_next[idx] = cn;
+  h_next[idx] = __fmul_rn(o, tanhf(cn));
+}
+
+// given gh = dL/dh', gcn = dL/dc' (from the next step; may be NULL): gcc (4*Ch per voxel) and gc = dL/dc
+__global__ void __launch_bounds__(256) lstm_cell_bwd_kernel(const float* __restrict__ cc, const float* __restrict__ c_cur,
+                                                            const float* __restrict__ gh, const float* __restrict__ gcn,
+                                                            float* __restrict__ gcc, float* __restrict__ gc, long nvox, int Ch) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= nvox * Ch) return;
+  const long v = idx / Ch;
+  const int c = (int)(idx - v * Ch);
+  const float* r = cc + v * 4 * Ch + c;
+  const float i = sigmoidf_(r[0]), f = sigmoidf_(r[Ch]), o = sigmoidf_(r[2 * Ch]), g = tanhf(r[3 * Ch]);
+  const float cc_ = c_cur[idx];
+  const float cn = f * cc_ + i * g;
+  const float tc = tanhf(cn);
+  const float ghv = gh ? gh[idx] : 0.f;
+  const float dcn = (gcn ? gcn[idx] : 0.f) + ghv * o * (1.f - tc * tc);
+  float* w = gcc + v * 4 * Ch + c;
+  w[0] = dcn * g * i * (1.f - i);
+  w[Ch] = dcn * cc_ * f * (1.f - f);
+  w[2 * Ch] = ghv * tc * o * (1.f - o);
+  w[3 * Ch] = dcn * i * (1.f - g * g);
+  gc[idx] = dcn * f;
+}
+
 }  // namespace
+
+extern "C" int lf_lstm_cell_fwd(const float* cc, const float* c_cur, float* h_next, float* c_next, long nvox, int Ch, void* stream) {
+  lf_clear_error();
+  if (nvox <= 0 || Ch <= 0 || nvox * Ch >= 0x7fffffff00L) return LF_EINVAL;
+  hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3((unsigned)((nvox * Ch + 255) / 256)), dim3(256), 0, (hipStream_t)stream, cc, c_cur,
+                     h_next, c_next, nvox, Ch);
+  return lf_launch_status();
+}
+
+extern "C" int lf_lstm_cell_bwd(const float* cc, const float* c_cur, const float* gh, const float* gcn, float* gcc, float* gc,
+                                long nvox, int Ch, void* stream) {
+  lf_clear_error();
+  if (nvox <= 0 || Ch <= 0 || nvox * Ch >= 0x7fffffff00L || (gh == nullptr && gcn == nullptr)) return LF_EINVAL;
+  hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3((unsigned)((nvox * Ch + 255) / 256)), dim3(256), 0, (hipStream_t)stream, cc, c_cur,
+                     gh, gcn, gcc, gc, nvox, Ch);
+  return lf_launch_status();
+}
 
 extern "C" int lf_gru_stage_b_bwd(const float* g, const float* h, const float* u, const float* cand, float* gh, float* gu,
                                   float* gc, long n, void* stream) {

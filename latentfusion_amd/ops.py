@@ -832,6 +832,42 @@ class _GruBlend(torch.autograd.Function):
         return gh, gu, gc
 
 
+class _LstmCell(torch.autograd.Function):
+    """(cc (N,4Ch,...), c) -> (h', c') of the ConvLSTM cell (modules/lstm.py:49-56; lf_lstm_cell_fwd/bwd): one kernel each
+    way instead of four activations, three products and a split."""
+
+    @staticmethod
+    def forward(ctx, cc, c_cur):
+        L = _lib.lib()
+        cc, c_cur = cl(_req(cc, 'cc')), cl(_req(c_cur, 'c'))
+        Ch = c_cur.shape[1]
+        if cc.shape[1] != 4 * Ch:
+            raise ValueError('lstm_cell: cc must hold 4 x hidden channels')
+        h, cn = torch.empty_like(c_cur), torch.empty_like(c_cur)
+        check(L.lf_lstm_cell_fwd(_ptr(cc), _ptr(c_cur), _ptr(h), _ptr(cn), c_cur.numel() // Ch, Ch, _stream()), 'lf_lstm_cell_fwd')
+        ctx.save_for_backward(cc, c_cur)
+        ctx.set_materialize_grads(False)
+        return h, cn
+
+    @staticmethod
+    def backward(ctx, gh, gcn):
+        L = _lib.lib()
+        cc, c_cur = ctx.saved_tensors
+        if gh is None and gcn is None:
+            return None, None
+        Ch = c_cur.shape[1]
+        gh = cl(gh) if gh is not None else None
+        gcn = cl(gcn) if gcn is not None else None
+        gcc, gc = torch.empty_like(cc), torch.empty_like(c_cur)
+        check(L.lf_lstm_cell_bwd(_ptr(cc), _ptr(c_cur), _ptr(gh) if gh is not None else None, _ptr(gcn) if gcn is not None else None,
+                                 _ptr(gcc), _ptr(gc), c_cur.numel() // Ch, Ch, _stream()), 'lf_lstm_cell_bwd')
+        return gcc, gc
+
+
+def lstm_cell(cc, c_cur):
+    return _LstmCell.apply(cc, c_cur)
+
+
 def gru_gates(upre, rpre, h):
     return _GruGates.apply(upre, rpre, h)
 

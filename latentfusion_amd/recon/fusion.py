@@ -174,7 +174,10 @@ class ConvLSTMCell(nn.Module):
     def forward(self, input_tensor, cur_state):
         h_cur, c_cur = cur_state
         cc = self.conv(torch.cat([input_tensor, h_cur], dim=1))
-        i, f, o, g = torch.split(cc, self.hidden_channels, dim=1)
+        if cc.is_cuda:                                        # gate arithmetic in one kernel (lf_lstm_cell_fwd / _bwd)
+            from .. import ops
+            return ops.lstm_cell(cc, c_cur)
+        i, f, o, g = torch.split(cc, self.hidden_channels, dim=1)          # (host tensors: CPU-side tests only)
         c_next = torch.sigmoid(f) * c_cur + torch.sigmoid(i) * torch.tanh(g)
         return torch.sigmoid(o) * torch.tanh(c_next), c_next
 
