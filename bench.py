@@ -169,13 +169,13 @@ def main():
         # secondary line (never `value`): the same loop with the split-precision conv3d kernels
         del est, st
         torch.cuda.empty_cache()
-        est2 = estimation.load_from_config(cfg, model, converge_patience=10 ** 6, conv_mode='winograd_f16x3')
+        est2 = estimation.load_from_config(cfg, model, converge_patience=10 ** 6, conv_mode='f16x3')
         st2 = est2.start(z_obj, target, init.zoom(None, model.input_size, model.camera_dist).to(dev))
         el2, tm2 = timed_loop(est2, st2)
-        d2 = [e0.elapsed_time(e1) for n_, e0, e1 in tm2 if n_ == 'conv3d_c16_wino_split']
-        alt = {'conv_mode': 'winograd_f16x3 (Winograd with fp32 transforms; each Winograd-domain product as 3 f16 MFMAs, '
-                            'fp32 accumulate; error vs fp64 within the fp32 kernels\', '
-                            'tests/test_engine_gpu.py::test_winograd_conv3d_matches_fp64)',
+        d2 = [e0.elapsed_time(e1) for n_, e0, e1 in tm2 if n_ == 'conv3d_c16_split']
+        alt = {'conv_mode': 'f16x3 (direct convolution, every fp32 product as 3 f16 MFMAs on hi/lo splits, fp32 accumulate; '
+                            'error vs fp64 within the fp32 kernels\', '
+                            'tests/test_engine_gpu.py::test_split_precision_conv_matches_fp32_and_fp64)',
                'value': world * a.steps / el2, 'unit': 'iters/s', 'ms_per_step': el2 / a.steps * 1e3,
                'conv_avg_launch_ms': sum(d2) / max(len(d2), 1)}
 

@@ -7,6 +7,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ['resample.hip', 'conv.hip', 'pointwise.hip', 'image.hip', 'optim.hip', 'resize.hip', 'conv_split.hip', 'conv_wino.hip', 'wgrad.hip', 'sample2d.hip', 'gru.hip', 'wino_gemm.hip', 'reduce.hip', 'wino_fused.hip', 'conv_bf16.hip']
 LIB = os.path.join(HERE, 'liblf_hip.so')
+# per-file extras (conv_split.hip: see split_piece there)
+EXTRA = {'conv_split.hip': ['-fno-slp-vectorize']}
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function']
 
 
@@ -38,7 +40,7 @@ def build(force=False, verbose=True):
             continue
         obj = os.path.join(HERE, src.replace('.hip', '.o'))
         objs.append(obj)
-        cmd = [hipcc, '-x', 'hip', '-c', path, '-o', obj] + FLAGS
+        cmd = [hipcc, '-x', 'hip', '-c', path, '-o', obj] + FLAGS + EXTRA.get(src, [])
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for cmd, p in procs:
         out, _ = p.communicate()

@@ -1,58 +1,152 @@
-// Split-precision variant of the dominant kernel: conv3d 16->16 on the f16 matrix cores with
+// Split-precision direct form of the dominant kernel: conv3d 16->16 on the f16 matrix cores with
 // fp32-equivalent accuracy ("f16x3").
+//
+//   y = PixelNorm(LeakyReLU(conv3d(x, W) * he + b))            latentfusion/modules/blocks.py:152-158
+//                                                              latentfusion/modules/equalized.py:57-64
+// and, with transposed / flipped weights and `prev_*` set, the data gradient fused with the previous layer's
+// LeakyReLU' / PixelNorm' (autograd of the same lines).
 //
 // Every fp32 operand x is split as x = hi + lo with hi = (f16)x, lo = (f16)(x - hi): 22 mantissa bits.
 // The product is formed from three f16 MFMAs accumulating in fp32,
 //     a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi          (dropped a_lo*b_lo <= 2^-22 |a b|),
-// each partial product being exact in fp32 (11 x 11 significant bits).  The f16 MFMA runs at 16x the
-// fp32 MFMA rate, so three of them cost 3/16 of the exact-fp32 kernel's matrix time and the kernel
-// becomes HBM/LDS-bound instead of MFMA-bound.  Activations stay fp32 in HBM: the split happens
-// on-chip, between the LDS-DMA'd fp32 halo tile and the f16 hi/lo tiles the MFMAs read.
+// each partial product being exact in fp32 (11 x 11 significant bits).  The f16 MFMA runs at 16x the fp32 MFMA
+// rate and on its own pipe (the fp32 MFMA shares the fp32 VALU's), so the convolution becomes a balanced
+// HBM / LDS / matrix-pipe problem instead of an issue-bound one.  Activations stay fp32 in HBM: the split happens
+// on-chip while the halo is staged.
 //
-// Range: forward activations are O(1) (PixelNorm output) and need no scaling.  Gradients can be tiny,
-// so data-gradient launches multiply the input by a power of two derived from the tensor's max-abs
-// (`amax_in`, produced by the previous kernel with an order-independent atomic max) and undo it
-// exactly in the epilogue; elements far below the tensor max lose relative but not absolute accuracy,
-// which is what a dot product needs.
+// Range: forward activations are O(1) (PixelNorm output) and need no scaling.  Gradients can be tiny, so
+// data-gradient launches multiply the input by a power of two derived from the tensor's max-abs (`amax_in`,
+// produced by the previous kernel with an order-independent atomic max) and undo it exactly in the epilogue;
+// elements far below the tensor max lose relative but not absolute accuracy, which is what a dot product needs.
 //
-// Structure (same skeleton as conv3d_c16_persistent_kernel in conv.hip): one 512-thread workgroup per
-// CU walks 4x8x16 tiles; weights (hi and lo, 14 tap pairs x 32-deep K) live in registers; halo of
-// tile t+1 is DMA'd (fp32) while tile t is multiplied; SIMD-partner waves skew their epilogues.
+// Organisation (gfx950):
+//   * 256-thread workgroups, TWO per CU (2 x 69,696 B of LDS), each walking up columns of 2 x 8 x 16-voxel tiles;
+//     wave w owns z plane w & 1, rows 4 (w >> 1) .. +3 of the tile: 4 rows x 16 voxels x 16 couts = 4 accumulators.
+//   * the halo lives in LDS as f16 hi / lo planes (32 B per voxel and plane kind, conflict-free for the
+//     ds_read_b128 operand reads without a swizzle) in a RING of 6 z-plane slots: a tile reads 4 planes (4 x 10 x 18
+//     voxels), the upper two of which are the lower two of the next tile up the column, and the two planes the next
+//     tile adds (23 KB of fp32) go to the two slots NOT being read: they are requested before the tile's MFMA phase
+//     (6 x 1 KiB buffer loads per wave), converted and written behind it, and one workgroup barrier per tile
+//     separates "everyone has read planes 0, 1" / "the new planes are visible" from the next tile.
+//   * taps are paired into K = 32 MFMAs (lane groups kg 0,1: first tap, 2,3: second tap) so that every B operand
+//     is a plain 16-lane-contiguous read, and so that ONE operand serves up to three output rows:
+//       pairs 0-8  : (kz=0,ky,kx) + (kz=1,ky,kx)      operand P[h][kx] = halo row h of planes p / p+1, used by rows
+//                                                      h, h-1, h-2 with the weights of ky = 0, 1, 2
+//       pairs 9-11 : (kz=2,ky,0) + (kz=2,ky,1)        operand Q[h]     = halo row h of plane p+2 at x, x+1
+//       pair 12    : (kz=2,0,2) + (kz=2,1,2)          operand R[h]     = plane p+2, rows h / h+1 at x+2
+//       pair 13    : (kz=2,2,2) + zero weights        operand R[h+2]
+//     = 30 operand reads (hi + lo: 60 ds_read_b128) for the 168 MFMAs of a wave and tile (the previous version of
+//     this kernel: 112 reads), weights (14 pairs x hi / lo) resident in 112 VGPRs.
 #include "lf_common.h"
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+
+#ifndef SPLIT_PF
+#define SPLIT_PF 2                                       // operand reads issued this many operands ahead of their MFMAs
+#endif
+#ifndef SPLIT_ABL
+#define SPLIT_ABL 0                                      // ablations for tools/split_ab.py: 1 no MFMAs, 2 no operand reads, 4 no halo fetch, 8 no stores, 16 no commit
+#endif
+#ifndef SPLIT_E0
+#define SPLIT_E0 1                                       // operand step at which the previous tile's epilogue starts (8 steps)
+#endif
+#ifndef SPLIT_C0
+#define SPLIT_C0 100                                     // operand step at which the conversion of the incoming planes starts (6 steps)
+#endif
+#ifndef SPLIT_CVT
+#define SPLIT_CVT 0                                      // 1: plain converts instead of the mixed-precision FMAs (A/B)
+#endif
+#ifndef SPLIT_WGS
+#define SPLIT_WGS 2
+#endif
+#ifndef SPLIT_PRIO
+#define SPLIT_PRIO 1                                     // raise the wave priority outside the MFMA phase
+#endif
 
 namespace {
 
-constexpr int TXs = 16, TYs = 8, TZs = 4, HXs = 18, HYs = 10, HZs = 6;
-constexpr int HALOs = HZs * HYs * HXs;                   // 1080 voxels
-constexpr int NSLOTs = (HALOs * 4 + 63) / 64;            // 68 DMA pieces (1 KiB each) per tile
-constexpr int NITs = (NSLOTs + 7) / 8;
-constexpr int RAW_FLOATS = NSLOTs * 256;                 // fp32 DMA target: 69,632 B
-constexpr int HALF_ELEMS = HALOs * 16;                   // one f16 plane: 34,560 B
-constexpr int NPAIR = 14;                                // 27 taps -> 13 pairs + 1 padded
+constexpr int TXs = 16, TYs = 8, TZs = 2, HXs = 18, HYs = 10, HZs = TZs + 2;
+constexpr int RYs = 4;                                   // output rows per wave
+constexpr int RINGs = 6;                                 // z-plane slots: 4 being read + 2 being filled
+constexpr int PLANE_VOX = HYs * HXs;                     // 180 voxels
+constexpr int PLANE_B = PLANE_VOX * 32;                  // 5,760 B per plane and kind (hi or lo)
+constexpr int LO_OFF = RINGs * PLANE_B;                  // 34,560: the lo planes follow the six hi plane slots
+constexpr int GUARD_B = 576;                             // operand R reads up to 18 voxels past its plane
+constexpr int LDSs = 2 * LO_OFF + GUARD_B;               // 69,696 B
+constexpr int NPAIR = 14;
+constexpr int NPIECE = 6;                                // 1 KiB buffer loads per wave and half plane: 5 rows + 1 (x = 16, 17)
+constexpr int NOP = 5 * (RYs + 2);                       // B operands per wave and tile: P[3][6], Q[6], R[6]
 
-// Tap pairing.  One K=32 MFMA consumes two taps (lanes kg 0,1: first tap; kg 2,3: second tap).  Pairs
-// are chosen so that the second tap sits at one of only three constant voxel offsets from the first
-// (+1 in x, +1 in y, +1 in z): the per-lane LDS address is then  base[class][row] + immediate, i.e. a
-// dozen base registers instead of one address register per (pair, row).
-//   pairs 0-8 : (kz,ky,kx=0) + (kz,ky,kx=1)      class 0, delta = 1
-//   pairs 9-11: (kz,ky=0,kx=2) + (kz,ky=1,kx=2)  class 1, delta = HX
-//   pair 12   : (kz=0,2,2) + (kz=1,2,2)          class 2, delta = HY*HX
-//   pair 13   : (kz=2,2,2) + zero weights        class 0
+// tap index = kz*9 + ky*3 + kx
 __host__ __device__ constexpr int pair_first(int p) {
-  return p < 9 ? (p / 3) * 9 + (p % 3) * 3 + 0 : (p < 12 ? (p - 9) * 9 + 0 * 3 + 2 : (p == 12 ? 0 * 9 + 2 * 3 + 2 : 26));
+  return p < 9 ? (p % 3) * 3 + (p / 3) : (p < 12 ? 18 + (p - 9) * 3 : (p == 12 ? 20 : 26));
 }
 __host__ __device__ constexpr int pair_second(int p) {
-  return p < 9 ? pair_first(p) + 1 : (p < 12 ? pair_first(p) + 3 : (p == 12 ? pair_first(p) + 9 : -1));
-}
-__host__ __device__ constexpr int pair_class(int p) { return p < 9 ? 0 : (p < 12 ? 1 : (p == 12 ? 2 : 0)); }
-__host__ __device__ constexpr int tap_off(int tap) {     // voxel offset of a tap inside the halo tile
-  return ((tap / 9) * HYs + (tap / 3) % 3) * HXs + tap % 3;
+  return p < 9 ? pair_first(p) + 9 : (p < 12 ? pair_first(p) + 1 : (p == 12 ? 23 : -1));
 }
 
-__global__ void __launch_bounds__(512, 2) conv3d_c16_f16x3_kernel(
+template <int I> struct IC { static constexpr int v = I; };
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) { f(IC<B>{}); static_for<B + 1, E>(f); }
+}
+// operand i: 0..17 = P[kx = i / 6][h = i % 6], 18..23 = Q[h], 24..29 = R[h]
+__host__ __device__ constexpr int op_cls(int i) { return i < 18 ? 0 : (i < 24 ? 1 : 2); }
+__host__ __device__ constexpr int op_h(int i) { return i % 6; }
+__host__ __device__ constexpr int op_kx(int i) { return i < 18 ? i / 6 : 0; }
+
+__device__ __forceinline__ void lds_barrier_s() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// sum over the four lanes n, n+16, n+32, n+48 (the four channel quarters of a voxel), same value in all four:
+// v_permlane32_swap / v_permlane16_swap exchange half-waves / neighbouring rows of 16 in the VALU (a __shfl_xor is a
+// ds_bpermute: an LDS round trip queued behind the operand reads of every wave on the CU)
+__device__ __forceinline__ float quarter_sum(float v) {
+#ifdef SPLIT_SHFL
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+#endif
+  const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+// v_rsq_f32 / v_rcp_f32 (1 ulp) + one Newton step
+__device__ __forceinline__ float fast_rsqrt_s(float x) {
+  const float r = __builtin_amdgcn_rsqf(x);
+  return r * (1.5f - 0.5f * x * r * r);
+}
+__device__ __forceinline__ float fast_rcp_s(float x) {
+  const float r = __builtin_amdgcn_rcpf(x);
+  return r * (2.f - x * r);
+}
+// x -> f16 hi = f16(x s), lo = f16(x s - hi) for the four floats of a staged piece.  Written as fp32 FMAs on purpose: with
+// SLP vectorisation off (build.py compiles this file with -fno-slp-vectorize) they become the mixed-precision FMAs
+// v_fma_mix{lo,hi}_f16, which read an f16 half as a source and write the f16 result into one half of the destination
+// (10 VALU instructions per piece; the convert / convert back / subtract / convert form costs 12 and packed-f32 ops).
+// NOT inline asm: the hazard recogniser does not look inside asm statements, and a VALU write from one into a register
+// that an in-flight MFMA still reads as its accumulator input (the allocator recycles those freely inside the MFMA
+// phase) corrupted the last rows of that MFMA's result now and then.
+typedef _Float16 f16x4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split_piece(const f32x4 v, float s, f16x4s& hi, f16x4s& lo) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+#if SPLIT_CVT
+    const float u = v[c] * s;
+    hi[c] = (_Float16)u;
+    lo[c] = (_Float16)(u - (float)hi[c]);
+#else
+    hi[c] = (_Float16)__builtin_fmaf(v[c], s, 0.f);
+    lo[c] = (_Float16)__builtin_fmaf(v[c], s, -(float)hi[c]);
+#endif
+  }
+}
+typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int mod6(int v) { return v >= 6 ? v - 6 : v; }      // v in [0, 12)
+
+template <bool GRAD>
+__global__ void __launch_bounds__(256, 2) conv3d_c16_f16x3_kernel(
     const float* __restrict__ x, const _Float16* __restrict__ wsplit, const float* __restrict__ bias,
     float* __restrict__ y, float* __restrict__ norm_out,
     int N, int D, int H, int W, int tiles_x, int tiles_y, int tiles_z, int ntiles,
@@ -60,17 +154,22 @@ __global__ void __launch_bounds__(512, 2) conv3d_c16_f16x3_kernel(
     const float* __restrict__ prev_y, const float* __restrict__ prev_norm, unsigned prev_flags,
     const float* __restrict__ amax_in, float* __restrict__ amax_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* raw = (float*)smem;                                         // fp32 halo (DMA target)
-  _Float16* bhi = (_Float16*)(smem + RAW_FLOATS * 4);                // f16 hi plane [vox][16]
-  _Float16* blo = bhi + HALF_ELEMS;                                  // f16 lo plane
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int li = lane & 15, kg = lane >> 4;
-  if (tid < 16) ((unsigned*)(blo + HALF_ELEMS))[tid] = 0u;            // guard voxel (0 * garbage would be NaN)
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pz = wv & 1, ry = wv >> 1;                    // this wave's output plane and row quad; also its fetch share
+  const int n = lane & 15, kg = lane >> 4;
+  // zero-weight K slots and the rows an operand reads past its wave's share meet whatever is in LDS: 0 * garbage
+  // could be NaN, so everything starts as zeros (the planes hold finite f16 values from then on)
+  for (int i = tid; i < LDSs / 16; i += 256) ((u32x4s*)smem)[i] = (u32x4s){0u, 0u, 0u, 0u};
+  __syncthreads();
 
-  const int per = (ntiles + gridDim.x - 1) / gridDim.x;
-  const int t_begin = blockIdx.x * per;
+  // workgroups b, b+8, b+16, ... run on the same XCD (one L2 each): give them consecutive tile ranges so that the
+  // halo columns shared by neighbouring ranges are fetched from HBM once
+  const int nb = gridDim.x;
+  const int lb = (nb % 8 == 0) ? (blockIdx.x % 8) * (nb / 8) + blockIdx.x / 8 : blockIdx.x;
+  const int per = (ntiles + nb - 1) / nb;
+  const int t_begin = lb * per;
   const int t_end = min(t_begin + per, ntiles);
   if (t_begin >= t_end) return;
 
@@ -88,222 +187,263 @@ __global__ void __launch_bounds__(512, 2) conv3d_c16_f16x3_kernel(
     }
   }
   const float out_scale = he / in_scale;
+  float scale_s = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, in_scale)));
+  asm volatile("" : "+s"(scale_s));                               // (opaque: an FMA by a visible 1.0 would be folded into converts)
 
-  // ---- DMA piece constants (identical to the fp32 kernel) ----
-  int rel[NITs], lxyz[NITs];
-#pragma unroll
-  for (int it = 0; it < NITs; ++it) {
-    const int e = (wave + 8 * it) * 64 + lane;
-    int v = e >> 2;
-    const int q = e & 3;
-    const int lx = v % HXs; v /= HXs;
-    const int ly = v % HYs;
-    const int lz = v / HYs;
-    rel[it] = ((lz * H + ly) * W + lx) * 64 + q * 16;
-    lxyz[it] = (e < HALOs * 4) ? (lx | (ly << 8) | (lz << 16)) : 0x7f7f7f;
-  }
-
-  // ---- weights (hi, lo) -> registers: [pair][term][cout 16][k 32] halfs ----
-  // weights: hi and lo halves of all 14 pairs in registers (112 VGPRs)
+  // ---- weights (hi, lo) -> registers: [pair][term][cout 16][k 32] halfs; A operand: lane (cout n, k = kg*8..+7) ----
   f16x8 whi[NPAIR], wlo[NPAIR];
   {
-    const _Float16* wl = wsplit + li * 32 + kg * 8;
+    const _Float16* wl = wsplit + n * 32 + kg * 8;
 #pragma unroll
     for (int p = 0; p < NPAIR; ++p) {
       whi[p] = *(const f16x8*)(wl + (p * 2 + 0) * 512);
       wlo[p] = *(const f16x8*)(wl + (p * 2 + 1) * 512);
     }
   }
-  f32x4 bv4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-  if (bias != nullptr) bv4 = *(const f32x4*)(bias + kg * 4);
 
-  // B-operand addressing: lanes kg 0,1 read the first tap of a pair (channels 0-7 / 8-15), lanes kg 2,3
-  // the second tap.  rowvox[j] = halo voxel of (row j, x = li) at tap offset 0.
-  // per-lane B base pointers (hi plane; the lo plane is a constant HALF_ELEMS further)
-  const _Float16* bbase[3][4];
+  // ---- halo pieces: wave w stages rows 5 ry .. +4 of incoming plane pz.  Piece it < 5 = row 5 ry + it, x = lane >> 2
+  // (0..15), quarter lane & 3: 1 KiB contiguous in HBM, 512 B contiguous in each LDS plane kind; piece 5 = x 16, 17
+  // of the five rows (lanes 0..39: row 5 ry + (lane >> 3)) ----
+  const int frow0 = 5 * ry;
+  const int px0 = lane >> 2;
+  const int erow = frow0 + (lane >> 3), ecol = 16 + ((lane >> 2) & 1);
+  const int eldso = (erow * HXs + ecol) * 32 + (lane & 3) * 8;
+  const bool e_ok = lane < 40;
+
+  u32x4s stg[NPIECE];
+  // request this wave's share of plane z (may be outside [0, D): the descriptor's range check returns zeros) of the
+  // halo of tile column (bx, by) of sample bn
+  auto fetch_plane = [&](int bx, int by, int z, int bn, bool on) {
+    // (`on` = false: a zero-sized descriptor -- the loads return zeros without touching memory.  Unconditional on
+    // purpose: loads issued under one branch and consumed under another make the compiler drain vmcnt at every join.)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long)(on ? bn : 0) * nvox * 16), 0,
+                                                                        on ? sample_bytes : 0u, 0x00020000);
+    const int ox = bx * TXs - 1, oy = by * TYs - 1;
+    const int base = ((z * H + oy + frow0) * W + ox) * 64;               // wave-uniform (may be negative: out of range)
+    // x / y positions outside the volume (first and last tile of a row of tiles) get an out-of-range offset.  Branch-free on
+    // purpose: rows are wave-uniform (scalar select), columns are a per-lane mask folded in with one v_and_or_b32.
+    const int mx = (unsigned)(ox + px0) < (unsigned)W ? -1 : 0;
+    const int bad = ~mx & (int)0x80000000;
+    int l16 = lane * 16;
+    asm volatile("" : "+v"(l16));                                        // keep base + ... out of loop-invariant hoisting
+#pragma unroll
+    for (int it = 0; it < 5; ++it) {
+      const int rb = (unsigned)(oy + frow0 + it) < (unsigned)H ? base + it * W * 64 : (int)0x80000000;   // + l16 stays >= 2^31
+      stg[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((rb + l16) & mx) | bad, 0, 0);
+    }
+    const int me = (e_ok && (unsigned)(ox + ecol) < (unsigned)W && (unsigned)(oy + erow) < (unsigned)H) ? -1 : 0;
+    stg[5] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((base + ((lane >> 3) * W + ecol) * 64 + (lane & 3) * 16) & me) | (~me & (int)0x80000000), 0, 0);
+  };
+  // fp32 -> f16 hi / lo of staged piece `it`, into the plane slot at dst
+  auto commit_piece = [&](unsigned char* dst, auto itc) {
+    constexpr int it = decltype(itc)::v;
+    f16x4s h, l;
+    split_piece(__builtin_bit_cast(f32x4, stg[it]), scale_s, h, l);
+    if constexpr (it < 5) {
+      *(f16x4s*)(dst + (frow0 + it) * (HXs * 32) + lane * 8) = h;
+      *(f16x4s*)(dst + (frow0 + it) * (HXs * 32) + lane * 8 + LO_OFF) = l;
+    } else if (e_ok) {
+      *(f16x4s*)(dst + eldso) = h;
+      *(f16x4s*)(dst + eldso + LO_OFF) = l;
+    }
+  };
+  auto commit_plane = [&](int slot) {
+    unsigned char* const dst = smem + slot * PLANE_B;
+    static_for<0, NPIECE>([&](auto itc) { commit_piece(dst, itc); });
+  };
+
+  // tile coordinates are stepped, not divided: (cx, cy, cz, cn) = tile t, (nx, ny, nz, nn) = tile t + 1
+  int cx, cy, cz, cn;
   {
-    const int second = kg >> 1, chan8 = (kg & 1) * 8;
-    const int delta[3] = {1, HXs, HYs * HXs};
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int r = wave * 4 + j;
-        const int vox = ((r >> 3) * HYs + (r & 7)) * HXs + li + second * delta[c];
-        bbase[c][j] = bhi + vox * 16 + chan8;
-      }
+    int tt = t_begin;                                            // z fastest: a workgroup walks up columns of tiles
+    cz = tt % tiles_z; tt /= tiles_z;
+    cx = tt % tiles_x; tt /= tiles_x;
+    cy = tt % tiles_y; cn = tt / tiles_y;
   }
+  // ring state: halo plane hp (0..3) of the current tile sits in slot (rot + hp) % 6
+  int rot = 0;
+  fetch_plane(cx, cy, cz * TZs - 1 + pz, cn, true);
+  commit_plane(pz);
+  fetch_plane(cx, cy, cz * TZs + 1 + pz, cn, true);
+  commit_plane(2 + pz);
+  lds_barrier_s();
 
-  auto issue_dma = [&](int t) {
-    int tt = t;
-    const int bx = tt % tiles_x; tt /= tiles_x;
-    const int by = tt % tiles_y; tt /= tiles_y;
-    const int bz = tt % tiles_z; tt /= tiles_z;
-    const int ox = bx * TXs - 1, oy = by * TYs - 1, oz = bz * TZs - 1;
-    const int tile_off = ((oz * H + oy) * W + ox) * 64;
-    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long)tt * nvox * 16), 0, sample_bytes,
-                                                                  0x00020000);
-#pragma unroll
-    for (int it = 0; it < NITs; ++it) {
-      const int s = wave + 8 * it;
-      if (s < NSLOTs) {
-        const int gx = ox + (lxyz[it] & 0xff), gy = oy + ((lxyz[it] >> 8) & 0xff), gz = oz + (lxyz[it] >> 16);
-        const bool ok = (unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H && (unsigned)gz < (unsigned)D;
-        const int voff = ok ? (rel[it] + tile_off) : 0x7fffffff;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(raw + s * 256), 16, voff, 0, 0, 0);
-      }
-    }
-  };
-
-  // fp32 halo -> f16 hi / lo planes (each thread converts 9 float4 pieces)
-  auto convert = [&]() {
-#pragma unroll 1
-    for (int it = 0; it < NITs; ++it) {
-      const int e = tid + it * 512;                                   // float4 index, linear in the halo buffer
-      if (e < HALOs * 4) {
-        const f32x4 v = *(const f32x4*)(raw + e * 4) * in_scale;
-        f16x4 h, l;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          h[c] = (_Float16)v[c];
-          l[c] = (_Float16)(v[c] - (float)h[c]);
-        }
-        *(f16x4*)(bhi + e * 4) = h;
-        *(f16x4*)(blo + e * 4) = l;
-      }
-    }
-  };
-
-  f32x4 acc[4];
-  auto compute = [&]() {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // (no explicit B double-buffer here: 112 VGPRs of weights leave no room; the partner wave on the
-    //  SIMD covers the LDS latency)
-#pragma unroll
-    for (int p = 0; p < NPAIR; ++p) {
-      constexpr int dummy = 0; (void)dummy;
-      const int off = tap_off(pair_first(p)) * 16;                      // compile-time after unrolling
-      const int cls = pair_class(p);
-      f16x8 bh[4], bl[4];
-      const f16x8 wl_p = wlo[p];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        bh[j] = *(const f16x8*)(bbase[cls][j] + off);
-        bl[j] = *(const f16x8*)(bbase[cls][j] + off + HALF_ELEMS);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[p], bl[j], acc[j], 0, 0, 0);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl_p, bh[j], acc[j], 0, 0, 0);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[p], bh[j], acc[j], 0, 0, 0);
-    }
-  };
-
-  f32x4 pyv[4];
-  float pnv[4];
-  auto prefetch_prev = [&](int t) {
-    if (prev_y == nullptr) return;
-    int tt = t;
-    const int bx = tt % tiles_x; tt /= tiles_x;
-    const int by = tt % tiles_y; tt /= tiles_y;
-    const int bz = tt % tiles_z; tt /= tiles_z;
-    const float* pybase = prev_y + (long)tt * nvox * 16;
-    const float* pnbase = prev_norm ? prev_norm + (long)tt * nvox : nullptr;
-    const int gx = bx * TXs + li;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = wave * 4 + j;
-      const int gz = bz * TZs + (r >> 3), gy = by * TYs + (r & 7);
-      const bool ok = gx < W && gy < H && gz < D;
-      const int vox = ok ? (gz * H + gy) * W + gx : 0;
-      pyv[j] = ok ? *(const f32x4*)(pybase + vox * 16 + kg * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
-      pnv[j] = (ok && pnbase) ? pnbase[vox] : 1.f;
-    }
-  };
-
+  f32x4 bv4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (!GRAD && bias != nullptr) bv4 = *(const f32x4*)(bias + kg * 4);
+  const int lane_b = (4 * ry * HXs + n) * 32 + (kg & 1) * 16;     // B operand: halo row 4 ry (+ h), voxel n, channel half kg & 1
   float wave_amax = 0.f;
-  auto epilogue = [&](int t) {
-    int tt = t;
-    const int bx = tt % tiles_x; tt /= tiles_x;
-    const int by = tt % tiles_y; tt /= tiles_y;
-    const int bz = tt % tiles_z; tt /= tiles_z;
-    float* ybase = y + (long)tt * nvox * 16;
-    float* nbase = norm_out ? norm_out + (long)tt * nvox : nullptr;
-    const int gx = bx * TXs + li;
+
+  // ---- epilogue of one tile, in 2 parts per output row so that it can be spread over the NEXT tile's MFMA phase (a
+  // wave alone issues dependent VALU work at ~10 cycles per instruction; between MFMAs it is free).  Lane holds couts
+  // kg*4..+3 of voxel (gz, gy0 + r, gx). ----
+  struct Epi { int vox[RYs]; bool ok[RYs]; float* ybase; float* nbase; };
+  f32x4 ev[RYs];                                                  // part 0 -> part 1
+  float et[RYs];
+  f32x4 pyv[RYs];
+  float pnv[RYs];
+  auto epi_coords = [&](Epi& E, int bx, int by, int bz, int bn, bool valid) {
+    const int gz = bz * TZs + pz, gx = bx * TXs + n, gy0 = by * TYs + RYs * ry;
+    const bool colok = valid && gx < W && gz < D;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = wave * 4 + j;
-      const int gz = bz * TZs + (r >> 3), gy = by * TYs + (r & 7);
-      const bool ok = gx < W && gy < H && gz < D;
-      const int vox = ok ? (gz * H + gy) * W + gx : 0;
-      if (prev_y != nullptr) {
-        const f32x4 yp = pyv[j];
-        f32x4 g = acc[j] * out_scale;
+    for (int r = 0; r < RYs; ++r) {
+      E.ok[r] = colok && gy0 + r < H;
+      E.vox[r] = E.ok[r] ? (gz * H + gy0 + r) * W + gx : 0;
+    }
+    E.ybase = y + (long)bn * nvox * 16;
+    E.nbase = norm_out ? norm_out + (long)bn * nvox : nullptr;
+    if constexpr (GRAD) {
+      const float* pybase = prev_y + (long)bn * nvox * 16;
+      const float* pnbase = prev_norm ? prev_norm + (long)bn * nvox : nullptr;
+#pragma unroll
+      for (int r = 0; r < RYs; ++r) {
+        pyv[r] = E.ok[r] ? *(const f32x4*)(pybase + (long)E.vox[r] * 16 + kg * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        pnv[r] = (E.ok[r] && pnbase) ? pnbase[E.vox[r]] : 1.f;
+      }
+    }
+  };
+  auto epi_part = [&](const Epi& E, const f32x4 (&a)[RYs], auto rc, auto pc) {
+    constexpr int r = decltype(rc)::v, part = decltype(pc)::v;
+    if constexpr (part == 0) {
+      if constexpr (GRAD) {
+        ev[r] = a[r] * out_scale;
+        et[r] = quarter_sum(ev[r][0] * pyv[r][0] + ev[r][1] * pyv[r][1] + ev[r][2] * pyv[r][2] + ev[r][3] * pyv[r][3]) * (1.f / 16.f);
+      } else {
+        float ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float u = a[r][e] * out_scale + bv4[e];
+          if (flags & LF_EPI_LRELU) u = fmaxf(u, u * slope);
+          ev[r][e] = u;
+          ss += u * u;
+        }
+        et[r] = quarter_sum(ss) * (1.f / 16.f) + eps;
+      }
+    } else {
+      f32x4 v = ev[r];
+      float rn = 1.f;
+      if constexpr (GRAD) {
+        const f32x4 yp = pyv[r];
         if (prev_flags & LF_EPI_PIXELNORM) {
-          float dot = g[0] * yp[0] + g[1] * yp[1] + g[2] * yp[2] + g[3] * yp[3];
-          dot += __shfl_xor(dot, 16, 64);
-          dot += __shfl_xor(dot, 32, 64);
-          dot *= (1.f / 16.f);
-          const float rinv = 1.0f / pnv[j];
+          const float rinv = fast_rcp_s(pnv[r]);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) g[e] = (g[e] - yp[e] * dot) * rinv;
+          for (int e = 0; e < 4; ++e) v[e] = (v[e] - yp[e] * et[r]) * rinv;
         }
         if (prev_flags & LF_EPI_LRELU) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) g[e] = yp[e] > 0.f ? g[e] : g[e] * slope;
+          for (int e = 0; e < 4; ++e) v[e] = yp[e] > 0.f ? v[e] : v[e] * slope;
         }
-        if (ok) {
-          *(f32x4*)(ybase + vox * 16 + kg * 4) = g;
-          wave_amax = fmaxf(wave_amax, fmaxf(fmaxf(fabsf(g[0]), fabsf(g[1])), fmaxf(fabsf(g[2]), fabsf(g[3]))));
-        }
-        continue;
+      } else if (flags & LF_EPI_PIXELNORM) {
+        const float rinv = fast_rsqrt_s(et[r]);
+        rn = et[r] * rinv;
+        v *= rinv;
       }
-      f32x4 v;
-      float ss = 0.f;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float u = acc[j][e] * out_scale + bv4[e];
-        if (flags & LF_EPI_LRELU) u = fmaxf(u, u * slope);
-        v[e] = u;
-        ss += u * u;
-      }
-      float r_ = 1.f;
-      if (flags & LF_EPI_PIXELNORM) {
-        ss += __shfl_xor(ss, 16, 64);
-        ss += __shfl_xor(ss, 32, 64);
-        r_ = sqrtf(ss / 16.f + eps);
-        const float rinv = 1.0f / r_;
-        v[0] *= rinv; v[1] *= rinv; v[2] *= rinv; v[3] *= rinv;
-      }
-      if (ok) {
-        *(f32x4*)(ybase + vox * 16 + kg * 4) = v;
-        if ((flags & LF_EPI_PIXELNORM) && nbase != nullptr && kg == 0) nbase[vox] = r_;
-        wave_amax = fmaxf(wave_amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+      if (E.ok[r] && (!(SPLIT_ABL & 8) || v[0] == 123.456f)) {
+        __builtin_nontemporal_store(v, (f32x4*)(E.ybase + (long)E.vox[r] * 16 + kg * 4));   // streamed: L2 is for halos
+        if (!(SPLIT_ABL & 32) && !GRAD && (flags & LF_EPI_PIXELNORM) && E.nbase != nullptr && kg == 0) E.nbase[E.vox[r]] = rn;
+        if (amax_out != nullptr)
+          wave_amax = fmaxf(wave_amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
       }
     }
   };
 
-  // ---- pipeline: raw <- DMA(t+1) while MFMA(t) reads the f16 planes; convert between barriers ----
-  issue_dma(t_begin);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  convert();
-  __syncthreads();
-  // Every wave stores tile t-1's results at the START of iteration t: the global stores then drain
-  // behind tile t's MFMAs instead of stalling the vmcnt(0) that guards the barrier.
+#if SPLIT_ABL & 32
+#define TS(k) do { if (blockIdx.x == 11 && lane == 0) ((unsigned*)norm_out)[((t - t_begin) * 4 + wv) * 8 + (k)] = (unsigned)__builtin_readcyclecounter(); } while (0)
+#else
+#define TS(k) do {} while (0)
+#endif
+  f32x4 accP[RYs];                                                // the previous tile's sums, finished under this tile's MFMAs
+#pragma unroll
+  for (int r = 0; r < RYs; ++r) accP[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int px_ = 0, py_ = 0, pz_ = 0, pn_ = 0;
   for (int t = t_begin; t < t_end; ++t) {
-    if (t + 1 < t_end) issue_dma(t + 1);
-    if (t > t_begin) epilogue(t - 1);
-    prefetch_prev(t);
-    compute();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                  // everyone is done reading the f16 planes; DMA landed
-    if (t + 1 < t_end) convert();
-    __syncthreads();
+    TS(0);
+    int nx = cx, ny = cy, nz = cz + 1, nn = cn;
+    if (nz == tiles_z) { nz = 0; ++nx; }
+    if (nx == tiles_x) { nx = 0; ++ny; }
+    if (ny == tiles_y) { ny = 0; ++nn; }
+    const bool on = t + 1 < t_end;
+    const bool slide = on && nz != 0;
+    Epi E;
+    epi_coords(E, px_, py_, pz_, pn_, t > t_begin);    // (gradient form: the previous layer's activations, requested first)
+    // the two planes the next tile adds (slide: its halo planes 2, 3; new column: its planes 0, 1): in flight under
+    // the MFMA phase, bound for the two ring slots this tile does not read
+    if (!(SPLIT_ABL & 4)) fetch_plane(nx, ny, nz * TZs - 1 + (slide ? 2 : 0) + pz, nn, on);
+    __builtin_amdgcn_sched_barrier(0);                 // (the scheduler would sink the loads to their use, behind the MFMAs)
+    TS(1);
+
+    // ---- operand base addresses of this wave: planes pz, pz+1 (pairs along z) and pz+2 ----
+    const int s0 = mod6(rot + pz), s1 = mod6(s0 + 1), s2 = mod6(s1 + 1);
+    const int aP = ((kg >> 1) ? s1 : s0) * PLANE_B + lane_b;
+    const int aQ = s2 * PLANE_B + lane_b + (kg >> 1) * 32;
+    const int aR = s2 * PLANE_B + lane_b + 2 * 32 + (kg >> 1) * (HXs * 32);
+    unsigned char* const cdst = smem + mod6(rot + 4 + pz) * PLANE_B;
+
+    f32x4 acc[RYs];
+#pragma unroll
+    for (int r = 0; r < RYs; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {
+      f16x8 bh[SPLIT_PF + 1], bl[SPLIT_PF + 1];
+      static_for<0, NOP + SPLIT_PF>([&](auto ic) {
+        constexpr int i = decltype(ic)::v;
+        if constexpr (i < NOP && !(SPLIT_ABL & 2)) {
+          constexpr int cls = op_cls(i), h = op_h(i), kx = op_kx(i);
+          const int addr = cls == 0 ? aP : (cls == 1 ? aQ : aR);
+          constexpr int imm = (h * HXs + kx) * 32;
+          bh[i % (SPLIT_PF + 1)] = *(const f16x8*)(smem + addr + imm);
+          bl[i % (SPLIT_PF + 1)] = *(const f16x8*)(smem + addr + imm + LO_OFF);
+        }
+        if constexpr (i >= SPLIT_PF && !(SPLIT_ABL & 1)) {
+          constexpr int j = i - SPLIT_PF;
+          constexpr int cls = op_cls(j), h = op_h(j), kx = op_kx(j);
+          const f16x8 vh = bh[j % (SPLIT_PF + 1)], vl = bl[j % (SPLIT_PF + 1)];
+          // up to three (row, pair) uses of this operand; the three product terms are issued term-major so that
+          // consecutive MFMAs go to different accumulators
+          static_for<0, 9>([&](auto uc) {
+            constexpr int term = decltype(uc)::v / 3, u = decltype(uc)::v % 3;
+            constexpr int r = cls < 2 ? h - u : (u == 0 ? h : (u == 1 ? h - 2 : -1));
+            constexpr int p = cls == 0 ? kx * 3 + u : (cls == 1 ? 9 + u : 12 + u);
+            if constexpr (r >= 0 && r < RYs) {
+              if constexpr (term == 0) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[p], vl, acc[r], 0, 0, 0);
+              if constexpr (term == 1) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo[p], vh, acc[r], 0, 0, 0);
+              if constexpr (term == 2) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[p], vh, acc[r], 0, 0, 0);
+            }
+          });
+        }
+        // the non-MFMA work of the tile rides in the issue slots between the MFMAs: the previous tile's epilogue early
+        // (its inputs are ready), the conversion of the incoming planes late (their loads left at the top of the tile)
+        if constexpr (i >= SPLIT_E0 && i < SPLIT_E0 + 2 * RYs) epi_part(E, accP, IC<(i - SPLIT_E0) / 2>{}, IC<(i - SPLIT_E0) % 2>{});
+        if constexpr (i >= SPLIT_C0 && i < SPLIT_C0 + NPIECE && !(SPLIT_ABL & 16)) commit_piece(cdst, IC<i - SPLIT_C0>{});
+        // keep the software pipeline as written: left alone, the scheduler moves every read next to its first use
+        // and the wave then waits out the full LDS latency once per operand
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    }
+    TS(2);
+    if constexpr (SPLIT_E0 >= NOP + SPLIT_PF)          // (A/B: epilogue / conversion behind the MFMA phase instead of inside it)
+      static_for<0, 2 * RYs>([&](auto ic) { epi_part(E, accP, IC<decltype(ic)::v / 2>{}, IC<decltype(ic)::v % 2>{}); });
+    if constexpr (SPLIT_C0 >= NOP + SPLIT_PF && !(SPLIT_ABL & 16)) static_for<0, NPIECE>([&](auto itc) { commit_piece(cdst, itc); });
+    lds_barrier_s();                                   // this tile's planes 0, 1 are free; the new planes are visible
+    TS(6);
+    if (on && !slide) {
+      // bottom of a new column: what was fetched are its planes 0, 1 (now in slots rot+4, rot+5); planes 2, 3 go to
+      // the slots this tile has just released (exposed once per column)
+      rot = mod6(rot + 4);
+      fetch_plane(nx, ny, nz * TZs + 1 + pz, nn, true);
+      commit_plane(mod6(rot + 2 + pz));
+      lds_barrier_s();
+    } else {
+      rot = mod6(rot + 2);
+    }
+#pragma unroll
+    for (int r = 0; r < RYs; ++r) accP[r] = acc[r];
+    px_ = cx; py_ = cy; pz_ = cz; pn_ = cn;
+    cx = nx; cy = ny; cz = nz; cn = nn;
   }
-  epilogue(t_end - 1);
+  {                                                    // the last tile's epilogue
+    Epi E;
+    epi_coords(E, px_, py_, pz_, pn_, true);
+    static_for<0, 2 * RYs>([&](auto ic) { epi_part(E, accP, IC<decltype(ic)::v / 2>{}, IC<decltype(ic)::v % 2>{}); });
+  }
   if (amax_out != nullptr) {
     float m = wave_amax;
 #pragma unroll
@@ -340,18 +480,22 @@ extern "C" int lf_conv3d_c16_split(const float* x, const void* wsplit, const flo
     cus = (hipGetDevice(&dev) == hipSuccess &&
            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
   }
-  // + one zeroed guard voxel: the zero-weight second tap of pair 13 reads one voxel past each plane
-  const size_t shmem = (size_t)RAW_FLOATS * 4 + (size_t)HALF_ELEMS * 2 * 2 + 64;   // 69,632 + 69,120 + 64 B
+  const size_t shmem = (size_t)LDSs;
+  typedef void (*kern_t)(const float*, const _Float16*, const float*, float*, float*, int, int, int, int, int, int, int, int, float,
+                         unsigned, float, float, const float*, const float*, unsigned, const float*, float*);
+  static const kern_t kerns[2] = {conv3d_c16_f16x3_kernel<false>, conv3d_c16_f16x3_kernel<true>};
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv3d_c16_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)shmem);
-    if (e != hipSuccess) return (int)e;
+    for (int i = 0; i < 2; ++i) {
+      hipError_t e = hipFuncSetAttribute((const void*)kerns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+      if (e != hipSuccess) return (int)e;
+    }
     attr_set = true;
   }
-  const unsigned grid = (unsigned)(pt < cus ? pt : cus);
-  hipLaunchKernelGGL(conv3d_c16_f16x3_kernel, dim3(grid), dim3(512), shmem, (hipStream_t)stream, x, (const _Float16*)wsplit,
-                     bias, y, norm_out, N, D, H, W, ptx, pty, ptz, (int)pt, he, flags, slope, eps, prev_y, prev_norm,
-                     prev_flags, amax_in, amax_out);
+  const long want = (long)SPLIT_WGS * cus;                        // two resident workgroups per CU
+  const unsigned grid = (unsigned)(pt < want ? pt : want);
+  const kern_t kern = kerns[prev_y != nullptr ? 1 : 0];
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shmem, (hipStream_t)stream, x, (const _Float16*)wsplit, bias, y, norm_out, N, D, H,
+                     W, ptx, pty, ptz, (int)pt, he, flags, slope, eps, prev_y, prev_norm, prev_flags, amax_in, amax_out);
   return lf_launch_status();
 }
