@@ -36,7 +36,18 @@
 //       pair 12    : (kz=2,0,2) + (kz=2,1,2)          operand R[h]     = plane p+2, rows h / h+1 at x+2
 //       pair 13    : (kz=2,2,2) + zero weights        operand R[h+2]
 //     = 30 operand reads (hi + lo: 60 ds_read_b128) for the 168 MFMAs of a wave and tile (the previous version of
-//     this kernel: 112 reads), weights (14 pairs x hi / lo) resident in 112 VGPRs.
+//     this kernel: 112 reads), weights (14 pairs x hi / lo) resident in 112 VGPRs.  The reads run two operands ahead of
+//     their MFMAs, pinned with sched_barriers (the scheduler otherwise sinks every read to its first use).
+//   * a wave alone issues dependent non-MFMA work at ~10 cycles per instruction and its SIMD partner (the other
+//     workgroup) does not speed that up, so the per-tile instruction stream outside the MFMAs is what is left to cut:
+//     the finished tile's epilogue (scale, bias, LeakyReLU, PixelNorm via v_permlane swaps, 1 KiB buffer stores) rides
+//     between the NEXT tile's MFMAs, and all addressing is per COLUMN of tiles (per-lane offsets, out-of-volume lanes
+//     = out-of-range offsets that the buffer hardware drops) with the z plane as the instructions' scalar offset.
+//   Measured (tools/split_ab.py, tools/split_timeline.py, 8 x 128^3): 0.65-0.75 ms per launch (previous version 1.0-1.1),
+//   MFMA phase 2.9k of 7.8k cycles per tile and wave.  tools/ub/coexec.hip: plain fp32 VALU work of the partner wave is
+//   free beside f16 MFMAs, packed-fp32 (v_pk_*) and v_fma_mix work is not.
+//   This file is compiled with -fno-slp-vectorize (build.py): SLP-packed fp32 arithmetic inside the MFMA phase gave rare
+//   run-to-run differences in the gradient form (tests/test_engine_gpu.py::test_split_conv3d_is_run_to_run_identical).
 #include "lf_common.h"
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -47,22 +58,16 @@ typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
 #define SPLIT_PF 2                                       // operand reads issued this many operands ahead of their MFMAs
 #endif
 #ifndef SPLIT_ABL
-#define SPLIT_ABL 0                                      // ablations for tools/split_ab.py: 1 no MFMAs, 2 no operand reads, 4 no halo fetch, 8 no stores, 16 no commit
+#define SPLIT_ABL 0                                      // ablations (tools/split_ab.py): 1 no MFMAs, 2 no operand reads, 4 no halo fetch, 8 no stores, 16 no commit; 32 = cycle stamps (tools/split_timeline.py)
 #endif
 #ifndef SPLIT_E0
 #define SPLIT_E0 1                                       // operand step at which the previous tile's epilogue starts (8 steps)
 #endif
 #ifndef SPLIT_C0
-#define SPLIT_C0 100                                     // operand step at which the conversion of the incoming planes starts (6 steps)
-#endif
-#ifndef SPLIT_CVT
-#define SPLIT_CVT 0                                      // 1: plain converts instead of the mixed-precision FMAs (A/B)
+#define SPLIT_C0 100                                     // operand step at which the conversion of the incoming planes starts (6 steps); >= 32: behind the MFMA phase (faster)
 #endif
 #ifndef SPLIT_WGS
-#define SPLIT_WGS 2
-#endif
-#ifndef SPLIT_PRIO
-#define SPLIT_PRIO 1                                     // raise the wave priority outside the MFMA phase
+#define SPLIT_WGS 2                                      // resident workgroups per CU (1: timeline without a SIMD partner)
 #endif
 
 namespace {
@@ -131,14 +136,8 @@ typedef _Float16 f16x4s __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void split_piece(const f32x4 v, float s, f16x4s& hi, f16x4s& lo) {
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-#if SPLIT_CVT
-    const float u = v[c] * s;
-    hi[c] = (_Float16)u;
-    lo[c] = (_Float16)(u - (float)hi[c]);
-#else
     hi[c] = (_Float16)__builtin_fmaf(v[c], s, 0.f);
     lo[c] = (_Float16)__builtin_fmaf(v[c], s, -(float)hi[c]);
-#endif
   }
 }
 typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
@@ -203,36 +202,39 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_f16x3_kernel(
 
   // ---- halo pieces: wave w stages rows 5 ry .. +4 of incoming plane pz.  Piece it < 5 = row 5 ry + it, x = lane >> 2
   // (0..15), quarter lane & 3: 1 KiB contiguous in HBM, 512 B contiguous in each LDS plane kind; piece 5 = x 16, 17
-  // of the five rows (lanes 0..39: row 5 ry + (lane >> 3)) ----
+  // of the five rows (lanes 0..39: row 5 ry + (lane >> 3)).
+  // Addressing is split into what changes per COLUMN of tiles and what changes per tile: foff[] = per-lane byte offsets
+  // inside one z plane of the sample (0x80000000 where the halo leaves the volume in x or y: the buffer load then
+  // returns zeros), recomputed when the walk enters a new column; the plane itself is the instruction's SCALAR offset,
+  // and a plane outside [0, D) -- wave-uniform, every wave fetches one plane -- gets a zero-sized descriptor. ----
+  constexpr int OOB = (int)0x80000000;
   const int frow0 = 5 * ry;
-  const int px0 = lane >> 2;
   const int erow = frow0 + (lane >> 3), ecol = 16 + ((lane >> 2) & 1);
   const int eldso = (erow * HXs + ecol) * 32 + (lane & 3) * 8;
   const bool e_ok = lane < 40;
+  const int plane_bytes = H * W * 64;
 
-  u32x4s stg[NPIECE];
-  // request this wave's share of plane z (may be outside [0, D): the descriptor's range check returns zeros) of the
-  // halo of tile column (bx, by) of sample bn
-  auto fetch_plane = [&](int bx, int by, int z, int bn, bool on) {
-    // (`on` = false: a zero-sized descriptor -- the loads return zeros without touching memory.  Unconditional on
-    // purpose: loads issued under one branch and consumed under another make the compiler drain vmcnt at every join.)
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long)(on ? bn : 0) * nvox * 16), 0,
-                                                                        on ? sample_bytes : 0u, 0x00020000);
+  int foff[NPIECE];
+  const float* f_x = x;
+  auto fetch_column = [&](int bx, int by, int bn) {
     const int ox = bx * TXs - 1, oy = by * TYs - 1;
-    const int base = ((z * H + oy + frow0) * W + ox) * 64;               // wave-uniform (may be negative: out of range)
-    // x / y positions outside the volume (first and last tile of a row of tiles) get an out-of-range offset.  Branch-free on
-    // purpose: rows are wave-uniform (scalar select), columns are a per-lane mask folded in with one v_and_or_b32.
-    const int mx = (unsigned)(ox + px0) < (unsigned)W ? -1 : 0;
-    const int bad = ~mx & (int)0x80000000;
-    int l16 = lane * 16;
-    asm volatile("" : "+v"(l16));                                        // keep base + ... out of loop-invariant hoisting
+    const int col = ox + (lane >> 2);
 #pragma unroll
     for (int it = 0; it < 5; ++it) {
-      const int rb = (unsigned)(oy + frow0 + it) < (unsigned)H ? base + it * W * 64 : (int)0x80000000;   // + l16 stays >= 2^31
-      stg[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((rb + l16) & mx) | bad, 0, 0);
+      const int row = oy + frow0 + it;
+      foff[it] = ((unsigned)col < (unsigned)W && (unsigned)row < (unsigned)H) ? (row * W + col) * 64 + (lane & 3) * 16 : OOB;
     }
-    const int me = (e_ok && (unsigned)(ox + ecol) < (unsigned)W && (unsigned)(oy + erow) < (unsigned)H) ? -1 : 0;
-    stg[5] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((base + ((lane >> 3) * W + ecol) * 64 + (lane & 3) * 16) & me) | (~me & (int)0x80000000), 0, 0);
+    const int row = oy + erow, c2 = ox + ecol;
+    foff[5] = (e_ok && (unsigned)c2 < (unsigned)W && (unsigned)row < (unsigned)H) ? (row * W + c2) * 64 + (lane & 3) * 16 : OOB;
+    f_x = x + (long)bn * nvox * 16;
+  };
+  u32x4s stg[NPIECE];
+  auto fetch_plane = [&](int z, bool on) {
+    const bool v = on && (unsigned)z < (unsigned)D;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)f_x, 0, v ? sample_bytes : 0u, 0x00020000);
+    const int soff = v ? z * plane_bytes : 0;
+#pragma unroll
+    for (int it = 0; it < NPIECE; ++it) stg[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, foff[it], soff, 0);
   };
   // fp32 -> f16 hi / lo of staged piece `it`, into the plane slot at dst
   auto commit_piece = [&](unsigned char* dst, auto itc) {
@@ -262,9 +264,10 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_f16x3_kernel(
   }
   // ring state: halo plane hp (0..3) of the current tile sits in slot (rot + hp) % 6
   int rot = 0;
-  fetch_plane(cx, cy, cz * TZs - 1 + pz, cn, true);
+  fetch_column(cx, cy, cn);
+  fetch_plane(cz * TZs - 1 + pz, true);
   commit_plane(pz);
-  fetch_plane(cx, cy, cz * TZs + 1 + pz, cn, true);
+  fetch_plane(cz * TZs + 1 + pz, true);
   commit_plane(2 + pz);
   lds_barrier_s();
 
@@ -274,30 +277,45 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_f16x3_kernel(
   float wave_amax = 0.f;
 
   // ---- epilogue of one tile, in 2 parts per output row so that it can be spread over the NEXT tile's MFMA phase (a
-  // wave alone issues dependent VALU work at ~10 cycles per instruction; between MFMAs it is free).  Lane holds couts
-  // kg*4..+3 of voxel (gz, gy0 + r, gx). ----
-  struct Epi { int vox[RYs]; bool ok[RYs]; float* ybase; float* nbase; };
+  // wave alone issues dependent VALU work at ~10 cycles per instruction; between MFMAs it is nearly free).  Lane holds
+  // couts kg*4..+3 of voxel (gz, gy0 + r, gx).  Same addressing split as the halo: eoff[] = per-lane byte offset of
+  // (gy0 + r, gx, couts kg*4..) inside a z plane of the sample, per column (OOB outside the volume: the store is
+  // dropped, loads return 0); plane gz through the scalar offset; gz >= D: zero-sized descriptors. ----
+  int eoff[RYs];
+#pragma unroll
+  for (int r = 0; r < RYs; ++r) eoff[r] = OOB;
+  const int kgmask = kg == 0 ? 0 : OOB;                           // one lane per voxel writes the norm
+  const float *e_y = y, *e_n = norm_out, *e_py = prev_y, *e_pn = prev_norm;
+  auto epi_column = [&](int bx, int by, int bn) {
+    const int gx = bx * TXs + n, gy0 = by * TYs + RYs * ry;
+#pragma unroll
+    for (int r = 0; r < RYs; ++r) eoff[r] = (gx < W && gy0 + r < H) ? ((gy0 + r) * W + gx) * 64 + kg * 16 : OOB;
+    e_y = y + (long)bn * nvox * 16;
+    e_n = norm_out ? norm_out + (long)bn * nvox : nullptr;
+    if constexpr (GRAD) {
+      e_py = prev_y + (long)bn * nvox * 16;
+      e_pn = prev_norm ? prev_norm + (long)bn * nvox : nullptr;
+    }
+  };
+  struct Epi { __amdgpu_buffer_rsrc_t rs_y, rs_n; int soff, soff_n; bool zv; };
   f32x4 ev[RYs];                                                  // part 0 -> part 1
   float et[RYs];
   f32x4 pyv[RYs];
   float pnv[RYs];
-  auto epi_coords = [&](Epi& E, int bx, int by, int bz, int bn, bool valid) {
-    const int gz = bz * TZs + pz, gx = bx * TXs + n, gy0 = by * TYs + RYs * ry;
-    const bool colok = valid && gx < W && gz < D;
-#pragma unroll
-    for (int r = 0; r < RYs; ++r) {
-      E.ok[r] = colok && gy0 + r < H;
-      E.vox[r] = E.ok[r] ? (gz * H + gy0 + r) * W + gx : 0;
-    }
-    E.ybase = y + (long)bn * nvox * 16;
-    E.nbase = norm_out ? norm_out + (long)bn * nvox : nullptr;
+  auto epi_tile = [&](Epi& E, int bz, bool valid) {
+    const int gz = bz * TZs + pz;
+    E.zv = valid && gz < D;
+    E.soff = E.zv ? gz * plane_bytes : 0;
+    E.soff_n = E.zv ? gz * (plane_bytes >> 4) : 0;
+    E.rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)e_y, 0, E.zv ? sample_bytes : 0u, 0x00020000);
+    E.rs_n = __builtin_amdgcn_make_buffer_rsrc((void*)e_n, 0, (E.zv && e_n != nullptr) ? (sample_bytes >> 4) : 0u, 0x00020000);
     if constexpr (GRAD) {
-      const float* pybase = prev_y + (long)bn * nvox * 16;
-      const float* pnbase = prev_norm ? prev_norm + (long)bn * nvox : nullptr;
+      const __amdgpu_buffer_rsrc_t rs_py = __builtin_amdgcn_make_buffer_rsrc((void*)e_py, 0, E.zv ? sample_bytes : 0u, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rs_pn = __builtin_amdgcn_make_buffer_rsrc((void*)e_pn, 0, (E.zv && e_pn != nullptr) ? (sample_bytes >> 4) : 0u, 0x00020000);
 #pragma unroll
       for (int r = 0; r < RYs; ++r) {
-        pyv[r] = E.ok[r] ? *(const f32x4*)(pybase + (long)E.vox[r] * 16 + kg * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        pnv[r] = (E.ok[r] && pnbase) ? pnbase[E.vox[r]] : 1.f;
+        pyv[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_py, eoff[r], E.soff, 0));
+        pnv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_pn, (eoff[r] >> 4) & ~3, E.soff_n, 0));
       }
     }
   };
@@ -337,11 +355,14 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_f16x3_kernel(
         rn = et[r] * rinv;
         v *= rinv;
       }
-      if (E.ok[r] && (!(SPLIT_ABL & 8) || v[0] == 123.456f)) {
-        __builtin_nontemporal_store(v, (f32x4*)(E.ybase + (long)E.vox[r] * 16 + kg * 4));   // streamed: L2 is for halos
-        if (!(SPLIT_ABL & 32) && !GRAD && (flags & LF_EPI_PIXELNORM) && E.nbase != nullptr && kg == 0) E.nbase[E.vox[r]] = rn;
-        if (amax_out != nullptr)
-          wave_amax = fmaxf(wave_amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+      if (!(SPLIT_ABL & 8) || v[0] == 123.456f) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, v), E.rs_y, eoff[r], E.soff, 2);   // nt: L2 is for halos
+        if (!(SPLIT_ABL & 32) && !GRAD && (flags & LF_EPI_PIXELNORM))
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, rn), E.rs_n, (eoff[r] >> 4) | kgmask, E.soff_n, 0);
+      }
+      if (amax_out != nullptr) {
+        const float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        wave_amax = fmaxf(wave_amax, (E.zv && eoff[r] >= 0) ? m : 0.f);      // (lanes outside the volume hold junk)
       }
     }
   };
@@ -354,7 +375,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_f16x3_kernel(
   f32x4 accP[RYs];                                                // the previous tile's sums, finished under this tile's MFMAs
 #pragma unroll
   for (int r = 0; r < RYs; ++r) accP[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  int px_ = 0, py_ = 0, pz_ = 0, pn_ = 0;
+  int px_ = cx, py_ = cy, pz_ = cz, pn_ = cn;
   for (int t = t_begin; t < t_end; ++t) {
     TS(0);
     int nx = cx, ny = cy, nz = cz + 1, nn = cn;
@@ -363,11 +384,14 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_f16x3_kernel(
     if (ny == tiles_y) { ny = 0; ++nn; }
     const bool on = t + 1 < t_end;
     const bool slide = on && nz != 0;
+    // per-column addressing, recomputed when the previous tile (epilogue) / the next tile (halo) starts a column
+    if (t == t_begin + 1 || (t > t_begin && pz_ == 0)) epi_column(px_, py_, pn_);
+    if (on && nz == 0) fetch_column(nx, ny, nn);
     Epi E;
-    epi_coords(E, px_, py_, pz_, pn_, t > t_begin);    // (gradient form: the previous layer's activations, requested first)
+    epi_tile(E, pz_, t > t_begin);                     // (gradient form: the previous layer's activations, requested first)
     // the two planes the next tile adds (slide: its halo planes 2, 3; new column: its planes 0, 1): in flight under
     // the MFMA phase, bound for the two ring slots this tile does not read
-    if (!(SPLIT_ABL & 4)) fetch_plane(nx, ny, nz * TZs - 1 + (slide ? 2 : 0) + pz, nn, on);
+    if (!(SPLIT_ABL & 4)) fetch_plane(nz * TZs - 1 + (slide ? 2 : 0) + pz, on);
     __builtin_amdgcn_sched_barrier(0);                 // (the scheduler would sink the loads to their use, behind the MFMAs)
     TS(1);
 
@@ -409,8 +433,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_f16x3_kernel(
             }
           });
         }
-        // the non-MFMA work of the tile rides in the issue slots between the MFMAs: the previous tile's epilogue early
-        // (its inputs are ready), the conversion of the incoming planes late (their loads left at the top of the tile)
+        // the previous tile's epilogue rides in the issue slots between the MFMAs (its inputs are ready)
         if constexpr (i >= SPLIT_E0 && i < SPLIT_E0 + 2 * RYs) epi_part(E, accP, IC<(i - SPLIT_E0) / 2>{}, IC<(i - SPLIT_E0) % 2>{});
         if constexpr (i >= SPLIT_C0 && i < SPLIT_C0 + NPIECE && !(SPLIT_ABL & 16)) commit_piece(cdst, IC<i - SPLIT_C0>{});
         // keep the software pipeline as written: left alone, the scheduler moves every read next to its first use
@@ -421,14 +444,20 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_f16x3_kernel(
     TS(2);
     if constexpr (SPLIT_E0 >= NOP + SPLIT_PF)          // (A/B: epilogue / conversion behind the MFMA phase instead of inside it)
       static_for<0, 2 * RYs>([&](auto ic) { epi_part(E, accP, IC<decltype(ic)::v / 2>{}, IC<decltype(ic)::v % 2>{}); });
+#if SPLIT_ABL & 32
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TS(3);
+#endif
+    // the next tile's new planes: converted and written to the two free ring slots (last tile: zeros nobody reads)
     if constexpr (SPLIT_C0 >= NOP + SPLIT_PF && !(SPLIT_ABL & 16)) static_for<0, NPIECE>([&](auto itc) { commit_piece(cdst, itc); });
+    TS(4);
     lds_barrier_s();                                   // this tile's planes 0, 1 are free; the new planes are visible
     TS(6);
     if (on && !slide) {
       // bottom of a new column: what was fetched are its planes 0, 1 (now in slots rot+4, rot+5); planes 2, 3 go to
       // the slots this tile has just released (exposed once per column)
       rot = mod6(rot + 4);
-      fetch_plane(nx, ny, nz * TZs + 1 + pz, nn, true);
+      fetch_plane(nz * TZs + 1 + pz, true);
       commit_plane(mod6(rot + 2 + pz));
       lds_barrier_s();
     } else {
@@ -440,8 +469,9 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_f16x3_kernel(
     cx = nx; cy = ny; cz = nz; cn = nn;
   }
   {                                                    // the last tile's epilogue
+    if (t_end - t_begin == 1 || pz_ == 0) epi_column(px_, py_, pn_);
     Epi E;
-    epi_coords(E, px_, py_, pz_, pn_, true);
+    epi_tile(E, pz_, true);
     static_for<0, 2 * RYs>([&](auto ic) { epi_part(E, accP, IC<decltype(ic)::v / 2>{}, IC<decltype(ic)::v % 2>{}); });
   }
   if (amax_out != nullptr) {

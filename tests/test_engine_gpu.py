@@ -263,6 +263,78 @@ def test_split_precision_conv_matches_fp32_and_fp64():
     assert (ggot - gref).abs().max().item() < 1e-5 * gref.abs().max().item()
 
 
+@pytest.mark.parametrize('shape', [(2, 16, 10, 20, 40), (1, 16, 5, 7, 9), (3, 16, 4, 8, 16), (1, 16, 13, 24, 33), (2, 16, 36, 64, 64)])
+def test_split_conv3d_matches_fp64(shape):
+    """lf_conv3d_c16_split (direct, three f16 MFMAs per product, z-sliding halo ring) on volumes with partial tiles on
+    every axis and, for the last shape, several tiles and a column change per workgroup: fused forward, raw data
+    gradient, and the data gradient with the fused previous-layer backward on a tiny-valued gradient through the max-abs
+    side channel.  Must be as close to fp64 as the direct fp32 MFMA kernel (x2 slack)."""
+    from latentfusion_amd import ops
+    from latentfusion_amd._lib import LF_EPI_LRELU, LF_EPI_PIXELNORM
+    g = torch.Generator().manual_seed(sum(shape))
+    flags = LF_EPI_LRELU | LF_EPI_PIXELNORM
+    w = torch.randn(16, 16, 3, 3, 3, generator=g)
+    b = torch.randn(16, generator=g) * 0.1
+    he = ops.he_constant(w)
+    xs = torch.randn(*shape, generator=g)
+    xs = xs / torch.sqrt((xs ** 2).mean(dim=1, keepdim=True))
+    y64 = torch.nn.functional.conv3d(xs.double(), w.double(), None, 1, 1) * he + b.double().view(1, -1, 1, 1, 1)
+    y64 = torch.nn.functional.leaky_relu(y64, 0.2)
+    n64 = torch.sqrt((y64 ** 2).mean(dim=1, keepdim=True) + 1e-8)
+    y64 = y64 / n64
+    xd, wd, bd = ops.cl(xs.to(DEV)), w.to(DEV), b.to(DEV)
+    sp, spt = ops.pack_conv3d_c16_split(wd), ops.pack_conv3d_c16_split(wd, transpose=True)
+    ref, nref = ops._conv3x3_raw(xd, ops.pack_conv3x3(wd), bd, 16, he, flags, True)
+    got, ngot = ops.conv3d_c16_split(xd, sp, bd, he, flags)
+    e_ref = (ref.cpu().double() - y64).abs().max().item()
+    e_got = (got.cpu().double() - y64).abs().max().item()
+    assert e_got < max(2 * e_ref, 5e-6), (e_got, e_ref)
+    assert (ngot.cpu().double().view(n64.shape) - n64).abs().max().item() < 2e-6
+    g64 = torch.nn.functional.conv_transpose3d(xs.double(), w.double(), None, 1, 1) * he
+    gw, _ = ops.conv3d_c16_split(xd, spt, None, he, 0)
+    gd = ops.conv3x3_bwd_data(xd, ops.pack_conv3x3(wd, transpose=True), 16, he, None)
+    assert (gw.cpu().double() - g64).abs().max().item() < max(2 * (gd.cpu().double() - g64).abs().max().item(), 5e-6)
+    prev = (ref, nref, flags)
+    tiny = xd * 3e-7
+    want = ops.conv3x3_bwd_data(tiny, ops.pack_conv3x3(wd, transpose=True), 16, he, prev)
+    am_in, am_out = ops.amax_buffer(tiny.abs().max(), DEV), ops.amax_buffer(None, DEV)
+    gw2, _ = ops.conv3d_c16_split(tiny, spt, None, he, 0, prev=prev, amax_in=am_in, amax_out=am_out)
+    assert (gw2 - want).abs().max().item() < 2e-6 * want.abs().max().item()
+    assert abs(am_out.max().item() - gw2.abs().max().item()) == 0.0
+
+
+def test_split_conv3d_is_run_to_run_identical():
+    """The split kernel spreads the previous tile's epilogue over the MFMA phase of the next one; a register hazard between
+    the two (seen with SLP-packed fp32 arithmetic in that phase: rare wrong elements in the gradient form) shows up as
+    run-to-run differences.  Ten launches of both forms on a volume with many tiles and column changes per workgroup
+    must be bit-identical and agree with the all-fp32 Winograd kernel."""
+    from latentfusion_amd import ops
+    from latentfusion_amd._lib import LF_EPI_LRELU, LF_EPI_PIXELNORM
+    g = torch.Generator().manual_seed(5)
+    flags = LF_EPI_LRELU | LF_EPI_PIXELNORM
+    shape = (4, 16, 76, 96, 96)                                    # 38 x 12 x 6 x 4 = 10,944 tiles: > 20 per workgroup
+    w = torch.randn(16, 16, 3, 3, 3, generator=g).to(DEV)
+    b = (torch.randn(16, generator=g) * 0.1).to(DEV)
+    he = ops.he_constant(w)
+    x = torch.randn(*shape, generator=g)
+    x = ops.cl((x / torch.sqrt((x ** 2).mean(dim=1, keepdim=True))).to(DEV))
+    gin = ops.cl((torch.randn(*shape, generator=g) * 1e-7).to(DEV))
+    sp, spt = ops.pack_conv3d_c16_split(w), ops.pack_conv3d_c16_split(w, transpose=True)
+    yw, nw = ops.conv3d_c16_wino(x, ops.pack_conv3d_c16_wino(w), b, he, flags)
+    gwant, _ = ops.conv3d_c16_wino(gin, ops.pack_conv3d_c16_wino(w, transpose=True), None, he, 0, prev=(yw, nw, flags))
+    am = ops.amax_buffer(gin.abs().max(), DEV)
+    y0 = g0 = None
+    for rep in range(10):
+        y, _ = ops.conv3d_c16_split(x, sp, b, he, flags)
+        gg, _ = ops.conv3d_c16_split(gin, spt, None, he, 0, prev=(yw, nw, flags), amax_in=am)
+        if rep == 0:
+            y0, g0 = y, gg
+            assert (y - yw).abs().max().item() < 3e-5
+            assert (gg - gwant).abs().max().item() < 5e-6 * gwant.abs().max().item()
+        else:
+            assert torch.equal(y, y0) and torch.equal(gg, g0), rep
+
+
 @pytest.mark.parametrize('shape', [(2, 16, 10, 20, 40), (1, 16, 5, 7, 9), (3, 16, 4, 8, 16), (1, 16, 13, 24, 33)])
 def test_winograd_conv3d_matches_fp64(shape):
     """lf_conv3d_c16_wino (F(2x2x2,3x3x3), all-fp32) on volumes with partial tiles on every axis:

@@ -46,11 +46,13 @@ for _ in range(3):
 torch.cuda.synchronize()
 T = int(os.environ.get("TL_T", 128))
 ts = nrm[:T * 4 * 8].cpu().numpy().view(np.uint32).reshape(T, 4, 8).astype(np.int64)
-names = ['fetch issue', 'MFMA phase', 'prio', 'commit (wait + convert + write)', 'epilogue + stores', 'barrier wait', 'to next top']
+# stamps: 0 top of tile, 1 halo loads issued, 2 MFMA phase (+ previous tile's epilogue) done, 3 staged loads landed,
+# 4 converted and written to LDS, 6 past the barrier
+seg = [('fetch issue', 0, 1), ('MFMA phase + previous epilogue', 1, 2), ('vmcnt(0) wait', 2, 3), ('convert + LDS write', 3, 4),
+       ('barrier', 4, 6)]
 sel = [i for i in range(8, T - 8) if i % 64 not in (62, 63, 0)]           # skip the column changes
 for wv in range(4):
-    d = [np.mean((ts[sel, wv, kk + 1] - ts[sel, wv, kk]) & 0xffffffff) for kk in range(6)]
-    d.append(np.mean((ts[[i + 1 for i in sel], wv, 0] - ts[sel, wv, 6]) & 0xffffffff))
+    d = [np.mean((ts[sel, wv, b_] - ts[sel, wv, a_]) & 0xffffffff) for _, a_, b_ in seg]
+    nxt = np.mean((ts[[i + 1 for i in sel], wv, 0] - ts[sel, wv, 6]) & 0xffffffff)
     tot = np.mean((ts[[i + 1 for i in sel], wv, 0] - ts[sel, wv, 0]) & 0xffffffff)
-    print(f'wave {wv}: total {tot:.0f} ticks/tile: ' + ', '.join(f'{n} {v:.0f}' for n, v in zip(names, d)))
-    print(f'        of the commit: vmcnt(0) wait {np.mean((ts[sel, wv, 7] - ts[sel, wv, 3]) & 0xffffffff):.0f}')
+    print(f'wave {wv}: total {tot:.0f} ticks/tile: ' + ', '.join(f'{n} {v:.0f}' for (n, _, _), v in zip(seg, d)) + f', to next top {nxt:.0f}')
