@@ -115,7 +115,7 @@ def _allreduce_worker(rank, size, port, q):
     from latentfusion_amd import parallel
     flat = torch.arange(1000, dtype=torch.float32) * (rank + 1)
     parallel.allreduce_flat_(flat, bucket_bytes=1024)          # 256 floats per bucket -> 4 collectives
-    q.put((rank, flat.clone()))
+    q.put((rank, flat.numpy().copy()))                      # by value: a tensor travels as a shared-memory fd its sender must outlive
     dist.destroy_process_group()
 
 
@@ -128,7 +128,7 @@ def test_flat_gradient_allreduce_world2():
     ps = [ctx.Process(target=_allreduce_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in ps:
         p.start()
-    got = dict(q.get(timeout=120) for _ in ps)
+    got = {r: torch.from_numpy(v) for r, v in (q.get(timeout=120) for _ in ps)}
     for p in ps:
         p.join(60)
     want = torch.arange(1000, dtype=torch.float32) * 1.5
@@ -195,7 +195,7 @@ def _estimator_worker(rank, size, port, q):
             torch.manual_seed(7 + (0 if not sharded else rank))      # rank 1's own RNG must not matter when sharded
             np.random.seed(7 + (0 if not sharded else rank))
             out[('ce', sharded)] = (_ranking_of(ce.estimate(z_obj, target, cameras=init)),)
-        q.put((rank, {k: tuple(t.clone() for t in v) if isinstance(v, tuple) else v.clone() for k, v in out.items()}))
+        q.put((rank, {k: tuple(t.numpy().copy() for t in v) if isinstance(v, tuple) else v.numpy().copy() for k, v in out.items()}))
     finally:
         dist.destroy_process_group()
 
@@ -210,7 +210,8 @@ def test_estimators_with_sharded_hypotheses_world2():
     procs = [ctx.Process(target=_estimator_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=300) for _ in procs)
+    res = {r: {k: tuple(torch.from_numpy(t) for t in v) if isinstance(v, tuple) else torch.from_numpy(v) for k, v in d.items()}
+           for r, d in (q.get(timeout=300) for _ in procs)}
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
