@@ -171,6 +171,9 @@ def main():
         torch.cuda.empty_cache()
         est2 = estimation.load_from_config(cfg, model, converge_patience=10 ** 6, conv_mode='f16x3')
         st2 = est2.start(z_obj, target, init.zoom(None, model.input_size, model.camera_dist).to(dev))
+        with torch.no_grad():
+            l2, g2 = st2['engine'].forward_backward(st2['cam'], need_grad=True)
+        alt0 = {'rank_loss': l2[:, 4].cpu(), 'grad': g2.cpu()}
         el2, tm2 = timed_loop(est2, st2)
         d2 = [e0.elapsed_time(e1) for n_, e0, e1 in tm2 if n_ == 'conv3d_c16_split']
         alt = {'conv_mode': 'f16x3 (direct convolution, every fp32 product as 3 f16 MFMAs on hi/lo splits, fp32 accumulate; '
@@ -178,6 +181,13 @@ def main():
                             'tests/test_engine_gpu.py::test_split_precision_conv_matches_fp32_and_fp64)',
                'value': world * a.steps / el2, 'unit': 'iters/s', 'ms_per_step': el2 / a.steps * 1e3,
                'conv_avg_launch_ms': sum(d2) / max(len(d2), 1)}
+        if d2:
+            ms2 = alt['conv_avg_launch_ms']
+            ab2 = (2 * C + 1) * N * S ** 3 * 4                       # read x, write y and one norm float per voxel
+            fl2 = 3 * 2.0 * 27 * C * C * N * S ** 3                  # three f16 products per fp32 product
+            alt['roofline'] = {'bound': 'hbm', 'kernel': 'conv3d_c16_f16x3_kernel', 'achieved': ab2 / (ms2 * 1e-3) / 1e9,
+                               'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ab2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               'f16_mfma_frac': fl2 / (ms2 * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS, 'launches_timed': len(d2)}
 
     # ---- roofline of the dominant kernel (fused conv3d 16->16 block step; 2 forward + 2 data-gradient launches per
     # iteration), from HIP events recorded on the launch stream inside the timed region -------------------------------
@@ -203,21 +213,25 @@ def main():
     floor_ms = max(exec_flops / (peak * 1e12), alg_bytes / (HBM_PEAK_GBS * 1e9)) * 1e3
     # measured HBM bytes per launch of this kernel (PMC passes, tools/pmc_collect.sh + tools/pmc_summary.py); refused when
     # the kernel sources changed since the counters were collected
-    traffic, traffic_src = None, None
     import glob
     import hashlib
-    for tpath in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_hbm_bytes.json')), reverse=True):
-        try:
-            tj = json.load(open(tpath))
-            stamp = tj.get('source_sha256', {})
-            fresh = bool(stamp) and all(
-                hashlib.sha256(open(os.path.join(ROOT, 'latentfusion_amd', 'csrc', f), 'rb').read()).hexdigest() == h
-                for f, h in stamp.items())
-            if fresh and S == 128 and C == 16 and N == 8 and kname in tj.get('kernels', {}):
-                traffic, traffic_src = tj['kernels'][kname]['bytes_per_launch'], os.path.basename(tpath)
-                break
-        except Exception:                                           # noqa: BLE001
-            continue
+
+    def pmc_traffic(key):
+        for tpath in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_hbm_bytes.json')), reverse=True):
+            try:
+                tj = json.load(open(tpath))
+                stamp = tj.get('source_sha256', {})
+                fresh = bool(stamp) and all(
+                    hashlib.sha256(open(os.path.join(ROOT, 'latentfusion_amd', 'csrc', f), 'rb').read()).hexdigest() == h
+                    for f, h in stamp.items())
+                if fresh and S == 128 and C == 16 and N == 8 and key in tj.get('kernels', {}):
+                    return tj['kernels'][key]['bytes_per_launch'], os.path.basename(tpath)
+            except Exception:                                       # noqa: BLE001
+                continue
+        return None, None
+    traffic, traffic_src = pmc_traffic(kname)
+    if alt is not None and 'roofline' in alt:
+        alt['roofline']['traffic'], alt['roofline']['traffic_source'] = pmc_traffic('conv3d_c16_f16x3_kernel')
     roofline = {
         'bound': 'mfma', 'kernel': kname + ' (fused conv3d 16->16 + He + bias + LeakyReLU + PixelNorm; forward and data-gradient forms)',
         'achieved': exec_tflops, 'peak': peak, 'unit': 'TFLOP/s', 'frac': exec_tflops / peak,
@@ -296,7 +310,15 @@ def main():
     }
     if world == 1 and not a.no_cpu_baseline:
         v, cores, ref0, cpu_dt = cpu_baseline(cks[:3] + (cks[3],), z_obj.cpu(), tdata, init_rec, cfg, a.cpu_iters)
-        gerr = (hip0['grad'] - ref0['grad']).norm(dim=1) / ref0['grad'].norm(dim=1).clamp_min(1e-30)
+
+        def parity(h):
+            gerr = (h['grad'] - ref0['grad']).norm(dim=1) / ref0['grad'].norm(dim=1).clamp_min(1e-30)
+            return {'rank_loss_max_abs_diff': (h['rank_loss'] - ref0['rank_loss']).abs().max().item(),
+                    'rank_loss_max_rel_diff': ((h['rank_loss'] - ref0['rank_loss']).abs()
+                                               / ref0['rank_loss'].abs().clamp_min(1e-30)).max().item(),
+                    'camera_grad_max_rel_l2_err': gerr.max().item(),
+                    'argmin_equal': bool(torch.argmin(h['rank_loss']) == torch.argmin(ref0['rank_loss'])),
+                    'ranking_equal': bool(torch.equal(torch.argsort(h['rank_loss']), torch.argsort(ref0['rank_loss'])))}
         out['cpu_baseline'] = {'value': v, 'unit': 'iters/s', 'cores': cores, 'host_cores': os.cpu_count(), 'kind': 'port',
                                'timed_s': cpu_dt,
                                'sample': f'{a.cpu_iters} timed iteration(s) of the same SYN({S},{C}) N={N} pose loop (oracle = CPU restatement '
@@ -304,14 +326,9 @@ def main():
                                          f'{cores} ATen threads of the {os.cpu_count()} host cores: more threads measured slower)',
                                # HIP path vs the oracle on iteration 0 of this very workload (same volume, target,
                                # initial cameras): per-hypothesis ranking loss and camera-parameter gradients
-                               'parity_at_full_size': {
-                                   'rank_loss_max_abs_diff': (hip0['rank_loss'] - ref0['rank_loss']).abs().max().item(),
-                                   'rank_loss_max_rel_diff': ((hip0['rank_loss'] - ref0['rank_loss']).abs()
-                                                              / ref0['rank_loss'].abs().clamp_min(1e-30)).max().item(),
-                                   'camera_grad_max_rel_l2_err': gerr.max().item(),
-                                   'argmin_equal': bool(torch.argmin(hip0['rank_loss']) == torch.argmin(ref0['rank_loss'])),
-                                   'ranking_equal': bool(torch.equal(torch.argsort(hip0['rank_loss']),
-                                                                     torch.argsort(ref0['rank_loss'])))}}
+                               'parity_at_full_size': parity(hip0)}
+        if alt is not None:
+            alt['parity_at_full_size'] = parity(alt0)
     if alt is not None:
         out['alt'] = alt
     if sharded is not None:

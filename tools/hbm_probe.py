@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Workload for the PMC passes (tools/pmc_collect.sh): a calibration copy of known size (1 GiB read + 1 GiB written)
 followed by the heavy kernels of one pose iteration at the bench shape SYN(128,16), N=8: the Winograd conv3d
-(forward form and data-gradient form with the fused previous-layer backward), the direct conv3d, the O2C resampler
+(forward form and data-gradient form with the fused previous-layer backward), the direct fp32 and f16x3 conv3d, the O2C resampler
 (forward and coefficient gradient), the factor projection (forward / backward) and the column sum."""
 import os
 import sys
@@ -34,6 +34,15 @@ for _ in range(REP):                   # Winograd, forward form
 torch.cuda.synchronize()
 for _ in range(REP):                   # Winograd, data-gradient form with the producer's epilogue backward fused
     gx, _ = ops.conv3d_c16_wino(x, upt, None, he, 0, prev=(y, nrm, flags))
+torch.cuda.synchronize()
+
+sp, spt = ops.pack_conv3d_c16_split(w), ops.pack_conv3d_c16_split(w, transpose=True)
+am = ops.amax_buffer(x.abs().max(), 'cuda')
+for _ in range(REP):                   # direct f16x3 kernel, forward form
+    ys, nrms = ops.conv3d_c16_split(x, sp, b, he, flags)
+torch.cuda.synchronize()
+for _ in range(REP):                   # ... and as a data gradient with the producer's epilogue backward fused
+    gs, _ = ops.conv3d_c16_split(x, spt, None, he, 0, prev=(y, nrm, flags), amax_in=am)
 torch.cuda.synchronize()
 
 # O2C resampler: one object volume broadcast to N pose hypotheses (the engine's call)

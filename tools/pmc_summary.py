@@ -23,6 +23,8 @@ KERNELS = collections.OrderedDict([
     # key -> (substring of the kernel name, algorithmic bytes per launch at N=8, C=16, S=128)
     ('conv3d_c16_wino_kernel', ('conv3d_c16_wino_kernel', 2 * 8 * 16 * 128 ** 3 * 4 + 8 * 128 ** 3 * 4)),
     ('conv3d_c16_persistent_kernel', ('conv3d_c16_persistent_kernel', 2 * 8 * 16 * 128 ** 3 * 4 + 8 * 128 ** 3 * 4)),
+    ('conv3d_c16_f16x3_kernel', ('conv3d_c16_f16x3_kernel<false>', 2 * 8 * 16 * 128 ** 3 * 4 + 8 * 128 ** 3 * 4)),
+    ('conv3d_c16_f16x3_kernel_bwd', ('conv3d_c16_f16x3_kernel<true>', 3 * 8 * 16 * 128 ** 3 * 4 + 8 * 128 ** 3 * 4)),
     ('resample_fwd', ('resample_fwd', 8 * 16 * 128 ** 3 * 4 + 16 * 128 ** 3 * 4)),
     ('resample_bwd_coef', ('resample_bwd_coef_', 8 * 16 * 128 ** 3 * 4 + 16 * 128 ** 3 * 4)),
     ('conv1x1_kernel', ('conv1x1_kernel', 8 * 16 * 128 ** 3 * 4)),
@@ -32,7 +34,7 @@ KERNELS = collections.OrderedDict([
 # producer's epilogue backward fused (reads the saved activation and norm as well): reported separately
 SPLIT = {'conv3d_c16_wino_kernel': (('forward form', 2 * 8 * 16 * 128 ** 3 * 4 + 8 * 128 ** 3 * 4),
                                     ('data-gradient form + fused previous-layer backward', 3 * 8 * 16 * 128 ** 3 * 4 + 8 * 128 ** 3 * 4))}
-SOURCES = ['conv_wino.hip', 'conv.hip', 'resample.hip', 'pointwise.hip', 'reduce.hip']
+SOURCES = ['conv_wino.hip', 'conv.hip', 'conv_split.hip', 'resample.hip', 'pointwise.hip', 'reduce.hip']
 
 
 def source_hashes():
