@@ -717,6 +717,7 @@ extern "C" int lf_set_tuning(int key, int value) {
     if (value >= 1 && value <= 3) g_resample_variant = value;
     return prev;
   }
+  if (key == 3) return lf_internal_fused_set_cfg(value);            // fused wide-conv GEMM: workgroup shape 0..3, -1 = by shape
   if (key == 2) {
     const int prev = g_bwd_coef_variant;
     if (value >= 1 && value <= 5) g_bwd_coef_variant = value;

@@ -24,17 +24,13 @@
 
 namespace {
 
-constexpr int MT = 64;      // Winograd tiles per workgroup   (B rows)
-constexpr int NT = 64;      // output channels per workgroup  (A rows)
 constexpr int KC = 32;      // input channels per stage
-constexpr int TILE_BYTES = 64 * KC * 4;                          // 8 KiB per operand chunk
-constexpr int NSTAGE = 4;                                        // LDS ring depth (stages of A + B chunks); a power of two
-constexpr int WF_LDS = NSTAGE * 2 * TILE_BYTES;                  // 64 KiB: two workgroups per CU
+constexpr int NSTAGE = 4;   // LDS ring depth (stages of A + B chunks); a power of two
 
 typedef unsigned u32;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-// byte offset of 16-byte chunk c (0..7) of row r in a 64 x 32-float LDS tile
+// byte offset of 16-byte chunk c (0..7) of row r in a rows x 32-float LDS tile
 __device__ __forceinline__ int lds_chunk(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
 
 // A^T = [[1, 1, 1, 0], [0, 1, -1, -1]]: coefficient of frequency component a in output o
@@ -42,36 +38,57 @@ __device__ __forceinline__ float at_coef(int o, int a) {
   return o == 0 ? (a < 3 ? 1.f : 0.f) : (a == 0 ? 0.f : (a == 1 ? 1.f : -1.f));
 }
 
-template <int DIMS>
-__global__ void __launch_bounds__(256, 2) wino_fused_kernel(
+// Workgroup shape: WM x WN waves, each owning BA x BB MFMA blocks (16 couts x 16 tiles each):
+//   NT = WM*BA*16 output channels (A rows) x MT = WN*BB*16 Winograd tiles (B rows) per workgroup.
+// The global -> LDS bytes per MFMA fall with the block area -- 64 x 64: (64+64)*128 B per stage for 32 MFMAs per wave and
+// four waves = 16 B per CU clock at the full fp32 MFMA rate, which is all the vector-memory path of a CU delivers
+// (measured: 0.50 of the MFMA peak); 128 x 64: 12 B/clk; 128 x 128: 8 B/clk -- but the 2^dims output accumulators per
+// block bound the blocks per wave (3-D: 36 VGPRs per block).
+template <int DIMS, int WM, int WN, int BA, int BB>
+__global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) wino_fused_kernel(
     const float* __restrict__ V, const float* __restrict__ U2, const float* __restrict__ bias, float* __restrict__ y,
     long T, int tz, int ty, int tx, int D, int H, int W, int Cin, int Cout, int CoutP, float he, unsigned flags, float slope,
     float* __restrict__ partial, long ysize) {
   constexpr int F = DIMS == 3 ? 64 : 16;
   constexpr int NO = DIMS == 3 ? 8 : 4;                          // outputs per tile
+  constexpr int NTc = WM * BA * 16, MTc = WN * BB * 16, NW = WM * WN;
+  constexpr int A_BYTES = NTc * 128, STAGE_BYTES = (NTc + MTc) * 128;
+  constexpr int PA = NTc / 8, PB = MTc / 8;                      // 1 KiB DMA pieces of the A / B chunk of a stage
+  constexpr int PPW = (PA + PB) / NW;                            // pieces per wave and stage
+  static_assert((PA + PB) % NW == 0 && PPW <= 4, "pieces must split evenly over the waves");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int wr = w >> 1, wc = w & 1;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = w / WN, wc = w % WN;
   const int lr = lane & 15, kg = lane >> 4;
-  const long m0 = (long)blockIdx.x * MT;                         // first tile of this workgroup
-  const int n0 = blockIdx.y * NT;                                // first output channel
+  const long m0 = (long)blockIdx.x * MTc;                        // first tile of this workgroup
+  const int n0 = blockIdx.y * NTc;                               // first output channel
 
   // ---- global -> LDS staging by LDS-DMA (buffer_load_dwordx4 ... lds): a wave-instruction deposits 64 x 16 B = 1 KiB
   // linearly at a wave-uniform LDS address, so the swizzle is applied on the GLOBAL side: the lane that lands on
   // LDS position pos = piece*64 + lane (row r = pos >> 3, slot pos & 7) fetches logical chunk c = slot ^ ((r >> 1) & 7)
-  // of that row.  A stage = 8 pieces of A + 8 of B; wave w issues pieces 2w, 2w+1 of each.  No staging registers,
-  // no ds_write; out-of-range chunks (k >= Cin, tile >= T) get an out-of-range offset and the DMA writes zeros. ----
+  // of that row.  A stage = PA pieces of A + PB of B; wave w issues pieces w*PPW .. +PPW-1 of the concatenated list.
+  // No staging registers, no ds_write; out-of-range chunks (k >= Cin, tile >= T, cout >= CoutP) get an out-of-range
+  // offset and the DMA writes zeros. ----
   const u32 slabV = (u32)((long)T * Cin * 4 <= 0xffffffffL ? (long)T * Cin * 4 : 0xffffffffL);
   const u32 slabU = (u32)((long)CoutP * Cin * 4);
-  u32 offA[2], offB[2];
-  int kch[2];
+  int voff[PPW], kch[PPW], ldso[PPW];
+  bool isA[PPW];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int pos = (w * 2 + i) * 64 + lane, r = pos >> 3, c = (pos & 7) ^ ((r >> 1) & 7);
+  for (int i = 0; i < PPW; ++i) {
+    const int p = w * PPW + i;                                   // wave-uniform
+    isA[i] = p < PA;
+    const int piece = isA[i] ? p : p - PA;
+    const int pos = piece * 64 + lane, r = pos >> 3, c = (pos & 7) ^ ((r >> 1) & 7);
     kch[i] = c * 4;
-    offA[i] = (u32)(n0 + r) * (u32)Cin * 4u + (u32)c * 16u;      // U2[f][n0 + r][k0 + 4c ..]
-    const long row = m0 + r;
-    offB[i] = row < T ? (u32)row * (u32)Cin * 4u + (u32)c * 16u : 0xffffffffu;
+    if (isA[i]) {
+      const long off = (long)(n0 + r) * Cin * 4 + c * 16;        // U2[f][n0 + r][k0 + 4c ..]
+      voff[i] = off < (long)slabU ? (int)(u32)off : 0x7fffffff;
+      ldso[i] = piece * 1024;
+    } else {
+      const long row = m0 + r;
+      voff[i] = row < T ? (int)((u32)row * (u32)Cin * 4u + (u32)c * 16u) : 0x7fffffff;
+      ldso[i] = A_BYTES + piece * 1024;
+    }
   }
   const int nk = (Cin + KC - 1) / KC;
   // frequency split (small problems: few tile / channel blocks): workgroup z handles frequencies
@@ -91,24 +108,17 @@ __global__ void __launch_bounds__(256, 2) wino_fused_kernel(
   __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)pV, 0, slabV, 0x00020000);
   int ik = 0, islot = 0, issued = 0;                             // cursor: k-chunk of the stage being issued, its ring slot
   const bool ktail = (Cin % KC) != 0;
-  const int vA[2] = {(int)offA[0], (int)offA[1]};
-  const int vB[2] = {offB[0] != 0xffffffffu ? (int)offB[0] : 0x7fffffff, offB[1] != 0xffffffffu ? (int)offB[1] : 0x7fffffff};
-  // piece q (0..3) of the cursor's stage for this wave: q = 2*i + (0: weights A, 1: inputs B)
+  // piece q (0 .. PPW-1) of the cursor's stage for this wave
   auto issue_piece = [&](int q) {
-    unsigned char* slot = smem + islot * 2 * TILE_BYTES;
-    const int i = q >> 1;
+    unsigned char* slot = smem + islot * STAGE_BYTES;
     const int k0b = ik * KC * 4;                                 // scalar byte offset of the k-chunk
-    int va = vA[i], vb = vB[i];
-    if (ktail && ik == nk - 1) {                                 // (wave-uniform) ragged last chunk: lanes beyond Cin read zeros
-      const bool kok = ik * KC + kch[i] < Cin;
-      va = kok ? va : 0x7fffffff;
-      vb = kok ? vb : 0x7fffffff;
-    }
-    if ((q & 1) == 0)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (__attribute__((address_space(3))) void*)(slot + (w * 2 + i) * 1024), 16, va, k0b, 0, 0);
+    int vo = voff[q];
+    if (ktail && ik == nk - 1) vo = (ik * KC + kch[q] < Cin) ? vo : 0x7fffffff;   // ragged last chunk: lanes beyond Cin read zeros
+    if (isA[q])
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (__attribute__((address_space(3))) void*)(slot + ldso[q]), 16, vo, k0b, 0, 0);
     else
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(slot + TILE_BYTES + (w * 2 + i) * 1024), 16, vb, k0b, 0, 0);
-    if (q == 3) {                                                // stage complete: advance the cursor
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(slot + ldso[q]), 16, vo, k0b, 0, 0);
+    if (q == PPW - 1) {                                          // stage complete: advance the cursor
       ++issued;
       islot = (islot + 1) & (NSTAGE - 1);
       if (++ik == nk) {
@@ -121,56 +131,55 @@ __global__ void __launch_bounds__(256, 2) wino_fused_kernel(
     }
   };
 
-  // ---- MFMA operand addressing: row of this lane in A (cout) and B (tile) for the two 16-row tiles of the wave ----
-  int rdA[2][2], rdB[2][2];                                      // [row tile][k-group j]
+  // ---- MFMA operand addressing: row of this lane in A (cout) and B (tile) for the 16-row blocks of the wave ----
+  int rdA[BA][2], rdB[BB][2];                                    // [row block][k-group j]
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int j = 0; j < 2; ++j) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int ra_ = wr * 32 + t * 16 + lr, rb_ = wc * 32 + t * 16 + lr;
-      rdA[t][j] = lds_chunk(ra_, j * 4 + kg);
-      rdB[t][j] = TILE_BYTES + lds_chunk(rb_, j * 4 + kg);
-    }
+    for (int t = 0; t < BA; ++t) rdA[t][j] = lds_chunk(wr * (BA * 16) + t * 16 + lr, j * 4 + kg);
+#pragma unroll
+    for (int t = 0; t < BB; ++t) rdB[t][j] = A_BYTES + lds_chunk(wc * (BB * 16) + t * 16 + lr, j * 4 + kg);
+  }
 
-  f32x4 Y[NO][2][2];
+  f32x4 Y[NO][BA][BB];
 #pragma unroll
   for (int o = 0; o < NO; ++o)
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < BA; ++a)
 #pragma unroll
-      for (int b = 0; b < 2; ++b) Y[o][a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  f32x4 acc[2][2];
+      for (int b = 0; b < BB; ++b) Y[o][a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[BA][BB];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < BA; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < BB; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // ring of NSTAGE stages: stages s+1 .. s+NSTAGE-1 are in flight while stage s feeds the MFMAs
   for (int s0 = 0; s0 < NSTAGE - 1 && s0 < S; ++s0)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) issue_piece(q);
+    for (int q = 0; q < PPW; ++q) issue_piece(q);
   int kc = 0, f = f_first;
   for (int s = 0; s < S; ++s) {
     // this wave's pieces of stage s have landed when at most the pieces of the later stages it issued are outstanding
-    // (4 DMA instructions per stage and wave); then the workgroup barrier makes every wave's pieces visible AND
+    // (PPW DMA instructions per stage and wave); then the workgroup barrier makes every wave's pieces visible AND
     // certifies that everybody is done reading stage s-1, whose ring slot the next issue overwrites
     const int ahead = min(NSTAGE - 2, S - 1 - s);
-    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (ahead >= 2) { if (PPW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else if (PPW == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+    else if (ahead == 1) { if (PPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else if (PPW == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     const bool more = issued < S;                                // wave-uniform
-    const unsigned char* base = smem + (s % NSTAGE) * 2 * TILE_BYTES;
-    f32x4 fa[2][2], fb[2][2];                                    // [k-group j][row tile]
+    const unsigned char* base = smem + (s % NSTAGE) * STAGE_BYTES;
+    f32x4 fa[2][BA], fb[2][BB];                                  // [k-group j][row block]
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 2; ++j) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        fa[j][t] = *(const f32x4*)(base + rdA[t][j]);
-        fb[j][t] = *(const f32x4*)(base + rdB[t][j]);
-      }
-    // the four DMA pieces of stage s+3 are issued BETWEEN groups of eight MFMAs: an LDS-DMA instruction holds the
-    // issuing (in-order) wave for ~60-180 cycles, which the 8 x 32 cycles of matrix work already queued ahead of it cover
+      for (int t = 0; t < BA; ++t) fa[j][t] = *(const f32x4*)(base + rdA[t][j]);
+#pragma unroll
+      for (int t = 0; t < BB; ++t) fb[j][t] = *(const f32x4*)(base + rdB[t][j]);
+    }
+    // the DMA pieces of stage s+3 are issued BETWEEN groups of MFMAs: an LDS-DMA instruction holds the issuing
+    // (in-order) wave for ~60-180 cycles, which the matrix work already queued ahead of it covers
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -178,12 +187,12 @@ __global__ void __launch_bounds__(256, 2) wino_fused_kernel(
 #pragma unroll
         for (int i = i2 * 2; i < i2 * 2 + 2; ++i)
 #pragma unroll
-          for (int a = 0; a < 2; ++a)
+          for (int a = 0; a < BA; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+            for (int b = 0; b < BB; ++b)
               acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j][a][i], fb[j][b][i], acc[a][b], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if (more) issue_piece(j * 2 + i2);
+        if (j * 2 + i2 < PPW && more) issue_piece(j * 2 + i2);
         __builtin_amdgcn_sched_barrier(0);
       }
     if (++kc == nk) {
@@ -196,23 +205,23 @@ __global__ void __launch_bounds__(256, 2) wino_fused_kernel(
         if (DIMS == 3) cf *= at_coef((o >> 2) & 1, fa_);
         if (cf != 0.f) {                                         // wave-uniform
 #pragma unroll
-          for (int a = 0; a < 2; ++a)
+          for (int a = 0; a < BA; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b) Y[o][a][b] += acc[a][b] * cf;
+            for (int b = 0; b < BB; ++b) Y[o][a][b] += acc[a][b] * cf;
         }
       }
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < BA; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < BB; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
       ++f;
     }
   }
 
-  // ---- epilogue: He scale, bias, LeakyReLU; lane holds couts n0 + wr*32 + a*16 + kg*4 .. +3 of tile column lr ----
+  // ---- epilogue: He scale, bias, LeakyReLU; lane holds couts n0 + wr*BA*16 + a*16 + kg*4 .. +3 of tile column lr ----
 #pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    const long tile = m0 + wc * 32 + b * 16 + lr;
+  for (int b = 0; b < BB; ++b) {
+    const long tile = m0 + wc * (BB * 16) + b * 16 + lr;
     if (tile >= T) continue;
     long r = tile;
     const int bx = (int)(r % tx); r /= tx;
@@ -220,8 +229,8 @@ __global__ void __launch_bounds__(256, 2) wino_fused_kernel(
     const int bz = DIMS == 3 ? (int)(r % tz) : 0;
     const long n = DIMS == 3 ? r / tz : r;
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      const int co = n0 + wr * 32 + a * 16 + kg * 4;
+    for (int a = 0; a < BA; ++a) {
+      const int co = n0 + wr * (BA * 16) + a * 16 + kg * 4;
       if (co >= Cout) continue;
       f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (bias != nullptr) bv = *(const f32x4*)(bias + co);
@@ -263,25 +272,65 @@ __global__ void __launch_bounds__(256) wino_fused_finish_kernel(const f32x4* __r
   y[i] = v;
 }
 
+// Workgroup shapes (NT output channels x MT tiles): 0 = 64 x 64 (4 waves, two workgroups per CU), 1 = 128 x 64,
+// 2 = 64 x 128, 3 = 128 x 128 (8 waves, one workgroup per CU; 2-D only: the 3-D kernel keeps 8 output accumulators per block)
+struct FusedCfg { int nt, mt, waves; };
+constexpr FusedCfg kCfg[4] = {{64, 64, 4}, {128, 64, 8}, {64, 128, 8}, {128, 128, 8}};
+int g_fused_cfg = -1;                                             // lf_set_tuning(3, v): -1 = pick by shape
+
+int pick_fused_cfg(int dims, long T, int CoutP) {
+  if (g_fused_cfg >= 0 && g_fused_cfg < 4 && !(dims == 3 && g_fused_cfg == 3)) return g_fused_cfg;
+  // measured per layer shape of the released model at N = 8 / 32 / 128 (tools/wide_conv_probe.py --cfgs,
+  // profiles/r02_wide_conv_cfgs_*.jsonl): the large shapes pay (+10..20 % on the GEMM stage) once there are >= 1-2 k tiles
+  // and >= 128 output channels; 64-channel layers and tiny maps stay on 64 x 64 with two workgroups per CU
+  if (CoutP >= 128 && dims == 2 && T >= 1024) return 3;
+  if (CoutP >= 128 && dims == 3 && T >= 32768) return 1;
+  if (CoutP >= 128 && dims == 3 && T >= 2048) return 2;
+  return 0;
+}
+
 // frequency split of a launch with gx x gy tile / channel blocks: enough workgroups to fill the chip
-int fused_zsplit(int dims, long gx, int gy) {
+int fused_zsplit(int dims, long gx, int gy, int waves) {
   const int F = dims == 3 ? 64 : 16;
+  const long want = waves == 4 ? 512 : 256;                      // two (4-wave) / one (8-wave) resident workgroups per CU
   int zs = 1;
-  while (zs < F && gx * gy * zs < 512) zs <<= 1;                 // >= two resident workgroups per CU (256 CUs)
+  while (zs < F && gx * gy * zs < want) zs <<= 1;
   return zs;
 }
 
 }  // namespace
 
-extern "C" int lf_wino_fused_cout_padded(int Cout) { return (Cout + NT - 1) / NT * NT; }
+extern "C" int lf_wino_fused_cout_padded(int Cout) { return (Cout + 63) / 64 * 64; }
 
-// bytes of scratch lf_wino_fused_gemm needs for this shape (0: none)
+// bytes of scratch lf_wino_fused_gemm needs for this shape (0: none).  (An upper bound over the workgroup shapes.)
 extern "C" size_t lf_wino_fused_scratch_bytes(int dims, int N, int D, int H, int W, int Cout) {
   if ((dims != 2 && dims != 3) || N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
   const int tz = dims == 3 ? (D + 1) / 2 : 1, ty = (H + 1) / 2, tx = (W + 1) / 2;
   const long T = (long)N * tz * ty * tx;
-  const int zs = fused_zsplit(dims, (T + MT - 1) / MT, lf_wino_fused_cout_padded(Cout) / NT);
+  const int CoutP = lf_wino_fused_cout_padded(Cout);
+  int zs = 1;
+  for (int c = 0; c < 4; ++c) {
+    if (dims == 3 && c == 3) continue;
+    const int z = fused_zsplit(dims, (T + kCfg[c].mt - 1) / kCfg[c].mt, (CoutP + kCfg[c].nt - 1) / kCfg[c].nt, kCfg[c].waves);
+    zs = z > zs ? z : zs;
+  }
   return zs > 1 ? (size_t)zs * N * D * H * W * Cout * sizeof(float) : 0;
+}
+
+template <int DIMS, int WM, int WN, int BA, int BB>
+static int launch_fused(dim3 grid, hipStream_t s, const float* V, const float* U2, const float* bias, float* y, long T, int tz, int ty,
+                        int tx, int D, int H, int W, int Cin, int Cout, int CoutP, float he, unsigned flags, float slope,
+                        float* partial, long ysize) {
+  constexpr int lds = NSTAGE * (WM * BA * 16 + WN * BB * 16) * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)wino_fused_kernel<DIMS, WM, WN, BA, BB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((wino_fused_kernel<DIMS, WM, WN, BA, BB>), grid, dim3(WM * WN * 64), lds, s, V, U2, bias, y, T, tz, ty, tx, D, H, W,
+                     Cin, Cout, CoutP, he, flags, slope, partial, ysize);
+  return lf_launch_status();
 }
 
 // y = epilogue(output_transform(V[f] . U2[f]^T)):  V [F][T][Cin] from lf_wino{2,3}d_input_transform;
@@ -300,29 +349,33 @@ extern "C" int lf_wino_fused_gemm(const float* V, const float* U2, const float* 
   const int CoutP = lf_wino_fused_cout_padded(Cout);
   // 32-bit byte offsets inside one frequency slab
   if (T * Cin * 4 > 0xffffffffL || (long)CoutP * Cin * 4 > 0xffffffffL) return LF_EINVAL;
+  const int cfg = pick_fused_cfg(dims, T, CoutP);
+  const int MT = kCfg[cfg].mt, NT = kCfg[cfg].nt;
   const long gx = (T + MT - 1) / MT;
-  if (gx > 0x7fffffffL || CoutP / NT > 65535) return LF_EINVAL;
-  const int zs = fused_zsplit(dims, gx, CoutP / NT);
+  const int gy = (CoutP + NT - 1) / NT;
+  if (gx > 0x7fffffffL || gy > 65535) return LF_EINVAL;
+  const int zs = fused_zsplit(dims, gx, gy, kCfg[cfg].waves);
   const long ysize = (long)N * D * H * W * Cout;
   if (zs > 1 && (scratch == nullptr || scratch_bytes < (size_t)zs * ysize * sizeof(float) || !lf_aligned16(scratch))) return LF_ENOSPC;
   float* partial = zs > 1 ? (float*)scratch : nullptr;
-  dim3 grid((unsigned)gx, (unsigned)(CoutP / NT), (unsigned)zs), block(256);
+  dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)zs);
   hipStream_t s = (hipStream_t)stream;
-  static bool attr_set = false;
-  if (!attr_set) {                                               // 64 KiB of dynamic LDS
-    hipError_t e = hipFuncSetAttribute((const void*)wino_fused_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wino_fused_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
-  if (dims == 3)
-    hipLaunchKernelGGL((wino_fused_kernel<3>), grid, block, WF_LDS, s, V, U2, bias, y, T, tz, ty, tx, D, H, W, Cin, Cout, CoutP, he, flags, slope, partial, ysize);
-  else
-    hipLaunchKernelGGL((wino_fused_kernel<2>), grid, block, WF_LDS, s, V, U2, bias, y, T, tz, ty, tx, D, H, W, Cin, Cout, CoutP, he, flags, slope, partial, ysize);
-  int st = lf_launch_status();
+#define LF_FUSED(DIMS_, WM_, WN_, BA_, BB_) \
+  launch_fused<DIMS_, WM_, WN_, BA_, BB_>(grid, s, V, U2, bias, y, T, tz, ty, tx, D, H, W, Cin, Cout, CoutP, he, flags, slope, partial, ysize)
+  int st;
+  if (dims == 3) st = cfg == 1 ? LF_FUSED(3, 4, 2, 2, 2) : (cfg == 2 ? LF_FUSED(3, 2, 4, 2, 2) : LF_FUSED(3, 2, 2, 2, 2));
+  else st = cfg == 1 ? LF_FUSED(2, 4, 2, 2, 2) : (cfg == 2 ? LF_FUSED(2, 2, 4, 2, 2) : (cfg == 3 ? LF_FUSED(2, 4, 2, 2, 4) : LF_FUSED(2, 2, 2, 2, 2)));
+#undef LF_FUSED
   if (st || zs == 1) return st;
   const long n4 = ysize / 4;
   hipLaunchKernelGGL(wino_fused_finish_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (const f32x4*)partial, bias, (f32x4*)y,
                      n4, n4, zs, Cout / 4, he, flags, slope);
   return lf_launch_status();
+}
+
+// tuning hook for lf_set_tuning (key 3, resample.hip): workgroup shape of the fused GEMM, -1 = by shape
+int lf_internal_fused_set_cfg(int v) {
+  const int prev = g_fused_cfg;
+  if (v >= -1 && v < 4) g_fused_cfg = v;
+  return prev;
 }

@@ -5,7 +5,7 @@ output transform / epilogue folded in), 'bmm' = three-stage form with the per-fr
 Prints per shape: total ms of the conv (+ PixelNorm), ms of the GEMM stage alone (HIP events on the launch stream), the
 executed fp32-MFMA rate of that stage and the max abs difference between the two paths.
 
-    python tools/wide_conv_probe.py [N]
+    python tools/wide_conv_probe.py [N] [--cfgs]     (--cfgs: also time every workgroup shape of the fused GEMM, lf_set_tuning key 3)
 """
 import json
 import os
@@ -17,7 +17,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from latentfusion_amd import ops  # noqa: E402
 from latentfusion_amd._lib import LF_EPI_LRELU, LF_EPI_PIXELNORM  # noqa: E402
 
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+CFGS = '--cfgs' in sys.argv
+args = [a for a in sys.argv[1:] if not a.startswith('--')]
+N = int(args[0]) if args else 8
+from latentfusion_amd import _lib  # noqa: E402
+L = _lib.lib()
+L.lf_set_tuning.restype = __import__('ctypes').c_int
+L.lf_set_tuning.argtypes = [__import__('ctypes').c_int] * 2
 SHAPES = [(3, 256, 256, 16), (2, 64, 64, 256), (2, 128, 64, 256), (2, 196, 128, 128), (2, 256, 196, 64), (2, 512, 256, 32),
           (2, 1024, 512, 16), (2, 1024, 512, 8), (2, 512, 512, 4)]
 flags = LF_EPI_LRELU | LF_EPI_PIXELNORM
@@ -52,5 +58,22 @@ for dims, cin, cout, S in SHAPES:
         ys[mode] = y
     ops.WIDE_CONV_MODE = 'fused'
     rec['max_abs_diff'] = (ys['fused'] - ys['bmm']).abs().max().item()
+    if CFGS:
+        for cfg in range(4):
+            if dims == 3 and cfg == 3:
+                continue
+            L.lf_set_tuning(3, cfg)
+            for _ in range(3):
+                y, _n = ops.wide_conv(x, w, b, he, flags)
+            torch.cuda.synchronize()
+            ops.KERNEL_TIMER = []
+            for _ in range(10):
+                y, _n = ops.wide_conv(x, w, b, he, flags)
+            torch.cuda.synchronize()
+            tm, ops.KERNEL_TIMER = ops.KERNEL_TIMER, None
+            gemm = [a.elapsed_time(c) for n_, a, c in tm if n_.endswith('_fused')]
+            rec[f'cfg{cfg}'] = {'gemm_stage_ms': sum(gemm) / len(gemm), 'gemm_stage_TFLOPs': flops / (sum(gemm) / len(gemm) * 1e-3) / 1e12,
+                                'max_abs_diff_vs_bmm': (y - ys['bmm']).abs().max().item()}
+        L.lf_set_tuning(3, -1)
     out.append(rec)
     print(json.dumps(rec))
