@@ -52,8 +52,8 @@ int lf_device_name(char* buf, int buflen);
  * (32-bit buffer addressing, C % 4 == 0, volumes < 4 GB per sample; other shapes take the generic ones),
  * 3 = lean + the 16-channel specialisation of the gather (default).  key 2: lean coefficient-gradient kernel, sub-tiles in
  * flight per workgroup iteration: 1 = one, 2 = two (default), 3-5 = register-capped forms of 2 / 1.  key 3: workgroup
- * shape of lf_wino_fused_gemm (output channels x Winograd tiles): 0 = 64 x 64, 1 = 128 x 64, 2 = 64 x 128, 3 = 128 x 128
- * (2-D only), -1 = chosen from the problem shape (default).
+ * shape of lf_wino_fused_gemm (output channels x Winograd tiles): 0 = 64 x 64, 1 = 128 x 64, 2 = 64 x 128, 3 = 128 x 128,
+ * 4 = 64 x 256 (3, 4: 2-D only), -1 = chosen from the problem shape (default).
  * Returns the previous value or LF_EINVAL. */
 int lf_set_tuning(int key, int value);
 

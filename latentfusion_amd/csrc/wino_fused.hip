@@ -55,7 +55,7 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) wino_fus
   constexpr int A_BYTES = NTc * 128, STAGE_BYTES = (NTc + MTc) * 128;
   constexpr int PA = NTc / 8, PB = MTc / 8;                      // 1 KiB DMA pieces of the A / B chunk of a stage
   constexpr int PPW = (PA + PB) / NW;                            // pieces per wave and stage
-  static_assert((PA + PB) % NW == 0 && PPW <= 4, "pieces must split evenly over the waves");
+  static_assert((PA + PB) % NW == 0 && PPW <= 8, "pieces must split evenly over the waves");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = w / WN, wc = w % WN;
@@ -164,9 +164,10 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) wino_fus
     // (PPW DMA instructions per stage and wave); then the workgroup barrier makes every wave's pieces visible AND
     // certifies that everybody is done reading stage s-1, whose ring slot the next issue overwrites
     const int ahead = min(NSTAGE - 2, S - 1 - s);
-    if (ahead >= 2) { if (PPW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else if (PPW == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-    else if (ahead == 1) { if (PPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else if (PPW == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (ahead >= 2) __builtin_amdgcn_s_waitcnt(0x0f70 | ((2 * PPW) & 15) | (((2 * PPW) >> 4) << 14));     // vmcnt(2 PPW), the rest open
+    else if (ahead == 1) __builtin_amdgcn_s_waitcnt(0x0f70 | (PPW & 15));                                  // vmcnt(PPW)
+    else __builtin_amdgcn_s_waitcnt(0x0f70);                                                                // vmcnt(0)
+    asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
     const bool more = issued < S;                                // wave-uniform
     const unsigned char* base = smem + (s % NSTAGE) * STAGE_BYTES;
@@ -183,17 +184,20 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) wino_fus
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int i2 = 0; i2 < 2; ++i2) {
+      for (int i = 0; i < 4; ++i) {
 #pragma unroll
-        for (int i = i2 * 2; i < i2 * 2 + 2; ++i)
+        for (int a = 0; a < BA; ++a)
 #pragma unroll
-          for (int a = 0; a < BA; ++a)
-#pragma unroll
-            for (int b = 0; b < BB; ++b)
-              acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j][a][i], fb[j][b][i], acc[a][b], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (j * 2 + i2 < PPW && more) issue_piece(j * 2 + i2);
-        __builtin_amdgcn_sched_barrier(0);
+          for (int b = 0; b < BB; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j][a][i], fb[j][b][i], acc[a][b], 0, 0, 0);
+        // issue slots: after every second k-step (<= 4 pieces per wave) or after every k-step (more)
+        constexpr int SLOT_EVERY = PPW <= 4 ? 2 : 1;
+        if ((i + 1) % SLOT_EVERY == 0) {
+          const int slot_ = (j * 4 + i) / SLOT_EVERY;
+          __builtin_amdgcn_sched_barrier(0);
+          if (slot_ < PPW && more) issue_piece(slot_);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     if (++kc == nk) {
       // frequency f complete: fold it into the outputs, Y[o] += A^T[o][f] * M[f]
@@ -273,17 +277,20 @@ __global__ void __launch_bounds__(256) wino_fused_finish_kernel(const f32x4* __r
 }
 
 // Workgroup shapes (NT output channels x MT tiles): 0 = 64 x 64 (4 waves, two workgroups per CU), 1 = 128 x 64,
-// 2 = 64 x 128, 3 = 128 x 128 (8 waves, one workgroup per CU; 2-D only: the 3-D kernel keeps 8 output accumulators per block)
+// 2 = 64 x 128, 3 = 128 x 128, 4 = 64 x 256 (8 waves, one workgroup per CU; 3 and 4 are 2-D only: the 3-D kernel keeps 8 output
+// accumulators per block)
 struct FusedCfg { int nt, mt, waves; };
-constexpr FusedCfg kCfg[4] = {{64, 64, 4}, {128, 64, 8}, {64, 128, 8}, {128, 128, 8}};
+constexpr int NCFG = 5;
+constexpr FusedCfg kCfg[NCFG] = {{64, 64, 4}, {128, 64, 8}, {64, 128, 8}, {128, 128, 8}, {64, 256, 8}};
 int g_fused_cfg = -1;                                             // lf_set_tuning(3, v): -1 = pick by shape
 
 int pick_fused_cfg(int dims, long T, int CoutP) {
-  if (g_fused_cfg >= 0 && g_fused_cfg < 4 && !(dims == 3 && g_fused_cfg == 3)) return g_fused_cfg;
+  if (g_fused_cfg >= 0 && g_fused_cfg < NCFG && !(dims == 3 && g_fused_cfg >= 3)) return g_fused_cfg;
   // measured per layer shape of the released model at N = 8 / 32 / 128 (tools/wide_conv_probe.py --cfgs,
   // profiles/r02_wide_conv_cfgs_*.jsonl): the large shapes pay (+10..20 % on the GEMM stage) once there are >= 1-2 k tiles
   // and >= 128 output channels; 64-channel layers and tiny maps stay on 64 x 64 with two workgroups per CU
   if (CoutP >= 128 && dims == 2 && T >= 1024) return 3;
+  if (CoutP < 128 && dims == 2 && T >= 200000) return 4;        // 64-channel layers on the largest maps: 64 x 256
   if (CoutP >= 128 && dims == 3 && T >= 32768) return 1;
   if (CoutP >= 128 && dims == 3 && T >= 2048) return 2;
   return 0;
@@ -309,8 +316,8 @@ extern "C" size_t lf_wino_fused_scratch_bytes(int dims, int N, int D, int H, int
   const long T = (long)N * tz * ty * tx;
   const int CoutP = lf_wino_fused_cout_padded(Cout);
   int zs = 1;
-  for (int c = 0; c < 4; ++c) {
-    if (dims == 3 && c == 3) continue;
+  for (int c = 0; c < NCFG; ++c) {
+    if (dims == 3 && c >= 3) continue;
     const int z = fused_zsplit(dims, (T + kCfg[c].mt - 1) / kCfg[c].mt, (CoutP + kCfg[c].nt - 1) / kCfg[c].nt, kCfg[c].waves);
     zs = z > zs ? z : zs;
   }
@@ -364,7 +371,8 @@ extern "C" int lf_wino_fused_gemm(const float* V, const float* U2, const float* 
   launch_fused<DIMS_, WM_, WN_, BA_, BB_>(grid, s, V, U2, bias, y, T, tz, ty, tx, D, H, W, Cin, Cout, CoutP, he, flags, slope, partial, ysize)
   int st;
   if (dims == 3) st = cfg == 1 ? LF_FUSED(3, 4, 2, 2, 2) : (cfg == 2 ? LF_FUSED(3, 2, 4, 2, 2) : LF_FUSED(3, 2, 2, 2, 2));
-  else st = cfg == 1 ? LF_FUSED(2, 4, 2, 2, 2) : (cfg == 2 ? LF_FUSED(2, 2, 4, 2, 2) : (cfg == 3 ? LF_FUSED(2, 4, 2, 2, 4) : LF_FUSED(2, 2, 2, 2, 2)));
+  else st = cfg == 1 ? LF_FUSED(2, 4, 2, 2, 2) : (cfg == 2 ? LF_FUSED(2, 2, 4, 2, 2) : (cfg == 3 ? LF_FUSED(2, 4, 2, 2, 4) :
+            (cfg == 4 ? LF_FUSED(2, 1, 8, 4, 2) : LF_FUSED(2, 2, 2, 2, 2))));
 #undef LF_FUSED
   if (st || zs == 1) return st;
   const long n4 = ysize / 4;
@@ -376,6 +384,6 @@ extern "C" int lf_wino_fused_gemm(const float* V, const float* U2, const float* 
 // tuning hook for lf_set_tuning (key 3, resample.hip): workgroup shape of the fused GEMM, -1 = by shape
 int lf_internal_fused_set_cfg(int v) {
   const int prev = g_fused_cfg;
-  if (v >= -1 && v < 4) g_fused_cfg = v;
+  if (v >= -1 && v < NCFG) g_fused_cfg = v;
   return prev;
 }
