@@ -199,6 +199,41 @@ def test_wide_conv_fused_gemm(dims, cin, cout, S, N):
     close(gx, got['bmm'][2], atol=3e-5 * max(1.0, gwant.abs().max().item()), rtol=1e-4)
 
 
+@pytest.mark.parametrize('dims,cin,cout,S,N', [(3, 72, 132, 6, 1), (2, 68, 320, 6, 2), (2, 196, 128, 9, 1), (2, 64, 64, 13, 2), (3, 64, 196, 5, 3)])
+def test_wide_conv_fused_gemm_workgroup_shapes(dims, cin, cout, S, N):
+    """Every workgroup shape of lf_wino_fused_gemm (lf_set_tuning key 3: 64x64, 128x64, 64x128, 128x128, 64x256) on ragged
+    problems -- Cout / tile counts that do not fill the larger blocks, Cin not a multiple of the 32-channel stage -- gives
+    the result of the default pick, forward and data-gradient forms (bit-identical: the products and the summation order
+    inside a tile do not depend on the block that computes it)."""
+    import ctypes
+    from latentfusion_amd import _lib, ops
+    from latentfusion_amd._lib import LF_EPI_LRELU, LF_EPI_PIXELNORM
+    L = _lib.lib()
+    L.lf_set_tuning.restype = ctypes.c_int
+    L.lf_set_tuning.argtypes = [ctypes.c_int, ctypes.c_int]
+    g = torch.Generator().manual_seed(dims * 1000 + cin * 10 + cout)
+    xd = ops.cl(torch.randn((N, cin) + (S,) * dims, generator=g).to(DEV))
+    wd = torch.randn((cout, cin) + (3,) * dims, generator=g).to(DEV)
+    bd = (torch.randn(cout, generator=g) * 0.1).to(DEV)
+    gin = ops.cl(torch.randn((N, cout) + (S,) * dims, generator=g).to(DEV))
+    he = ops.he_constant(wd)
+    flags = LF_EPI_LRELU | LF_EPI_PIXELNORM
+    ref = None
+    try:
+        for cfg in (-1, 0, 1, 2, 3, 4):
+            if dims == 3 and cfg >= 3:
+                continue
+            assert L.lf_set_tuning(3, cfg) >= -1
+            y, nrm = ops.wide_conv(xd, wd, bd, he, flags)
+            gx, _ = ops.wide_conv(gin, wd, None, he, 0, transpose=True)
+            if ref is None:
+                ref = (y, nrm, gx)
+            else:
+                assert torch.equal(y, ref[0]) and torch.equal(nrm, ref[1]) and torch.equal(gx, ref[2]), cfg
+    finally:
+        L.lf_set_tuning(3, -1)
+
+
 @pytest.mark.parametrize('cin,cout,act,norm', [(16, 2, False, False), (4, 16, True, False), (35, 16, True, True),
                                                (16, 128, True, True), (20, 200, True, True)])
 def test_conv1x1_vs_torch(cin, cout, act, norm):
