@@ -23,8 +23,8 @@ KERNELS = collections.OrderedDict([
     # key -> (substring of the kernel name, algorithmic bytes per launch at N=8, C=16, S=128)
     ('conv3d_c16_wino_kernel', ('conv3d_c16_wino_kernel', 2 * 8 * 16 * 128 ** 3 * 4 + 8 * 128 ** 3 * 4)),
     ('conv3d_c16_persistent_kernel', ('conv3d_c16_persistent_kernel', 2 * 8 * 16 * 128 ** 3 * 4 + 8 * 128 ** 3 * 4)),
-    ('conv3d_c16_f16x3_kernel', ('conv3d_c16_f16x3_kernel<false>', 2 * 8 * 16 * 128 ** 3 * 4 + 8 * 128 ** 3 * 4)),
-    ('conv3d_c16_f16x3_kernel_bwd', ('conv3d_c16_f16x3_kernel<true>', 3 * 8 * 16 * 128 ** 3 * 4 + 8 * 128 ** 3 * 4)),
+    ('conv3d_c16_f16x3_kernel', (('conv3d_c16_f16x3_kernel<false>', 'conv3d_c16_f16x3_kernelILb0E'), 2 * 8 * 16 * 128 ** 3 * 4 + 8 * 128 ** 3 * 4)),
+    ('conv3d_c16_f16x3_kernel_bwd', (('conv3d_c16_f16x3_kernel<true>', 'conv3d_c16_f16x3_kernelILb1E'), 3 * 8 * 16 * 128 ** 3 * 4 + 8 * 128 ** 3 * 4)),
     ('resample_fwd', ('resample_fwd', 8 * 16 * 128 ** 3 * 4 + 16 * 128 ** 3 * 4)),
     ('resample_bwd_coef', ('resample_bwd_coef_', 8 * 16 * 128 ** 3 * 4 + 16 * 128 ** 3 * 4)),
     ('conv1x1_kernel', ('conv1x1_kernel', 8 * 16 * 128 ** 3 * 4)),
@@ -62,7 +62,8 @@ def mean(v):
 
 
 def find(data, sub, floor_counter=None, floor=0.0):
-    hits = [k for k in data if sub in k and 'coef_reduce' not in k]
+    subs = sub if isinstance(sub, tuple) else (sub,)                  # (rocprofv3 leaves names with _Float16 parameters mangled)
+    hits = [k for k in data if any(x in k for x in subs) and 'coef_reduce' not in k]
     if not hits:
         return None
     # several template instances may match: take the one with the most work
