@@ -91,11 +91,17 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
+    # Test hook for boxes with ONE GPU (the multi-rank code path cannot be exercised there with RCCL, which refuses two
+    # ranks on one device): LF_BENCH_SINGLE_DEVICE=1 puts every rank on cuda:0 and uses gloo for the collectives.  The
+    # numbers of such a run mean nothing (the ranks share the GPU); it only proves that the N > 1 path runs and agrees.
+    single = os.environ.get('LF_BENCH_SINGLE_DEVICE') == '1'
+    if single:
+        local = 0
     torch.cuda.set_device(local)
     dev = f'cuda:{local}'
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl')
+        dist.init_process_group('gloo' if single else 'nccl')
 
     from latentfusion_amd import ops, synth
     from latentfusion_amd.modules.geometry import Camera
