@@ -107,10 +107,6 @@ __device__ __forceinline__ void lds_barrier_s() { asm volatile("s_waitcnt lgkmcn
 // v_permlane32_swap / v_permlane16_swap exchange half-waves / neighbouring rows of 16 in the VALU (a __shfl_xor is a
 // ds_bpermute: an LDS round trip queued behind the operand reads of every wave on the CU)
 __device__ __forceinline__ float quarter_sum(float v) {
-#ifdef SPLIT_SHFL
-  v += __shfl_xor(v, 16, 64);
-  return v + __shfl_xor(v, 32, 64);
-#endif
   const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
   const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(s), __float_as_uint(s), false, false);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """A/B timing of builds of the split-precision (f16x3) direct conv kernel in ONE process:
 
-    hipcc -x hip --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -shared -Ilatentfusion_amd/csrc -Iinclude \
+    hipcc -x hip --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -fno-slp-vectorize -shared -Ilatentfusion_amd/csrc -Iinclude \
           latentfusion_amd/csrc/conv_split.hip -o scratch/split_a.so        (one per variant)
     python tools/split_ab.py scratch/split_a.so scratch/split_b.so ...
 

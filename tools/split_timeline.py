@@ -2,7 +2,7 @@
 """Per-phase timeline of one workgroup of the split-precision direct conv kernel (cycle-counter stamps written by lane 0
 of every wave when conv_split.hip is compiled with -DSPLIT_ABL=32):
 
-    hipcc -x hip --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -shared -DSPLIT_ABL=32 -Ilatentfusion_amd/csrc \
+    hipcc -x hip --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -fno-slp-vectorize -shared -DSPLIT_ABL=32 -Ilatentfusion_amd/csrc \
           -Iinclude latentfusion_amd/csrc/conv_split.hip -o scratch/split_ts.so
     python tools/split_timeline.py scratch/split_ts.so
 """
