@@ -27,6 +27,9 @@ L.lf_set_tuning.argtypes = [__import__('ctypes').c_int] * 2
 SHAPES = [(3, 256, 256, 16), (2, 64, 64, 256), (2, 128, 64, 256), (2, 196, 128, 128), (2, 256, 196, 64), (2, 512, 256, 32),
           (2, 1024, 512, 16), (2, 1024, 512, 8), (2, 512, 512, 4)]
 flags = LF_EPI_LRELU | LF_EPI_PIXELNORM
+if '--more' in sys.argv:                                         # low-channel / high-resolution layers (and transposed forms)
+    SHAPES = [(2, 64, 64, 256), (2, 64, 128, 256), (2, 128, 64, 256), (2, 64, 128, 128), (2, 128, 128, 128), (2, 128, 196, 64), (2, 196, 128, 64),
+              (2, 64, 64, 128), (3, 64, 64, 16), (3, 64, 64, 32)]
 out = []
 for dims, cin, cout, S in SHAPES:
     g = torch.Generator().manual_seed(cin + cout + S)
@@ -58,6 +61,18 @@ for dims, cin, cout, S in SHAPES:
         ys[mode] = y
     ops.WIDE_CONV_MODE = 'fused'
     rec['max_abs_diff'] = (ys['fused'] - ys['bmm']).abs().max().item()
+    if '--direct' in sys.argv:                                       # the direct implicit-GEMM kernel (no Winograd) on the same layer
+        wp = ops.pack_conv3x3(w)
+        for _ in range(3):
+            yd, _n = ops._conv3x3_raw(x, wp, b, cout, he, flags, True)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            yd, _n = ops._conv3x3_raw(x, wp, b, cout, he, flags, True)
+        e1.record()
+        torch.cuda.synchronize()
+        rec['direct'] = {'conv_ms': e0.elapsed_time(e1) / 10, 'max_abs_diff_vs_bmm': (yd - ys['bmm']).abs().max().item()}
     if CFGS:
         for cfg in range(5):
             if dims == 3 and cfg >= 3:
