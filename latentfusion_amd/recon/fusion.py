@@ -199,18 +199,21 @@ class GRUFuser(_ArgsFuser):
         if (not torch.is_grad_enabled() and z_obj.is_cuda and z_obj.shape[0] == 1 and z_obj.dim() == 6
                 and self.conv_module != EqualizedConv2d):
             return self._forward_inference(z_obj), {}
-        h = z_obj[:, 0]
+        # (unbind, not z_obj[:, i]: the backward of V selects is V zero-filled copies of the whole view stack plus V - 1
+        # full-size additions -- 1 GB each at 8 x 128^3 x 16; unbind's backward is one stack)
+        views = z_obj.unbind(1)
+        h = views[0]
         coords = (utils.get_normalized_pixel_coords(h) if self.conv_module == EqualizedConv2d
                   else utils.get_normalized_voxel_coords(h))
         if self.split_gates and self.gru.parts_ok(h, h):
             from .. import ops
             c16 = ops.empty_cl((h.shape[0], 16) + tuple(h.shape[2:]), h.device).zero_()
             c16[:, :3] = coords
-            for i in range(1, z_obj.shape[1]):
-                h = self.gru.forward_parts(z_obj[:, i], c16, h)
+            for v in views[1:]:
+                h = self.gru.forward_parts(v, c16, h)
             return h.unsqueeze(1), {}
-        for i in range(1, z_obj.shape[1]):
-            h = self.gru(torch.cat((z_obj[:, i], coords), dim=1), h)
+        for v in views[1:]:
+            h = self.gru(torch.cat((v, coords), dim=1), h)
         return h.unsqueeze(1), {}
 
     def _forward_inference(self, z_obj):
@@ -302,9 +305,10 @@ class LSTMFuser(_ArgsFuser):
         return {'in_channels': self.in_channels, 'cube_size': self.cube_size}
 
     def forward(self, z_obj, z_cam_mid, z_obj_mid, camera):
-        h = z_obj[:, 0]
+        views = z_obj.unbind(1)                                    # (one stack in the backward, see GRUFuser.forward)
+        h = views[0]
         c = torch.zeros_like(h)
         coords = utils.get_normalized_voxel_coords(h)
-        for i in range(1, z_obj.shape[1]):
-            h, c = self.lstm(torch.cat((z_obj[:, i], coords), dim=1), (h, c))
+        for v in views[1:]:
+            h, c = self.lstm(torch.cat((v, coords), dim=1), (h, c))
         return h.unsqueeze(1), {}
