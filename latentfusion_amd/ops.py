@@ -115,6 +115,39 @@ def _ptr(t):
     return t.data_ptr()
 
 
+class _SplitViews(torch.autograd.Function):
+    """(1, V, C, D, H, W) -> V tensors (1, C, D, H, W), like `unbind(1)`, for the fusers' walk over the views.  The point is
+    the backward: the V gradients are copied ONCE into a (V, C, D, H, W) channels-last block and handed back as its
+    (1, V, ...) view -- `unbind` / `z[:, i]` give a standard-layout stack that the view reshape and the producing kernels'
+    channels-last conversion then copy two more times (1 GB each at 8 x 128^3 x 16)."""
+
+    @staticmethod
+    def forward(ctx, z):
+        ctx.shape = tuple(z.shape)
+        return tuple(z[:, i] for i in range(z.shape[1]))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        B, V = ctx.shape[0], ctx.shape[1]
+        ref = next(g for g in grads if g is not None)
+        block = empty_cl((B * V,) + ctx.shape[2:], ref.device) if len(ctx.shape) == 6 else \
+            torch.empty((B * V,) + ctx.shape[2:], device=ref.device, dtype=ref.dtype, memory_format=torch.channels_last)
+        blk = block.view(B, V, *ctx.shape[2:])
+        for i, g in enumerate(grads):
+            if g is None:
+                blk[:, i].zero_()
+            else:
+                blk[:, i].copy_(g)
+        return blk
+
+
+def split_views(z):
+    """The views of a (B, V, C, [D,] H, W) stack as a tuple (autograd-friendly `unbind(1)`, see _SplitViews)."""
+    if z.dim() in (5, 6) and z.is_cuda and z.shape[0] == 1 and torch.is_grad_enabled() and z.requires_grad:
+        return _SplitViews.apply(z)
+    return z.unbind(1)
+
+
 # ---------------------------------------------------------------------------------------------
 # weight packing (host side, cached per parameter version)
 # ---------------------------------------------------------------------------------------------

@@ -199,9 +199,10 @@ class GRUFuser(_ArgsFuser):
         if (not torch.is_grad_enabled() and z_obj.is_cuda and z_obj.shape[0] == 1 and z_obj.dim() == 6
                 and self.conv_module != EqualizedConv2d):
             return self._forward_inference(z_obj), {}
-        # (unbind, not z_obj[:, i]: the backward of V selects is V zero-filled copies of the whole view stack plus V - 1
-        # full-size additions -- 1 GB each at 8 x 128^3 x 16; unbind's backward is one stack)
-        views = z_obj.unbind(1)
+        # (not z_obj[:, i]: the backward of V selects is V zero-filled copies of the whole view stack plus V - 1 full-size
+        # additions -- 1 GB each at 8 x 128^3 x 16; ops.split_views assembles the V gradients in one pass)
+        from .. import ops as _ops
+        views = _ops.split_views(z_obj)
         h = views[0]
         coords = (utils.get_normalized_pixel_coords(h) if self.conv_module == EqualizedConv2d
                   else utils.get_normalized_voxel_coords(h))
@@ -305,7 +306,8 @@ class LSTMFuser(_ArgsFuser):
         return {'in_channels': self.in_channels, 'cube_size': self.cube_size}
 
     def forward(self, z_obj, z_cam_mid, z_obj_mid, camera):
-        views = z_obj.unbind(1)                                    # (one stack in the backward, see GRUFuser.forward)
+        from .. import ops as _ops
+        views = _ops.split_views(z_obj)                            # (one pass in the backward, see GRUFuser.forward)
         h = views[0]
         c = torch.zeros_like(h)
         coords = utils.get_normalized_voxel_coords(h)
