@@ -23,7 +23,11 @@ import os
 import sys
 import time
 
-import torch
+# RCCL / device-tensor sharing between the ranks needs dmabuf IPC on this platform (hipIpcGetMemHandle fails with the legacy
+# mode); the driver exports this already -- keep it when bench.py is started from a bare environment
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
