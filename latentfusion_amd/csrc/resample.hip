@@ -516,6 +516,54 @@ int g_bwd_coef_variant = 2;   // lean coefficient gradient: 1 = one sub-tile in 
                               // 3 = as 2 with a 128-register cap, 4 / 5 = one in flight capped at 6 / 8 waves/SIMD
 int g_resample_variant = 3;   // 1 = generic kernels, 2 = lean kernels, 3 = lean + 16-channel gather (lf_set_tuning)
 
+// Sample evaluation for the deterministic splats with floating-point contraction OFF: every operation is rounded on its own,
+// so the kernels that must agree with each other -- the bounding-box pass and the tile pass of the tiled form (a corner voxel
+// outside its block's box would be dropped), and the tiled and the atomic form -- get the same corner indices, fractions and
+// weights no matter how the surrounding code is scheduled (with contraction on, the backend fuses multiply-adds per call site).
+struct SplatTap { int x0, y0, z0, x1, y1, z1; float w[8]; };     // w index = z*4 + y*2 + x
+
+template <int KIND>
+__device__ __forceinline__ SplatTap splat_eval(const float* __restrict__ cf, int x, int y, int z, int W, int H, int D, Steps st) {
+#pragma clang fp contract(off)
+  const float a = (x < W / 2) ? st.w * (float)x : 1.f - st.w * (float)(W - 1 - x);
+  const float b = (y < H / 2) ? st.h * (float)y : 1.f - st.h * (float)(H - 1 - y);
+  const float k = (z < D / 2) ? st.d * (float)z : 1.f - st.d * (float)(D - 1 - z);
+  float g[3];
+  if (KIND == LF_MAP_O2C) {
+    const float ak = a * k, bk = b * k;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) g[c] = ((((cf[c] + cf[3 + c] * a) + cf[6 + c] * b) + cf[9 + c] * k) + cf[12 + c] * ak) + cf[15 + c] * bk;
+  } else {
+    const float lx = 2.f * a - 1.f, ly = 2.f * b - 1.f, lz = 2.f * k - 1.f;
+    const float n0 = ((cf[0] * lx + cf[1] * ly) + cf[2] * lz) + cf[3];
+    const float n1 = ((cf[4] * lx + cf[5] * ly) + cf[6] * lz) + cf[7];
+    const float n2 = ((cf[8] * lx + cf[9] * ly) + cf[10] * lz) + cf[11];
+    const float dn = ((cf[12] * lx + cf[13] * ly) + cf[14] * lz) + cf[15];
+    g[0] = n0 / dn;
+    g[1] = n1 / dn;
+    g[2] = n2;
+  }
+  const int size[3] = {W, H, D};
+  int i0[3], i1[3];
+  float t[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float p = ((g[c] + 1.f) * (float)size[c] - 1.f) * 0.5f;         // grid_sampler_unnormalize (align_corners=False)
+    p = fminf(fmaxf(p, 0.f), (float)(size[c] - 1));                 // border clip
+    if (!(p == p)) p = 0.f;                                         // NaN samples voxel 0 (ATen clip semantics)
+    const float f = floorf(p);
+    t[c] = p - f;
+    i0[c] = (int)f;
+    i1[c] = min(i0[c] + 1, size[c] - 1);
+  }
+  SplatTap s;
+  s.x0 = i0[0]; s.y0 = i0[1]; s.z0 = i0[2]; s.x1 = i1[0]; s.y1 = i1[1]; s.z1 = i1[2];
+  const float wx[2] = {1.f - t[0], t[0]}, wy[2] = {1.f - t[1], t[1]}, wz[2] = {1.f - t[2], t[2]};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s.w[i] = (wx[i & 1] * wy[(i >> 1) & 1]) * wz[i >> 2];
+  return s;
+}
+
 // ---- deterministic splat: the same scatter, accumulated in 64-bit fixed point ----------------------------------
 // Float atomics make the result depend on the order in which the hardware retires them.  Integer addition is
 // associative, so accumulating round(contribution * 2^K) with 64-bit integer atomics gives bit-identical results
@@ -552,18 +600,15 @@ __global__ void __launch_bounds__(256) resample_bwd_vol_fixed_kernel(
     const int x = (int)(v % W); v /= W;
     const int y = (int)(v % H);
     const int z = (int)(v / H);
-    float gx, gy, gz, a, b, k;
-    eval_grid<KIND>(cf, x, y, z, W, H, D, st, gx, gy, gz, a, b, k);
-    const Tap t = make_tap(gx, gy, gz, W, H, D);
+    const SplatTap t = splat_eval<KIND>(cf, x, y, z, W, H, D, st);
     const float go = gout[(long)n * per_sample + idx] * scale;   // exact: power-of-two scale
     unsigned long long* base = acc + (long)n * acc_bstride + c;
     const long sW = C, sH = (long)W * C, sD = (long)H * W * C;
-    const float wx1 = t.tx, wx0 = 1.f - t.tx, wy1 = t.ty, wy0 = 1.f - t.ty, wz1 = t.tz, wz0 = 1.f - t.tz;
-#define SPLAT(Z, Y, X, WGT) atomicAdd(base + (Z) * sD + (Y) * sH + (X) * sW, (unsigned long long)__float2ll_rn(go * (WGT)))
-    SPLAT(t.z0, t.y0, t.x0, wx0 * wy0 * wz0); SPLAT(t.z0, t.y0, t.x1, wx1 * wy0 * wz0);
-    SPLAT(t.z0, t.y1, t.x0, wx0 * wy1 * wz0); SPLAT(t.z0, t.y1, t.x1, wx1 * wy1 * wz0);
-    SPLAT(t.z1, t.y0, t.x0, wx0 * wy0 * wz1); SPLAT(t.z1, t.y0, t.x1, wx1 * wy0 * wz1);
-    SPLAT(t.z1, t.y1, t.x0, wx0 * wy1 * wz1); SPLAT(t.z1, t.y1, t.x1, wx1 * wy1 * wz1);
+#define SPLAT(Z, Y, X, WI) atomicAdd(base + (Z) * sD + (Y) * sH + (X) * sW, (unsigned long long)__float2ll_rn(go * t.w[WI]))
+    SPLAT(t.z0, t.y0, t.x0, 0); SPLAT(t.z0, t.y0, t.x1, 1);
+    SPLAT(t.z0, t.y1, t.x0, 2); SPLAT(t.z0, t.y1, t.x1, 3);
+    SPLAT(t.z1, t.y0, t.x0, 4); SPLAT(t.z1, t.y0, t.x1, 5);
+    SPLAT(t.z1, t.y1, t.x0, 6); SPLAT(t.z1, t.y1, t.x1, 7);
 #undef SPLAT
   }
 }
@@ -574,6 +619,123 @@ __global__ void __launch_bounds__(256) fixed_to_float_kernel(const long long* __
   if (i >= n) return;
   out[i] = (float)((double)acc[i] / (double)fixed_scale(amax));
 }
+
+// ---- the same sums without global atomics (C == 16): every SOURCE tile is owned by one workgroup ---------------------
+// The fixed-point scatter above is bound by the L2's atomic units (2.1e9 64-bit atomics per 8 x 128^3 x 16 launch: 16-19 ms,
+// a quarter of a training step).  Integer addition being associative, the same totals can be formed in any grouping:
+//   pass 1  one wave per 4x4x4 block of OUTPUT voxels: bounding box of the (clamped) corner voxels its samples touch;
+//   pass 2  one workgroup per 4x8x8 tile of SOURCE voxels: 64-bit accumulators for the tile in LDS (32 KB); it tests every
+//           output block's box against its tile (a ballot per 64 blocks; ~130 M box tests per view, cheap), re-evaluates the
+//           samples of the blocks that touch it and adds the contributions that land inside the tile with LDS atomics;
+//           border clamping needs no special case (the boxes are boxes of clamped indices); with one volume shared by all
+//           samples (vol_n == 1) the workgroup walks all samples, so their contributions meet in the same accumulators;
+//           finally the tile is converted and written with plain stores.
+// Same quantisation, same integer totals, same conversion => bit-identical to the atomic kernel.
+constexpr int STZ = 4, STY = 8, STX = 8;                          // source tile owned by a workgroup: 256 voxels
+
+template <int KIND>
+__global__ void __launch_bounds__(256) splat_bbox_kernel(const float* __restrict__ coef, uint3* __restrict__ bbox, int nblk, int nbx,
+                                                         int nby, int D, int H, int W, Steps st) {
+  const int lane = threadIdx.x & 63;
+  const int blk = blockIdx.x * 4 + (threadIdx.x >> 6), n = blockIdx.y;
+  if (blk >= nblk) return;                                        // (wave-uniform)
+  const int bx = blk % nbx, by = (blk / nbx) % nby, bz = blk / (nbx * nby);
+  const int x = bx * 4 + (lane & 3), y = by * 4 + ((lane >> 2) & 3), z = bz * 4 + (lane >> 4);
+  const bool live = x < W && y < H && z < D;
+  const SplatTap t = splat_eval<KIND>(coef + (long)n * LF_MAP_COEFS, live ? x : 0, live ? y : 0, live ? z : 0, W, H, D, st);
+  int lo[3] = {live ? t.x0 : 0x7fff, live ? t.y0 : 0x7fff, live ? t.z0 : 0x7fff};
+  int hi[3] = {live ? t.x1 : -1, live ? t.y1 : -1, live ? t.z1 : -1};
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      lo[c] = min(lo[c], __shfl_xor(lo[c], o, 64));
+      hi[c] = max(hi[c], __shfl_xor(hi[c], o, 64));
+    }
+  if (lane == 0)                                                  // (an empty block: lo = 0x7fff > hi = 0xffff as signed 16 bit = -1)
+    bbox[(long)n * nblk + blk] = make_uint3((unsigned)lo[0] | ((unsigned)(hi[0] & 0xffff) << 16), (unsigned)lo[1] | ((unsigned)(hi[1] & 0xffff) << 16),
+                                            (unsigned)lo[2] | ((unsigned)(hi[2] & 0xffff) << 16));
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(256) splat_tile_kernel(const float* __restrict__ gout, const float* __restrict__ coef,
+                                                         const uint3* __restrict__ bbox, const unsigned* __restrict__ amax,
+                                                         float* __restrict__ gvol, int vol_n, int N, int nblk, int nbx, int nby, int ntx,
+                                                         int nty, int D, int H, int W, Steps st) {
+  __shared__ unsigned long long acc[STZ * STY * STX * 16];         // 32 KB
+  __shared__ unsigned long long masks[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile = blockIdx.x;
+  const int tx0 = (tile % ntx) * STX, ty0 = ((tile / ntx) % nty) * STY, tz0 = (tile / (ntx * nty)) * STZ;
+  for (int i = tid; i < STZ * STY * STX * 16; i += 256) acc[i] = 0ull;
+  const float scale = fixed_scale(amax);
+  const long nvox = (long)D * H * W;
+  const int q = tid & 3, v = tid >> 2;                             // lane quad = one output voxel of the block, 4 channels each
+  const int px = v & 3, py = (v >> 2) & 3, pz = v >> 4;
+  const int n_first = vol_n == 1 ? 0 : blockIdx.y, n_last = vol_n == 1 ? N : blockIdx.y + 1;
+  __syncthreads();
+  for (int n = n_first; n < n_last; ++n) {
+    const float* cf = coef + (long)n * LF_MAP_COEFS;
+    const float* gs = gout + (long)n * nvox * 16;
+    const uint3* bb = bbox + (long)n * nblk;
+    for (int base = 0; base < nblk; base += 256) {
+      bool hit = false;
+      if (base + tid < nblk) {
+        const uint3 r = bb[base + tid];
+        const int x0 = (short)(r.x & 0xffff), x1 = (short)(r.x >> 16), y0 = (short)(r.y & 0xffff), y1 = (short)(r.y >> 16),
+                  z0 = (short)(r.z & 0xffff), z1 = (short)(r.z >> 16);
+        hit = x0 < tx0 + STX && x1 >= tx0 && y0 < ty0 + STY && y1 >= ty0 && z0 < tz0 + STZ && z1 >= tz0;
+      }
+      const unsigned long long m = __ballot(hit);
+      if (lane == 0) masks[wave] = m;
+      __syncthreads();
+#pragma unroll 1
+      for (int w = 0; w < 4; ++w) {
+        unsigned long long mm = masks[w];                          // (workgroup-uniform)
+        while (mm) {
+          const int bit = __builtin_ctzll(mm);
+          mm &= mm - 1;
+          const int blk = base + w * 64 + bit;
+          const int bx = blk % nbx, by = (blk / nbx) % nby, bz = blk / (nbx * nby);
+          const int x = bx * 4 + px, y = by * 4 + py, z = bz * 4 + pz;
+          if (x < W && y < H && z < D) {
+            const SplatTap t = splat_eval<KIND>(cf, x, y, z, W, H, D, st);
+            const f32x4 g4 = *(const f32x4*)(gs + (((long)z * H + y) * W + x) * 16 + q * 4);
+#define SPLAT_T(Z, Y, X, WI) do { \
+              const int lz_ = (Z) - tz0, ly_ = (Y) - ty0, lx_ = (X) - tx0; \
+              if ((unsigned)lz_ < (unsigned)STZ && (unsigned)ly_ < (unsigned)STY && (unsigned)lx_ < (unsigned)STX) { \
+                unsigned long long* d_ = acc + ((lz_ * STY + ly_) * STX + lx_) * 16 + q * 4; \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) atomicAdd(d_ + e, (unsigned long long)__float2ll_rn((g4[e] * scale) * t.w[WI])); \
+              } } while (0)
+            SPLAT_T(t.z0, t.y0, t.x0, 0); SPLAT_T(t.z0, t.y0, t.x1, 1);
+            SPLAT_T(t.z0, t.y1, t.x0, 2); SPLAT_T(t.z0, t.y1, t.x1, 3);
+            SPLAT_T(t.z1, t.y0, t.x0, 4); SPLAT_T(t.z1, t.y0, t.x1, 5);
+            SPLAT_T(t.z1, t.y1, t.x0, 6); SPLAT_T(t.z1, t.y1, t.x1, 7);
+#undef SPLAT_T
+          }
+        }
+      }
+      __syncthreads();                                             // masks[] is rewritten by the next chunk
+    }
+  }
+  __syncthreads();
+  // the tile: one thread per voxel, 16 channels = 4 float4 stores
+  const int lx = tid % STX, ly = (tid / STX) % STY, lz = tid / (STX * STY);
+  const int x = tx0 + lx, y = ty0 + ly, z = tz0 + lz;
+  if (x < W && y < H && z < D) {
+    float* dst = gvol + (vol_n == 1 ? 0 : (long)blockIdx.y * nvox * 16) + (((long)z * H + y) * W + x) * 16;
+    const double inv = (double)scale;
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) {
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (float)((double)(long long)acc[tid * 16 + c4 * 4 + e] / inv);
+      *(f32x4*)(dst + c4 * 4) = o;
+    }
+  }
+}
+
+int g_splat_variant = 2;      // deterministic splat (lf_set_tuning key 4): 1 = global 64-bit atomics, 2 = source tiles in LDS (C == 16)
 
 bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
@@ -717,6 +879,11 @@ extern "C" int lf_set_tuning(int key, int value) {
     if (value >= 1 && value <= 3) g_resample_variant = value;
     return prev;
   }
+  if (key == 4) {
+    const int prev = g_splat_variant;
+    if (value == 1 || value == 2) g_splat_variant = value;
+    return prev;
+  }
   if (key == 3) return lf_internal_fused_set_cfg(value);            // fused wide-conv GEMM: workgroup shape 0..3, -1 = by shape
   if (key == 2) {
     const int prev = g_bwd_coef_variant;
@@ -742,11 +909,36 @@ extern "C" int lf_resample3d_bwd_vol_det(const float* gout, const float* coef, i
   if (scratch == nullptr || scratch_bytes < lf_resample3d_bwd_vol_det_scratch_bytes(vol_n, D, H, W, C)) return LF_ENOSPC;
   if ((((uintptr_t)scratch) & 7u) != 0) return LF_EALIGN;
   hipStream_t s = (hipStream_t)stream;
+  const long ng = items * N;
+  const int nbx = (W + 3) / 4, nby = (H + 3) / 4, nbz = (D + 3) / 4;
+  const long nblk = (long)nbx * nby * nbz;
+  const int ntx = (W + STX - 1) / STX, nty = (H + STY - 1) / STY, ntz = (D + STZ - 1) / STZ;
+  if (g_splat_variant == 2 && C == 16 && lf_aligned16(gout) && lf_aligned16(gvol) && D < 0x7fff && H < 0x7fff && W < 0x7fff &&
+      nblk < 0x7fffffffL / 4 && (long)ntx * nty * ntz < 0x7fffffffL && N <= 65535 &&
+      scratch_bytes >= 256 + (size_t)N * nblk * sizeof(uint3)) {
+    // tiled form: scratch = [amax (256 B)] [bounding boxes: N x blocks x 12 B]
+    unsigned* amax = (unsigned*)scratch;
+    uint3* bbox = (uint3*)((char*)scratch + 256);
+    hipError_t e = hipMemsetAsync(scratch, 0, 256, s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)min((ng + 255) / 256, 4096L)), dim3(256), 0, s, gout, ng, amax);
+    const Steps stp = make_steps(D, H, W);
+    const dim3 gb((unsigned)((nblk + 3) / 4), (unsigned)N), gt((unsigned)((long)ntx * nty * ntz), (unsigned)vol_n);
+    if (kind == LF_MAP_O2C) {
+      hipLaunchKernelGGL((splat_bbox_kernel<LF_MAP_O2C>), gb, dim3(256), 0, s, coef, bbox, (int)nblk, nbx, nby, D, H, W, stp);
+      hipLaunchKernelGGL((splat_tile_kernel<LF_MAP_O2C>), gt, dim3(256), 0, s, gout, coef, bbox, amax, gvol, vol_n, N, (int)nblk, nbx, nby,
+                         ntx, nty, D, H, W, stp);
+    } else {
+      hipLaunchKernelGGL((splat_bbox_kernel<LF_MAP_C2O>), gb, dim3(256), 0, s, coef, bbox, (int)nblk, nbx, nby, D, H, W, stp);
+      hipLaunchKernelGGL((splat_tile_kernel<LF_MAP_C2O>), gt, dim3(256), 0, s, gout, coef, bbox, amax, gvol, vol_n, N, (int)nblk, nbx, nby,
+                         ntx, nty, D, H, W, stp);
+    }
+    return lf_launch_status();
+  }
   unsigned long long* acc = (unsigned long long*)scratch;
   unsigned* amax = (unsigned*)((char*)scratch + (size_t)total * sizeof(long long));
   hipError_t e = hipMemsetAsync(scratch, 0, (size_t)total * sizeof(long long) + 256, s);
   if (e != hipSuccess) return (int)e;
-  const long ng = items * N;
   hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)min((ng + 255) / 256, 4096L)), dim3(256), 0, s, gout, ng, amax);
   int st = lf_launch_status();
   if (st) return st;

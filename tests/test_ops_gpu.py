@@ -332,6 +332,40 @@ def test_resize_vs_torch(dims, mode, factor, S, C):
     close(xd.grad, x.grad, atol=1e-5)
 
 
+@pytest.mark.parametrize('S', [(20, 24, 40), (9, 13, 7), (32, 32, 32)])
+def test_volume_splat_tiled_equals_atomic(golden, S):
+    """lf_resample3d_bwd_vol_det at C = 16: the source-tile form (LDS accumulators, no global atomics; lf_set_tuning key 4 = 2,
+    default) gives bit-identical results to the global-atomic form (key 4 = 1) -- both add the same integers -- for both map
+    kinds, shared and per-sample volumes, extents that do not fill the 4x8x8 tiles / 4x4x4 blocks, and cameras whose samples
+    leave the volume (border clamping)."""
+    import ctypes
+    from latentfusion_amd import _lib, ops
+    from latentfusion_amd.modules.geometry import c2o_coefficients, o2c_coefficients
+    L = _lib.lib()
+    L.lf_set_tuning.restype = ctypes.c_int
+    L.lf_set_tuning.argtypes = [ctypes.c_int, ctypes.c_int]
+    cam = prod_camera(golden('g2_resample')['cam'])
+    D, H, W = S
+    g = torch.Generator().manual_seed(sum(S))
+    try:
+        for kind, coef in (('o2c', o2c_coefficients(cam, 1.0)), ('c2o', c2o_coefficients(cam, 1.0))):
+            for vol_n in (1, len(cam)):
+                vol = torch.randn(vol_n, 16, D, H, W, generator=g).to(DEV)
+                gout = (torch.randn(len(cam), 16, D, H, W, generator=g) * 1e-3).to(DEV)
+                fn = ops.resample_o2c if kind == 'o2c' else ops.resample_c2o
+                grads = []
+                for variant in (1, 2, 2):
+                    L.lf_set_tuning(4, variant)
+                    v = vol.clone().requires_grad_(True)
+                    src = v.expand(len(cam), -1, -1, -1, -1) if vol_n == 1 else v
+                    fn(src, coef.to(DEV)).backward(gout)
+                    grads.append(v.grad.clone())
+                assert grads[0].abs().max().item() > 0
+                assert torch.equal(grads[0], grads[1]) and torch.equal(grads[1], grads[2]), (kind, vol_n)
+    finally:
+        L.lf_set_tuning(4, 2)
+
+
 @pytest.mark.parametrize('mode,padding', [('bilinear', 'zeros'), ('bilinear', 'border'), ('nearest', 'zeros'),
                                           ('nearest', 'border')])
 def test_grid_sample2d_vs_torch(mode, padding):
@@ -379,4 +413,8 @@ def test_volume_splat_is_deterministic(golden):
                 grads.setdefault(det, []).append(v.grad.clone())
             assert torch.equal(grads[True][0], grads[True][1]), (kind, vol_n)
             scale = grads[False][0].abs().max().item()
-            close(grads[True][0], grads[False][0], atol=2e-6 * scale, rtol=1e-4)
+            # (the deterministic kernels evaluate the sample positions with fp contraction off, the atomic-float kernel with
+            # the compiler's fused multiply-adds: a sample within one rounding of a cell boundary can move a corner, i.e.
+            # one contribution of size |gout| x weight ~ 1e-6 x scale -- 47 of 512,000 elements on this fixture)
+            d = (grads[True][0] - grads[False][0]).abs()
+            assert d.max().item() < 1e-5 * scale and (d > 2e-6 * scale).float().mean().item() < 1e-3
