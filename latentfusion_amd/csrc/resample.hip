@@ -624,8 +624,9 @@ __global__ void __launch_bounds__(256) fixed_to_float_kernel(const long long* __
 // The fixed-point scatter above is bound by the L2's atomic units (2.1e9 64-bit atomics per 8 x 128^3 x 16 launch: 16-19 ms,
 // a quarter of a training step).  Integer addition being associative, the same totals can be formed in any grouping:
 //   pass 1  one wave per 4x4x4 block of OUTPUT voxels: bounding box of the (clamped) corner voxels its samples touch;
-//   pass 2  one workgroup per 4x8x8 tile of SOURCE voxels: 64-bit accumulators for the tile in LDS (32 KB); it tests every
-//           output block's box against its tile (a ballot per 64 blocks; ~130 M box tests per view, cheap), re-evaluates the
+//   pass 2  one workgroup per 4x8x8 tile of SOURCE voxels: 64-bit accumulators for the tile in LDS (32 KB); it culls the
+//           output blocks in two levels (boxes of 16^3 super-blocks, then the 64 block boxes of those that overlap; a
+//           ballot per 64 boxes, every wave redundantly: no exchange, no barriers), re-evaluates the
 //           samples of the blocks that touch it and adds the contributions that land inside the tile with LDS atomics;
 //           border clamping needs no special case (the boxes are boxes of clamped indices); with one volume shared by all
 //           samples (vol_n == 1) the workgroup walks all samples, so their contributions meet in the same accumulators;
@@ -657,14 +658,41 @@ __global__ void __launch_bounds__(256) splat_bbox_kernel(const float* __restrict
                                             (unsigned)lo[2] | ((unsigned)(hi[2] & 0xffff) << 16));
 }
 
+// union of the boxes of the 4x4x4 blocks of a super-block (16^3 output voxels): one wave per super-block
+__global__ void __launch_bounds__(256) splat_bbox2_kernel(const uint3* __restrict__ bbox, uint3* __restrict__ sbox, int nblk, int nsb,
+                                                          int nbx, int nby, int nbz, int nsx, int nsy) {
+  const int lane = threadIdx.x & 63;
+  const int sb = blockIdx.x * 4 + (threadIdx.x >> 6), n = blockIdx.y;
+  if (sb >= nsb) return;                                          // (wave-uniform)
+  const int bx = (sb % nsx) * 4 + (lane & 3), by = ((sb / nsx) % nsy) * 4 + ((lane >> 2) & 3), bz = (sb / (nsx * nsy)) * 4 + (lane >> 4);
+  int lo[3] = {0x7fff, 0x7fff, 0x7fff}, hi[3] = {-1, -1, -1};
+  if (bx < nbx && by < nby && bz < nbz) {
+    const uint3 r = bbox[(long)n * nblk + ((long)bz * nby + by) * nbx + bx];
+    lo[0] = (short)(r.x & 0xffff); hi[0] = (short)(r.x >> 16);
+    lo[1] = (short)(r.y & 0xffff); hi[1] = (short)(r.y >> 16);
+    lo[2] = (short)(r.z & 0xffff); hi[2] = (short)(r.z >> 16);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      lo[c] = min(lo[c], __shfl_xor(lo[c], o, 64));
+      hi[c] = max(hi[c], __shfl_xor(hi[c], o, 64));
+    }
+  if (lane == 0)
+    sbox[(long)n * nsb + sb] = make_uint3((unsigned)(lo[0] & 0xffff) | ((unsigned)(hi[0] & 0xffff) << 16),
+                                          (unsigned)(lo[1] & 0xffff) | ((unsigned)(hi[1] & 0xffff) << 16),
+                                          (unsigned)(lo[2] & 0xffff) | ((unsigned)(hi[2] & 0xffff) << 16));
+}
+
 template <int KIND>
 __global__ void __launch_bounds__(256) splat_tile_kernel(const float* __restrict__ gout, const float* __restrict__ coef,
-                                                         const uint3* __restrict__ bbox, const unsigned* __restrict__ amax,
-                                                         float* __restrict__ gvol, int vol_n, int N, int nblk, int nbx, int nby, int ntx,
-                                                         int nty, int D, int H, int W, Steps st) {
+                                                         const uint3* __restrict__ bbox, const uint3* __restrict__ sbox,
+                                                         const unsigned* __restrict__ amax, float* __restrict__ gvol, int vol_n, int N,
+                                                         int nblk, int nsb, int nbx, int nby, int nbz, int nsx, int nsy, int ntx, int nty,
+                                                         int D, int H, int W, Steps st) {
   __shared__ unsigned long long acc[STZ * STY * STX * 16];         // 32 KB
-  __shared__ unsigned long long masks[4];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int tile = blockIdx.x;
   const int tx0 = (tile % ntx) * STX, ty0 = ((tile / ntx) % nty) * STY, tz0 = (tile / (ntx * nty)) * STZ;
   for (int i = tid; i < STZ * STY * STX * 16; i += 256) acc[i] = 0ull;
@@ -673,30 +701,33 @@ __global__ void __launch_bounds__(256) splat_tile_kernel(const float* __restrict
   const int q = tid & 3, v = tid >> 2;                             // lane quad = one output voxel of the block, 4 channels each
   const int px = v & 3, py = (v >> 2) & 3, pz = v >> 4;
   const int n_first = vol_n == 1 ? 0 : blockIdx.y, n_last = vol_n == 1 ? N : blockIdx.y + 1;
+  auto overlaps = [&](const uint3 r) {
+    const int x0 = (short)(r.x & 0xffff), x1 = (short)(r.x >> 16), y0 = (short)(r.y & 0xffff), y1 = (short)(r.y >> 16),
+              z0 = (short)(r.z & 0xffff), z1 = (short)(r.z >> 16);
+    return x0 < tx0 + STX && x1 >= tx0 && y0 < ty0 + STY && y1 >= ty0 && z0 < tz0 + STZ && z1 >= tz0;
+  };
   __syncthreads();
+  // Two-level culling, done redundantly by every wave (same data -> same masks -> same walk; no LDS exchange, no barriers:
+  // the LDS atomics commute): 64 super-block boxes per test, then the 64 block boxes of a super-block that overlaps the tile.
   for (int n = n_first; n < n_last; ++n) {
     const float* cf = coef + (long)n * LF_MAP_COEFS;
     const float* gs = gout + (long)n * nvox * 16;
     const uint3* bb = bbox + (long)n * nblk;
-    for (int base = 0; base < nblk; base += 256) {
-      bool hit = false;
-      if (base + tid < nblk) {
-        const uint3 r = bb[base + tid];
-        const int x0 = (short)(r.x & 0xffff), x1 = (short)(r.x >> 16), y0 = (short)(r.y & 0xffff), y1 = (short)(r.y >> 16),
-                  z0 = (short)(r.z & 0xffff), z1 = (short)(r.z >> 16);
-        hit = x0 < tx0 + STX && x1 >= tx0 && y0 < ty0 + STY && y1 >= ty0 && z0 < tz0 + STZ && z1 >= tz0;
-      }
-      const unsigned long long m = __ballot(hit);
-      if (lane == 0) masks[wave] = m;
-      __syncthreads();
-#pragma unroll 1
-      for (int w = 0; w < 4; ++w) {
-        unsigned long long mm = masks[w];                          // (workgroup-uniform)
-        while (mm) {
-          const int bit = __builtin_ctzll(mm);
-          mm &= mm - 1;
-          const int blk = base + w * 64 + bit;
-          const int bx = blk % nbx, by = (blk / nbx) % nby, bz = blk / (nbx * nby);
+    const uint3* sbb = sbox + (long)n * nsb;
+    for (int sbase = 0; sbase < nsb; sbase += 64) {
+      unsigned long long sm = __ballot(sbase + lane < nsb && overlaps(sbb[min(sbase + lane, nsb - 1)]));
+      while (sm) {
+        const int sbit = __builtin_ctzll(sm);
+        sm &= sm - 1;
+        const int sb = sbase + sbit;
+        const int cbx = (sb % nsx) * 4 + (lane & 3), cby = ((sb / nsx) % nsy) * 4 + ((lane >> 2) & 3), cbz = (sb / (nsx * nsy)) * 4 + (lane >> 4);
+        const bool cok = cbx < nbx && cby < nby && cbz < nbz;
+        const long cid = ((long)cbz * nby + cby) * nbx + cbx;
+        unsigned long long cm = __ballot(cok && overlaps(bb[cok ? cid : 0]));
+        while (cm) {
+          const int cbit = __builtin_ctzll(cm);
+          cm &= cm - 1;
+          const int bx = (sb % nsx) * 4 + (cbit & 3), by = ((sb / nsx) % nsy) * 4 + ((cbit >> 2) & 3), bz = (sb / (nsx * nsy)) * 4 + (cbit >> 4);
           const int x = bx * 4 + px, y = by * 4 + py, z = bz * 4 + pz;
           if (x < W && y < H && z < D) {
             const SplatTap t = splat_eval<KIND>(cf, x, y, z, W, H, D, st);
@@ -715,7 +746,6 @@ __global__ void __launch_bounds__(256) splat_tile_kernel(const float* __restrict
           }
         }
       }
-      __syncthreads();                                             // masks[] is rewritten by the next chunk
     }
   }
   __syncthreads();
@@ -913,26 +943,31 @@ extern "C" int lf_resample3d_bwd_vol_det(const float* gout, const float* coef, i
   const int nbx = (W + 3) / 4, nby = (H + 3) / 4, nbz = (D + 3) / 4;
   const long nblk = (long)nbx * nby * nbz;
   const int ntx = (W + STX - 1) / STX, nty = (H + STY - 1) / STY, ntz = (D + STZ - 1) / STZ;
+  const int nsx = (nbx + 3) / 4, nsy = (nby + 3) / 4, nsz = (nbz + 3) / 4, nsb = nsx * nsy * nsz;
   if (g_splat_variant == 2 && C == 16 && lf_aligned16(gout) && lf_aligned16(gvol) && D < 0x7fff && H < 0x7fff && W < 0x7fff &&
       nblk < 0x7fffffffL / 4 && (long)ntx * nty * ntz < 0x7fffffffL && N <= 65535 &&
-      scratch_bytes >= 256 + (size_t)N * nblk * sizeof(uint3)) {
-    // tiled form: scratch = [amax (256 B)] [bounding boxes: N x blocks x 12 B]
+      scratch_bytes >= 256 + (size_t)N * (nblk + nsb) * sizeof(uint3)) {
+    // tiled form: scratch = [amax (256 B)] [block boxes: N x blocks x 12 B] [super-block boxes: N x super-blocks x 12 B]
     unsigned* amax = (unsigned*)scratch;
     uint3* bbox = (uint3*)((char*)scratch + 256);
+    uint3* sbox = bbox + (size_t)N * nblk;
     hipError_t e = hipMemsetAsync(scratch, 0, 256, s);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)min((ng + 255) / 256, 4096L)), dim3(256), 0, s, gout, ng, amax);
     const Steps stp = make_steps(D, H, W);
-    const dim3 gb((unsigned)((nblk + 3) / 4), (unsigned)N), gt((unsigned)((long)ntx * nty * ntz), (unsigned)vol_n);
-    if (kind == LF_MAP_O2C) {
+    const dim3 gb((unsigned)((nblk + 3) / 4), (unsigned)N), gs2((unsigned)((nsb + 3) / 4), (unsigned)N),
+        gt((unsigned)((long)ntx * nty * ntz), (unsigned)vol_n);
+    if (kind == LF_MAP_O2C)
       hipLaunchKernelGGL((splat_bbox_kernel<LF_MAP_O2C>), gb, dim3(256), 0, s, coef, bbox, (int)nblk, nbx, nby, D, H, W, stp);
-      hipLaunchKernelGGL((splat_tile_kernel<LF_MAP_O2C>), gt, dim3(256), 0, s, gout, coef, bbox, amax, gvol, vol_n, N, (int)nblk, nbx, nby,
-                         ntx, nty, D, H, W, stp);
-    } else {
+    else
       hipLaunchKernelGGL((splat_bbox_kernel<LF_MAP_C2O>), gb, dim3(256), 0, s, coef, bbox, (int)nblk, nbx, nby, D, H, W, stp);
-      hipLaunchKernelGGL((splat_tile_kernel<LF_MAP_C2O>), gt, dim3(256), 0, s, gout, coef, bbox, amax, gvol, vol_n, N, (int)nblk, nbx, nby,
-                         ntx, nty, D, H, W, stp);
-    }
+    hipLaunchKernelGGL(splat_bbox2_kernel, gs2, dim3(256), 0, s, bbox, sbox, (int)nblk, nsb, nbx, nby, nbz, nsx, nsy);
+    if (kind == LF_MAP_O2C)
+      hipLaunchKernelGGL((splat_tile_kernel<LF_MAP_O2C>), gt, dim3(256), 0, s, gout, coef, bbox, sbox, amax, gvol, vol_n, N, (int)nblk, nsb,
+                         nbx, nby, nbz, nsx, nsy, ntx, nty, D, H, W, stp);
+    else
+      hipLaunchKernelGGL((splat_tile_kernel<LF_MAP_C2O>), gt, dim3(256), 0, s, gout, coef, bbox, sbox, amax, gvol, vol_n, N, (int)nblk, nsb,
+                         nbx, nby, nbz, nsx, nsy, ntx, nty, D, H, W, stp);
     return lf_launch_status();
   }
   unsigned long long* acc = (unsigned long long*)scratch;
