@@ -341,6 +341,12 @@ int lf_grid_sample2d_bwd(const float* img, const float* grid, const float* gout,
 size_t lf_conv_bwd_weight_scratch_bytes(int dims, int N, int D, int H, int W, int Cin, int Cout);
 int lf_conv_bwd_weight(const float* x, const float* gpre, float* gw, void* scratch, size_t scratch_bytes,
                        int dims, int N, int D, int H, int W, int Cin, int Cout, float scale, void* stream);
+/* The same weight gradient on the bf16 MFMA (autocast policy of the training step; recon/models.py:199,405): x and gpre
+ * are rounded to bf16 (RNE) as they are staged -- the identity on operands the policy has already rounded -- products
+ * are exact, accumulation fp32, partials summed in a fixed order in fp64 like lf_conv_bwd_weight (same scratch size).
+ * 3-D 16 -> 16 layers with N*D*H*W >= 8192 only: LF_EINVAL otherwise (the caller keeps lf_conv_bwd_weight for the rest). */
+int lf_conv_bwd_weight_bf16(const float* x, const float* gpre, float* gw, void* scratch, size_t scratch_bytes,
+                            int dims, int N, int D, int H, int W, int Cin, int Cout, float scale, void* stream);
 
 /* Standalone PixelNorm over the last (channel) axis of [rows][C], in place allowed.
  * norm_out[rows] receives sqrt(mean+eps).  modules/__init__.py:14-15. */

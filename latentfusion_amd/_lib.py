@@ -83,6 +83,7 @@ SIGNATURES = {
     'lf_grid_sample2d_bwd': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     'lf_conv_bwd_weight_scratch_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     'lf_conv_bwd_weight': (c_int, [P, P, P, P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, P]),
+    'lf_conv_bwd_weight_bf16': (c_int, [P, P, P, P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, P]),
     'lf_pixelnorm_fwd': (c_int, [P, P, P, c_long, c_int, c_float, P]),
     'lf_epilogue_bwd': (c_int, [P, P, P, P, c_long, c_int, c_uint, c_float, P]),
     'lf_resize_fwd': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),

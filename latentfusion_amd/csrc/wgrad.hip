@@ -10,6 +10,7 @@
 // reduces a contiguous run of voxels for one (tap, 16x16 channel tile); block partials are summed in a
 // fixed order in fp64 by a second kernel, so the result does not depend on scheduling.
 // x == NULL stands for an all-ones single-channel input: gw[0][co][0] is then the bias gradient.
+#include <type_traits>
 #include "lf_common.h"
 
 namespace {
@@ -57,16 +58,35 @@ __global__ void __launch_bounds__(256) wgrad_partial_kernel(
   partial[(((long)blockIdx.x * gridDim.y + tap) * gridDim.z + blockIdx.z) * 256 + t] = s;
 }
 
-// gw[tap][co][ci] = scale * sum over blocks (fixed order, fp64)
+// gw[tap][co][ci] = scale * sum over blocks (fixed order, fp64).  grid (taps, channel tiles, 4): a workgroup sums 64 of a
+// tile's 256 outputs, four interleaved runs of blocks in parallel (one per wave, eight loads in flight each), combined
+// as (s0 + s1) + (s2 + s3): one serial walk per output took 60-120 us for 256-512 blocks, latency-bound.
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ gw,
                                                            int nblk, int taps, int ntiles, int ncit, int Cin, int Cout,
                                                            float scale) {
-  const int tap = blockIdx.x, tile = blockIdx.y, t = threadIdx.x;
+  const int tap = blockIdx.x, tile = blockIdx.y, t = blockIdx.z * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+  const long stride = (long)taps * ntiles * 256;
+  const float* src = partial + ((long)tap * ntiles + tile) * 256 + t;
   double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += (double)partial[(((long)b * taps + tap) * ntiles + tile) * 256 + t];
-  const int ct = tile / ncit, cit = tile - ct * ncit;
-  const int co = ct * 16 + (t >> 4), ci = cit * 16 + (t & 15);
-  if (co < Cout && ci < Cin) gw[((long)tap * Cout + co) * Cin + ci] = (float)(s * (double)scale);
+  int b = g;
+  for (; b + 28 < nblk; b += 32) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[(long)(b + 4 * u) * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += (double)v[u];
+  }
+  for (; b < nblk; b += 4) s += (double)src[(long)b * stride];
+  __shared__ double red[4][64];
+  red[g][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (g == 0) {
+    const int o = threadIdx.x;
+    const double tot = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
+    const int ct = tile / ncit, cit = tile - ct * ncit;
+    const int co = ct * 16 + (t >> 4), ci = cit * 16 + (t & 15);
+    if (co < Cout && ci < Cin) gw[((long)tap * Cout + co) * Cin + ci] = (float)(tot * (double)scale);
+  }
 }
 
 
@@ -189,6 +209,197 @@ __global__ void __launch_bounds__(512) wgrad3d_c16_kernel(
   }
 }
 
+// ---- the same product on the bf16 MFMA (autocast policy of the training step) ------------------------------------------
+// v_mfma_f32_16x16x32_bf16 contracts 32 voxels per instruction at 8x the fp32 MFMA's rate per voxel, but wants its K
+// run -- 8 consecutive voxels of ONE channel per lane -- where channels-last memory has 16 channels of one voxel: the
+// tile is transposed on its way into LDS.  A thread loads the same 16-byte quarter (4 channels) of TWO voxels adjacent
+// in x into registers, rounds to bf16 (RNE, v_cvt_pk_bf16_f32: the identity on operands autocast has already rounded),
+// and writes four dwords = the two voxels of each of its channels (v_perm) into channel-major planes:
+// x [16 ch][4][10][18 (+6)] and gpre [16 ch][2][8][16], channel strides padded to spread the planes over the banks.  A
+// lane then reads its 8-voxel K run with one ds_read_b128; the kx = 0, 1, 2 taps of a row come from the SAME five
+// dwords (kx = 2: a dword later; kx = 1: v_alignbyte).  Four waves; wave w owns the (kz, ky) stencil rows 2w, 2w+1 for all
+// eight 32-voxel K groups (2 rows x 16 voxels) of the tile and row 8 for K groups 2w, 2w+1: 54 MFMAs per wave and tile,
+// nine accumulators, and only row 8 is summed across waves (through LDS, fixed order) at the end.  Two workgroups per CU
+// (2 x 39 KB of LDS each: the next tile is loaded while this one is contracted, then converted).
+// Products of bf16 operands are exact in fp32 and accumulation is fp32 as on the fp32 kernel: same result up to
+// summation order.  Partials: one 27 x 256 block per workgroup, summed by wgrad_reduce_kernel (fixed order, fp64).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr int BRS = 48;                                          // bytes per halo row: 18 bf16 (+6)
+constexpr int BXS = WHZ * WHY * BRS + 16;                        // channel stride of the x planes (1936 B)
+constexpr int BGR = 32;                                          // bytes per gpre row: 16 bf16
+constexpr int BGS = WTZ * WTY * BGR + 16;                        // channel stride of the gpre planes (528 B)
+constexpr int BXB = 16 * BXS;                                    // 30,976 B
+constexpr int BBUF = BXB + 16 * BGS;                             // 39,424 B per buffer
+constexpr int BHP = WHALO / 2;                                   // 360 voxel pairs in the halo (18 is even: pairs never straddle rows)
+constexpr int BHIT = (BHP * 4 + 255) / 256;                      // 6 halo pair-pieces per thread and tile ...
+constexpr int BNIT = BHIT + (WTZ * WTY * WTX / 2) * 4 / 256;     // ... + 2 gpre pair-pieces
+
+__global__ void __launch_bounds__(256, 2) wgrad3d_c16_bf16_kernel(
+    const float* __restrict__ x, const float* __restrict__ gp, float* __restrict__ partial,
+    int N, int D, int H, int W, int tiles_x, int tiles_y, int tiles_z, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15, k = lane >> 4;
+  const int nb = gridDim.x;
+  const int lb = (nb % 8 == 0) ? (blockIdx.x % 8) * (nb / 8) + blockIdx.x / 8 : blockIdx.x;   // XCD-aware ranges
+  const int per = (ntiles + nb - 1) / nb;
+  const int t_begin = lb * per;
+  const int t_end = min(t_begin + per, ntiles);
+  const long nvox = (long)D * H * W;
+  const unsigned sample_bytes = (unsigned)(nvox * 64);
+
+  f32x4 acc[9];                                                  // rows 2w, 2w+1 (x 3 kx), then this wave's share of row 8
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (t_begin < t_end) {
+    const int q = lane & 3;
+    // pair-piece constants, coordinates relative to the halo origin (tile origin - 1): lxy = x | y << 8 of the pair's first
+    // voxel, poff = its byte offset from that origin, dst = LDS byte offset of channel 4q's dword.  Iterations 0..5 are
+    // halo pieces and 6, 7 gpre pieces for every wave (nothing below branches on the wave); the slots past the 360th pair
+    // repeat it -- same data, same address.
+    int lxy[BNIT], poff[BNIT], dst[BNIT];
+#pragma unroll
+    for (int it = 0; it < BNIT; ++it) {
+      int lx, ly, lz;
+      if (it < BHIT) {
+        const int pr = min((wave + 4 * it) * 16 + (lane >> 2), BHP - 1);
+        const int row = pr / (WHX / 2);
+        lx = 2 * (pr - row * (WHX / 2)); ly = row % WHY; lz = row / WHY;
+        dst[it] = 4 * q * BXS + (lz * WHY + ly) * BRS + lx * 2;
+      } else {
+        const int pr = (wave + 4 * (it - BHIT)) * 16 + (lane >> 2);
+        lx = 2 * (pr & 7); ly = (pr >> 3) & 7; lz = pr >> 6;
+        dst[it] = BXB + 4 * q * BGS + (lz * WTY + ly) * BGR + lx * 2;
+        ++lx; ++ly; ++lz;
+      }
+      lxy[it] = lx | (ly << 8);
+      poff[it] = ((lz * H + ly) * W + lx) * 64 + q * 16;
+    }
+    u32x4 st[BNIT][2];
+    auto issue = [&](int t) {
+      int tt = t;
+      const int bx = tt % tiles_x; tt /= tiles_x;
+      const int by = tt % tiles_y; tt /= tiles_y;
+      const int bz = tt % tiles_z; tt /= tiles_z;
+      const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long)tt * nvox * 16), 0, sample_bytes, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)(gp + (long)tt * nvox * 16), 0, sample_bytes, 0x00020000);
+      const int x0 = bx * WTX - 1, y0 = by * WTY - 1, z0 = bz * WTZ - 1;
+      const int toff = ((z0 * H + y0) * W + x0) * 64;
+      // planes outside the sample fall outside the buffer (negative or >= its size) and read as zero; rows and columns
+      // outside it would wrap into their neighbours and are masked -- on the tiles that have any
+      if (x0 >= 0 && x0 + WHX <= W && y0 >= 0 && y0 + WHY <= H) {
+#pragma unroll
+        for (int it = 0; it < BNIT; ++it) {
+          st[it][0] = __builtin_amdgcn_raw_buffer_load_b128(it < BHIT ? rx : rg, poff[it] + toff, 0, 0);
+          st[it][1] = __builtin_amdgcn_raw_buffer_load_b128(it < BHIT ? rx : rg, poff[it] + toff + 64, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int it = 0; it < BNIT; ++it) {
+          const unsigned gx = (unsigned)(x0 + (lxy[it] & 0xff));
+          const bool oky = (unsigned)(y0 + (lxy[it] >> 8)) < (unsigned)H;
+          st[it][0] = __builtin_amdgcn_raw_buffer_load_b128(it < BHIT ? rx : rg, (oky && gx < (unsigned)W) ? poff[it] + toff : (int)0x80000000, 0, 0);
+          st[it][1] = __builtin_amdgcn_raw_buffer_load_b128(it < BHIT ? rx : rg, (oky && gx + 1 < (unsigned)W) ? poff[it] + toff + 64 : (int)0x80000000, 0, 0);
+        }
+      }
+    };
+    auto commit = [&](int bufsel) {
+      unsigned char* base = smem + bufsel * BBUF;
+#pragma unroll
+      for (int it = 0; it < BNIT; ++it) {
+        const f32x4 e = __builtin_bit_cast(f32x4, st[it][0]), o = __builtin_bit_cast(f32x4, st[it][1]);
+        const unsigned e01 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){e[0], e[1]}, bf16x2));
+        const unsigned e23 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){e[2], e[3]}, bf16x2));
+        const unsigned o01 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){o[0], o[1]}, bf16x2));
+        const unsigned o23 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){o[2], o[3]}, bf16x2));
+        const int cs = it < BHIT ? BXS : BGS;
+        unsigned char* d = base + dst[it];
+        // one dword per channel: [voxel x, voxel x + 1]
+        *(unsigned*)(d) = __builtin_amdgcn_perm(o01, e01, 0x05040100u);
+        *(unsigned*)(d + cs) = __builtin_amdgcn_perm(o01, e01, 0x07060302u);
+        *(unsigned*)(d + 2 * cs) = __builtin_amdgcn_perm(o23, e23, 0x05040100u);
+        *(unsigned*)(d + 3 * cs) = __builtin_amdgcn_perm(o23, e23, 0x07060302u);
+      }
+    };
+    // operand offsets: K group kg = (plane z = kg >> 2, row pair rp = kg & 3); lane group k -> row 2*rp + (k >> 1), x half k & 1
+    const int a_lane = BXB + m * BGS + (k >> 1) * BGR + (k & 1) * 16;                             // + (z*WTY + 2*rp) * BGR
+    const int b_lane = m * BXS + (k >> 1) * BRS + (k & 1) * 16;                                   // + ((z + kz)*WHY + ky + 2*rp) * BRS
+    const int row_base = ((2 * wave) / 3 * WHY + (2 * wave) % 3) * BRS;                           // stencil row 2w; row 2w+1 below
+    const int row_next = ((2 * wave + 1) / 3 * WHY + (2 * wave + 1) % 3) * BRS;
+    auto three_taps = [&](const bf16x8 a, const unsigned char* row, f32x4* c) {
+      const u32x4 d = *(const u32x4*)row;
+      const unsigned d4 = *(const unsigned*)(row + 16);
+      const u32x4 b1 = (u32x4){__builtin_amdgcn_alignbyte(d[1], d[0], 2), __builtin_amdgcn_alignbyte(d[2], d[1], 2),
+                               __builtin_amdgcn_alignbyte(d[3], d[2], 2), __builtin_amdgcn_alignbyte(d4, d[3], 2)};
+      const u32x4 b2 = (u32x4){d[1], d[2], d[3], d4};
+      c[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, d), c[0], 0, 0, 0);
+      c[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, b1), c[1], 0, 0, 0);
+      c[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, b2), c[2], 0, 0, 0);
+    };
+    auto contract = [&](const unsigned char* buf) {
+#pragma unroll
+      for (int kg = 0; kg < 8; ++kg) {
+        const int z = kg >> 2, rp = kg & 3;
+        const bf16x8 a = *(const bf16x8*)(buf + a_lane + (z * WTY + 2 * rp) * BGR);
+        const unsigned char* rows = buf + b_lane + (z * WHY + 2 * rp) * BRS;
+        three_taps(a, rows + row_base, acc);
+        three_taps(a, rows + row_next, acc + 3);
+      }
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {                               // stencil row 8 = (kz, ky) = (2, 2): K groups 2w, 2w + 1
+        const int kg = 2 * wave + g, z = kg >> 2, rp = kg & 3;
+        const bf16x8 a = *(const bf16x8*)(buf + a_lane + (z * WTY + 2 * rp) * BGR);
+        three_taps(a, buf + b_lane + ((z + 2) * WHY + 2 + 2 * rp) * BRS, acc + 6);
+      }
+    };
+
+    issue(t_begin);
+    __builtin_amdgcn_sched_barrier(0);
+    commit(0);
+    __syncthreads();
+    for (int t = t_begin; t < t_end; ++t) {
+      const int cur = (t - t_begin) & 1;
+      const unsigned char* buf = smem + cur * BBUF;
+      const bool more = t + 1 < t_end;
+      if (more) issue(t + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      contract(buf);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) commit(cur ^ 1);
+      __syncthreads();
+    }
+  }
+  // row 8 (taps 24..26): waves 1..3 hand their shares to wave 0 through LDS, summed in wave order
+  f32x4* red = (f32x4*)smem;                                    // [wave - 1][3][64 lanes]
+  __syncthreads();
+  if (wave > 0) {
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) red[((wave - 1) * 3 + kx) * 64 + lane] = acc[6 + kx];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) acc[6 + kx] += red[(w * 3 + kx) * 64 + lane];
+  }
+  float* out = partial + (long)blockIdx.x * 27 * 256;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    if (r == 2 && wave != 0) break;
+    const int zy = r == 2 ? 8 : 2 * wave + r;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) out[(zy * 3 + kx) * 256 + (4 * k + i) * 16 + m] = acc[r * 3 + kx][i];
+  }
+}
+
 // ---- bias gradient of a 16-channel layer: column sums of gpre [rows][16] ------------------------------
 // A streaming reduction (the generic path runs it as a GEMM against a vector of ones with at most 512 blocks,
 // 250 us for 134 MB; this takes ~40).  Fixed order: rows strided inside a block, blocks summed in fp64.
@@ -299,7 +510,7 @@ extern "C" int lf_conv_bwd_weight(const float* x, const float* gpre, float* gw, 
                        ptz, (int)pt);
     int st = lf_launch_status();
     if (st) return st;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(27, 1), dim3(256), 0, s, (const float*)scratch, gw, cus, 27, 1, 1, 16, 16,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(27, 1, 4), dim3(256), 0, s, (const float*)scratch, gw, cus, 27, 1, 1, 16, 16,
                        scale);
     return lf_launch_status();
   }
@@ -318,7 +529,32 @@ extern "C" int lf_conv_bwd_weight(const float* x, const float* gpre, float* gw, 
     hipLaunchKernelGGL((wgrad_partial_kernel<0>), grid, block, 0, s, x, gpre, partial, N, D, H, W, Cin, Cout, p.chunk, p.ncit);
   int st = lf_launch_status();
   if (st) return st;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(p.taps, p.nct * p.ncit), block, 0, s, partial, gw, p.nblk, p.taps,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(p.taps, p.nct * p.ncit, 4), block, 0, s, partial, gw, p.nblk, p.taps,
                      p.nct * p.ncit, p.ncit, Cin, Cout, scale);
+  return lf_launch_status();
+}
+
+extern "C" int lf_conv_bwd_weight_bf16(const float* x, const float* gpre, float* gw, void* scratch, size_t scratch_bytes,
+                                       int dims, int N, int D, int H, int W, int Cin, int Cout, float scale, void* stream) {
+  lf_clear_error();
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || x == nullptr || gpre == nullptr || gw == nullptr) return LF_EINVAL;
+  if (!wgrad_fast3d(dims, N, D, H, W, Cin, Cout) || !lf_aligned16(x) || !lf_aligned16(gpre)) return LF_EINVAL;
+  const int nb = 2 * wgrad_cus();
+  if (scratch_bytes < (size_t)nb * 27 * 256 * sizeof(float)) return LF_ENOSPC;
+  const int ptx = (W + WTX - 1) / WTX, pty = (H + WTY - 1) / WTY, ptz = (D + WTZ - 1) / WTZ;
+  const long pt = (long)ptx * pty * ptz * N;
+  if (pt > 0x7fffffffL) return LF_EINVAL;
+  const size_t shmem = (size_t)2 * BBUF;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)wgrad3d_c16_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(wgrad3d_c16_bf16_kernel, dim3(nb), dim3(256), shmem, s, x, gpre, (float*)scratch, N, D, H, W, ptx, pty, ptz, (int)pt);
+  int st = lf_launch_status();
+  if (st) return st;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(27, 1, 4), dim3(256), 0, s, (const float*)scratch, gw, nb, 27, 1, 1, 16, 16, scale);
   return lf_launch_status();
 }

@@ -672,8 +672,13 @@ def conv_bwd_weight(x, gp, dims, cin, he, want_bias=True):
     nbytes = max(L.lf_conv_bwd_weight_scratch_bytes(dims, N, D, H, W, cin, cout),
                  L.lf_conv_bwd_weight_scratch_bytes(0, N, D, H, W, 0, cout))
     scratch = torch.empty(nbytes // 4 + 1, device=gp.device, dtype=torch.float32)
-    check(L.lf_conv_bwd_weight(_ptr(x), _ptr(gp), _ptr(gw), _ptr(scratch), scratch.numel() * 4, dims, N, D, H, W, cin, cout,
-                               he, _stream()), 'lf_conv_bwd_weight')
+    if AUTOCAST is not None and dims == 3 and cin == 16 and cout == 16 and N * D * H * W >= 8192:
+        # autocast: both operands are bf16 values -- the bf16 MFMA forms the same exact products 8x faster
+        check(L.lf_conv_bwd_weight_bf16(_ptr(x), _ptr(gp), _ptr(gw), _ptr(scratch), scratch.numel() * 4, dims, N, D, H, W, cin, cout,
+                                        he, _stream()), 'lf_conv_bwd_weight_bf16')
+    else:
+        check(L.lf_conv_bwd_weight(_ptr(x), _ptr(gp), _ptr(gw), _ptr(scratch), scratch.numel() * 4, dims, N, D, H, W, cin, cout,
+                                   he, _stream()), 'lf_conv_bwd_weight')
     if not want_bias:
         return gw, None
     check(L.lf_conv_bwd_weight(None, _ptr(gp), _ptr(gb), _ptr(scratch), scratch.numel() * 4, 0, N, D, H, W, 0, cout,

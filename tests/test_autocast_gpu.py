@@ -50,6 +50,35 @@ def test_conv3d_c16_bf16_kernel(shape):
     assert float((err > 1e-9).float().mean()) < 5e-3
 
 
+@pytest.mark.parametrize('shape', [(1, 16, 16, 16, 32), (2, 16, 9, 21, 45), (3, 16, 6, 40, 35), (1, 16, 64, 64, 64)])
+def test_weight_gradient_on_the_bf16_mfma(shape):
+    """lf_conv_bwd_weight_bf16 (transposing bf16 staging, v_mfma_f32_16x16x32_bf16) against the fp64 contraction of the
+    bf16-rounded operands, on un-rounded inputs (the kernel rounds) and ragged extents (partial tiles on every axis); it
+    also equals the fp32-MFMA kernel on pre-rounded operands up to summation order, and is run-to-run identical."""
+    from latentfusion_amd import ops
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(shape, generator=g)
+    gp = torch.randn(shape, generator=g) * 1e-3
+    xd, gd = ops.cl(x.to(DEV)), ops.cl(gp.to(DEV))
+    he = 0.37
+    with ops.autocast():
+        gw, gb = ops.conv_bwd_weight(xd, gd, 3, 16, he, want_bias=False)           # [27][co][ci]
+        gw2, _ = ops.conv_bwd_weight(xd, gd, 3, 16, he, want_bias=False)
+    assert gb is None and torch.equal(gw, gw2)
+    xp = F.pad(bf(x).double(), (1, 1, 1, 1, 1, 1))
+    gq = bf(gp).double()
+    D, H, W = shape[2:]
+    want = torch.empty(27, 16, 16, dtype=torch.float64)
+    for kz in range(3):
+        for ky in range(3):
+            for kx in range(3):
+                want[(kz * 3 + ky) * 3 + kx] = he * torch.einsum('nodhw,nidhw->oi', gq, xp[:, :, kz:kz + D, ky:ky + H, kx:kx + W])
+    scale = want.abs().max().item()
+    assert (gw.cpu().double() - want).abs().max().item() < 2e-6 * scale
+    ref, _ = ops.conv_bwd_weight(ops.round_bf16(xd), ops.round_bf16(gd), 3, 16, he, want_bias=False)   # fp32 MFMA, same products
+    assert (gw - ref).abs().max().item() < 2e-6 * scale
+
+
 def test_round_bf16():
     from latentfusion_amd import ops
     x = torch.randn(3, 5, 7, generator=torch.Generator().manual_seed(0)) * 100
