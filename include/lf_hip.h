@@ -423,6 +423,10 @@ int lf_nhwc_to_nchw(const float* src, float* dst, int N, int C, long P, void* st
  * -> dst [N][S][P][C0], optionally scaling row (n,p) by 1/norm[n*P+p] (deferred PixelNorm). */
 int lf_lift_unfold(const float* src, const float* norm_or_null, float* dst,
                    int N, long P, int C0, int S, void* stream);
+/* The same permutation for the training step, either way (autograd of the .view above and of
+ * FactorProjection3d2d's reshape, geometry.py:745): fold = 0: src [N][P][C0*S] -> dst [N][S][P][C0];
+ * fold = 1: src [N][S][P][C0] -> dst [N][P][C0*S].  4 * C0 * (S + 1) * 4 bytes of LDS must fit 64 KB (LF_EINVAL). */
+int lf_lift_permute(const float* src, float* dst, int N, long P, int C0, int S, int fold, void* stream);
 
 #ifdef __cplusplus
 }

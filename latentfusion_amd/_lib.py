@@ -97,6 +97,7 @@ SIGNATURES = {
     'lf_nchw_to_nhwc': (c_int, [P, P, c_int, c_int, c_long, P]),
     'lf_nhwc_to_nchw': (c_int, [P, P, c_int, c_int, c_long, P]),
     'lf_lift_unfold': (c_int, [P, P, P, c_int, c_long, c_int, c_int, P]),
+    'lf_lift_permute': (c_int, [P, P, c_int, c_long, c_int, c_int, c_int, P]),
 }
 
 _lib = None

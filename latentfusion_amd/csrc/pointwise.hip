@@ -136,6 +136,46 @@ __global__ void __launch_bounds__(256) lift_unfold_kernel(const float* __restric
   }
 }
 
+// The same permutation for the training step, both ways, FT pixels per workgroup so that global accesses on the volume side
+// are FT * C0 * 4 contiguous bytes (the per-pixel kernel above writes 64-byte pieces when C0 = 16); the tile is
+// [pixel][c][d] with d padded by one word: consecutive d on the 2-D side, consecutive (pixel, c) on the volume side, both
+// conflict-free.  FOLD = false: src [N][P][C0*S] -> dst [N][S][P][C0];  FOLD = true: src [N][S][P][C0] -> dst [N][P][C0*S].
+constexpr int FT = 4;
+template <bool FOLD>
+__global__ void __launch_bounds__(256) lift_permute_kernel(const float* __restrict__ src, float* __restrict__ dst, long P, int C0, int S) {
+  extern __shared__ float tile[];                           // [FT][C0][S + 1]
+  const int n = blockIdx.y, CS = C0 * S, SP = S + 1;
+  const long p0 = (long)blockIdx.x * FT;
+  const int npx = (int)min((long)FT, P - p0);
+  const float* flat = (FOLD ? dst : src) + ((long)n * P + p0) * CS;           // 2-D side: [pixel][c*S + d]
+  const float* vol = (FOLD ? src : dst) + (long)n * S * P * C0 + p0 * C0;     // volume side: + (d*P + px)*C0 + c
+  if (!FOLD) {
+    for (int i = threadIdx.x; i < npx * CS; i += 256) {
+      const int px = i / CS, j = i - px * CS, c = j / S, d = j - c * S;
+      tile[(px * C0 + c) * SP + d] = flat[i];
+    }
+  } else {
+    for (int i = threadIdx.x; i < S * npx * C0; i += 256) {
+      const int c = i % C0, px = (i / C0) % npx, d = i / (C0 * npx);
+      tile[(px * C0 + c) * SP + d] = vol[((long)d * P + px) * C0 + c];
+    }
+  }
+  __syncthreads();
+  if (!FOLD) {
+    float* v = const_cast<float*>(vol);
+    for (int i = threadIdx.x; i < S * npx * C0; i += 256) {
+      const int c = i % C0, px = (i / C0) % npx, d = i / (C0 * npx);
+      v[((long)d * P + px) * C0 + c] = tile[(px * C0 + c) * SP + d];
+    }
+  } else {
+    float* f = const_cast<float*>(flat);
+    for (int i = threadIdx.x; i < npx * CS; i += 256) {
+      const int px = i / CS, j = i - px * CS, c = j / S, d = j - c * S;
+      f[i] = tile[(px * C0 + c) * SP + d];
+    }
+  }
+}
+
 bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 template <int MODE>
@@ -199,6 +239,19 @@ extern "C" int lf_lift_unfold(const float* src, const float* norm_or_null, float
   if (shmem > 64 * 1024) return LF_EINVAL;
   const unsigned gx = (unsigned)(P < 8192 ? P : 8192);
   hipLaunchKernelGGL(lift_unfold_kernel, dim3(gx, N), dim3(256), shmem, (hipStream_t)stream, src, norm_or_null, dst, P, C0, S);
+  return lf_launch_status();
+}
+
+extern "C" int lf_lift_permute(const float* src, float* dst, int N, long P, int C0, int S, int fold, void* stream) {
+  lf_clear_error();
+  if (N <= 0 || P <= 0 || C0 <= 0 || S <= 0 || src == nullptr || dst == nullptr) return LF_EINVAL;
+  const size_t shmem = (size_t)FT * C0 * (S + 1) * sizeof(float);
+  if (shmem > 64 * 1024 || (P + FT - 1) / FT > 0x7fffffffL) return LF_EINVAL;
+  const dim3 grid((unsigned)((P + FT - 1) / FT), (unsigned)N);
+  if (fold)
+    hipLaunchKernelGGL((lift_permute_kernel<true>), grid, dim3(256), shmem, (hipStream_t)stream, src, dst, P, C0, S);
+  else
+    hipLaunchKernelGGL((lift_permute_kernel<false>), grid, dim3(256), shmem, (hipStream_t)stream, src, dst, P, C0, S);
   return lf_launch_status();
 }
 

@@ -637,11 +637,14 @@ def bias_grad(gp, dims):
     return gb.reshape(cout)
 
 
-def conv_bwd_weight(x, gp, dims, cin, he, want_bias=True):
+def conv_bwd_weight(x, gp, dims, cin, he, want_bias=True, bf16=None):
     """Weight and bias gradients of y = conv(x, W) * he + b from the pre-activation gradient `gp`
     (lf_conv_bwd_weight).  x, gp: channels-last (N,C,[D,]H,W), or plain [rows][C] matrices for dims = 0.
-    Returns (gw [taps][Cout][Cin], gb [Cout] or None when want_bias is False)."""
+    Returns (gw [taps][Cout][Cin], gb [Cout] or None when want_bias is False).  bf16: both operands are bf16 values (None:
+    the ambient autocast policy) -- 3-D 16 -> 16 layers then run on the bf16 MFMA (lf_conv_bwd_weight_bf16)."""
     L = _lib.lib()
+    if bf16 is None:
+        bf16 = AUTOCAST is not None
     if dims == 3 and gp.shape[1] == 16 and cin > 16:
         # the LDS-staged 16 -> 16 kernel is ~4x faster than the generic one even with the slice copies:
         # the weight gradient of a wider input is the concatenation of the gradients of its channel chunks
@@ -653,10 +656,10 @@ def conv_bwd_weight(x, gp, dims, cin, he, want_bias=True):
                 # also takes the LDS-staged kernel (0.25 ms instead of 6.6 ms on the generic one at 128^3)
                 xc = empty_cl((x.shape[0], 16) + tuple(x.shape[2:]), x.device).zero_()
                 xc[:, :c1 - c0] = x[:, c0:c1]
-                gw_c, gb_c = conv_bwd_weight(xc, gp, dims, 16, he, want_bias and c0 == 0)
+                gw_c, gb_c = conv_bwd_weight(xc, gp, dims, 16, he, want_bias and c0 == 0, bf16)
                 gw_c = gw_c[:, :, :c1 - c0]
             else:
-                gw_c, gb_c = conv_bwd_weight(cl(x[:, c0:c1]), gp, dims, 16, he, want_bias and c0 == 0)
+                gw_c, gb_c = conv_bwd_weight(cl(x[:, c0:c1]), gp, dims, 16, he, want_bias and c0 == 0, bf16)
             gb = gb_c if c0 == 0 else gb                       # the bias gradient (column sums of gp) once, not per chunk
             parts.append(gw_c)
         return torch.cat(parts, dim=2), gb
@@ -672,7 +675,7 @@ def conv_bwd_weight(x, gp, dims, cin, he, want_bias=True):
     nbytes = max(L.lf_conv_bwd_weight_scratch_bytes(dims, N, D, H, W, cin, cout),
                  L.lf_conv_bwd_weight_scratch_bytes(0, N, D, H, W, 0, cout))
     scratch = torch.empty(nbytes // 4 + 1, device=gp.device, dtype=torch.float32)
-    if AUTOCAST is not None and dims == 3 and cin == 16 and cout == 16 and N * D * H * W >= 8192:
+    if bf16 and dims == 3 and cin == 16 and cout == 16 and N * D * H * W >= 8192:
         # autocast: both operands are bf16 values -- the bf16 MFMA forms the same exact products 8x faster
         check(L.lf_conv_bwd_weight_bf16(_ptr(x), _ptr(gp), _ptr(gw), _ptr(scratch), scratch.numel() * 4, dims, N, D, H, W, cin, cout,
                                         he, _stream()), 'lf_conv_bwd_weight_bf16')
@@ -808,7 +811,7 @@ class _Conv3x3Sum16(torch.autograd.Function):
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             cols = []
             for i, (p, wdt) in enumerate(zip(saved_parts, ctx.widths)):
-                g_i, gb_i = conv_bwd_weight(p, gy, 3, 16, ctx.he, want_bias=(i == 0))
+                g_i, gb_i = conv_bwd_weight(p, gy, 3, 16, ctx.he, want_bias=(i == 0), bf16=ctx.ac)
                 gb = gb_i if i == 0 else gb
                 cols.append(g_i[:, :, :wdt])
             gwt = torch.cat(cols, dim=2)                                   # [27][16][sum widths]
@@ -1030,8 +1033,11 @@ class _FactorProject(torch.autograd.Function):
             gx = _ac_in(gx)
             if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
                 # rows = pixels, K = (c, d) in the reference's order c*D + d: one copy of the volume (training only)
-                xr = x_saved.permute(0, 3, 4, 1, 2).reshape(N * H * W, C * D)
-                gwt, gb = conv_bwd_weight(xr.contiguous(), gp.permute(0, 2, 3, 1).reshape(N * H * W, cout), 0, C * D, ctx.he,
+                if _lift_ok(C, D):
+                    xr = _lift_permute(x_saved, N, H * W, C, D, True, torch.empty(N * H * W, C * D, device=gp.device, dtype=torch.float32))
+                else:
+                    xr = x_saved.permute(0, 3, 4, 1, 2).reshape(N * H * W, C * D).contiguous()
+                gwt, gb = conv_bwd_weight(xr, gp.permute(0, 2, 3, 1).reshape(N * H * W, cout), 0, C * D, ctx.he,
                                           want_bias=not ctx.ac)
                 if ctx.ac and ctx.needs_input_grad[2]:
                     gb = bias_grad(gp_full.permute(0, 2, 3, 1).reshape(N * H * W, cout), 0)
@@ -1041,6 +1047,33 @@ class _FactorProject(torch.autograd.Function):
 
 def factor_project(x, weight, bias):
     return _FactorProject.apply(x, weight, bias)
+
+
+def _lift_permute(src, V, P, c0, S, fold, out):
+    check(_lib.lib().lf_lift_permute(_ptr(src), _ptr(out), V, P, c0, S, 1 if fold else 0, _stream()), 'lf_lift_permute')
+    return out
+
+
+class _LiftView(torch.autograd.Function):
+    """(V, c0*S, H, W) channels-last, channel = c*S + d  ->  (V, c0, S, H, W) channels-last volume: the `.view` of
+    FactorProjection2d3d (modules/geometry.py:728) as ONE permutation kernel each way (lf_lift_permute) instead of a
+    strided ATen copy (1.9 ms per GB here; the kernel moves full lines both sides)."""
+
+    @staticmethod
+    def forward(ctx, y, c0, S):
+        y = cl(y)
+        V, cs, H, W = y.shape
+        ctx.dims = (V, H, W, c0, S)
+        return _lift_permute(y, V, H * W, c0, S, False, empty_cl((V, c0, S, H, W), y.device))
+
+    @staticmethod
+    def backward(ctx, g):
+        V, H, W, c0, S = ctx.dims
+        return _lift_permute(cl(g), V, H * W, c0, S, True, empty_cl((V, c0 * S, H, W), g.device)), None, None
+
+
+def _lift_ok(c0, S):
+    return 4 * c0 * (S + 1) * 4 <= 64 * 1024
 
 
 def lift(x, weight, bias, out_size):
@@ -1056,6 +1089,8 @@ def lift(x, weight, bias, out_size):
     c0 = cs // out_size
     if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)):
         y = conv1x1(x, weight, bias, lrelu=True, pixelnorm=True)            # (V, c0*S, H, W), channel = c*S + d
+        if _lift_ok(c0, out_size):
+            return _LiftView.apply(y, c0, out_size)
         return cl(y.view(V, c0, out_size, H, W))
     he = he_constant(weight)
     wpack = _cached(weight, 'c1f', lambda: pack_conv1x1(weight.reshape(cs, cin)))

@@ -259,7 +259,7 @@ def test_conv1x1_vs_torch(cin, cout, act, norm):
     close(bd.grad, b.grad, atol=2e-4 * b.grad.abs().max().item(), rtol=1e-3)
 
 
-@pytest.mark.parametrize('C,S,cout', [(16, 16, 16), (32, 8, 16), (16, 12, 8)])
+@pytest.mark.parametrize('C,S,cout', [(16, 16, 16), (32, 8, 16), (16, 12, 8), (16, 9, 8)])
 def test_factor_projection_vs_torch(C, S, cout):
     from latentfusion_amd import ops
     g = torch.Generator().manual_seed(C + S)
@@ -289,6 +289,29 @@ def test_lift_vs_torch(cin, c0, S):
     want = nets.act_norm(nets.eq_conv(x, {'c.module.weight': w, 'c.bias': b}, 'c', 0)).view(3, c0, S, S, S)
     got = ops.lift(x.to(DEV), w.to(DEV), b.to(DEV), S)
     close(got, want, atol=3e-5)
+
+
+@pytest.mark.parametrize('cin,c0,S,H,W', [(16, 8, 16, 16, 16), (16, 16, 8, 5, 7), (12, 4, 8, 3, 3), (16, 16, 128, 6, 6)])
+def test_lift_training_path_vs_torch(cin, c0, S, H, W):
+    """The differentiable form of FactorProjection2d3d: pointwise conv + lf_lift_permute for the .view (and its adjoint for the
+    gradient), against autograd of the oracle; pixel counts that are not a multiple of the kernel's 4-pixel tile included."""
+    from latentfusion_amd import ops
+    g = torch.Generator().manual_seed(cin + c0 + S + H)
+    x = torch.randn(3, cin, H, W, generator=g, requires_grad=True)
+    w = torch.randn(c0 * S, cin, 1, 1, generator=g, requires_grad=True)
+    b = (torch.randn(c0 * S, generator=g) * 0.1).requires_grad_(True)
+    want = nets.act_norm(nets.eq_conv(x, {'c.module.weight': w, 'c.bias': b}, 'c', 0)).view(3, c0, S, H, W)
+    gw = torch.randn(want.shape, generator=g)
+    (want * gw).sum().backward()
+    xd = x.detach().to(DEV).requires_grad_(True)
+    wd, bd = w.detach().to(DEV).requires_grad_(True), b.detach().to(DEV).requires_grad_(True)
+    got = ops.lift(xd, wd, bd, S)
+    assert got.shape == want.shape
+    close(got, want, atol=3e-5)
+    (got * gw.to(DEV)).sum().backward()
+    close(xd.grad, x.grad, atol=3e-4, rtol=1e-3)
+    close(wd.grad, w.grad, atol=2e-4 * w.grad.abs().max().item(), rtol=1e-3)
+    close(bd.grad, b.grad, atol=2e-4 * b.grad.abs().max().item(), rtol=1e-3)
 
 
 def test_pixelnorm_and_epilogue_bwd():
