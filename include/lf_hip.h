@@ -213,6 +213,18 @@ int lf_round_bf16(const float* x, float* y, long n, void* stream);
 size_t lf_conv3d_c16_bf16_wpack_elems(void);
 int lf_conv3d_c16_bf16(const float* x, const void* wpack, const float* bias, float* y, float* norm_out, int N, int D, int H,
                        int W, float he, unsigned flags, float slope, float eps, int round_out, void* stream);
+/* The same arithmetic on the ring organisation of lf_conv3d_c16_split (column walk over 2 x 8 x 16 tiles, six z-plane slots
+ * of bf16 halo in LDS, tap pairs on v_mfma_f32_16x16x32_bf16, the epilogue under the next tile's MFMAs): the form the
+ * autocast training step uses.  round_out: 0 = fp32 epilogue on the accumulator, 1 = bf16(bf16(acc) * he) before the bias
+ * (autocast forward; with flags = 0 and bias = NULL also its data gradient).  addend != NULL (bias = NULL, flags = 0,
+ * round_out = 0): y = conv(x) * he + addend, the running sum of the ConvGRU gates evaluated without the channel
+ * concatenation (modules/gru.py:31-40).
+ * wpack: lf_conv3d_c16_ring_bf16_wpack_elems() bf16 values, [14 pairs][16 cout][32 = 2 taps x 16 cin], the tap pairs of
+ * lf_conv3d_c16_split_pairs (a missing second tap = zeros). */
+size_t lf_conv3d_c16_ring_bf16_wpack_elems(void);
+int lf_conv3d_c16_ring_bf16(const float* x, const void* wpack, const float* bias, float* y, float* norm_out,
+                            int N, int D, int H, int W, float he, unsigned flags, float slope, float eps,
+                            const float* addend, int round_out, void* stream);
 
 /* Winograd F(2x2x2,3x3x3) for wide 3-D convolutions in three stages (input transform, 64 library GEMMs
  * M[f] = V[f] @ U[f] on the host side, output transform with the fused epilogue).  x, y channels-last;

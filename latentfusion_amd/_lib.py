@@ -54,6 +54,8 @@ SIGNATURES = {
     'lf_round_bf16': (c_int, [P, P, c_long, P]),
     'lf_conv3d_c16_bf16_wpack_elems': (c_size_t, []),
     'lf_conv3d_c16_bf16': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint, c_float, c_float, c_int, P]),
+    'lf_conv3d_c16_ring_bf16_wpack_elems': (c_size_t, []),
+    'lf_conv3d_c16_ring_bf16': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint, c_float, c_float, P, c_int, P]),
     'lf_wino3d_tiles': (c_long, [c_int, c_int, c_int, c_int]),
     'lf_wino3d_input_transform': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'lf_wino3d_output_transform': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_uint, c_float, c_float, P]),

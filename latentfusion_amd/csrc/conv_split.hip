@@ -48,8 +48,11 @@
 //   free beside f16 MFMAs, packed-fp32 (v_pk_*) and v_fma_mix work is not.
 //   This file is compiled with -fno-slp-vectorize (build.py): SLP-packed fp32 arithmetic inside the MFMA phase gave rare
 //   run-to-run differences in the gradient form (tests/test_engine_gpu.py::test_split_conv3d_is_run_to_run_identical).
+#include <type_traits>
 #include "lf_common.h"
 
+typedef __bf16 bf16x8s __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4s __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
@@ -138,17 +141,29 @@ __device__ __forceinline__ void split_piece(const f32x4 v, float s, f16x4s& hi, 
 }
 typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
 
+__device__ __forceinline__ f32x4 mfma_k32(const f16x8 a, const f16x8 b, const f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mfma_k32(const bf16x8s a, const bf16x8s b, const f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ float rb16(float v) { return (float)(__bf16)v; }
 __device__ __forceinline__ int mod6(int v) { return v >= 6 ? v - 6 : v; }      // v in [0, 12)
 
-template <bool GRAD>
+// NP = 3: the f16 hi / lo split above.  NP = 1: the bf16-autocast policy of the training step on the same ring -- one bf16
+// piece per operand (RNE while staging: what autocast's cast does), one v_mfma_f32_16x16x32_bf16 per product, no lo planes
+// (35 KB of LDS), no pre-scaling (bf16 has fp32's range); `round_out` = 1 rounds the result the way autocast's
+// half-precision convolution and `* he` do (conv_bf16.hip); GRAD with LF_EPI_ADD in prev_flags adds prev_y instead of
+// applying the previous layer's backward epilogue (the addend form of the ConvGRU gates).
+template <bool GRAD, int NP>
 __global__ void __launch_bounds__(256, 2) conv3d_c16_f16x3_kernel(
-    const float* __restrict__ x, const _Float16* __restrict__ wsplit, const float* __restrict__ bias,
+    const float* __restrict__ x, const void* __restrict__ wsplit_v, const float* __restrict__ bias,
     float* __restrict__ y, float* __restrict__ norm_out,
     int N, int D, int H, int W, int tiles_x, int tiles_y, int tiles_z, int ntiles,
     float he, unsigned flags, float slope, float eps,
     const float* __restrict__ prev_y, const float* __restrict__ prev_norm, unsigned prev_flags,
-    const float* __restrict__ amax_in, float* __restrict__ amax_out) {
+    const float* __restrict__ amax_in, float* __restrict__ amax_out, int round_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using h8 = std::conditional_t<NP == 1, bf16x8s, f16x8>;
+  using h1 = std::conditional_t<NP == 1, __bf16, _Float16>;
+  constexpr int LDS_B = NP == 1 ? LO_OFF + GUARD_B : LDSs;
+  const h1* wsplit = (const h1*)wsplit_v;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -156,7 +171,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_f16x3_kernel(
   const int n = lane & 15, kg = lane >> 4;
   // zero-weight K slots and the rows an operand reads past its wave's share meet whatever is in LDS: 0 * garbage
   // could be NaN, so everything starts as zeros (the planes hold finite f16 values from then on)
-  for (int i = tid; i < LDSs / 16; i += 256) ((u32x4s*)smem)[i] = (u32x4s){0u, 0u, 0u, 0u};
+  for (int i = tid; i < LDS_B / 16; i += 256) ((u32x4s*)smem)[i] = (u32x4s){0u, 0u, 0u, 0u};
   __syncthreads();
 
   // workgroups b, b+8, b+16, ... run on the same XCD (one L2 each): give them consecutive tile ranges so that the
@@ -173,7 +188,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_f16x3_kernel(
 
   // power-of-two input scale from the tensor's max-abs (gradient launches); 1 otherwise
   float in_scale = 1.f;
-  if (amax_in != nullptr) {
+  if (NP != 1 && amax_in != nullptr) {
     const float am = lf_amax_read(amax_in, lane);
     if (am > 0.f && am < 3.0e38f) {
       int ex;
@@ -186,13 +201,17 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_f16x3_kernel(
   asm volatile("" : "+s"(scale_s));                               // (opaque: an FMA by a visible 1.0 would be folded into converts)
 
   // ---- weights (hi, lo) -> registers: [pair][term][cout 16][k 32] halfs; A operand: lane (cout n, k = kg*8..+7) ----
-  f16x8 whi[NPAIR], wlo[NPAIR];
+  h8 whi[NPAIR], wlo[NP == 1 ? 1 : NPAIR];
   {
-    const _Float16* wl = wsplit + n * 32 + kg * 8;
+    const h1* wl = wsplit + n * 32 + kg * 8;
 #pragma unroll
     for (int p = 0; p < NPAIR; ++p) {
-      whi[p] = *(const f16x8*)(wl + (p * 2 + 0) * 512);
-      wlo[p] = *(const f16x8*)(wl + (p * 2 + 1) * 512);
+      if constexpr (NP == 1) {
+        whi[p] = *(const h8*)(wl + p * 512);
+      } else {
+        whi[p] = *(const h8*)(wl + (p * 2 + 0) * 512);
+        wlo[p] = *(const h8*)(wl + (p * 2 + 1) * 512);
+      }
     }
   }
 
@@ -235,14 +254,20 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_f16x3_kernel(
   // fp32 -> f16 hi / lo of staged piece `it`, into the plane slot at dst
   auto commit_piece = [&](unsigned char* dst, auto itc) {
     constexpr int it = decltype(itc)::v;
-    f16x4s h, l;
-    split_piece(__builtin_bit_cast(f32x4, stg[it]), scale_s, h, l);
-    if constexpr (it < 5) {
-      *(f16x4s*)(dst + (frow0 + it) * (HXs * 32) + lane * 8) = h;
-      *(f16x4s*)(dst + (frow0 + it) * (HXs * 32) + lane * 8 + LO_OFF) = l;
-    } else if (e_ok) {
-      *(f16x4s*)(dst + eldso) = h;
-      *(f16x4s*)(dst + eldso + LO_OFF) = l;
+    if constexpr (NP == 1) {
+      const bf16x4s h = __builtin_convertvector(__builtin_bit_cast(f32x4, stg[it]), bf16x4s);
+      if constexpr (it < 5) *(bf16x4s*)(dst + (frow0 + it) * (HXs * 32) + lane * 8) = h;
+      else if (e_ok) *(bf16x4s*)(dst + eldso) = h;
+    } else {
+      f16x4s h, l;
+      split_piece(__builtin_bit_cast(f32x4, stg[it]), scale_s, h, l);
+      if constexpr (it < 5) {
+        *(f16x4s*)(dst + (frow0 + it) * (HXs * 32) + lane * 8) = h;
+        *(f16x4s*)(dst + (frow0 + it) * (HXs * 32) + lane * 8 + LO_OFF) = l;
+      } else if (e_ok) {
+        *(f16x4s*)(dst + eldso) = h;
+        *(f16x4s*)(dst + eldso + LO_OFF) = l;
+      }
     }
   };
   auto commit_plane = [&](int slot) {
@@ -325,7 +350,9 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_f16x3_kernel(
         float ss = 0.f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float u = a[r][e] * out_scale + bv4[e];
+          float u = a[r][e] * out_scale;
+          if (NP == 1 && round_out) u = rb16(rb16(a[r][e]) * out_scale);   // autocast: half conv result, `* he` in half, fp32 bias
+          u += bv4[e];
           if (flags & LF_EPI_LRELU) u = fmaxf(u, u * slope);
           ev[r][e] = u;
           ss += u * u;
@@ -337,6 +364,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_f16x3_kernel(
       float rn = 1.f;
       if constexpr (GRAD) {
         const f32x4 yp = pyv[r];
+        if (prev_flags & LF_EPI_ADD) v += yp;
         if (prev_flags & LF_EPI_PIXELNORM) {
           const float rinv = fast_rcp_s(pnv[r]);
 #pragma unroll
@@ -402,20 +430,20 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_f16x3_kernel(
 #pragma unroll
     for (int r = 0; r < RYs; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
     {
-      f16x8 bh[SPLIT_PF + 1], bl[SPLIT_PF + 1];
+      h8 bh[SPLIT_PF + 1], bl[NP == 1 ? 1 : SPLIT_PF + 1];
       static_for<0, NOP + SPLIT_PF>([&](auto ic) {
         constexpr int i = decltype(ic)::v;
         if constexpr (i < NOP && !(SPLIT_ABL & 2)) {
           constexpr int cls = op_cls(i), h = op_h(i), kx = op_kx(i);
           const int addr = cls == 0 ? aP : (cls == 1 ? aQ : aR);
           constexpr int imm = (h * HXs + kx) * 32;
-          bh[i % (SPLIT_PF + 1)] = *(const f16x8*)(smem + addr + imm);
-          bl[i % (SPLIT_PF + 1)] = *(const f16x8*)(smem + addr + imm + LO_OFF);
+          bh[i % (SPLIT_PF + 1)] = *(const h8*)(smem + addr + imm);
+          if constexpr (NP != 1) bl[i % (SPLIT_PF + 1)] = *(const h8*)(smem + addr + imm + LO_OFF);
         }
         if constexpr (i >= SPLIT_PF && !(SPLIT_ABL & 1)) {
           constexpr int j = i - SPLIT_PF;
           constexpr int cls = op_cls(j), h = op_h(j), kx = op_kx(j);
-          const f16x8 vh = bh[j % (SPLIT_PF + 1)], vl = bl[j % (SPLIT_PF + 1)];
+          const h8 vh = bh[j % (SPLIT_PF + 1)], vl = bl[NP == 1 ? 0 : j % (SPLIT_PF + 1)];
           // up to three (row, pair) uses of this operand; the three product terms are issued term-major so that
           // consecutive MFMAs go to different accumulators
           static_for<0, 9>([&](auto uc) {
@@ -423,9 +451,9 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_f16x3_kernel(
             constexpr int r = cls < 2 ? h - u : (u == 0 ? h : (u == 1 ? h - 2 : -1));
             constexpr int p = cls == 0 ? kx * 3 + u : (cls == 1 ? 9 + u : 12 + u);
             if constexpr (r >= 0 && r < RYs) {
-              if constexpr (term == 0) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[p], vl, acc[r], 0, 0, 0);
-              if constexpr (term == 1) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo[p], vh, acc[r], 0, 0, 0);
-              if constexpr (term == 2) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[p], vh, acc[r], 0, 0, 0);
+              if constexpr (term == 0 && NP != 1) acc[r] = mfma_k32(whi[p], vl, acc[r]);
+              if constexpr (term == 1 && NP != 1) acc[r] = mfma_k32(wlo[NP == 1 ? 0 : p], vh, acc[r]);
+              if constexpr (term == 2) acc[r] = mfma_k32(whi[p], vh, acc[r]);
             }
           });
         }
@@ -507,9 +535,9 @@ extern "C" int lf_conv3d_c16_split(const float* x, const void* wsplit, const flo
            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
   }
   const size_t shmem = (size_t)LDSs;
-  typedef void (*kern_t)(const float*, const _Float16*, const float*, float*, float*, int, int, int, int, int, int, int, int, float,
-                         unsigned, float, float, const float*, const float*, unsigned, const float*, float*);
-  static const kern_t kerns[2] = {conv3d_c16_f16x3_kernel<false>, conv3d_c16_f16x3_kernel<true>};
+  typedef void (*kern_t)(const float*, const void*, const float*, float*, float*, int, int, int, int, int, int, int, int, float,
+                         unsigned, float, float, const float*, const float*, unsigned, const float*, float*, int);
+  static const kern_t kerns[2] = {conv3d_c16_f16x3_kernel<false, 3>, conv3d_c16_f16x3_kernel<true, 3>};
   static bool attr_set = false;
   if (!attr_set) {
     for (int i = 0; i < 2; ++i) {
@@ -521,7 +549,40 @@ extern "C" int lf_conv3d_c16_split(const float* x, const void* wsplit, const flo
   const long want = (long)SPLIT_WGS * cus;                        // two resident workgroups per CU
   const unsigned grid = (unsigned)(pt < want ? pt : want);
   const kern_t kern = kerns[prev_y != nullptr ? 1 : 0];
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shmem, (hipStream_t)stream, x, (const _Float16*)wsplit, bias, y, norm_out, N, D, H,
-                     W, ptx, pty, ptz, (int)pt, he, flags, slope, eps, prev_y, prev_norm, prev_flags, amax_in, amax_out);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shmem, (hipStream_t)stream, x, wsplit, bias, y, norm_out, N, D, H,
+                     W, ptx, pty, ptz, (int)pt, he, flags, slope, eps, prev_y, prev_norm, prev_flags, amax_in, amax_out, 0);
+  return lf_launch_status();
+}
+
+// bf16 elements of the weight pack of the bf16 form: [14 pairs][16 cout][32 = 2 taps x 16 cin] (pairs: lf_conv3d_c16_split_pairs)
+extern "C" size_t lf_conv3d_c16_ring_bf16_wpack_elems(void) { return (size_t)NPAIR * 16 * 32; }
+
+extern "C" int lf_conv3d_c16_ring_bf16(const float* x, const void* wpack, const float* bias, float* y, float* norm_out,
+                                       int N, int D, int H, int W, float he, unsigned flags, float slope, float eps,
+                                       const float* addend, int round_out, void* stream) {
+  lf_clear_error();
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || round_out < 0 || round_out > 1) return LF_EINVAL;
+  if ((long)D * H * W * 64 >= 0x7fffffffL || !(slope > 0.f && slope < 1.f)) return LF_EINVAL;
+  if (flags & ~(LF_EPI_LRELU | LF_EPI_PIXELNORM)) return LF_EINVAL;
+  if (!lf_aligned16(x) || !lf_aligned16(y) || !lf_aligned16(wpack) || (bias && !lf_aligned16(bias)) || (addend && !lf_aligned16(addend))) return LF_EALIGN;
+  if (addend != nullptr && (flags != 0 || bias != nullptr || round_out != 0)) return LF_EINVAL;
+  const int ptx = (W + TXs - 1) / TXs, pty = (H + TYs - 1) / TYs, ptz = (D + TZs - 1) / TZs;
+  const long pt = (long)ptx * pty * ptz * N;
+  if (pt > 0x7fffffffL) return LF_EINVAL;
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, v = 0;
+    cus = (hipGetDevice(&dev) == hipSuccess &&
+           hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+  }
+  const size_t shmem = (size_t)(LO_OFF + GUARD_B);
+  typedef void (*kern_t)(const float*, const void*, const float*, float*, float*, int, int, int, int, int, int, int, int, float,
+                         unsigned, float, float, const float*, const float*, unsigned, const float*, float*, int);
+  static const kern_t kerns[2] = {conv3d_c16_f16x3_kernel<false, 1>, conv3d_c16_f16x3_kernel<true, 1>};
+  const long want = (long)SPLIT_WGS * cus;
+  const unsigned grid = (unsigned)(pt < want ? pt : want);
+  hipLaunchKernelGGL(kerns[addend != nullptr ? 1 : 0], dim3(grid), dim3(256), shmem, (hipStream_t)stream, x, wpack, bias, y, norm_out,
+                     N, D, H, W, ptx, pty, ptz, (int)pt, he, flags, slope, eps, addend, (const float*)nullptr, (unsigned)LF_EPI_ADD,
+                     (const float*)nullptr, (float*)nullptr, round_out);
   return lf_launch_status();
 }

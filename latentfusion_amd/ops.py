@@ -286,6 +286,38 @@ def conv3d_c16_bf16(x, wpack, bias, he, flags, round_out):
     return y, norm
 
 
+def pack_conv3d_c16_ring_bf16(weight, transpose=False):
+    """[16,16,3,3,3] -> bf16 [14 pairs][16 cout][32 = 2 taps x 16 cin] for lf_conv3d_c16_ring_bf16 (the tap pairs of
+    lf_conv3d_c16_split_pairs; the second tap of the last pair is zero)."""
+    w = weight.detach().float()
+    if transpose:
+        w = w.transpose(0, 1).flip(dims=(2, 3, 4))
+    assert tuple(w.shape) == (16, 16, 3, 3, 3)
+    import ctypes
+    table = (ctypes.c_int * 28)()
+    _lib.lib().lf_conv3d_c16_split_pairs(table)
+    taps = w.reshape(16, 16, 27)
+    k = torch.zeros(14, 16, 32, device=w.device)
+    for p in range(14):
+        for sel in range(2):
+            if table[2 * p + sel] >= 0:
+                k[p, :, sel * 16:(sel + 1) * 16] = taps[:, :, table[2 * p + sel]]
+    return k.to(torch.bfloat16).contiguous()
+
+
+def conv3d_c16_ring_bf16(x, wpack, bias, he, flags, round_out, addend=None):
+    """Launch lf_conv3d_c16_ring_bf16 on a channels-last (N,16,D,H,W) tensor (un-rounded input: the kernel rounds)."""
+    L = _lib.lib()
+    N, _, D, H, W = x.shape
+    y = empty_cl((N, 16, D, H, W), x.device)
+    norm = torch.empty(N * D * H * W, device=x.device, dtype=torch.float32) if (flags & LF_EPI_PIXELNORM) else None
+    with _timed('conv3d_c16_ring_bf16'):
+        check(L.lf_conv3d_c16_ring_bf16(_ptr(x), _ptr(wpack), _ptr(bias) if bias is not None else None, _ptr(y),
+                                        _ptr(norm) if norm is not None else None, N, D, H, W, he, flags, SLOPE, PN_EPS,
+                                        _ptr(addend) if addend is not None else None, round_out, _stream()), 'lf_conv3d_c16_ring_bf16')
+    return y, norm
+
+
 _WINO_G = ((1.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.5, -0.5, 0.5), (0.0, 0.0, 1.0))
 
 
@@ -637,6 +669,11 @@ def bias_grad(gp, dims):
     return gb.reshape(cout)
 
 
+def _wgrad_bf16_ok(gp, dims, cin, cout):
+    """Shapes lf_conv_bwd_weight_bf16 takes (the rest stays on lf_conv_bwd_weight with pre-rounded operands)."""
+    return dims == 3 and cin == 16 and cout == 16 and gp.numel() // gp.shape[1] >= 8192
+
+
 def conv_bwd_weight(x, gp, dims, cin, he, want_bias=True, bf16=None):
     """Weight and bias gradients of y = conv(x, W) * he + b from the pre-activation gradient `gp`
     (lf_conv_bwd_weight).  x, gp: channels-last (N,C,[D,]H,W), or plain [rows][C] matrices for dims = 0.
@@ -675,7 +712,7 @@ def conv_bwd_weight(x, gp, dims, cin, he, want_bias=True, bf16=None):
     nbytes = max(L.lf_conv_bwd_weight_scratch_bytes(dims, N, D, H, W, cin, cout),
                  L.lf_conv_bwd_weight_scratch_bytes(0, N, D, H, W, 0, cout))
     scratch = torch.empty(nbytes // 4 + 1, device=gp.device, dtype=torch.float32)
-    if bf16 and dims == 3 and cin == 16 and cout == 16 and N * D * H * W >= 8192:
+    if bf16 and _wgrad_bf16_ok(gp, dims, cin, cout):
         # autocast: both operands are bf16 values -- the bf16 MFMA forms the same exact products 8x faster
         check(L.lf_conv_bwd_weight_bf16(_ptr(x), _ptr(gp), _ptr(gw), _ptr(scratch), scratch.numel() * 4, dims, N, D, H, W, cin, cout,
                                         he, _stream()), 'lf_conv_bwd_weight_bf16')
@@ -707,8 +744,10 @@ class _Conv3x3(torch.autograd.Function):
         b = bias.detach() if bias is not None else None
         ctx.ac = AUTOCAST is not None
         if ctx.ac and _wino_ok(x, weight):                    # autocast, 3-D 16 -> 16: direct conv on the bf16 MFMA
-            y, norm = conv3d_c16_bf16(x, _pk(weight, 'b3f', pack_conv3d_c16_bf16), b, he, flags, 1)
-            x = round_bf16(x) if (weight.requires_grad or (bias is not None and bias.requires_grad)) else x
+            y, norm = conv3d_c16_ring_bf16(x, _pk(weight, 'r3f', pack_conv3d_c16_ring_bf16), b, he, flags, 1)
+            # (the input is saved un-rounded: the bf16 weight-gradient kernel rounds it while staging, like this one)
+            if (weight.requires_grad or (bias is not None and bias.requires_grad)) and not _wgrad_bf16_ok(x, 3, 16, 16):
+                x = round_bf16(x)
         else:
             x = _ac_in(x)
             if _wino_ok(x, weight):                           # 3-D 16 -> 16: the all-fp32 Winograd kernel
@@ -733,7 +772,7 @@ class _Conv3x3(torch.autograd.Function):
         with autocast(ctx.ac):                                # the backward runs under the policy of its forward
             if ctx.needs_input_grad[0]:
                 if ctx.ac and _wino_ok(gp, w):
-                    gx, _ = conv3d_c16_bf16(gp, _pk(w, 'b3b', lambda t: pack_conv3d_c16_bf16(t, transpose=True)), None, ctx.he, 0, 2)
+                    gx, _ = conv3d_c16_ring_bf16(gp, _pk(w, 'r3b', lambda t: pack_conv3d_c16_ring_bf16(t, transpose=True)), None, ctx.he, 0, 1)
                 else:
                     gpc = _ac_in(gp)
                     if _wino_ok(gpc, w):
@@ -748,7 +787,8 @@ class _Conv3x3(torch.autograd.Function):
                 dims = w.dim() - 2
                 # (autocast: the weight gradient sees the half-precision gradient; the bias is added in fp32, so its
                 # gradient is the column sum of the un-rounded one)
-                gwt, gb = conv_bwd_weight(x_saved, _ac_in(gp), dims, w.shape[1], ctx.he, want_bias=not ctx.ac)
+                in_kernel = ctx.ac and _wgrad_bf16_ok(gp, dims, w.shape[1], w.shape[0])       # that kernel rounds its operands itself
+                gwt, gb = conv_bwd_weight(x_saved, gp if in_kernel else _ac_in(gp), dims, w.shape[1], ctx.he, want_bias=not ctx.ac)
                 if ctx.ac and ctx.needs_input_grad[2]:
                     gb = bias_grad(gp, dims)
                 k = (3,) * dims
@@ -775,25 +815,34 @@ class _Conv3x3Sum16(torch.autograd.Function):
         he = he_constant(weight)
 
         ctx.ac = AUTOCAST is not None
-        parts = tuple(_ac_in(cl(p)) for p in parts)
+        nvox = parts[0].numel() // parts[0].shape[1]
+        # autocast: the bf16 ring kernel (and the bf16 weight-gradient kernel) round their operands while staging them; only
+        # volumes too small for the latter keep the rounding pass in front
+        ctx.pre_round = ctx.ac and nvox < 8192
+        parts = tuple((round_bf16(cl(p)) if ctx.pre_round else cl(p)) for p in parts)
 
         def make():
             wd, packs, c0 = _wsrc(weight).detach(), [], 0
+            pack = pack_conv3d_c16_ring_bf16 if ctx.ac else pack_conv3d_c16_wino
             for wdt in widths:
                 wp = wd.new_zeros(16, 16, 3, 3, 3)
                 wp[:, :wdt] = wd[:, c0:c0 + wdt]
-                packs.append((pack_conv3d_c16_wino(wp), pack_conv3d_c16_wino(wp, transpose=True)))
+                packs.append((pack(wp), pack(wp, transpose=True)))
                 c0 += wdt
             return packs
         packs = _cached(weight, 'sum16_' + '_'.join(map(str, widths)) + ('@ac' if ctx.ac else ''), make)
         y = None
         for i, (p, (pf, _pt)) in enumerate(zip(parts, packs)):
             _req(p, 'part')
-            prev = None if y is None else (y, None, _lib.LF_EPI_ADD)
-            y, _ = conv3d_c16_wino(cl(p), pf, bias.detach() if (bias is not None and i == 0) else None, he, 0, prev=prev)
+            b = bias.detach() if (bias is not None and i == 0) else None
+            if ctx.ac:
+                y, _ = conv3d_c16_ring_bf16(p, pf, b, he, 0, 0, addend=y)
+            else:
+                prev = None if y is None else (y, None, _lib.LF_EPI_ADD)
+                y, _ = conv3d_c16_wino(p, pf, b, he, 0, prev=prev)
         ctx.he, ctx.widths, ctx.packs = he, widths, packs
         need_w = weight.requires_grad or (bias is not None and bias.requires_grad)
-        ctx.save_for_backward(weight, *([cl(p) for p in parts] if need_w else []))
+        ctx.save_for_backward(weight, *(parts if need_w else []))
         return y
 
     @staticmethod
@@ -801,12 +850,16 @@ class _Conv3x3Sum16(torch.autograd.Function):
         gy = cl(gy)
         gy_full = gy
         w, *saved_parts = ctx.saved_tensors
-        if ctx.ac:
+        if ctx.pre_round:
             gy = round_bf16(gy)
         gparts = []
         for i, (_pf, pt) in enumerate(ctx.packs):
-            gpart = conv3d_c16_wino(gy, pt, None, ctx.he, 0)[0] if ctx.needs_input_grad[3 + i] else None
-            gparts.append(round_bf16(gpart) if (ctx.ac and gpart is not None) else gpart)
+            if not ctx.needs_input_grad[3 + i]:
+                gparts.append(None)
+            elif ctx.ac:
+                gparts.append(conv3d_c16_ring_bf16(gy, pt, None, ctx.he, 0, 1)[0])     # (rounded like autocast's conv backward)
+            else:
+                gparts.append(conv3d_c16_wino(gy, pt, None, ctx.he, 0)[0])
         gw = gb = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             cols = []

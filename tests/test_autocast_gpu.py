@@ -50,6 +50,45 @@ def test_conv3d_c16_bf16_kernel(shape):
     assert float((err > 1e-9).float().mean()) < 5e-3
 
 
+@pytest.mark.parametrize('shape', [(2, 16, 8, 8, 16), (1, 16, 5, 9, 21), (3, 16, 4, 16, 32), (1, 16, 7, 35, 50), (2, 16, 33, 20, 17)])
+def test_conv3d_c16_ring_bf16_kernel(shape):
+    """lf_conv3d_c16_ring_bf16 (the f16x3 kernel's ring organisation with one bf16 piece: the kernel the autocast step
+    uses) against the same emulation of autocast as above -- forward with both epilogues, the data gradient, and the
+    addend form of the ConvGRU gates; ragged extents, odd depths, several columns per workgroup; run-to-run identical."""
+    from latentfusion_amd import ops
+    from latentfusion_amd._lib import LF_EPI_LRELU, LF_EPI_PIXELNORM
+    g = torch.Generator().manual_seed(sum(shape) + 1)
+    x = torch.randn(shape, generator=g)
+    w = torch.randn(16, 16, 3, 3, 3, generator=g)
+    b = torch.randn(16, generator=g) * 0.1
+    he = ops.he_constant(w)
+    xd = ops.cl(x.to(DEV))
+    wp = ops.pack_conv3d_c16_ring_bf16(w.to(DEV))
+    acc = F.conv3d(bf(x).double(), bf(w).double(), None, 1, 1)
+    y0, n0 = ops.conv3d_c16_ring_bf16(xd, wp, b.to(DEV), he, LF_EPI_LRELU | LF_EPI_PIXELNORM, 0)
+    y0b, _ = ops.conv3d_c16_ring_bf16(xd, wp, b.to(DEV), he, LF_EPI_LRELU | LF_EPI_PIXELNORM, 0)
+    assert torch.equal(y0, y0b)
+    pre = F.leaky_relu(acc * he + b.double().view(1, -1, 1, 1, 1), 0.2)
+    nrm = torch.sqrt((pre ** 2).mean(dim=1, keepdim=True) + 1e-8)
+    torch.testing.assert_close(y0.cpu().double(), pre / nrm, atol=2e-5, rtol=1e-5)
+    torch.testing.assert_close(n0.view(shape[0], *shape[2:]).cpu().double(), nrm.squeeze(1), atol=1e-5, rtol=1e-5)
+    y1, _ = ops.conv3d_c16_ring_bf16(xd, wp, b.to(DEV), he, LF_EPI_LRELU, 1)
+    want = F.leaky_relu(bf(bf(acc.float()) * he) + b.view(1, -1, 1, 1, 1), 0.2)
+    err = (y1.cpu() - want).abs()
+    assert float(err.max()) <= 2 ** -7 * float(want.abs().max()), float(err.max())
+    assert float((err > 1e-6).float().mean()) < 5e-3
+    gy = torch.randn(shape, generator=g) * 1e-3
+    gx, _ = ops.conv3d_c16_ring_bf16(ops.cl(gy.to(DEV)), ops.pack_conv3d_c16_ring_bf16(w.to(DEV), transpose=True), None, he, 0, 1)
+    gwant = bf(bf(F.conv_transpose3d(bf(gy).double(), bf(w).double(), None, 1, 1).float()) * he)
+    err = (gx.cpu() - gwant).abs()
+    assert float(err.max()) <= 2 ** -7 * float(gwant.abs().max())
+    assert float((err > 1e-9).float().mean()) < 5e-3
+    # addend form: y = conv(x) * he + addend, fp32 on the accumulator
+    add = torch.randn(shape, generator=g)
+    ya, _ = ops.conv3d_c16_ring_bf16(xd, wp, None, he, 0, 0, addend=ops.cl(add.to(DEV)))
+    torch.testing.assert_close(ya.cpu().double(), acc * he + add.double(), atol=2e-5, rtol=1e-5)
+
+
 @pytest.mark.parametrize('shape', [(1, 16, 16, 16, 32), (2, 16, 9, 21, 45), (3, 16, 6, 40, 35), (1, 16, 64, 64, 64)])
 def test_weight_gradient_on_the_bf16_mfma(shape):
     """lf_conv_bwd_weight_bf16 (transposing bf16 staging, v_mfma_f32_16x16x32_bf16) against the fp64 contraction of the
@@ -136,7 +175,7 @@ def test_generator_step_under_bf16_autocast():
         tags = {n for n, _, _ in ops.KERNEL_TIMER}
     finally:
         ops.KERNEL_TIMER = None
-    assert 'conv3d_c16_bf16' in tags, tags
+    assert 'conv3d_c16_ring_bf16' in tags, tags
     tot = float(got['total'])
     # within bf16 noise of the autocast oracle, and the deviation from fp32 is of the same order as the oracle's own
     assert abs(tot - want16) / want16 < 2e-2, (tot, want16, want32)
