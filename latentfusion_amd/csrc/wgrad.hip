@@ -214,28 +214,37 @@ __global__ void __launch_bounds__(512) wgrad3d_c16_kernel(
 // run -- 8 consecutive voxels of ONE channel per lane -- where channels-last memory has 16 channels of one voxel: the
 // tile is transposed on its way into LDS.  A thread loads the same 16-byte quarter (4 channels) of TWO voxels adjacent
 // in x into registers, rounds to bf16 (RNE, v_cvt_pk_bf16_f32: the identity on operands autocast has already rounded),
-// and writes four dwords = the two voxels of each of its channels (v_perm) into channel-major planes:
-// x [16 ch][4][10][18 (+6)] and gpre [16 ch][2][8][16], channel strides padded to spread the planes over the banks.  A
-// lane then reads its 8-voxel K run with one ds_read_b128; the kx = 0, 1, 2 taps of a row come from the SAME five
-// dwords (kx = 2: a dword later; kx = 1: v_alignbyte).  Four waves; wave w owns the (kz, ky) stencil rows 2w, 2w+1 for all
-// eight 32-voxel K groups (2 rows x 16 voxels) of the tile and row 8 for K groups 2w, 2w+1: 54 MFMAs per wave and tile,
-// nine accumulators, and only row 8 is summed across waves (through LDS, fixed order) at the end.  Two workgroups per CU
-// (2 x 39 KB of LDS each: the next tile is loaded while this one is contracted, then converted).
+// and writes four dwords = the two voxels of each of its channels (v_perm) into channel-major planes.  A lane then reads
+// its 8-voxel K run with one ds_read_b128; the kx = 0, 1, 2 taps of a row come from the SAME five dwords (kx = 2: a dword
+// later; kx = 1: v_alignbyte).
+// With the MFMAs this cheap the kernel is bound by what it asks of L2 / HBM, so a workgroup walks UP a column of
+// 2 x 8 x 16 tiles and keeps the x halo in a ring of six z-plane slots ([16 ch][6 slots][10 rows][18 (+6) x] bf16): a
+// tile reads four planes, two of which the next tile reads again, so only the two new planes (and the tile's own 2 x 8 x 16
+// block of gpre, double-buffered) are fetched per tile -- 39 KB instead of 62 KB -- while the current tile is contracted.
+// Four waves; wave w owns the (kz, ky) stencil rows 2w, 2w+1 for all eight 32-voxel K groups (2 rows x 16 voxels) of the
+// tile and row 8 for K groups 2w, 2w+1: 54 MFMAs per wave and tile, nine accumulators, and only row 8 is summed across
+// waves (through LDS, fixed order) at the end.  Two workgroups per CU (62 KB of LDS each).
 // Products of bf16 operands are exact in fp32 and accumulation is fp32 as on the fp32 kernel: same result up to
 // summation order.  Partials: one 27 x 256 block per workgroup, summed by wgrad_reduce_kernel (fixed order, fp64).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr int BRING = 6;                                         // z-plane slots: 4 being read + 2 being filled
 constexpr int BRS = 48;                                          // bytes per halo row: 18 bf16 (+6)
-constexpr int BXS = WHZ * WHY * BRS + 16;                        // channel stride of the x planes (1936 B)
+constexpr int BPL = WHY * BRS;                                   // 480 B per plane slot and channel
+constexpr int BXS = BRING * BPL + 16;                            // channel stride of the x planes (2896 B: 20 banks)
 constexpr int BGR = 32;                                          // bytes per gpre row: 16 bf16
 constexpr int BGS = WTZ * WTY * BGR + 16;                        // channel stride of the gpre planes (528 B)
-constexpr int BXB = 16 * BXS;                                    // 30,976 B
-constexpr int BBUF = BXB + 16 * BGS;                             // 39,424 B per buffer
-constexpr int BHP = WHALO / 2;                                   // 360 voxel pairs in the halo (18 is even: pairs never straddle rows)
-constexpr int BHIT = (BHP * 4 + 255) / 256;                      // 6 halo pair-pieces per thread and tile ...
-constexpr int BNIT = BHIT + (WTZ * WTY * WTX / 2) * 4 / 256;     // ... + 2 gpre pair-pieces
+constexpr int BXB = 16 * BXS;                                    // 46,336 B
+constexpr int BGB = 16 * BGS;                                    // 8,448 B per gpre buffer
+constexpr int BLDS = BXB + 2 * BGB;                              // 63,232 B
+constexpr int BPP = 2 * WHY * (WHX / 2);                         // 180 voxel pairs in two halo planes
+constexpr int BXIT = (BPP * 4 + 255) / 256;                      // 3 x pair-pieces per thread and tile ...
+constexpr int BNIT = BXIT + (WTZ * WTY * WTX / 2) * 4 / 256;     // ... + 2 gpre pair-pieces
+constexpr unsigned BOOB = 0x80000000u;
+
+__device__ __forceinline__ int bmod6(int v) { return v >= 6 ? v - 6 : v; }      // v in [0, 12)
 
 __global__ void __launch_bounds__(256, 2) wgrad3d_c16_bf16_kernel(
     const float* __restrict__ x, const float* __restrict__ gp, float* __restrict__ partial,
@@ -251,6 +260,7 @@ __global__ void __launch_bounds__(256, 2) wgrad3d_c16_bf16_kernel(
   const int t_end = min(t_begin + per, ntiles);
   const long nvox = (long)D * H * W;
   const unsigned sample_bytes = (unsigned)(nvox * 64);
+  const unsigned plane_bytes = (unsigned)(H * W * 64);
 
   f32x4 acc[9];                                                  // rows 2w, 2w+1 (x 3 kx), then this wave's share of row 8
 #pragma unroll
@@ -258,67 +268,70 @@ __global__ void __launch_bounds__(256, 2) wgrad3d_c16_bf16_kernel(
 
   if (t_begin < t_end) {
     const int q = lane & 3;
-    // pair-piece constants, coordinates relative to the halo origin (tile origin - 1): lxy = x | y << 8 of the pair's first
-    // voxel, poff = its byte offset from that origin, dst = LDS byte offset of channel 4q's dword.  Iterations 0..5 are
-    // halo pieces and 6, 7 gpre pieces for every wave (nothing below branches on the wave); the slots past the 360th pair
-    // repeat it -- same data, same address.
-    int lxy[BNIT], poff[BNIT], dst[BNIT];
+    // pair-piece constants.  x pieces (it < 3): pair P of the two incoming planes = (plane P / 90, row, x pair); gpre pieces:
+    // pair of the tile's 2 x 8 x 16 block.  lxy = x | y << 8 | plane << 16 relative to the tile origin - 1 (x) / the tile
+    // origin (gpre); dst = LDS byte offset of channel 4q's dword inside slot 0 / gpre buffer 0.  The slots past the 180th
+    // pair repeat it (same data, same address), so nothing below branches on the wave.
+    int lxy[BNIT], dst[BNIT];
 #pragma unroll
     for (int it = 0; it < BNIT; ++it) {
-      int lx, ly, lz;
-      if (it < BHIT) {
-        const int pr = min((wave + 4 * it) * 16 + (lane >> 2), BHP - 1);
-        const int row = pr / (WHX / 2);
-        lx = 2 * (pr - row * (WHX / 2)); ly = row % WHY; lz = row / WHY;
-        dst[it] = 4 * q * BXS + (lz * WHY + ly) * BRS + lx * 2;
+      if (it < BXIT) {
+        const int pr = min((wave + 4 * it) * 16 + (lane >> 2), BPP - 1);
+        const int pl = pr / (BPP / 2), rem = pr - pl * (BPP / 2), row = rem / (WHX / 2), px = rem - row * (WHX / 2);
+        lxy[it] = (2 * px) | (row << 8) | (pl << 16);
+        dst[it] = 4 * q * BXS + row * BRS + px * 4;
       } else {
-        const int pr = (wave + 4 * (it - BHIT)) * 16 + (lane >> 2);
-        lx = 2 * (pr & 7); ly = (pr >> 3) & 7; lz = pr >> 6;
+        const int pr = (wave + 4 * (it - BXIT)) * 16 + (lane >> 2);
+        const int lx = 2 * (pr & 7), ly = (pr >> 3) & 7, lz = pr >> 6;
+        lxy[it] = lx | (ly << 8) | (lz << 16);
         dst[it] = BXB + 4 * q * BGS + (lz * WTY + ly) * BGR + lx * 2;
-        ++lx; ++ly; ++lz;
       }
-      lxy[it] = lx | (ly << 8);
-      poff[it] = ((lz * H + ly) * W + lx) * 64 + q * 16;
     }
-    u32x4 st[BNIT][2];
-    auto issue = [&](int t) {
-      int tt = t;
-      const int bx = tt % tiles_x; tt /= tiles_x;
-      const int by = tt % tiles_y; tt /= tiles_y;
-      const int bz = tt % tiles_z; tt /= tiles_z;
-      const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long)tt * nvox * 16), 0, sample_bytes, 0x00020000);
-      const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)(gp + (long)tt * nvox * 16), 0, sample_bytes, 0x00020000);
-      const int x0 = bx * WTX - 1, y0 = by * WTY - 1, z0 = bz * WTZ - 1;
-      const int toff = ((z0 * H + y0) * W + x0) * 64;
-      // planes outside the sample fall outside the buffer (negative or >= its size) and read as zero; rows and columns
-      // outside it would wrap into their neighbours and are masked -- on the tiles that have any
-      if (x0 >= 0 && x0 + WHX <= W && y0 >= 0 && y0 + WHY <= H) {
-#pragma unroll
-        for (int it = 0; it < BNIT; ++it) {
-          st[it][0] = __builtin_amdgcn_raw_buffer_load_b128(it < BHIT ? rx : rg, poff[it] + toff, 0, 0);
-          st[it][1] = __builtin_amdgcn_raw_buffer_load_b128(it < BHIT ? rx : rg, poff[it] + toff + 64, 0, 0);
-        }
-      } else {
-#pragma unroll
-        for (int it = 0; it < BNIT; ++it) {
-          const unsigned gx = (unsigned)(x0 + (lxy[it] & 0xff));
-          const bool oky = (unsigned)(y0 + (lxy[it] >> 8)) < (unsigned)H;
-          st[it][0] = __builtin_amdgcn_raw_buffer_load_b128(it < BHIT ? rx : rg, (oky && gx < (unsigned)W) ? poff[it] + toff : (int)0x80000000, 0, 0);
-          st[it][1] = __builtin_amdgcn_raw_buffer_load_b128(it < BHIT ? rx : rg, (oky && gx + 1 < (unsigned)W) ? poff[it] + toff + 64 : (int)0x80000000, 0, 0);
-        }
-      }
-    };
-    auto commit = [&](int bufsel) {
-      unsigned char* base = smem + bufsel * BBUF;
+    // per COLUMN of tiles: byte offsets inside the sample of each piece's first voxel with the incoming plane pair / the
+    // tile at z = 0, and which of its two voxels lie inside the volume in x and y (bits 2 it, 2 it + 1); the plane itself is
+    // added per tile, and planes outside [0, D) fall outside the buffer (below zero wraps) and read as zero
+    unsigned coff[BNIT];
+    unsigned okm = 0;
+    const float *cx_ptr = x, *cg_ptr = gp;
+    auto column = [&](int bx, int by, int bn) {
+      okm = 0;
 #pragma unroll
       for (int it = 0; it < BNIT; ++it) {
+        const int halo = it < BXIT ? 1 : 0;
+        const int gx = bx * WTX - halo + (lxy[it] & 0xff), gy = by * WTY - halo + ((lxy[it] >> 8) & 0xff);
+        coff[it] = (unsigned)((gy * W + gx) * 64 + q * 16) + (unsigned)(lxy[it] >> 16) * plane_bytes;
+        const bool oky = (unsigned)gy < (unsigned)H;
+        okm |= ((oky && (unsigned)gx < (unsigned)W) ? 1u : 0u) << (2 * it);
+        okm |= ((oky && (unsigned)(gx + 1) < (unsigned)W) ? 1u : 0u) << (2 * it + 1);
+      }
+      cx_ptr = x + (long)bn * nvox * 16;
+      cg_ptr = gp + (long)bn * nvox * 16;
+    };
+    u32x4 st[BNIT][2];
+    // x planes zx, zx + 1 of the column (and, with_g, the gpre block of the tile at planes zg, zg + 1) -> registers
+    auto issue = [&](int zx, int zg, bool with_g) {
+      const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)cx_ptr, 0, sample_bytes, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)cg_ptr, 0, with_g ? sample_bytes : 0u, 0x00020000);
+      const unsigned zoffx = (unsigned)zx * plane_bytes, zoffg = (unsigned)zg * plane_bytes;
+#pragma unroll
+      for (int it = 0; it < BNIT; ++it) {
+        const unsigned o = coff[it] + (it < BXIT ? zoffx : zoffg);
+        st[it][0] = __builtin_amdgcn_raw_buffer_load_b128(it < BXIT ? rx : rg, (int)(((okm >> (2 * it)) & 1u) ? o : BOOB), 0, 0);
+        st[it][1] = __builtin_amdgcn_raw_buffer_load_b128(it < BXIT ? rx : rg, (int)(((okm >> (2 * it + 1)) & 1u) ? o + 64u : BOOB), 0, 0);
+      }
+    };
+    // registers -> bf16 planes: x pieces into ring slots s0 (first plane) / s1, gpre pieces into buffer gsel
+    auto commit = [&](int s0, int s1, int gsel, bool with_g) {
+#pragma unroll
+      for (int it = 0; it < BNIT; ++it) {
+        if (it >= BXIT && !with_g) continue;                       // (uniform)
         const f32x4 e = __builtin_bit_cast(f32x4, st[it][0]), o = __builtin_bit_cast(f32x4, st[it][1]);
         const unsigned e01 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){e[0], e[1]}, bf16x2));
         const unsigned e23 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){e[2], e[3]}, bf16x2));
         const unsigned o01 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){o[0], o[1]}, bf16x2));
         const unsigned o23 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){o[2], o[3]}, bf16x2));
-        const int cs = it < BHIT ? BXS : BGS;
-        unsigned char* d = base + dst[it];
+        const int cs = it < BXIT ? BXS : BGS;
+        unsigned char* d = smem + dst[it] + (it < BXIT ? ((lxy[it] >> 16) ? s1 : s0) * BPL : gsel * BGB);
         // one dword per channel: [voxel x, voxel x + 1]
         *(unsigned*)(d) = __builtin_amdgcn_perm(o01, e01, 0x05040100u);
         *(unsigned*)(d + cs) = __builtin_amdgcn_perm(o01, e01, 0x07060302u);
@@ -327,10 +340,9 @@ __global__ void __launch_bounds__(256, 2) wgrad3d_c16_bf16_kernel(
       }
     };
     // operand offsets: K group kg = (plane z = kg >> 2, row pair rp = kg & 3); lane group k -> row 2*rp + (k >> 1), x half k & 1
-    const int a_lane = BXB + m * BGS + (k >> 1) * BGR + (k & 1) * 16;                             // + (z*WTY + 2*rp) * BGR
-    const int b_lane = m * BXS + (k >> 1) * BRS + (k & 1) * 16;                                   // + ((z + kz)*WHY + ky + 2*rp) * BRS
-    const int row_base = ((2 * wave) / 3 * WHY + (2 * wave) % 3) * BRS;                           // stencil row 2w; row 2w+1 below
-    const int row_next = ((2 * wave + 1) / 3 * WHY + (2 * wave + 1) % 3) * BRS;
+    const int a_lane = BXB + m * BGS + (k >> 1) * BGR + (k & 1) * 16;                             // + gsel*BGB + (z*WTY + 2*rp) * BGR
+    const int b_lane = m * BXS + (k >> 1) * BRS + (k & 1) * 16;                                   // + slot(z + kz)*BPL + (ky + 2*rp) * BRS
+    const int kz0 = (2 * wave) / 3, ky0 = (2 * wave) % 3, kz1 = (2 * wave + 1) / 3, ky1 = (2 * wave + 1) % 3;
     auto three_taps = [&](const bf16x8 a, const unsigned char* row, f32x4* c) {
       const u32x4 d = *(const u32x4*)row;
       const unsigned d4 = *(const unsigned*)(row + 16);
@@ -341,37 +353,78 @@ __global__ void __launch_bounds__(256, 2) wgrad3d_c16_bf16_kernel(
       c[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, b1), c[1], 0, 0, 0);
       c[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, b2), c[2], 0, 0, 0);
     };
-    auto contract = [&](const unsigned char* buf) {
+    auto contract = [&](int rot, int gsel) {
+      // halo plane hp (0..3) of the tile sits in ring slot (rot + hp) % 6
+      const unsigned char* ab = smem + a_lane + gsel * BGB;
+      const unsigned char* r0[2], *r1[2], *r8[2];
+#pragma unroll
+      for (int z = 0; z < 2; ++z) {
+        r0[z] = smem + b_lane + bmod6(rot + z + kz0) * BPL + ky0 * BRS;
+        r1[z] = smem + b_lane + bmod6(rot + z + kz1) * BPL + ky1 * BRS;
+        r8[z] = smem + b_lane + bmod6(rot + z + 2) * BPL + 2 * BRS;
+      }
 #pragma unroll
       for (int kg = 0; kg < 8; ++kg) {
         const int z = kg >> 2, rp = kg & 3;
-        const bf16x8 a = *(const bf16x8*)(buf + a_lane + (z * WTY + 2 * rp) * BGR);
-        const unsigned char* rows = buf + b_lane + (z * WHY + 2 * rp) * BRS;
-        three_taps(a, rows + row_base, acc);
-        three_taps(a, rows + row_next, acc + 3);
+        const bf16x8 a = *(const bf16x8*)(ab + (z * WTY + 2 * rp) * BGR);
+        three_taps(a, r0[z] + 2 * rp * BRS, acc);
+        three_taps(a, r1[z] + 2 * rp * BRS, acc + 3);
       }
 #pragma unroll
       for (int g = 0; g < 2; ++g) {                               // stencil row 8 = (kz, ky) = (2, 2): K groups 2w, 2w + 1
-        const int kg = 2 * wave + g, z = kg >> 2, rp = kg & 3;
-        const bf16x8 a = *(const bf16x8*)(buf + a_lane + (z * WTY + 2 * rp) * BGR);
-        three_taps(a, buf + b_lane + ((z + 2) * WHY + 2 + 2 * rp) * BRS, acc + 6);
+        const int kg = 2 * wave + g, z = kg >> 2, rp = kg & 3;    // (wave-uniform)
+        const bf16x8 a = *(const bf16x8*)(ab + (z * WTY + 2 * rp) * BGR);
+        three_taps(a, (z ? r8[1] : r8[0]) + 2 * rp * BRS, acc + 6);
       }
     };
 
-    issue(t_begin);
+    // tile coordinates are stepped, not divided; z fastest: the range walks up columns
+    int cx, cy, cz, cn;
+    {
+      int tt = t_begin;
+      cz = tt % tiles_z; tt /= tiles_z;
+      cx = tt % tiles_x; tt /= tiles_x;
+      cy = tt % tiles_y; cn = tt / tiles_y;
+    }
+    int rot = 0;
+    column(cx, cy, cn);
+    issue(cz * WTZ - 1, 0, false);
     __builtin_amdgcn_sched_barrier(0);
-    commit(0);
+    commit(0, 1, 0, false);
+    issue(cz * WTZ + 1, cz * WTZ, true);
+    __builtin_amdgcn_sched_barrier(0);
+    commit(2, 3, 0, true);
     __syncthreads();
     for (int t = t_begin; t < t_end; ++t) {
-      const int cur = (t - t_begin) & 1;
-      const unsigned char* buf = smem + cur * BBUF;
-      const bool more = t + 1 < t_end;
-      if (more) issue(t + 1);
+      const int gsel = (t - t_begin) & 1;
+      int nx = cx, ny = cy, nz = cz + 1, nn = cn;
+      if (nz == tiles_z) { nz = 0; ++nx; }
+      if (nx == tiles_x) { nx = 0; ++ny; }
+      if (ny == tiles_y) { ny = 0; ++nn; }
+      const bool on = t + 1 < t_end;
+      const bool slide = on && nz != 0;
+      if (on) {
+        if (!slide) column(nx, ny, nn);
+        // the two planes the next tile adds (slide: its halo planes 2, 3; new column: its planes 0, 1) and its gpre block
+        issue(nz * WTZ - 1 + (slide ? 2 : 0), nz * WTZ, true);
+      }
       __builtin_amdgcn_sched_barrier(0);
-      contract(buf);
+      contract(rot, gsel);
       __builtin_amdgcn_sched_barrier(0);
-      if (more) commit(cur ^ 1);
-      __syncthreads();
+      if (on) commit(bmod6(rot + 4), bmod6(rot + 5), gsel ^ 1, true);
+      __syncthreads();                                          // this tile's planes 0, 1 are free; the new planes are visible
+      if (on && !slide) {
+        // bottom of a new column: what arrived are its planes 0, 1 (slots rot+4, rot+5); planes 2, 3 go to the slots this
+        // tile has just released (exposed once per column)
+        rot = bmod6(rot + 4);
+        issue(nz * WTZ + 1, 0, false);
+        __builtin_amdgcn_sched_barrier(0);
+        commit(bmod6(rot + 2), bmod6(rot + 3), 0, false);
+        __syncthreads();
+      } else {
+        rot = bmod6(rot + 2);
+      }
+      cx = nx; cy = ny; cz = nz; cn = nn;
     }
   }
   // row 8 (taps 24..26): waves 1..3 hand their shares to wave 0 through LDS, summed in wave order
@@ -544,7 +597,7 @@ extern "C" int lf_conv_bwd_weight_bf16(const float* x, const float* gpre, float*
   const int ptx = (W + WTX - 1) / WTX, pty = (H + WTY - 1) / WTY, ptz = (D + WTZ - 1) / WTZ;
   const long pt = (long)ptx * pty * ptz * N;
   if (pt > 0x7fffffffL) return LF_EINVAL;
-  const size_t shmem = (size_t)2 * BBUF;
+  const size_t shmem = (size_t)BLDS;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)wgrad3d_c16_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);

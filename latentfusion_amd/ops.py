@@ -224,6 +224,23 @@ def amax_buffer(value=None, device='cuda', rows=1):
     return buf
 
 
+_PAIR_TABLE = {}
+
+
+def _pair_taps(w):
+    """[16 cout][16 cin][3,3,3] -> [14 pairs][16 cout][32 = 2 taps x 16 cin] in the tap-pair order of the ring kernels
+    (lf_conv3d_c16_split_pairs; a missing second tap = zeros): one gather, not 28 slice copies per pack -- the training
+    step repacks every weight every iteration."""
+    idx = _PAIR_TABLE.get(w.device)
+    if idx is None:
+        import ctypes
+        table = (ctypes.c_int * 28)()
+        _lib.lib().lf_conv3d_c16_split_pairs(table)
+        idx = _PAIR_TABLE[w.device] = torch.tensor([t if t >= 0 else 27 for t in table], device=w.device)
+    taps = torch.cat((w.reshape(16, 16, 27), w.new_zeros(16, 16, 1)), dim=2)       # tap 27 = zeros
+    return taps[:, :, idx].reshape(16, 16, 14, 2).permute(2, 0, 3, 1).reshape(14, 16, 32)
+
+
 def pack_conv3d_c16_split(weight, transpose=False):
     """[16,16,3,3,3] fp32 -> f16 hi/lo packs [14 pairs][hi,lo][16 cout][32 = 2 taps x 16 cin] for
     lf_conv3d_c16_split (the second tap of the last pair is zero)."""
@@ -231,17 +248,7 @@ def pack_conv3d_c16_split(weight, transpose=False):
     if transpose:
         w = w.transpose(0, 1).flip(dims=(2, 3, 4))
     assert tuple(w.shape) == (16, 16, 3, 3, 3)
-    import ctypes
-    L = _lib.lib()
-    table = (ctypes.c_int * 28)()
-    L.lf_conv3d_c16_split_pairs(table)
-    taps = w.reshape(16, 16, 27)                                   # [cout][cin][tap]
-    k = torch.zeros(14, 16, 32, device=w.device)                   # [pair][cout][tapsel*16 + cin]
-    for p in range(14):
-        for sel in range(2):
-            tap = table[2 * p + sel]
-            if tap >= 0:
-                k[p, :, sel * 16:(sel + 1) * 16] = taps[:, :, tap]
+    k = _pair_taps(w)                                              # [14 pairs][cout][tapsel*16 + cin]
     hi = k.half()
     lo = (k - hi.float()).half()
     return torch.stack((hi, lo), dim=1).contiguous()              # [14][2][16][32]
@@ -293,15 +300,7 @@ def pack_conv3d_c16_ring_bf16(weight, transpose=False):
     if transpose:
         w = w.transpose(0, 1).flip(dims=(2, 3, 4))
     assert tuple(w.shape) == (16, 16, 3, 3, 3)
-    import ctypes
-    table = (ctypes.c_int * 28)()
-    _lib.lib().lf_conv3d_c16_split_pairs(table)
-    taps = w.reshape(16, 16, 27)
-    k = torch.zeros(14, 16, 32, device=w.device)
-    for p in range(14):
-        for sel in range(2):
-            if table[2 * p + sel] >= 0:
-                k[p, :, sel * 16:(sel + 1) * 16] = taps[:, :, table[2 * p + sel]]
+    k = _pair_taps(w)
     return k.to(torch.bfloat16).contiguous()
 
 
