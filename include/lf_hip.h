@@ -54,7 +54,8 @@ int lf_device_name(char* buf, int buflen);
  * flight per workgroup iteration: 1 = one, 2 = two (default), 3-5 = register-capped forms of 2 / 1.  key 3: workgroup
  * shape of lf_wino_fused_gemm (output channels x Winograd tiles): 0 = 64 x 64, 1 = 128 x 64, 2 = 64 x 128, 3 = 128 x 128,
  * 4 = 64 x 256 (3, 4: 2-D only), -1 = chosen from the problem shape (default).  key 4: lf_resample3d_bwd_vol_det, 1 = global
- * 64-bit atomics, 2 = source tiles accumulated in LDS (default; C == 16; bit-identical results).
+ * 64-bit atomics, 2 = source tiles accumulated in LDS (default; C == 16; bit-identical results).  key 5: resident workgroups
+ * per CU of lf_conv3d_c16_ring_bf16, 2 (default) or 3.
  * Returns the previous value or LF_EINVAL. */
 int lf_set_tuning(int key, int value);
 

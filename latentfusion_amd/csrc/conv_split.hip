@@ -554,6 +554,13 @@ extern "C" int lf_conv3d_c16_split(const float* x, const void* wsplit, const flo
   return lf_launch_status();
 }
 
+static int g_ring_bf16_wgs = 2;
+int lf_internal_ring_bf16_set_wgs(int v) {
+  const int prev = g_ring_bf16_wgs;
+  if (v == 2 || v == 3) g_ring_bf16_wgs = v;
+  return prev;
+}
+
 // bf16 elements of the weight pack of the bf16 form: [14 pairs][16 cout][32 = 2 taps x 16 cin] (pairs: lf_conv3d_c16_split_pairs)
 extern "C" size_t lf_conv3d_c16_ring_bf16_wpack_elems(void) { return (size_t)NPAIR * 16 * 32; }
 
@@ -579,7 +586,7 @@ extern "C" int lf_conv3d_c16_ring_bf16(const float* x, const void* wpack, const 
   typedef void (*kern_t)(const float*, const void*, const float*, float*, float*, int, int, int, int, int, int, int, int, float,
                          unsigned, float, float, const float*, const float*, unsigned, const float*, float*, int);
   static const kern_t kerns[2] = {conv3d_c16_f16x3_kernel<false, 1>, conv3d_c16_f16x3_kernel<true, 1>};
-  const long want = (long)SPLIT_WGS * cus;
+  const long want = (long)g_ring_bf16_wgs * cus;               // (35 KB of LDS and < 170 VGPRs: three fit)
   const unsigned grid = (unsigned)(pt < want ? pt : want);
   hipLaunchKernelGGL(kerns[addend != nullptr ? 1 : 0], dim3(grid), dim3(256), shmem, (hipStream_t)stream, x, wpack, bias, y, norm_out,
                      N, D, H, W, ptx, pty, ptz, (int)pt, he, flags, slope, eps, addend, (const float*)nullptr, (unsigned)LF_EPI_ADD,

@@ -50,4 +50,5 @@ __device__ __forceinline__ float lf_amax_read(const float* base, int lane) {
 __device__ __forceinline__ float lf_lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 
 // A/B switches that live in other translation units (lf_set_tuning dispatches to them)
+int lf_internal_ring_bf16_set_wgs(int v);                         // conv_split.hip: workgroups per CU of lf_conv3d_c16_ring_bf16 (2 or 3)
 int lf_internal_fused_set_cfg(int v);                             // wino_fused.hip: workgroup shape of the fused GEMM, -1 = by shape

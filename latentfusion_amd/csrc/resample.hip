@@ -915,6 +915,7 @@ extern "C" int lf_set_tuning(int key, int value) {
     return prev;
   }
   if (key == 3) return lf_internal_fused_set_cfg(value);            // fused wide-conv GEMM: workgroup shape 0..3, -1 = by shape
+  if (key == 5) return lf_internal_ring_bf16_set_wgs(value);        // bf16 ring convolution: resident workgroups per CU
   if (key == 2) {
     const int prev = g_bwd_coef_variant;
     if (value >= 1 && value <= 5) g_bwd_coef_variant = value;

@@ -121,3 +121,42 @@ def test_hip_is_as_close_to_fp64_as_the_fp32_reference(S):
     lerr_hip = ((losses[:, 4].cpu().double() - l64).abs() / l64.abs()).max().item()
     print(f"S={S}: loss error vs fp64: HIP {lerr_hip:.2e}, fp32 oracle {lerr_ref:.2e}")
     assert lerr_hip < 2 * lerr_ref + 2e-6, (lerr_hip, lerr_ref)
+
+
+def test_fullsize_bf16_training_kernels_agree_with_their_fp32_mfma_forms():
+    """The bf16-MFMA kernels of the autocast training step at the full 8 x 128^3 x 16 size, against independent kernels that
+    form the same exact products in a different order: the ring convolution vs the all-fp32 Winograd kernel fed bf16-rounded
+    operands (Winograd pre-adds are not bf16-exact, hence the looser bound) and vs the non-ring bf16 kernel; the bf16 weight
+    gradient vs the fp32-MFMA weight gradient of pre-rounded operands; linearity in the addend; run-to-run identity."""
+    from latentfusion_amd import ops
+    from latentfusion_amd._lib import LF_EPI_LRELU, LF_EPI_PIXELNORM
+    g = torch.Generator().manual_seed(11)
+    x = ops.cl(torch.randn(8, 16, 128, 128, 128, generator=g).to(DEV))
+    w = torch.randn(16, 16, 3, 3, 3, generator=g).to(DEV)
+    b = (torch.randn(16, generator=g) * 0.1).to(DEV)
+    he = ops.he_constant(w)
+    flags = LF_EPI_LRELU | LF_EPI_PIXELNORM
+    wp = ops.pack_conv3d_c16_ring_bf16(w)
+    y, nrm = ops.conv3d_c16_ring_bf16(x, wp, b, he, flags, 0)
+    y2, _ = ops.conv3d_c16_ring_bf16(x, wp, b, he, flags, 0)
+    assert torch.equal(y, y2)
+    yo, no = ops.conv3d_c16_bf16(x, ops.pack_conv3d_c16_bf16(w), b, he, flags, 0)             # same products, other kernel
+    assert (y - yo).abs().max().item() < 2e-5 and (nrm - no).abs().max().item() < 2e-5
+    wr = ops.round_bf16(w)
+    yw, _ = ops.conv3d_c16_wino(ops.round_bf16(x), ops.pack_conv3d_c16_wino(wr), b, he, flags)
+    assert (y - yw).abs().max().item() < 2e-4
+    del yo, yw, y2
+    # addend form: conv(x) * he + a, and linearity in a
+    a = ops.cl(torch.randn(8, 16, 128, 128, 128, generator=g).to(DEV))
+    y0, _ = ops.conv3d_c16_ring_bf16(x, wp, None, he, 0, 0)
+    ya, _ = ops.conv3d_c16_ring_bf16(x, wp, None, he, 0, 0, addend=a)
+    assert (ya - (y0 + a)).abs().max().item() < 1e-5
+    del ya, y0
+    # weight gradient
+    gp = ops.cl((torch.randn(8, 16, 128, 128, 128, generator=g) * 1e-3).to(DEV))
+    with ops.autocast():
+        gw, _ = ops.conv_bwd_weight(x, gp, 3, 16, he, want_bias=False)
+        gw2, _ = ops.conv_bwd_weight(x, gp, 3, 16, he, want_bias=False)
+    assert torch.equal(gw, gw2)
+    ref, _ = ops.conv_bwd_weight(ops.round_bf16(x), ops.round_bf16(gp), 3, 16, he, want_bias=False)
+    assert (gw - ref).abs().max().item() < 2e-6 * ref.abs().max().item()
