@@ -23,8 +23,8 @@ KERNELS = collections.OrderedDict([
     # key -> (substring of the kernel name, algorithmic bytes per launch at N=8, C=16, S=128)
     ('conv3d_c16_wino_kernel', ('conv3d_c16_wino_kernel', 2 * 8 * 16 * 128 ** 3 * 4 + 8 * 128 ** 3 * 4)),
     ('conv3d_c16_persistent_kernel', ('conv3d_c16_persistent_kernel', 2 * 8 * 16 * 128 ** 3 * 4 + 8 * 128 ** 3 * 4)),
-    ('conv3d_c16_f16x3_kernel', (('conv3d_c16_f16x3_kernel<false>', 'conv3d_c16_f16x3_kernelILb0E'), 2 * 8 * 16 * 128 ** 3 * 4 + 8 * 128 ** 3 * 4)),
-    ('conv3d_c16_f16x3_kernel_bwd', (('conv3d_c16_f16x3_kernel<true>', 'conv3d_c16_f16x3_kernelILb1E'), 3 * 8 * 16 * 128 ** 3 * 4 + 8 * 128 ** 3 * 4)),
+    ('conv3d_c16_f16x3_kernel', (('conv3d_c16_f16x3_kernel<false, 3>', 'conv3d_c16_f16x3_kernel<false>', 'conv3d_c16_f16x3_kernelILb0ELi3E'), 2 * 8 * 16 * 128 ** 3 * 4 + 8 * 128 ** 3 * 4)),
+    ('conv3d_c16_f16x3_kernel_bwd', (('conv3d_c16_f16x3_kernel<true, 3>', 'conv3d_c16_f16x3_kernel<true>', 'conv3d_c16_f16x3_kernelILb1ELi3E'), 3 * 8 * 16 * 128 ** 3 * 4 + 8 * 128 ** 3 * 4)),
     ('resample_fwd', ('resample_fwd', 8 * 16 * 128 ** 3 * 4 + 16 * 128 ** 3 * 4)),
     ('resample_bwd_coef', ('resample_bwd_coef_', 8 * 16 * 128 ** 3 * 4 + 16 * 128 ** 3 * 4)),
     ('conv1x1_kernel', ('conv1x1_kernel', 8 * 16 * 128 ** 3 * 4)),
