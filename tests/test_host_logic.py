@@ -579,3 +579,30 @@ def test_photographer_skip_connections_allocation(golden):
         assert ph.create_checkpoint()['args']['skip_connections'] is True
     with pytest.raises(ValueError):
         ph(torch.zeros(1, 4, 8, 8, 8), type('C', (), {'__len__': lambda self: 1})())
+
+
+def test_tap_pair_packs_match_the_kernel_table():
+    """The weight packs of the ring kernels (lf_conv3d_c16_split, lf_conv3d_c16_ring_bf16) are built with one gather; the
+    layout contract is the C side's tap-pair table (lf_conv3d_c16_split_pairs, a host function): pair p holds taps
+    table[2p], table[2p+1] in K slots [0,16) and [16,32), a missing second tap is zeros, every tap appears exactly once."""
+    import ctypes
+    from latentfusion_amd import _lib, ops
+    table = (ctypes.c_int * 28)()
+    _lib.lib().lf_conv3d_c16_split_pairs(table)
+    taps = [t for t in table if t >= 0]
+    assert sorted(taps) == list(range(27)) and list(table).count(-1) == 1
+    w = torch.randn(16, 16, 3, 3, 3, generator=torch.Generator().manual_seed(0))
+    for transpose in (False, True):
+        wt = w.transpose(0, 1).flip(dims=(2, 3, 4)) if transpose else w
+        flat = wt.reshape(16, 16, 27)
+        want = torch.zeros(14, 16, 32)
+        for p in range(14):
+            for sel in range(2):
+                if table[2 * p + sel] >= 0:
+                    want[p, :, sel * 16:(sel + 1) * 16] = flat[:, :, table[2 * p + sel]]
+        bf = ops.pack_conv3d_c16_ring_bf16(w, transpose=transpose)
+        assert bf.dtype == torch.bfloat16 and torch.equal(bf.float(), want.to(torch.bfloat16).float())
+        sp = ops.pack_conv3d_c16_split(w, transpose=transpose)                        # [14][hi, lo][16][32] f16
+        assert torch.equal(sp[:, 0].float(), want.half().float())
+        assert torch.equal(sp[:, 1].float(), (want - want.half().float()).half().float())
+        assert bf.numel() == _lib.lib().lf_conv3d_c16_ring_bf16_wpack_elems()
