@@ -30,6 +30,15 @@ KERNELS = collections.OrderedDict([
     ('conv1x1_kernel', ('conv1x1_kernel', 8 * 16 * 128 ** 3 * 4)),
     ('column_sum_fwd_kernel', ('column_sum_fwd_kernel', 8 * 16 * 128 ** 3 * 4)),
 ])
+# --train: the kernels of tools/train_kernels_probe.py (training step, 8 x 128^3 x 16)
+V = 8 * 16 * 128 ** 3 * 4
+TRAIN_KERNELS = collections.OrderedDict([
+    ('conv3d_c16_ring_bf16', (('conv3d_c16_f16x3_kernel<false, 1>', 'conv3d_c16_f16x3_kernelILb0ELi1E'), 2 * V + V // 16)),
+    ('conv3d_c16_ring_bf16_addend', (('conv3d_c16_f16x3_kernel<true, 1>', 'conv3d_c16_f16x3_kernelILb1ELi1E'), 3 * V)),
+    ('wgrad3d_c16_bf16_kernel', ('wgrad3d_c16_bf16_kernel', 2 * V)),
+    ('wgrad3d_c16_kernel', ('wgrad3d_c16_kernel', 2 * V)),
+    ('splat_tile_kernel', ('splat_tile_kernel', 2 * V)),
+])
 # hbm_probe.py launches the Winograd kernel REP times in its forward form, then REP times as a data gradient with the
 # producer's epilogue backward fused (reads the saved activation and norm as well): reported separately
 SPLIT = {'conv3d_c16_wino_kernel': (('forward form', 2 * 8 * 16 * 128 ** 3 * 4 + 8 * 128 ** 3 * 4),
@@ -70,7 +79,8 @@ def find(data, sub, floor_counter=None, floor=0.0):
     return max(hits, key=lambda k: mean(data[k].get('SQ_WAVE_CYCLES', data[k].get('FETCH_SIZE', [0]))) or 0)
 
 
-def main(dirname, prefix):
+def main(dirname, prefix, kernels=None, probe='tools/hbm_probe.py'):
+    kernels = kernels or KERNELS
     data = load(dirname)
     GiB = 1024.0 ** 3
     cal = find(data, 'copyBuffer') or find(data, 'direct_copy_kernel')
@@ -78,12 +88,12 @@ def main(dirname, prefix):
     calw = [v for v in data.get(cal, {}).get('WRITE_SIZE', []) if v > 1e5] if cal else []
     corr = (GiB / 1024.0) / mean(calf) if calf else 2.0
     wcorr = (GiB / 1024.0) / mean(calw) if calw else 1.0
-    lines = [f'# PMC counters per launch (means over the dispatches of tools/hbm_probe.py), from {dirname}',
+    lines = [f'# PMC counters per launch (means over the dispatches of {probe}), from {dirname}',
              '# bench shape SYN(128,16), N = 8: 8 x 128^3 voxels x 16 channels fp32 per volume',
              f'# FETCH_SIZE correction (1 GiB copy in the same run): x{corr:.4f};  WRITE_SIZE: x{wcorr:.4f}', '']
     hbm = {'shape': 'N=8, C=16, S=128 (SYN(128,16) bench shape), fp32', 'collected': 'tools/pmc_collect.sh (separate --pmc passes)',
            'fetch_correction': corr, 'write_correction': wcorr, 'source_sha256': source_hashes(), 'kernels': {}}
-    for key, (sub, alg) in KERNELS.items():
+    for key, (sub, alg) in kernels.items():
         k = find(data, sub)
         if k is None:
             continue
@@ -125,4 +135,7 @@ def summarise(lines, hbm, key, vkey, k, alg, c, corr, wcorr):
 
 
 if __name__ == '__main__':
-    main(sys.argv[1], sys.argv[2])
+    if sys.argv[1] == '--train':
+        main(sys.argv[2], sys.argv[3], TRAIN_KERNELS, 'tools/train_kernels_probe.py')
+    else:
+        main(sys.argv[1], sys.argv[2])
