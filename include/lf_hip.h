@@ -357,7 +357,8 @@ int lf_conv_bwd_weight(const float* x, const float* gpre, float* gw, void* scrat
 /* The same weight gradient on the bf16 MFMA (autocast policy of the training step; recon/models.py:199,405): x and gpre
  * are rounded to bf16 (RNE) as they are staged -- the identity on operands the policy has already rounded -- products
  * are exact, accumulation fp32, partials summed in a fixed order in fp64 like lf_conv_bwd_weight (same scratch size).
- * 3-D 16 -> 16 layers with N*D*H*W >= 8192 only: LF_EINVAL otherwise (the caller keeps lf_conv_bwd_weight for the rest). */
+ * 3-D 16 -> 16 layers with N*D*H*W >= 8192, D*H*W*64 < 2^31 and (D+3)*H*W*64 < 2^32 only: LF_EINVAL otherwise (the caller
+ * keeps lf_conv_bwd_weight for the rest). */
 int lf_conv_bwd_weight_bf16(const float* x, const float* gpre, float* gw, void* scratch, size_t scratch_bytes,
                             int dims, int N, int D, int H, int W, int Cin, int Cout, float scale, void* stream);
 

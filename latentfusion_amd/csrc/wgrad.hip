@@ -592,6 +592,8 @@ extern "C" int lf_conv_bwd_weight_bf16(const float* x, const float* gpre, float*
   lf_clear_error();
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || x == nullptr || gpre == nullptr || gw == nullptr) return LF_EINVAL;
   if (!wgrad_fast3d(dims, N, D, H, W, Cin, Cout) || !lf_aligned16(x) || !lf_aligned16(gpre)) return LF_EINVAL;
+  // the kernel's 32-bit offsets reach three planes past the sample (halo planes of the last tile + the pair's second plane)
+  if ((long)(D + 3) * H * W * 64 > 0xffffffffL) return LF_EINVAL;
   const int nb = 2 * wgrad_cus();
   if (scratch_bytes < (size_t)nb * 27 * 256 * sizeof(float)) return LF_ENOSPC;
   const int ptx = (W + WTX - 1) / WTX, pty = (H + WTY - 1) / WTY, ptz = (D + WTZ - 1) / WTZ;

@@ -670,7 +670,10 @@ def bias_grad(gp, dims):
 
 def _wgrad_bf16_ok(gp, dims, cin, cout):
     """Shapes lf_conv_bwd_weight_bf16 takes (the rest stays on lf_conv_bwd_weight with pre-rounded operands)."""
-    return dims == 3 and cin == 16 and cout == 16 and gp.numel() // gp.shape[1] >= 8192
+    if not (dims == 3 and cin == 16 and cout == 16 and gp.numel() // gp.shape[1] >= 8192):
+        return False
+    D, H, W = gp.shape[2:]
+    return D * H * W * 64 < 2 ** 31 and (D + 3) * H * W * 64 <= 0xffffffff
 
 
 def conv_bwd_weight(x, gp, dims, cin, he, want_bias=True, bf16=None):
