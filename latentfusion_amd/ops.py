@@ -817,10 +817,9 @@ class _Conv3x3Sum16(torch.autograd.Function):
         he = he_constant(weight)
 
         ctx.ac = AUTOCAST is not None
-        nvox = parts[0].numel() // parts[0].shape[1]
         # autocast: the bf16 ring kernel (and the bf16 weight-gradient kernel) round their operands while staging them; only
-        # volumes too small for the latter keep the rounding pass in front
-        ctx.pre_round = ctx.ac and nvox < 8192
+        # volumes the latter does not take keep the rounding pass in front
+        ctx.pre_round = ctx.ac and not _wgrad_bf16_ok(parts[0], 3, 16, 16)
         parts = tuple((round_bf16(cl(p)) if ctx.pre_round else cl(p)) for p in parts)
 
         def make():
