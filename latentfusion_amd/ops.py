@@ -804,16 +804,20 @@ def conv3x3(x, weight, bias, lrelu=True, pixelnorm=True):
 
 
 class _Conv3x3Sum16(torch.autograd.Function):
-    """conv3d(cat(parts), W) * he + b for a 16-channel output, evaluated WITHOUT the concatenation as a sum of
-    16 -> 16 Winograd convolutions (the addend form of lf_conv3d_c16_wino), one per part.  `parts` are
-    channels-last (N,16,D,H,W) tensors; part p stands for `widths[p]` input channels of W (narrower parts -- the
-    3 coordinate channels of the ConvGRU gates -- are zero-padded to 16 by the caller).  Backward: per-part data
-    gradients on the same kernel, weight gradients on the LDS-staged 16 -> 16 kernel, no slice copies."""
+    """sum_p conv3d(parts[p], W[:, c0_p : c0_p + w_p]) * he (+ b) (+ addend) for a 16-channel output: a convolution over a
+    channel concatenation evaluated WITHOUT the concatenation, as a sum of 16 -> 16 convolutions (the addend form of
+    lf_conv3d_c16_wino / lf_conv3d_c16_ring_bf16), one per part.  `parts` are channels-last (N,16,D,H,W) tensors; part p
+    stands for the input channels cols[p] = (c0_p, w_p) of W (narrower parts -- the 3 coordinate channels of the ConvGRU
+    gates -- are zero-padded to 16 by the caller).  The parts need not cover W: a part that is the same in every call (those
+    coordinates) is convolved ONCE, bias included, and handed to the other calls as `addend`; autograd then sums its
+    gradient over the calls, and its weight / bias gradients are one launch instead of one per call.  Backward: per-part
+    data gradients on the same kernel, weight gradients on the LDS-staged 16 -> 16 kernels, no slice copies."""
 
     @staticmethod
-    def forward(ctx, weight, bias, widths, *parts):
+    def forward(ctx, weight, bias, cols, addend, *parts):
         _req(weight, 'weight')
-        assert weight.dim() == 5 and weight.shape[0] == 16 and sum(widths) == weight.shape[1] and len(widths) == len(parts)
+        assert weight.dim() == 5 and weight.shape[0] == 16 and len(cols) == len(parts) >= 1
+        assert all(0 <= c0 and 0 < wdt <= 16 and c0 + wdt <= weight.shape[1] for c0, wdt in cols)
         he = he_constant(weight)
 
         ctx.ac = AUTOCAST is not None
@@ -823,25 +827,27 @@ class _Conv3x3Sum16(torch.autograd.Function):
         parts = tuple((round_bf16(cl(p)) if ctx.pre_round else cl(p)) for p in parts)
 
         def make():
-            wd, packs, c0 = _wsrc(weight).detach(), [], 0
+            wd, packs = _wsrc(weight).detach(), []
             pack = pack_conv3d_c16_ring_bf16 if ctx.ac else pack_conv3d_c16_wino
-            for wdt in widths:
+            for c0, wdt in cols:
                 wp = wd.new_zeros(16, 16, 3, 3, 3)
                 wp[:, :wdt] = wd[:, c0:c0 + wdt]
                 packs.append((pack(wp), pack(wp, transpose=True)))
-                c0 += wdt
             return packs
-        packs = _cached(weight, 'sum16_' + '_'.join(map(str, widths)) + ('@ac' if ctx.ac else ''), make)
-        y = None
+        packs = _cached(weight, 'sum16_' + '_'.join(f'{c0}+{wdt}' for c0, wdt in cols) + ('@ac' if ctx.ac else ''), make)
+        y = cl(addend) if addend is not None else None
         for i, (p, (pf, _pt)) in enumerate(zip(parts, packs)):
             _req(p, 'part')
             b = bias.detach() if (bias is not None and i == 0) else None
+            if b is not None and y is not None:                  # (the addend forms take no bias: fold it in beforehand)
+                y = y + b.view(1, -1, 1, 1, 1)
+                b = None
             if ctx.ac:
                 y, _ = conv3d_c16_ring_bf16(p, pf, b, he, 0, 0, addend=y)
             else:
                 prev = None if y is None else (y, None, _lib.LF_EPI_ADD)
                 y, _ = conv3d_c16_wino(p, pf, b, he, 0, prev=prev)
-        ctx.he, ctx.widths, ctx.packs = he, widths, packs
+        ctx.he, ctx.cols, ctx.packs = he, cols, packs
         need_w = weight.requires_grad or (bias is not None and bias.requires_grad)
         ctx.save_for_backward(weight, *(parts if need_w else []))
         return y
@@ -855,7 +861,7 @@ class _Conv3x3Sum16(torch.autograd.Function):
             gy = round_bf16(gy)
         gparts = []
         for i, (_pf, pt) in enumerate(ctx.packs):
-            if not ctx.needs_input_grad[3 + i]:
+            if not ctx.needs_input_grad[4 + i]:
                 gparts.append(None)
             elif ctx.ac:
                 gparts.append(conv3d_c16_ring_bf16(gy, pt, None, ctx.he, 0, 1)[0])     # (rounded like autocast's conv backward)
@@ -863,18 +869,18 @@ class _Conv3x3Sum16(torch.autograd.Function):
                 gparts.append(conv3d_c16_wino(gy, pt, None, ctx.he, 0)[0])
         gw = gb = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
-            cols = []
-            for i, (p, wdt) in enumerate(zip(saved_parts, ctx.widths)):
-                g_i, gb_i = conv_bwd_weight(p, gy, 3, 16, ctx.he, want_bias=(i == 0), bf16=ctx.ac)
+            gwt = torch.zeros(27, 16, w.shape[1], device=gy.device, dtype=torch.float32)      # columns of other calls stay zero
+            for i, (p, (c0, wdt)) in enumerate(zip(saved_parts, ctx.cols)):
+                g_i, gb_i = conv_bwd_weight(p, gy, 3, 16, ctx.he, want_bias=(i == 0 and ctx.needs_input_grad[1] and not ctx.ac), bf16=ctx.ac)
                 gb = gb_i if i == 0 else gb
-                cols.append(g_i[:, :, :wdt])
-            gwt = torch.cat(cols, dim=2)                                   # [27][16][sum widths]
+                gwt[:, :, c0:c0 + wdt] = g_i[:, :, :wdt]
             gw = gwt.reshape(3, 3, 3, 16, w.shape[1]).permute(3, 4, 0, 1, 2).contiguous()
             if ctx.ac:
                 gw = round_bf16(gw)
                 if ctx.needs_input_grad[1]:
                     gb = bias_grad(gy_full, 3)
-        return (gw if ctx.needs_input_grad[0] else None, gb if ctx.needs_input_grad[1] else None, None, *gparts)
+        return (gw if ctx.needs_input_grad[0] else None, gb if ctx.needs_input_grad[1] else None, None,
+                gy_full if ctx.needs_input_grad[3] else None, *gparts)
 
 
 class _GruGates(torch.autograd.Function):
@@ -971,9 +977,15 @@ def gru_blend(h, u, cand):
     return _GruBlend.apply(h, u, cand)
 
 
-def conv3x3_sum16(weight, bias, widths, parts):
-    """See _Conv3x3Sum16."""
-    return _Conv3x3Sum16.apply(weight, bias, tuple(widths), *parts)
+def conv3x3_sum16(weight, bias, widths, parts, cols=None, addend=None):
+    """See _Conv3x3Sum16.  `widths`: the parts cover W's input channels back to back; or `cols` = ((first, width), ...)."""
+    if cols is None:
+        cols, c0 = [], 0
+        for wdt in widths:
+            cols.append((c0, wdt))
+            c0 += wdt
+        assert c0 == weight.shape[1]
+    return _Conv3x3Sum16.apply(weight, bias, tuple(tuple(c) for c in cols), addend, *parts)
 
 
 def _conv1x1_raw(x_ptr_tensor, wpack, bias, N, P, cin, ksl, xbs, xss, cout, y2d, he, flags, yaddr=None):

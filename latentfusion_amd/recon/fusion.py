@@ -152,14 +152,25 @@ class ConvGRUCell(nn.Module):
         return (z.is_cuda and z.dim() == 5 and w.dim() == 5 and self.hidden_dim == 16 and self.input_dim == 19
                 and z.shape[1] == 16 and h.shape[1] == 16 and z.shape[2] * z.shape[3] * z.shape[4] * 64 < 2 ** 31)
 
-    def forward_parts(self, z, c16, h_cur):
-        """forward(cat(z, coords), h_cur) with the coordinate channels given zero-padded to 16 (`c16`)."""
+    def coords_base(self, c16):
+        """conv(coords) * he + bias of the three gates: the part of every gate pre-activation that does not depend on the
+        view or the state, evaluated once per forward (the inference path does the same); its weight columns and the bias
+        get their gradients from the sum of the gate gradients over the views."""
+        from .. import ops
+        return tuple(ops.conv3x3_sum16(g.module.weight, g.bias, None, (c16,), cols=((16, 3),))
+                     for g in (self.update_gate, self.reset_gate, self.out_gate))
+
+    def forward_parts(self, z, c16, h_cur, base=None):
+        """forward(cat(z, coords), h_cur) with the coordinate channels given zero-padded to 16 (`c16`), or with their share of
+        the three gates precomputed (`base` = coords_base(c16))."""
         from .. import ops
 
-        def gate(g, state):
+        def gate(i, g, state):
+            if base is not None:
+                return ops.conv3x3_sum16(g.module.weight, None, None, (z, state), cols=((0, 16), (19, 16)), addend=base[i])
             return ops.conv3x3_sum16(g.module.weight, g.bias, (16, 3, 16), (z, c16, state))
-        update, rh = ops.gru_gates(gate(self.update_gate, h_cur), gate(self.reset_gate, h_cur), h_cur)
-        return ops.gru_blend(h_cur, update, gate(self.out_gate, rh))
+        update, rh = ops.gru_gates(gate(0, self.update_gate, h_cur), gate(1, self.reset_gate, h_cur), h_cur)
+        return ops.gru_blend(h_cur, update, gate(2, self.out_gate, rh))
 
 
 class ConvLSTMCell(nn.Module):
@@ -191,6 +202,7 @@ class GRUFuser(_ArgsFuser):
         n_coord = 2 if conv_module == EqualizedConv2d else 3
         self.gru = ConvGRUCell(in_channels + n_coord, in_channels, kernel_size=3, bias=True, conv_module=conv_module)
         self.split_gates = True        # False: always the concatenated 35-channel convolutions (tests compare the two)
+        self.hoist_coords = True       # the coordinate channels' share of the gates once per forward, not once per view
 
     def _args(self):
         return {'in_channels': self.in_channels, 'cube_size': self.cube_size}
@@ -210,8 +222,9 @@ class GRUFuser(_ArgsFuser):
             from .. import ops
             c16 = ops.empty_cl((h.shape[0], 16) + tuple(h.shape[2:]), h.device).zero_()
             c16[:, :3] = coords
+            base = self.gru.coords_base(c16) if self.hoist_coords else None
             for v in views[1:]:
-                h = self.gru.forward_parts(v, c16, h)
+                h = self.gru.forward_parts(v, c16, h, base)
             return h.unsqueeze(1), {}
         for v in views[1:]:
             h = self.gru(torch.cat((v, coords), dim=1), h)

@@ -420,18 +420,20 @@ def test_gru_fuser_split_gates_match_concatenated_gates_under_autograd():
     z0 = torch.randn(1, 3, 16, 10, 24, 33, generator=gen).to(DEV)
     gout = torch.randn(1, 1, 16, 10, 24, 33, generator=gen).to(DEV)
     res = {}
-    for split in (False, True):
-        fu.split_gates = split
+    for split in (False, True, 'per-view coords'):
+        fu.split_gates = bool(split)
+        fu.hoist_coords = split is True              # True: the coordinate share of the gates once per forward (default)
         fu.zero_grad()
         z = z0.clone().requires_grad_(True)
         out, _ = fu(z, None, None, None)
         (out * gout).sum().backward()
         res[split] = (out.detach(), z.grad.clone(), {k: p.grad.clone() for k, p in fu.named_parameters()})
-    close(res[True][0], res[False][0], atol=3e-5, rtol=1e-4)
-    scale = res[False][1].abs().max().item()
-    close(res[True][1], res[False][1], atol=2e-5 * scale, rtol=1e-3)
-    for k, g in res[False][2].items():
-        close(res[True][2][k], g, atol=2e-5 * max(g.abs().max().item(), 1e-3), rtol=1e-3)
+    for form in (True, 'per-view coords'):
+        close(res[form][0], res[False][0], atol=3e-5, rtol=1e-4)
+        scale = res[False][1].abs().max().item()
+        close(res[form][1], res[False][1], atol=2e-5 * scale, rtol=1e-3)
+        for k, g in res[False][2].items():
+            close(res[form][2][k], g, atol=2e-5 * max(g.abs().max().item(), 1e-3), rtol=1e-3)
 
 
 def test_skip_connections_quirk(golden):
