@@ -228,7 +228,9 @@ __global__ void __launch_bounds__(256) fuse_views_fwd_kernel(const T* __restrict
 #pragma unroll
       for (int e = 0; e < O::W; ++e) {
         const float a = O::get(c, e), b = O::get(r, e);
-        const bool take = (kind == LF_FUSE_MAX) ? (a > b) : (fabsf(a) > fabsf(b));   // first maximum wins ties
+        // first maximum wins ties; a NaN in ANY view wins over every number and is then kept (torch.max / abs().max()
+        // propagate NaN, and so do the host and the sharded all-reduce forms of the same pool)
+        const bool take = ((kind == LF_FUSE_MAX) ? (a > b) : (fabsf(a) > fabsf(b))) || (a != a && b == b);
         if (take) { O::set(r, e, a); sel[e] = v; }
       }
     };
@@ -416,7 +418,7 @@ extern "C" int lf_column_scale_bwd(const float* gout, const float* z, const floa
 extern "C" int lf_fuse_views_fwd(const float* z, float* out, int* idx, int kind, int V, long n, long view_stride, void* stream) {
   lf_clear_error();
   if (V <= 0 || n <= 0 || kind < LF_FUSE_MEAN || kind > LF_FUSE_MEDIAN || (V > 1 && view_stride < n)) return LF_EINVAL;
-  if (kind == LF_FUSE_MEDIAN && V > 64) return LF_EINVAL;
+  if (kind == LF_FUSE_MEDIAN && V > 1024) return LF_EINVAL;          // rank counting is O(V^2) per element: any V works, slowly
   hipStream_t s = (hipStream_t)stream;
   if (n % 4 == 0 && view_stride % 4 == 0 && lf_aligned16(z) && lf_aligned16(out) && (idx == nullptr || lf_aligned16(idx))) {
     const long nv = n / 4;

@@ -583,7 +583,9 @@ __device__ __forceinline__ float fixed_scale(const unsigned* amax) {
   if (!(am > 0.f)) return 1.f;
   int ex;
   frexpf(am, &ex);                                               // am = m * 2^ex, m in [0.5, 1)
-  return ldexpf(1.f, 38 - ex);                                   // |contribution| * scale < 2^38
+  // |contribution| * scale < 2^38; the exponent is capped so that tiny gradients (max|g| < 2^-88) keep a FINITE scale
+  // (2^126: they then simply use fewer of the 64 bits) instead of inf * 0 = NaN
+  return ldexpf(1.f, min(38 - ex, 126));
 }
 
 // round-to-nearest-even of v (|v| < 2^39) as a 64-bit integer, in 8 VALU instructions instead of the ~20 of the generic

@@ -76,9 +76,27 @@ def reproject_views(image_in, depth_in, depth_out, camera_in, camera_out):
     return b2bv(image_re, v_i), b2bv(depth_re, v_i)
 
 
+def reproject_views_batch(image_in, depth_in, depth_out, camera_in, camera_out):
+    """reproject_views per object of a batch (reference ibr.py:96-138).
+
+    image_in (B,V_i,C,H,W), depth_in (B,V_i,1,H,W), depth_out (B,V_o,1,H,W); cameras flat, object-major.
+    Returns reprojected images and depths (B,V_o,V_i,.,H,W) and the rotation / position distances between every
+    output and input camera, each (B,V_o,V_i): angular distance / pi (acos clamp 1e-2) and cosine distance / 2."""
+    nb, n_in, n_out = image_in.shape[0], image_in.shape[1], depth_out.shape[1]
+    imgs, deps, dist_r, dist_t = [], [], [], []
+    for i in range(nb):
+        cin, cout = camera_in[i * n_in:(i + 1) * n_in], camera_out[i * n_out:(i + 1) * n_out]
+        dist_r.append(three.quaternion.angular_distance(cout.quaternion, cin.quaternion, eps=1e-2) / math.pi)
+        dist_t.append(outer_distance(cout.position, cin.position, metric='cosine') / 2.0)
+        img_re, dep_re = reproject_views(image_in[i], depth_in[i], depth_out[i], cin, cout)
+        imgs.append(img_re)
+        deps.append(dep_re)
+    return torch.stack(imgs, dim=0), torch.stack(deps, dim=0), torch.stack(dist_r, dim=0), torch.stack(dist_t, dim=0)
+
+
 def render_ibr(camera_in, camera_out, image_in, depth_fake_in, depth_fake_out, p=0.5, weight_type='cam_dist', eps=1e-2):
     """Blend of the reprojected input views, weights softmax(1 / clamp(d^p, eps)) over the inputs
-    (reference ibr.py:181-222)."""
+    (reference ibr.py:181-222; weight types cam_dist / cam_angle / cam_hybrid / depth)."""
     outs, reprojs = [], []
     nb = image_in.shape[0]
     n_in, n_out = len(camera_in) // nb, len(camera_out) // nb
@@ -86,15 +104,58 @@ def render_ibr(camera_in, camera_out, image_in, depth_fake_in, depth_fake_out, p
         cin, cout = camera_in[i * n_in:(i + 1) * n_in], camera_out[i * n_out:(i + 1) * n_out]
         img_re, depth_re = reproject_views(image_in[i], depth_fake_in[i], depth_fake_out[i], cin, cout)
         reprojs.append(img_re)
-        if weight_type == 'cam_dist':
-            d = outer_distance(cout.position, cin.position, metric='cosine', eps=eps) / 2.0
-        elif weight_type == 'cam_angle':
-            d = three.quaternion.angular_distance(cout.quaternion, cin.quaternion) / math.pi
+        if weight_type == 'depth':
+            diff = (depth_re - depth_fake_out[i].unsqueeze(1).expand_as(depth_re)).abs()
+            wgt = torch.softmax(1.0 / ((diff / diff.max()) ** p + eps), dim=1).squeeze(2)
         else:
-            raise ValueError(f'Unknown weight_type {weight_type}')
-        wgt = torch.softmax(1.0 / (d[..., None, None] ** p).clamp(min=eps), dim=1)
+            if weight_type == 'cam_dist':
+                d = outer_distance(cout.position, cin.position, metric='cosine', eps=eps) / 2.0
+            elif weight_type == 'cam_angle':
+                d = three.quaternion.angular_distance(cout.quaternion, cin.quaternion) / math.pi
+            elif weight_type == 'cam_hybrid':
+                d_t = outer_distance(cout.position, cin.position, metric='cosine') / 2.0
+                d_r = (three.quaternion.angular_distance(cout.quaternion, cin.quaternion) / (math.pi / 8)).clamp(0.0, 1.0)
+                d = 1.0 - (1.0 - d_t) * (1.0 - d_r)
+            else:
+                raise ValueError(f'Unknown weight_type {weight_type}')
+            wgt = torch.softmax(1.0 / (d[..., None, None] ** p).clamp(min=eps), dim=1)
         outs.append((wgt.unsqueeze(2) * img_re).sum(dim=1))
     return torch.stack(outs, dim=0), torch.stack(reprojs, dim=0)
+
+
+def render_latent_ibr(photographer, z_obj, camera_in, camera_out, image_in, p=0.5, weight_type='cam_dist', eps=0.0001):
+    """Depths of the input and output views from the latent renderer, colour by IBR; differentiable, returns
+    (colour, depth_out, mask_out, reprojections) (reference ibr.py:141-154)."""
+    fake_in, _, _ = photographer.decode(z_obj, camera_in)
+    fake_out, _, _ = photographer.decode(z_obj, camera_out)
+    color, reproj = render_ibr(camera_in, camera_out, image_in, fake_in['depth'], fake_out['depth'], p, weight_type, eps)
+    return color, fake_out['depth'], fake_out['mask'], reproj
+
+
+def blend_logits(logits, image_reproj):
+    """Per-pixel softmax blend of the reprojected views: logits (B,V_i,H,W), image_reproj (B,V_i,C,H,W)
+    (reference ibr.py:225-228)."""
+    weights = torch.softmax(logits, dim=1).unsqueeze(2)
+    return (weights * image_reproj).sum(dim=1), weights
+
+
+def warp_blend_logits(logits, image_reproj, flow_size):
+    """Softmax blend + a learned residual flow of at most `flow_size` pixels per view: logits (B,3*V_i,H,W) =
+    [blend | flow x | flow y], image_reproj (B,V_i,C,H,W).  Returns (image, weights, flow_dx, flow_dy)
+    (reference ibr.py:231-249: identity lattice linspace(-1,1), tanh-bounded offsets, grid clamped to [-1,1],
+    bilinear sampling with zeros padding -- lf_grid_sample2d_fwd on the device)."""
+    dev = image_reproj.device
+    v_i = image_reproj.shape[1]
+    h, w = image_reproj.shape[-2:]
+    blend, fx_logits, fy_logits = torch.split(logits, v_i, dim=1)
+    weights = torch.softmax(blend, dim=1).unsqueeze(2)
+    flow_dx = flow_size / w * torch.tanh(fx_logits)
+    flow_dy = flow_size / h * torch.tanh(fy_logits)
+    gy, gx = torch.meshgrid(torch.linspace(-1, 1, h, device=dev), torch.linspace(-1, 1, w, device=dev), indexing='ij')
+    grid = torch.stack((gx[None, None].expand_as(flow_dx) + flow_dx, gy[None, None].expand_as(flow_dy) + flow_dy),
+                       dim=-1).clamp(-1, 1)
+    warped = b2bv(image_ops._sample(bv2b(image_reproj).contiguous(), bv2b(grid).contiguous(), 'bilinear', 'zeros'), v_i)
+    return (weights * warped).sum(dim=1), weights, flow_dx, flow_dy
 
 
 def render_latent_ibr2(photographer, z_obj, camera_in, camera_out, image_in, p=0.5, weight_type='cam_dist',

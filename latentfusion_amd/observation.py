@@ -102,7 +102,16 @@ class Observation:
         camera_json = cam.to_kwargs()
         camera_json['meta'] = self.meta
         with open(path / 'cameras.json', 'w') as f:
-            json.dump(camera_json, f, indent=2, default=lambda o: o.tolist() if torch.is_tensor(o) else str(o))
+            def encode(o):
+                # reference utils.MyEncoder: paths as strings, arrays as lists, anything else is an error (a silently
+                # stringified object would not survive the round trip through Observation.load)
+                from pathlib import PurePath
+                if isinstance(o, PurePath):
+                    return str(o)
+                if torch.is_tensor(o) or isinstance(o, np.ndarray):
+                    return o.tolist()
+                raise TypeError(f'Object of type {type(o).__name__} is not JSON serializable')
+            json.dump(camera_json, f, indent=2, default=encode)
         color, depth, mask = self.color.cpu(), self.depth.cpu(), self.mask.cpu()
         for i in range(len(self)):
             Image.fromarray((255.0 * color[i].permute(1, 2, 0).numpy()).astype(np.uint8)).save(path / f'{i:04d}.color.png')

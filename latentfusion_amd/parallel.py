@@ -45,6 +45,16 @@ def _pool(z, kind):
     return pool_tensor(z, kind, dim=1)
 
 
+def ops_blend_partial(z_local, logits, gmax):
+    """This rank's share of the blend: [sum_v z_v e_v | sum_v e_v] with e = exp(logit - global max), (1,1,C+1,S,S,S)."""
+    C = z_local.shape[2]
+    e = torch.exp(logits - gmax)
+    buf = z_local.new_empty((1, 1, C + 1) + tuple(z_local.shape[3:]))
+    buf[:, :, :C] = (z_local * e).sum(dim=1, keepdim=True)
+    buf[:, :, C:] = e.sum(dim=1, keepdim=True)
+    return buf
+
+
 def fuse_sharded(fuser, z_local, num_views_total, group=None, z_cam_mid_local=None, camera_local=None):
     """Fuses per-view latent volumes that are sharded over ranks.
 
@@ -59,9 +69,11 @@ def fuse_sharded(fuser, z_local, num_views_total, group=None, z_cam_mid_local=No
     blend         per-view logits l (BlendFuser.compute_blend_logits on the local views): g = all-reduce(MAX, max_v l);
                   e = exp(l - g); ONE all-reduce(SUM) of [sum_v z e | sum_v e] ((C+1)*S^3 floats); out = num / den --
                   the same max-subtracted softmax as the single-process fuser (recon/fusion.py:139-148)
-    others        all-gather of the per-view volumes in rank (= view) order, then the fuser runs replicated on the
-                  full, ordered view list: GRU/LSTM fusion is an order-dependent recurrence (reference
-                  recon/fusion.py:180-201), and the median needs every view.
+    gru / lstm    order-dependent recurrences (reference recon/fusion.py:180-201): the hidden state is handed
+                  from rank to rank (send / recv of ONE volume per hop), each rank runs the steps of its own views, the
+                  last rank broadcasts the result (_fuse_recurrent_pipelined)
+    median        all-gather of the per-view volumes in rank (= view) order (the median needs every view), then the
+                  fuser runs replicated on the full, ordered view list.
     """
     rank, size = world()
     kind = type(fuser).__name__
@@ -86,23 +98,34 @@ def fuse_sharded(fuser, z_local, num_views_total, group=None, z_cam_mid_local=No
         cand = torch.where(a.abs() == m, a, -m).contiguous()
         dist.all_reduce(cand, op=dist.ReduceOp.MAX, group=group)
         return cand
-    if kind == 'BlendFuser' and z_cam_mid_local is not None:
+    if kind == 'BlendFuser':
+        # the branch is chosen from rank-independent information only (a rank WITHOUT local views must still take part in
+        # the same three collectives); a rank that has views but not the mid volumes the logits need is a caller error,
+        # which every rank learns about through the first collective instead of some ranks hanging in it
         C = z_local.shape[2]
+        bad = have and z_cam_mid_local is None
+        flag = z_local.new_tensor([1.0 if bad else 0.0])
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+        if flag.item() > 0:
+            raise ValueError('view-sharded BlendFuser needs the camera-block mid volumes (z_cam_mid_local) on every rank '
+                             'that holds views')
         if have:
             logits = fuser.compute_blend_logits(z_cam_mid_local, camera_local)          # (1, V_local, 1, S, S, S)
             gmax = logits.max(dim=1, keepdim=True)[0].contiguous()
         else:
             gmax = z_local.new_full((1, 1, 1) + tuple(z_local.shape[3:]), float('-inf'))
         dist.all_reduce(gmax, op=dist.ReduceOp.MAX, group=group)
-        buf = z_local.new_zeros((1, 1, C + 1) + tuple(z_local.shape[3:]))
         if have:
-            e = torch.exp(logits - gmax)
-            buf[:, :, :C] = (z_local * e).sum(dim=1, keepdim=True)
-            buf[:, :, C:] = e.sum(dim=1, keepdim=True)
+            buf = ops_blend_partial(z_local, logits, gmax)                             # (1, 1, C+1, S, S, S)
+        else:
+            buf = z_local.new_zeros((1, 1, C + 1) + tuple(z_local.shape[3:]))
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
         return (buf[:, :, :C] / buf[:, :, C:]).contiguous()
-    # ordered all-gather (ragged: ranks may hold different numbers of views)
     counts = [shard_range(num_views_total, r, size) for r in range(size)]
+    recurrence = getattr(fuser, 'recurrence', None)
+    if recurrence in ('gru', 'lstm'):
+        return _fuse_recurrent_pipelined(fuser, z_local, counts, rank, size, group, recurrence)
+    # ordered all-gather (ragged: ranks may hold different numbers of views): the median needs every view
     vmax = max(e - b for b, e in counts)
 
     def gather_views(t):
@@ -113,6 +136,60 @@ def fuse_sharded(fuser, z_local, num_views_total, group=None, z_cam_mid_local=No
         return torch.cat([p[:, :e - b] for p, (b, e) in zip(parts, counts)], dim=1)
     z_all = gather_views(z_local)
     return fuser(z_all, None, None, None)[0]
+
+
+def _send(t, dst, group):
+    """Point-to-point send; gloo moves host memory only (its send / recv take the raw data pointer), so device tensors
+    are staged through the host there -- the test-only configuration (two ranks on one GPU); RCCL sends device memory."""
+    if t.is_cuda and dist.get_backend(group) == 'gloo':
+        t = t.cpu()
+    dist.send(t.contiguous(), dst=dst, group=group)
+
+
+def _recv(t, src, group):
+    if t.is_cuda and dist.get_backend(group) == 'gloo':
+        h = torch.empty(t.shape, dtype=t.dtype)
+        dist.recv(h, src=src, group=group)
+        t.copy_(h)
+    else:
+        dist.recv(t, src=src, group=group)
+    return t
+
+
+def _fuse_recurrent_pipelined(fuser, z_local, counts, rank, size, group, recurrence):
+    """GRU / LSTM fusion of view-sharded volumes as a PIPELINE of the hidden state: the recurrence
+    (reference recon/fusion.py:180-201, 226-246) is h <- cell(view_i, h) in view order with h_0 = view 0, so rank r
+    continues it over its own contiguous views from the state rank r-1 hands over -- one point-to-point message of the
+    C*S^3 state per hop (134 MB at SYN(128,16); two volumes for the LSTM's (h, c)) and one broadcast of the result,
+    instead of an all-gather of all V per-view volumes into every rank (V x 134 MB) followed by V-1 replicated steps.
+    The arithmetic is the single-process recurrence in the same order on the same kernels: bit-identical.
+
+    GRU: the incoming state enters as "view 0" of the local stack (h_0 = view 0 is un-gated, so this IS the
+    continuation).  LSTM: the fuser takes / returns its (h, c) through `initial_state` / the 'state' entry."""
+    holders = [r for r, (b, e) in enumerate(counts) if e > b]                 # contiguous from rank 0 (shard_range)
+    last = holders[-1]
+    have = z_local.shape[1] > 0
+    vol = (1, 1) + tuple(z_local.shape[2:])
+    nstate = 2 if recurrence == 'lstm' else 1
+    out = z_local.new_empty(vol)
+    if have:
+        state = None
+        if rank > 0:
+            state = z_local.new_empty((nstate,) + vol)
+            _recv(state, rank - 1, group)
+        if recurrence == 'gru':
+            stack = z_local if state is None else torch.cat((state[0], z_local), dim=1)
+            out = fuser(stack, None, None, None)[0].contiguous()
+            nxt = out.unsqueeze(0)
+        else:
+            init = None if state is None else (state[0][:, 0], state[1][:, 0])
+            out, extra = fuser(z_local, None, None, None, initial_state=init)
+            out = out.contiguous()
+            nxt = torch.stack((out, extra['state'][1].unsqueeze(1)), dim=0)
+        if rank < last:
+            _send(nxt, rank + 1, group)
+    dist.broadcast(out, src=last, group=group)
+    return out
 
 
 def build_latent_object_sharded(model, observation, group=None):

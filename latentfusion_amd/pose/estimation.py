@@ -12,6 +12,7 @@ MI355X design notes (vs. the reference loop, pose/estimation.py:579-679):
     plateau schedulers, the ranking and the convergence test -- all host-side scalar logic;
   * weight gradients of the renderer are never formed.
 """
+import contextlib
 import copy
 import math
 from collections import defaultdict
@@ -93,7 +94,15 @@ class PoseEstimator:
     def estimate(self, z_obj, target_obs, **kwargs):
         if len(target_obs) > 1:
             raise ValueError('The pose can only be estiamted for one observation at a time.')
-        return self._estimate(z_obj, target_obs, **kwargs)
+        with self._frozen_model():
+            return self._estimate(z_obj, target_obs, **kwargs)
+
+    def _frozen_model(self):
+        """The estimators differentiate w.r.t. the cameras only: run with the network's parameters frozen (no
+        weight-gradient kernels; the reference accumulates gradients nobody reads) and give every parameter
+        its own flag back afterwards.  Models without the facade's frozen() (stubs in tests) run as they are."""
+        frozen = getattr(self.model, 'frozen', None)
+        return frozen() if callable(frozen) else contextlib.nullcontext()
 
     def _sharding(self):
         """(rank, size) when hypothesis sharding is active, else (0, 1)."""
@@ -513,8 +522,10 @@ class GradientPoseEstimator(PoseEstimator):
     def iterate(self, st):
         """One pose-optimisation iteration: render the N samples, loss, backward to the camera
         parameters, rank, optimiser + scheduler step.  Returns True when converged."""
-        if 'engine' in st:
-            return self._iterate_engine(st)
+        with self._frozen_model():
+            return self._iterate_engine(st) if 'engine' in st else self._iterate_modules(st)
+
+    def _iterate_modules(self, st):
         cam, params, target_obs, step = st['cam'], st['params'], st['target'], st['step']
         for p in params:
             p.grad = None

@@ -196,6 +196,8 @@ class ConvLSTMCell(nn.Module):
 class GRUFuser(_ArgsFuser):
     """h0 = view 0; for each further view x = cat(z_i, voxel coords (z,y,x)) (reference :152-201)."""
 
+    recurrence = 'gru'             # parallel.fuse_sharded pipelines the state over the ranks
+
     def __init__(self, in_channels, cube_size=1.0, conv_module=EqualizedConv3d):
         super().__init__()
         self.in_channels, self.cube_size, self.conv_module = in_channels, cube_size, conv_module
@@ -310,6 +312,8 @@ class GRUFuser(_ArgsFuser):
 
 
 class LSTMFuser(_ArgsFuser):
+    recurrence = 'lstm'            # parallel.fuse_sharded pipelines (h, c) over the ranks
+
     def __init__(self, in_channels, cube_size=1.0, conv_module=EqualizedConv3d):
         super().__init__()
         self.in_channels, self.cube_size = in_channels, cube_size
@@ -318,12 +322,18 @@ class LSTMFuser(_ArgsFuser):
     def _args(self):
         return {'in_channels': self.in_channels, 'cube_size': self.cube_size}
 
-    def forward(self, z_obj, z_cam_mid, z_obj_mid, camera):
+    def forward(self, z_obj, z_cam_mid, z_obj_mid, camera, initial_state=None):
+        """reference :226-246 (h0 = view 0, c0 = 0).  `initial_state` = (h, c) continues a recurrence begun elsewhere
+        (every view of `z_obj` is then a step; view-sharded reconstruction, parallel.fuse_sharded); the final (h, c) is
+        returned in the second result under 'state'."""
         from .. import ops as _ops
         views = _ops.split_views(z_obj)                            # (one pass in the backward, see GRUFuser.forward)
-        h = views[0]
-        c = torch.zeros_like(h)
+        if initial_state is None:
+            h, steps = views[0], views[1:]
+            c = torch.zeros_like(h)
+        else:
+            (h, c), steps = initial_state, views
         coords = utils.get_normalized_voxel_coords(h)
-        for v in views[1:]:
+        for v in steps:
             h, c = self.lstm(torch.cat((v, coords), dim=1), (h, c))
-        return h.unsqueeze(1), {}
+        return h.unsqueeze(1), {'state': (h, c)}

@@ -8,6 +8,23 @@ from ..observation import Observation
 from . import models
 
 
+class _Frozen:
+    def __init__(self, model):
+        self.params = None
+        self.model = model
+
+    def __enter__(self):
+        self.params = [p for p in self.model.parameters() if p.requires_grad]
+        for p in self.params:
+            p.requires_grad_(False)
+        return self.model
+
+    def __exit__(self, *exc):
+        for p in self.params:
+            p.requires_grad_(True)
+        return False
+
+
 class LatentFusionModel:
     @classmethod
     def from_checkpoint(cls, checkpoint, device='cpu'):
@@ -27,15 +44,36 @@ class LatentFusionModel:
     def eval(self):
         return self.train(False)
 
-    def train(self, train):
-        """eval() also freezes the parameters (requires_grad False): the pose estimators differentiate w.r.t. the
-        camera only, and the reference's backward through this facade accumulates weight gradients nobody reads
-         -- here those kernels are simply not launched.  train(True) re-enables them."""
-        for m in (self.sculptor, self.photographer, self.fuser, self.generator):
-            if m is not None:
-                m.train(train)
-                m.requires_grad_(bool(train))
+    def train(self, train=True):
+        """Switches the modules' train / eval mode, like the reference (recon/inference.py:39-49).  Whether parameters
+        take gradients is a separate matter: see freeze() / frozen()."""
+        for m in self._modules():
+            m.train(train)
         return self
+
+    def _modules(self):
+        return [m for m in (self.sculptor, self.photographer, self.fuser, self.generator) if m is not None]
+
+    def parameters(self):
+        for m in self._modules():
+            yield from m.parameters()
+
+    def freeze(self):
+        """requires_grad False on every parameter: no weight-gradient kernel is launched by a backward through this
+        model (the reference's pose loops accumulate weight gradients nobody reads)."""
+        for p in self.parameters():
+            p.requires_grad_(False)
+        return self
+
+    def unfreeze(self):
+        for p in self.parameters():
+            p.requires_grad_(True)
+        return self
+
+    def frozen(self):
+        """Context manager: parameters frozen inside, every parameter's own flag restored on exit.  The pose
+        estimators run under it, so a model that is also being trained keeps its flags."""
+        return _Frozen(self)
 
     def zoom_observation(self, observation):
         if not observation.meta['is_zoomed']:
@@ -85,6 +123,42 @@ class LatentFusionModel:
         if return_latent:
             z = z.squeeze(0)
         return {k: v.squeeze(0) for k, v in y.items()}, z
+
+    def render_ibr(self, z_obj, input_obs, camera_out, return_latent=True):
+        """Colour by the learned IBR generator (reference recon/inference.py:151-191): the reprojected input views,
+        their reprojected depths and a camera-similarity plane per view are stacked into the generator U-Net, whose
+        logits blend the views per pixel after a residual flow of at most 5 pixels (ibr.warp_blend_logits)."""
+        from .. import ibr
+        if self.generator is None:
+            raise ValueError('this checkpoint carries no IBR generator (modules.generator)')
+        input_obs = self.preprocess_observation(input_obs)
+        y_out, z_out, image_reproj, depth_reproj, _mask_out, depth_out, _dist_r, dist_t = self._render_reprojections(
+            z_obj, input_obs.color, input_obs.camera, camera_out)
+        if return_latent:
+            z_out = z_out.squeeze(0)
+        sims = 1.0 - dist_t * 2
+        x = torch.cat((image_reproj, depth_reproj,
+                       sims[:, :, None, None, None].expand(-1, -1, -1, *image_reproj.shape[-2:])), dim=2)
+        x = x.reshape(-1, x.shape[1] * x.shape[2], x.shape[3], x.shape[4])              # views folded into channels
+        x = torch.cat((depth_out, x), dim=1)
+        logits = self.generator(x)
+        y_out['color'], _, _, _ = ibr.warp_blend_logits(logits, image_reproj, 5)
+        return {k: v.squeeze(0) for k, v in y_out.items()}, z_out
+
+    def _render_reprojections(self, z_obj, color_in, camera_in, camera_out, return_latent=True):
+        """reference recon/inference.py:193-217: depths of the input and output views from the latent renderer, the
+        input views reprojected into every output view and masked by the predicted output mask."""
+        from .. import ibr
+        from ..three.batchview import bv2b
+        y_in, _, _ = self.photographer.decode(z_obj, camera_in)
+        y_out, z_out, _ = self.photographer.decode(z_obj, camera_out, return_latent=return_latent)
+        mask_out, depth_out = y_out['mask'], y_out['depth']
+        image_reproj, depth_reproj, dist_r, dist_t = ibr.reproject_views_batch(color_in.unsqueeze(0), y_in['depth'],
+                                                                                y_out['depth'], camera_in, camera_out)
+        image_reproj = image_reproj * mask_out.unsqueeze(2)
+        depth_reproj = (depth_reproj + 1.0) * mask_out.unsqueeze(2) - 1.0
+        return (y_out, z_out, bv2b(image_reproj), bv2b(depth_reproj), bv2b(mask_out), bv2b(depth_out), bv2b(dist_r),
+                bv2b(dist_t))
 
     def render_full(self, z_obj, camera, input_obs=None, p=0.5):
         """Full-frame depth/mask(/colour).  Note SURVEY Q6: in the reference the input_obs=None branch

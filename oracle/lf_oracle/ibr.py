@@ -1,5 +1,7 @@
 """ORACLE (test infrastructure, not product): image-based rendering on CPU
 (restates latentfusion/ibr.py:11-222 with the oracle camera record)."""
+import math
+
 import torch
 import torch.nn.functional as F
 
@@ -68,3 +70,75 @@ def render_latent_ibr2(pck, z_obj, cam_in, cam_out, image_in, p=0.5, eps=1e-4, a
         color = color * (y_out['mask'] > 0.5)
     y_out['color'] = color
     return y_out, lat
+
+
+def reproject_views_batch(image_in, depth_in, depth_out, cam_in, cam_out):
+    """ibr.py:96-138.  image_in (B,Vi,C,H,W), depth_in (B,Vi,1,H,W), depth_out (B,Vo,1,H,W); cameras object-major."""
+    from . import quat
+    nb, vi, vo = image_in.shape[0], image_in.shape[1], depth_out.shape[1]
+    imgs, deps, dr, dt = [], [], [], []
+    for i in range(nb):
+        ci, co = cam_in[i * vi:(i + 1) * vi], cam_out[i * vo:(i + 1) * vo]
+        dr.append(quat.angular_distance(co.quaternion, ci.quaternion, eps=1e-2) / math.pi)
+        a, b = co.position, ci.position
+        dt.append((1.0 - (a @ b.t()) / (a.norm(dim=1, keepdim=True) @ b.norm(dim=1, keepdim=True).t()).clamp(min=1e-8)) / 2.0)
+        im, de = reproject_views(image_in[i], depth_in[i], depth_out[i], ci, co)
+        imgs.append(im)
+        deps.append(de)
+    return torch.stack(imgs), torch.stack(deps), torch.stack(dr), torch.stack(dt)
+
+
+def blend_logits(logits, image_reproj):
+    """ibr.py:225-228."""
+    w = torch.softmax(logits, dim=1).unsqueeze(2)
+    return (w * image_reproj).sum(dim=1), w
+
+
+def warp_blend_logits(logits, image_reproj, flow_size):
+    """ibr.py:231-249."""
+    vi = image_reproj.shape[1]
+    h, w = image_reproj.shape[-2:]
+    bl, fx, fy = torch.split(logits, vi, dim=1)
+    wgt = torch.softmax(bl, dim=1).unsqueeze(2)
+    dx = flow_size / w * torch.tanh(fx)
+    dy = flow_size / h * torch.tanh(fy)
+    gy, gx = torch.meshgrid(torch.linspace(-1, 1, h), torch.linspace(-1, 1, w), indexing='ij')
+    grid = torch.stack((gx[None, None] + dx, gy[None, None] + dy), dim=-1).clamp(-1, 1)
+    flat = F.grid_sample(image_reproj.reshape(-1, *image_reproj.shape[2:]), grid.reshape(-1, h, w, 2), mode='bilinear',
+                         align_corners=False)
+    img = flat.view(-1, vi, *flat.shape[1:])
+    return (wgt * img).sum(dim=1), wgt, dx, dy
+
+
+def render_latent_ibr(pck, z_obj, cam_in, cam_out, image_in, p=0.5, eps=1e-4):
+    """ibr.py:141-154 (weight_type 'cam_dist'): (colour, depth_out, mask_out, reprojections)."""
+    y_in, _, _ = nets.decode(pck, z_obj, cam_in)
+    y_out, _, _ = nets.decode(pck, z_obj, cam_out)
+    img_re, _ = reproject_views(image_in[0], y_in['depth'][0], y_out['depth'][0], cam_in, cam_out)
+    a, b = cam_out.position, cam_in.position
+    d = (1.0 - (a @ b.t()) / (a.norm(dim=1, keepdim=True) @ b.norm(dim=1, keepdim=True).t()).clamp(min=eps)) / 2.0
+    wgt = torch.softmax(1.0 / (d[..., None, None] ** p).clamp(min=eps), dim=1)
+    return (wgt.unsqueeze(2) * img_re).sum(dim=1).unsqueeze(0), y_out['depth'], y_out['mask'], img_re.unsqueeze(0)
+
+
+def render_ibr_generator(pck, gck, z_obj, color_in, cam_in, cam_out):
+    """LatentFusionModel.render_ibr on PREPROCESSED inputs (recon/inference.py:151-217): the generator U-Net `gck`
+    sees [depth_out | per input view: reprojected colour (3), reprojected depth (1), camera similarity (1)]."""
+    y_in, _, _ = nets.decode(pck, z_obj, cam_in)
+    y_out, lat, _ = nets.decode(pck, z_obj, cam_out)
+    mask_out, depth_out = y_out['mask'], y_out['depth']
+    img_re, dep_re, _dr, dt = reproject_views_batch(color_in.unsqueeze(0), y_in['depth'], y_out['depth'], cam_in, cam_out)
+    img_re = (img_re * mask_out.unsqueeze(2)).flatten(0, 1)
+    dep_re = ((dep_re + 1.0) * mask_out.unsqueeze(2) - 1.0).flatten(0, 1)
+    sims = 1.0 - dt.flatten(0, 1) * 2
+    x = torch.cat((img_re, dep_re, sims[:, :, None, None, None].expand(-1, -1, -1, *img_re.shape[-2:])), dim=2)
+    x = x.reshape(-1, x.shape[1] * x.shape[2], x.shape[3], x.shape[4])
+    x = torch.cat((depth_out.flatten(0, 1), x), dim=1)
+    ga = gck['args']
+    gsd = {'g.' + k: v for k, v in gck['state_dict'].items()}
+    logits = nets.unet(x, gsd, 'g', ga['block_config'], ga['in_channels'], ga['out_channels'])
+    color, wgt, dx, dy = warp_blend_logits(logits, img_re, 5)
+    out = dict(y_out)
+    out['color'] = color
+    return {k: v.squeeze(0) for k, v in out.items()}, lat.squeeze(0), {'logits': logits, 'image_reproj': img_re,
+                                                                       'depth_reproj': dep_re, 'flow_dx': dx, 'flow_dy': dy}

@@ -897,6 +897,76 @@ def g22_photographer_skip(lf):
     save('g22_photographer_skip', {'in_size': S, 'image_config': img, 'cases': out})
 
 
+def g23_ibr_generator(lf):
+    """a14 remainder: reproject_views_batch, render_latent_ibr, blend_logits / warp_blend_logits and the facade's
+    generator-driven LatentFusionModel.render_ibr (ibr.py:96-154,225-249; recon/inference.py:151-217)."""
+    from latentfusion import ibr
+    from latentfusion.modules import unet
+    from latentfusion.observation import Observation
+    from latentfusion.recon.inference import LatentFusionModel
+    S, C, VI, VO = 16, 8, 3, 2
+    sc, fu, ph = syn_ckpts(lf, S, C, fuser='pool:mean', seed=230)
+    dist = lf.recon.utils.optimal_camera_dist(615.4991, S, 0.5, slack=128 / S)
+    torch.manual_seed(231)
+    gen = unet.UNet2d(in_channels=1 + 5 * VI, out_channels=(VI, VI, VI), block_config=[[12, 'D', 16, 'D', 16], [16, 'U', 16, 'U', 12]]).eval()
+    for k, prm in gen.named_parameters():
+        if k.endswith('bias'):
+            prm.data.normal_(0, 0.1)
+    model = LatentFusionModel(sc, fu, ph, dist, 'cpu')
+    model.generator = gen
+    cam_in = rand_cameras(lf, VI, zoomed_size=S, dist=dist, seed=232)
+    cam_out = rand_cameras(lf, VO, zoomed_size=S, dist=dist, seed=233)
+    g = torch.Generator().manual_seed(234)
+    z_obj = torch.randn(1, 1, C, S, S, S, generator=g)
+    color = torch.rand(VI, 3, S, S, generator=g) * 2 - 1              # a preprocessed (zoomed, normalised) observation
+    depth = torch.rand(VI, 1, S, S, generator=g) * 2 - 1
+    mask = (torch.rand(VI, 1, S, S, generator=g) > 0.3).float()
+    obs = Observation(color, depth, mask, cam_in, is_zoomed=True, is_prepared=True, is_normalized=True)
+    with torch.no_grad():
+        y, z_out = model.render_ibr(z_obj, obs, cam_out)
+        y_out, _, img_re, dep_re, mask_o, depth_o, dist_r, dist_t = model._render_reprojections(z_obj, color, cam_in, cam_out)
+        col, d_out, m_out, reproj = ibr.render_latent_ibr(ph, z_obj, cam_in, cam_out, color.unsqueeze(0), p=0.5)
+        logits = torch.randn(VO, 3 * VI, S, S, generator=g)
+        wb = ibr.warp_blend_logits(logits, img_re, 5)
+        bl = ibr.blend_logits(logits[:, :VI], img_re)
+    save('g23_ibr_generator', {
+        'photographer': ck(ph), 'generator': ck(gen), 'camera_dist': dist, 'z_obj': z_obj,
+        'cam_in': cam_dict(cam_in), 'cam_out': cam_dict(cam_out), 'color_in': color, 'depth_in': depth, 'mask_in': mask,
+        'y': {k: v.clone() for k, v in y.items()}, 'z_out': z_out.clone(),
+        'image_reproj': img_re.clone(), 'depth_reproj': dep_re.clone(), 'cam_dist_r': dist_r.clone(), 'cam_dist_t': dist_t.clone(),
+        'latent_ibr': {'color': col.clone(), 'depth': d_out.clone(), 'mask': m_out.clone(), 'reproj': reproj.clone()},
+        'logits': logits, 'warp_blend': [t.clone() for t in wb], 'blend': [t.clone() for t in bl]})
+
+
+def g24_tile_projection(lf):
+    """a4: TileProjection2d3d (modules/geometry.py:693-708) inside a Sculptor(projection_type='tile') encode, SYN(16,8);
+    outputs and the gradient of a scalar w.r.t. the images (the lift's data gradient)."""
+    from latentfusion.recon.models import Sculptor
+    from latentfusion.recon import fusion
+    S, C, V = 16, 8, 3
+    torch.manual_seed(240)
+    sc = Sculptor(in_size=S, image_config=[[16, 32], [32, 16]], camera_config=[C, C], object_config=[C, C],
+                  projection_type='tile', input_color=True, input_depth=False, input_mask=True, scale_mode='nearest').eval()
+    fu = fusion.get_fuser('pool:mean', C, 1.0).eval()
+    for k, prm in sc.named_parameters():
+        if k.endswith('bias'):
+            prm.data.normal_(0, 0.1)
+    dist = lf.recon.utils.optimal_camera_dist(615.4991, S, 0.5, slack=128 / S)
+    cam = rand_cameras(lf, V, zoomed_size=S, dist=dist, seed=241)
+    g = torch.Generator().manual_seed(242)
+    color = (torch.rand(1, V, 3, S, S, generator=g) * 2 - 1).requires_grad_(True)
+    mask = (torch.rand(1, V, 1, S, S, generator=g) > 0.3).float()
+    wz = torch.randn(1, 1, C, S, S, S, generator=g)
+    x2d = torch.randn(2, 16, S, S, generator=g)
+    z_obj, _ = sc.encode(fu, cam, color, None, mask)
+    (z_obj * wz).sum().backward()
+    with torch.no_grad():
+        lifted = sc.projection_block(x2d)
+    save('g24_tile_projection', {'sculptor': ck(sc), 'fuser': ck(fu), 'cam': cam_dict(cam), 'color': color.detach().clone(),
+                                 'mask': mask, 'wz': wz, 'z_obj': z_obj.detach().clone(), 'grad_color': color.grad.clone(),
+                                 'x2d': x2d, 'lifted': lifted.clone()})
+
+
 def main():
     lf = refharness.load_reference()
     import latentfusion.recon.utils  # noqa
@@ -904,7 +974,7 @@ def main():
     gens = [g0_preprocess, g1_camera, g2_resample, g3_block, g4_fusers, g5_decode, g6_loss, g7_g10_loop, g9_ibr,
             g11_released_like, g12_latent_code, g13_metrics, g14_initial_pose, g15_losses, g16_bop_reader, g17_api_helpers, g18_training_prep,
             g19_metropolis, g20_released_width, g21_bop_scene,
-            g22_photographer_skip]
+            g22_photographer_skip, g23_ibr_generator, g24_tile_projection]
     only = sys.argv[1:]                                  # e.g. `python oracle/make_golden.py g13` regenerates one group
     for fn in gens:
         if not only or any(fn.__name__.startswith(o + '_') or fn.__name__ == o for o in only):

@@ -146,6 +146,68 @@ def test_g9_ibr_on_hip(golden):
     close(img_re, g['image_reproj'], atol=2e-3, rtol=1e-2)
 
 
+def test_g23_ibr_generator_on_hip(golden):
+    """Row a14 remainder on the device: LatentFusionModel.render_ibr with a loaded generator U-Net (depths from the HIP
+    renderer, reprojection + learned flow through lf_grid_sample2d_fwd, the generator through the 2-D conv kernels),
+    reproject_views_batch with its camera distances, render_latent_ibr, blend_logits / warp_blend_logits -- against the
+    real reference's outputs (ibr.py:96-154,225-249; recon/inference.py:151-217)."""
+    from latentfusion_amd import ibr
+    from latentfusion_amd.modules.unet import UNet2d
+    from latentfusion_amd.observation import Observation
+    from latentfusion_amd.recon import fusion
+    from latentfusion_amd.recon.inference import LatentFusionModel
+    from latentfusion_amd.recon.models import Photographer, Sculptor
+    g = golden('g23_ibr_generator')
+    e = golden('g10_encode_pool_mean')                      # any sculptor / fuser of the same size: render_ibr never encodes
+    ph = Photographer.from_checkpoint(g['photographer'])
+    model = LatentFusionModel(Sculptor.from_checkpoint(e['sculptor']), fusion.from_checkpoint(e['fuser']), ph,
+                              g['camera_dist'], DEV, generator=UNet2d.from_checkpoint(g['generator']))
+    cam_in, cam_out = prod_camera(g['cam_in']), prod_camera(g['cam_out'])
+    obs = Observation(g['color_in'], g['depth_in'], g['mask_in'], prod_camera(g['cam_in'], 'cpu'), is_zoomed=True,
+                      is_prepared=True, is_normalized=True).to(DEV)
+    z_obj = g['z_obj'].to(DEV)
+    with torch.no_grad():
+        y, z_out = model.render_ibr(z_obj, obs, cam_out)
+        _, _, img_re, dep_re, _, _, dist_r, dist_t = model._render_reprojections(z_obj, obs.color, cam_in, cam_out)
+        col, d_out, m_out, reproj = ibr.render_latent_ibr(model.photographer, z_obj, cam_in, cam_out, obs.color.unsqueeze(0), p=0.5)
+        wb = ibr.warp_blend_logits(g['logits'].to(DEV), g['image_reproj'].to(DEV), 5)
+        bl = ibr.blend_logits(g['logits'][:, :3].to(DEV), g['image_reproj'].to(DEV))
+    for k in ('depth', 'mask', 'depth_logits', 'mask_logits'):
+        close(y[k], g['y'][k], atol=2e-4, rtol=2e-3)
+    close(img_re, g['image_reproj'], atol=2e-3, rtol=1e-2)
+    close(dep_re, g['depth_reproj'], atol=2e-3, rtol=1e-2)
+    close(dist_r, g['cam_dist_r'], atol=1e-5, rtol=1e-4)
+    close(dist_t, g['cam_dist_t'], atol=1e-5, rtol=1e-4)
+    close(y['color'], g['y']['color'], atol=3e-3, rtol=1e-2)
+    close(z_out, g['z_out'], atol=3e-4, rtol=3e-3)
+    close(col, g['latent_ibr']['color'], atol=2e-3, rtol=1e-2)
+    close(d_out, g['latent_ibr']['depth'], atol=2e-4, rtol=2e-3)
+    close(reproj, g['latent_ibr']['reproj'], atol=2e-3, rtol=1e-2)
+    for a, b in zip(wb, g['warp_blend']):                   # same inputs as the reference: only the sampler differs
+        close(a, b, atol=2e-5, rtol=1e-4)
+    for a, b in zip(bl, g['blend']):
+        close(a, b, atol=1e-5, rtol=1e-4)
+
+
+def test_g24_tile_projection_on_hip(golden):
+    """Row a4: TileProjection2d3d (modules/geometry.py:693-708) -- the module alone and inside a
+    Sculptor(projection_type='tile') encode, with the gradient w.r.t. the input images."""
+    from latentfusion_amd.recon import fusion
+    from latentfusion_amd.recon.models import Sculptor
+    g = golden('g24_tile_projection')
+    sc = Sculptor.from_checkpoint(g['sculptor']).to(DEV)
+    fu = fusion.from_checkpoint(g['fuser']).to(DEV)
+    assert sc.projection_type == 'tile' and type(sc.projection_block).__name__ == 'TileProjection2d3d'
+    with torch.no_grad():
+        lifted = sc.projection_block(g['x2d'].to(DEV))
+    close(lifted, g['lifted'], atol=2e-5, rtol=1e-4)
+    color = g['color'].to(DEV).requires_grad_(True)
+    z, _ = sc.encode(fu, prod_camera(g['cam']), color, None, g['mask'].to(DEV))
+    close(z, g['z_obj'], atol=1e-4, rtol=1e-3)
+    (z * g['wz'].to(DEV)).sum().backward()
+    close(color.grad, g['grad_color'], atol=5e-4, rtol=5e-3)
+
+
 def test_g12_latent_code_on_hip(golden):
     """compute_latent_code (encode the target crop under each candidate camera + decode) and the
     latent term of the pose loss -- the path used by adam_latent / cross_entropy_latent."""

@@ -355,6 +355,20 @@ def test_from_checkpoint_training_format(golden, tmp_path):
     for k, v in g['photographer']['state_dict'].items():
         assert torch.equal(model.photographer.state_dict()[k], v)
     assert type(model.fuser).__name__ == 'GRUFuser'
+    # train() / eval() switch the modules' mode only (reference recon/inference.py:39-49); freezing is explicit and the
+    # frozen() context gives every parameter its own flag back
+    params = list(model.parameters())
+    assert params and all(p.requires_grad for p in params) and not model.photographer.training
+    params[0].requires_grad_(False)                                   # a parameter the user froze deliberately
+    model.train(True)
+    assert model.photographer.training and not params[0].requires_grad and all(p.requires_grad for p in params[1:])
+    model.eval()
+    assert not model.sculptor.training and all(p.requires_grad for p in params[1:])
+    with model.frozen():
+        assert not any(p.requires_grad for p in params)
+    assert not params[0].requires_grad and all(p.requires_grad for p in params[1:])
+    assert not any(p.requires_grad for p in model.freeze().parameters())
+    assert all(p.requires_grad for p in model.unfreeze().parameters())
 
 
 def test_pose_metrics_golden(golden):
@@ -539,6 +553,17 @@ def test_observation_save_load_roundtrip(tmp_path):
     assert cam.translation.shape == (3, 3) and float(cam.translation[:, 2].min()) > 0.5
     z = obs.zoom_estimate(1.5, 32)
     assert z.color.shape[-2:] == (32, 32)
+    # meta values the reference's encoder knows (paths, tensors) are written; anything else is an error, not a string
+    import pathlib
+    obs.meta['source'] = pathlib.Path('/data/scene')
+    obs.meta['extent'] = torch.tensor([1.0, 2.0])
+    obs.save(tmp_path / 'obs2')
+    import json
+    meta = json.load(open(tmp_path / 'obs2' / 'cameras.json'))['meta']
+    assert meta['source'] == '/data/scene' and meta['extent'] == [1.0, 2.0]
+    obs.meta['bad'] = object()
+    with pytest.raises(TypeError):
+        obs.save(tmp_path / 'obs3')
 
 
 def test_committed_bench_line_has_the_contract_fields():

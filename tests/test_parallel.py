@@ -26,6 +26,8 @@ def _free_port():
 class OracleGRUFuser:
     """Same call signature as latentfusion_amd.recon.fusion.GRUFuser, evaluated on CPU."""
 
+    recurrence = 'gru'
+
     def __init__(self, ck):
         self.ck = ck
 
@@ -33,7 +35,28 @@ class OracleGRUFuser:
         return nets.fuse(self.ck, z_obj), {}
 
 
-def _worker(rank, size, port, case, q):
+class OracleLSTMFuser:
+    """Same call signature as latentfusion_amd.recon.fusion.LSTMFuser (incl. initial_state / 'state'), evaluated on CPU."""
+
+    recurrence = 'lstm'
+
+    def __init__(self, ck):
+        self.ck = ck
+
+    def __call__(self, z_obj, a, b, c, initial_state=None):
+        sd = self.ck['state_dict']
+        if initial_state is None:
+            h, first = z_obj[:, 0], 1
+            cs = torch.zeros_like(h)
+        else:
+            (h, cs), first = initial_state, 0
+        coords = nets.voxel_coords_zyx(h)
+        for i in range(first, z_obj.shape[1]):
+            h, cs = nets.lstm_step(sd, 'lstm', torch.cat((z_obj[:, i], coords), dim=1), h, cs)
+        return h.unsqueeze(1), {'state': (h, cs)}
+
+
+def _worker(rank, size, port, case, q, V=5):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=size)
@@ -41,7 +64,7 @@ def _worker(rank, size, port, case, q):
         from latentfusion_amd import parallel
         from latentfusion_amd.recon.fusion import PoolFuser
         g = torch.Generator().manual_seed(0)
-        V, C, S = 5, 4, 6                       # 5 views over 2 ranks: ragged 3 + 2
+        C, S = 4, 6                             # default 5 views over 2 ranks: ragged 3 + 2; V = 1: rank 1 holds none
         z = torch.randn(1, V, C, S, S, S, generator=g)
         b, e = parallel.shard_range(V, rank, size)
         mids = cams = None
@@ -60,6 +83,12 @@ def _worker(rank, size, port, case, q):
                     return torch.sum(z_obj * w, dim=1, keepdim=True), {}
             fuser = BlendFuser()
             want = fuser(z, [mids], None, None)[0]
+        elif case == 'lstm':
+            gen = torch.Generator().manual_seed(1)
+            sd = {'lstm.conv.module.weight': torch.randn(4 * C, 2 * C + 3, 3, 3, 3, generator=gen),
+                  'lstm.conv.bias': torch.randn(4 * C, generator=gen) * 0.1}
+            fuser = OracleLSTMFuser({'type': 'LSTMFuser', 'state_dict': sd})
+            want = nets.fuse(fuser.ck, z)
         else:
             gen = torch.Generator().manual_seed(1)
             sd = {}
@@ -80,12 +109,16 @@ def _worker(rank, size, port, case, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('case', ['mean', 'max', 'abs_max', 'blend', 'median', 'gru'])
-def test_view_sharded_fusion_world2(case):
+@pytest.mark.parametrize('case,V', [('mean', 5), ('max', 5), ('abs_max', 5), ('blend', 5), ('median', 5), ('gru', 5), ('lstm', 5),
+                                    # fewer views than ranks: rank 1 holds NO view and must still join every collective
+                                    ('mean', 1), ('max', 1), ('abs_max', 1), ('blend', 1), ('median', 1), ('gru', 1), ('lstm', 1)])
+def test_view_sharded_fusion_world2(case, V):
+    """gru / lstm: the hidden state is handed from rank to rank (send / recv) and the result broadcast: bit-identical to the
+    single-process recurrence.  mean / max / abs_max / blend: all-reduce forms.  median: ordered all-gather."""
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, case, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, case, q, V)) for r in range(2)]
     for p in procs:
         p.start()
     results = [q.get(timeout=120) for _ in procs]
