@@ -50,6 +50,13 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-iters', type=int, default=3, help='timed oracle iterations of the CPU baseline (after 1 warm-up)')
     ap.add_argument('--no-alt', action='store_true', help='skip the secondary f16x3 measurement')
+    ap.add_argument('--repeats', type=int, default=5,
+                    help='the timed region (exactly --steps iterations between barriers) is run this many times back to back; '
+                         '`value` is steps / MEDIAN block time, every block time is reported (box-to-box and run-to-run '
+                         'spread of a 0.1 s region is a few per cent)')
+    ap.add_argument('--no-build-parity', action='store_true',
+                    help='skip the CPU oracle reconstruction of the 16-view object (build_parity_at_full_size); the CPU pose '
+                         'loop then runs on the GPU-built volume')
     ap.add_argument('--sharded-build', action='store_true',
                     help='reconstruct ONE pool:mean object with its reference views sharded over the ranks and fused by the '
                          'RCCL all-reduce of the latent volume (parallel.build_latent_object_sharded); reported as '
@@ -61,9 +68,10 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(cks, z_obj_cpu, target_data, init, cfg, iters):
-    """The oracle (CPU restatement of the reference, pinned by tests/golden) on the SAME workload:
-    `iters` timed iterations of the same loop after one warm-up iteration."""
+def cpu_baseline(cks, z_obj_gpu_cpu, ref_data, target_data, init, cfg, iters, build):
+    """The oracle (CPU restatement of the reference, pinned by tests/golden) on the SAME workload: reconstruction of the
+    object from the same reference views (`build`), then `iters` timed iterations of the same pose loop after one warm-up
+    iteration -- on the ORACLE's own volume, so that nothing on this leg comes from the GPU."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import lf_oracle as O
     from lf_oracle import pose as opose
@@ -72,6 +80,18 @@ def cpu_baseline(cks, z_obj_cpu, target_data, init, cfg, iters):
     # threads -> 1.52/1.33/1.57/2.80 s per SYN(64,16) iteration); more threads only oversubscribe
     torch.set_num_threads(min(32, os.cpu_count()))
     model = opose.Model(sck, fck, pck, dist)
+    build_info, z_obj_cpu = None, z_obj_gpu_cpu
+    if build:
+        ref = opose.Obs(ref_data['color'], ref_data['depth'], ref_data['mask'],
+                        O.Cam.from_extrinsic(ref_data['intrinsic'], ref_data['extrinsic']))
+        t0 = time.perf_counter()
+        z_obj_cpu = model.build_latent_object(ref)
+        t_b = time.perf_counter() - t0
+        d = z_obj_gpu_cpu - z_obj_cpu
+        build_info = {'t_oracle_build_s': t_b, 'max_abs_diff': d.abs().max().item(), 'max_abs': z_obj_cpu.abs().max().item(),
+                      'rel_l2': (d.norm() / z_obj_cpu.norm()).item(),
+                      'what': 'fused latent volume of the HIP reconstruction vs the CPU oracle reconstruction of the same '
+                              'reference views (per-view encode, camera->object resampling, ConvGRU recurrence)'}
     target = opose.Obs(None, target_data['depth'], target_data['mask'],
                        O.Cam.from_extrinsic(target_data['intrinsic'], target_data['extrinsic']))
     cam0 = O.Cam(init['K'], init['log_q'], init['t'])
@@ -84,10 +104,10 @@ def cpu_baseline(cks, z_obj_cpu, target_data, init, cfg, iters):
     t0 = time.perf_counter()
     opose.gradient_estimate(model, z_obj_cpu, target, cam0, c)
     dt = time.perf_counter() - t0
-    # iteration 0 of the oracle on the SAME latent volume / target / initial cameras: the full-size parity check
+    # iteration 0 of the oracle on ITS volume / the same target / initial cameras: the full-size parity check
     ref0 = {'rank_loss': first['rank_loss'][0],
             'grad': torch.cat((first['grad_log_q'][0], first['grad_t'][0], first['grad_viewport'][0]), dim=1)}
-    return iters / dt, torch.get_num_threads(), ref0, dt
+    return iters / dt, torch.get_num_threads(), ref0, dt, build_info, z_obj_cpu
 
 
 def main():
@@ -103,9 +123,10 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = f'cuda:{local}'
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group('gloo' if single else 'nccl')
+    import torch.distributed as dist
+    launched = 'RANK' in os.environ and 'MASTER_ADDR' in os.environ          # torchrun / torch.distributed.run
+    if world > 1 or launched:
+        dist.init_process_group('gloo' if single else 'nccl')                # "nccl" IS RCCL on ROCm
 
     from latentfusion_amd import ops, synth
     from latentfusion_amd.modules.geometry import Camera
@@ -116,7 +137,11 @@ def main():
         a.conv_mode = 'fp32'                       # the Winograd / split kernels are written for the 16-channel blocks
     # every rank owns its own object: different weights seed -> different volume, same shapes
     model, cks = synth.build_model(S, C, a.fuser, seed=rank, device=dev)
-    ref_obs = synth.make_observation(V, seed=100 + rank, device=dev)
+    rdata = synth.make_observation_data(V, seed=100 + rank)
+    from latentfusion_amd.observation import Observation as _Obs
+    ref_obs = _Obs(rdata['color'], rdata['depth'], rdata['mask'],
+                   Camera(rdata['intrinsic'], rdata['extrinsic'], width=rdata['width'], height=rdata['height'])).to(dev)
+    model.freeze()            # inference process: no weight-gradient kernels anywhere (the estimators would freeze per call)
     tdata = synth.make_observation_data(1, seed=200 + rank)
     from latentfusion_amd.observation import Observation
     target = Observation(tdata['color'], tdata['depth'], tdata['mask'],
@@ -157,23 +182,33 @@ def main():
             torch.cuda.synchronize()
 
     def timed_loop(est_, st_):
+        """W warm-up iterations, then `--repeats` blocks of EXACTLY K iterations, each bracketed by barrier + synchronize
+        and reduced with MAX over the ranks.  Returns (median block time, all block times, the kernel events of all blocks)."""
         for _ in range(a.warmup):
             est_.iterate(st_)
-        barrier()
-        ops.KERNEL_TIMER = []
-        t0_ = time.perf_counter()
-        for _ in range(a.steps):
-            est_.iterate(st_)
-        barrier()
-        el = time.perf_counter() - t0_
-        timer_, ops.KERNEL_TIMER = ops.KERNEL_TIMER, None
-        if world > 1:
-            tt = torch.tensor([el], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            el = tt.item()
-        return el, timer_
+        blocks, timer_ = [], []
+        for _rep in range(max(1, a.repeats)):
+            barrier()
+            ops.KERNEL_TIMER = []
+            t0_ = time.perf_counter()
+            for _ in range(a.steps):
+                est_.iterate(st_)
+            barrier()
+            el = time.perf_counter() - t0_
+            timer_ += ops.KERNEL_TIMER
+            ops.KERNEL_TIMER = None
+            if world > 1:
+                tt = torch.tensor([el], device=dev, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                el = tt.item()
+            blocks.append(el)
+        return sorted(blocks)[len(blocks) // 2], blocks, timer_
 
-    elapsed, timer = timed_loop(est, st)
+    def est_for_parity(z_):
+        e_ = estimation.load_from_config(cfg, model, converge_patience=10 ** 6, conv_mode=a.conv_mode)
+        return e_.start(z_, target, init.zoom(None, model.input_size, model.camera_dist).to(dev))
+
+    elapsed, blocks, timer = timed_loop(est, st)
     alt = None
     if a.conv_mode in ('fp32', 'winograd') and not a.no_alt and C == 16:
         # secondary line (never `value`): the same loop with the split-precision conv3d kernels
@@ -184,12 +219,13 @@ def main():
         with torch.no_grad():
             l2, g2 = st2['engine'].forward_backward(st2['cam'], need_grad=True)
         alt0 = {'rank_loss': l2[:, 4].cpu(), 'grad': g2.cpu()}
-        el2, tm2 = timed_loop(est2, st2)
+        el2, blocks2, tm2 = timed_loop(est2, st2)
         d2 = [e0.elapsed_time(e1) for n_, e0, e1 in tm2 if n_ == 'conv3d_c16_split']
         alt = {'conv_mode': 'f16x3 (direct convolution, every fp32 product as 3 f16 MFMAs on hi/lo splits, fp32 accumulate; '
                             'error vs fp64 within the fp32 kernels\', '
                             'tests/test_engine_gpu.py::test_split_precision_conv_matches_fp32_and_fp64)',
                'value': world * a.steps / el2, 'unit': 'iters/s', 'ms_per_step': el2 / a.steps * 1e3,
+               'ms_per_step_blocks': [b / a.steps * 1e3 for b in blocks2],
                'conv_avg_launch_ms': sum(d2) / max(len(d2), 1)}
         if d2:
             ms2 = alt['conv_avg_launch_ms']
@@ -297,7 +333,27 @@ def main():
                    'allreduce_algbw_GBps': (z_full.numel() * 4 / 1e9) / (ar_ms * 1e-3) if ar_ms else None}
         del model0, obs0, z_sh, z_full
 
-    if world > 1:
+    # RCCL on this box: under a launcher the process group above IS an RCCL communicator; a plain `python bench.py` run
+    # initialises a world-size-1 group here (after the timed regions, so it cannot touch the number) and runs one
+    # all-reduce of a latent-volume-sized tensor through it
+    rccl = {'backend': None, 'ranks_seen': world}
+    try:
+        if not dist.is_initialized():
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', str(29400 + os.getpid() % 500))
+            dist.init_process_group('nccl', rank=0, world_size=1)
+        rccl['backend'] = dist.get_backend()
+        rccl['ranks_seen'] = dist.get_world_size()
+        if rccl['backend'] == 'nccl':
+            rccl['rccl_version'] = '.'.join(str(v) for v in torch.cuda.nccl.version())
+        probe = torch.ones(C * S ** 3, device=dev)
+        dist.all_reduce(probe)
+        torch.cuda.synchronize()
+        rccl['allreduce_ok'] = bool(probe[0].item() == dist.get_world_size() and probe[-1].item() == dist.get_world_size())
+        del probe
+    except Exception as e:                                           # noqa: BLE001  (reported, never fatal for the bench line)
+        rccl['error'] = f'{type(e).__name__}: {e}'[:300]
+    if dist.is_initialized():
         barrier()
         dist.destroy_process_group()
     if rank != 0:
@@ -307,6 +363,11 @@ def main():
         'metric': f'pose-optim iters/sec (reconstruct+render+backward), {V} views, {S}^3 voxels',
         'value': value, 'unit': 'iters/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
         'ms_per_step': elapsed / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'timing': {'what': f'{len(blocks)} back-to-back blocks of exactly {a.steps} iterations, each between barrier + '
+                           'synchronize, max over ranks; value = steps / MEDIAN block time',
+                   'ms_per_step_blocks': [b / a.steps * 1e3 for b in blocks],
+                   'spread_pct': (max(blocks) - min(blocks)) / elapsed * 100.0},
+        'rccl': rccl,
         'dtype': 'f32' if a.conv_mode in ('fp32', 'winograd') else 'f32 (conv3d products split into 3 f16 MFMAs, fp32 accumulate)', 'data': 'synthetic (SYN(S,C) random-init weights, synthetic observations)',
         'config': {'workload': f'SYN({S},{C}) latent volume, {V} reference views, adam_quick pose loop, '
                                f'{N} pose samples per iteration, one object per GPU',
@@ -319,7 +380,16 @@ def main():
                           'frac': iter_floor_ms / (elapsed / a.steps * 1e3), 'kernels': others},
     }
     if world == 1 and not a.no_cpu_baseline:
-        v, cores, ref0, cpu_dt = cpu_baseline(cks[:3] + (cks[3],), z_obj.cpu(), tdata, init_rec, cfg, a.cpu_iters)
+        v, cores, ref0, cpu_dt, build_info, z_ora = cpu_baseline(cks[:3] + (cks[3],), z_obj.cpu(), rdata, tdata, init_rec, cfg,
+                                                                  a.cpu_iters, build=not a.no_build_parity)
+        # the HIP render + loss + camera gradients on the ORACLE-built volume (iteration 0): render parity that does not
+        # rest on the GPU reconstruction
+        hip_on_oracle = None
+        if build_info is not None:
+            st3 = est_for_parity(z_ora.to(dev))
+            with torch.no_grad():
+                l3, g3 = st3['engine'].forward_backward(st3['cam'], need_grad=True)
+            hip_on_oracle = {'rank_loss': l3[:, 4].cpu(), 'grad': g3.cpu()}
 
         def parity(h):
             gerr = (h['grad'] - ref0['grad']).norm(dim=1) / ref0['grad'].norm(dim=1).clamp_min(1e-30)
@@ -332,11 +402,18 @@ def main():
         out['cpu_baseline'] = {'value': v, 'unit': 'iters/s', 'cores': cores, 'host_cores': os.cpu_count(), 'kind': 'port',
                                'timed_s': cpu_dt,
                                'sample': f'{a.cpu_iters} timed iteration(s) of the same SYN({S},{C}) N={N} pose loop (oracle = CPU restatement '
-                                         f'of the reference, after 1 warm-up iteration; latent volume taken from the GPU build; '
-                                         f'{cores} ATen threads of the {os.cpu_count()} host cores: more threads measured slower)',
-                               # HIP path vs the oracle on iteration 0 of this very workload (same volume, target,
-                               # initial cameras): per-hypothesis ranking loss and camera-parameter gradients
+                                         f'of the reference, after 1 warm-up iteration; latent volume '
+                                         + ('reconstructed by the oracle itself from the same reference views'
+                                            if build_info is not None else 'taken from the GPU build')
+                                         + f'; {cores} ATen threads of the {os.cpu_count()} host cores: more threads measured slower)',
+                               # END TO END: HIP reconstruction + HIP iteration 0 vs oracle reconstruction + oracle iteration 0
+                               # (same reference views, target, initial cameras): per-hypothesis ranking loss and
+                               # camera-parameter gradients
                                'parity_at_full_size': parity(hip0)}
+        if build_info is not None:
+            out['cpu_baseline']['build_parity_at_full_size'] = build_info
+            out['cpu_baseline']['render_parity_on_oracle_built_volume'] = parity(hip_on_oracle)
+            out['cpu_baseline']['e2e_100_iters_per_s'] = 100.0 / (build_info['t_oracle_build_s'] + 100.0 / v)
         if alt is not None:
             alt['parity_at_full_size'] = parity(alt0)
     if alt is not None:

@@ -103,3 +103,47 @@ def build_model(S, C, fuser='gru', seed=0, device='cuda', bias_std=0.0):
     model = LatentFusionModel(Sculptor.from_checkpoint(sck), fusion.from_checkpoint(fck),
                               Photographer.from_checkpoint(pck), dist, device)
     return model, (sck, fck, pck, dist)
+
+
+# the released recipe's architecture (reference tools/train/train.sh:28-66, decoded in SURVEY appendix A10): 256^2 inputs,
+# 16^3 x 256-channel latent volume, 512-channel U-Net levels, GRU fuser -- 68 M parameters
+RELEASED_SCULPTOR = dict(in_size=256, image_config=[[64, 'D', 128, 'D', 196, 'D', 256, 'D', 512, 'D', 512, 'D', 512],
+                                                    [512, 'U', 512, 'U', 256]],
+                         camera_config=[64, 128, 256], object_config=[256, 256], projection_type='factor',
+                         input_color=True, input_depth=False, input_mask=True, scale_mode='nearest')
+RELEASED_PHOTOGRAPHER = dict(in_size=16, image_config=[[256, 'D', 512, 'D', 512],
+                                                       [512, 'U', 512, 'U', 512, 'U', 256, 'U', 196, 'U', 128, 'U', 64]],
+                             camera_config=[256, 256], object_config=[], projection_type='factor',
+                             predict_depth=True, predict_mask=True, scale_mode='nearest')
+
+
+def seeded_state_dict(template, seed, bias_std=0.0):
+    """A state_dict with the keys / shapes of `template`, filled in SORTED KEY ORDER from one CPU generator: weights
+    N(0,1) (He-equalised layers), biases N(0, bias_std).  Independent of the order in which a module's constructor
+    happens to create its parameters, so any implementation with the same checkpoint keys -- this package, the CPU
+    oracle, the reference itself (oracle/make_golden.py g25) -- gets the SAME network from a seed: 68 M parameters
+    pinned by one integer."""
+    gen = torch.Generator().manual_seed(seed)
+    out = {}
+    for k in sorted(template):
+        shape = tuple(template[k].shape)
+        out[k] = torch.randn(shape, generator=gen) * (bias_std if k.endswith('bias') else 1.0)
+    return out
+
+
+def build_released_model(device='cuda', seed=0, bias_std=0.0):
+    """The released ARCHITECTURE with random He-equalised weights (the public checkpoint is not obtainable offline):
+    (LatentFusionModel on `device`, (sculptor, fuser, photographer checkpoints, camera_dist)).  The checkpoints are
+    reference-format dicts, so the CPU oracle evaluates the same network (tests/test_fullshape_gpu.py, tools/rel_probe.py);
+    the weights come from seeded_state_dict (seed, seed + 1, seed + 2 for sculptor, fuser, photographer)."""
+    from .recon import fusion
+    from .recon.inference import LatentFusionModel
+    from .recon.models import Photographer, Sculptor
+    sc = Sculptor(**RELEASED_SCULPTOR)
+    ph = Photographer(**RELEASED_PHOTOGRAPHER)
+    fu = fusion.get_fuser('gru', 256, 1.0)
+    for i, m in enumerate((sc, fu, ph)):
+        m.load_state_dict(seeded_state_dict(m.state_dict(), seed + i, bias_std))
+    dist = optimal_camera_dist(consts.INTRINSIC[1][1], 256, 0.5, slack=0.5)
+    cks = (sc.create_checkpoint(), fu.create_checkpoint(), ph.create_checkpoint(), dist)
+    return LatentFusionModel(sc.eval(), fu.eval(), ph.eval(), dist, device), cks

@@ -967,6 +967,54 @@ def g24_tile_projection(lf):
                                  'x2d': x2d, 'lifted': lifted.clone()})
 
 
+def g25_released_arch(lf):
+    """BASELINE cfg 3 at the TRUE released architecture (tools/train/train.sh:28-66: 256^2 inputs, 16^3 x 256-channel volume,
+    512-channel U-Net levels, GRU fuser; 68 M parameters) evaluated by the REAL reference: 8-view reconstruction and one
+    cross_entropy_linemod-style evaluation of 4 x 4 flipped cameras.  The network is pinned by a SEED -- weights from
+    latentfusion_amd.synth.seeded_state_dict (sorted-key order, plain torch RNG calls), observations from the seeded SURVEY 8d
+    generator (asserted identical to the product's synth.make_observation_data) -- so the fixture holds outputs only."""
+    from latentfusion.recon.models import Sculptor, Photographer
+    from latentfusion.recon import fusion
+    from latentfusion.recon.inference import LatentFusionModel
+    from latentfusion.pose import estimation, utils as pu
+    from latentfusion.modules.geometry import Camera
+    sys.path.insert(0, os.path.dirname(HERE))
+    from latentfusion_amd import synth                                   # seeded inputs only: no product compute is used
+    seed, V = 2500, 8
+    sc, ph = Sculptor(**synth.RELEASED_SCULPTOR).eval(), Photographer(**synth.RELEASED_PHOTOGRAPHER).eval()
+    fu = fusion.get_fuser('gru', 256, 1.0).eval()
+    for i, m in enumerate((sc, fu, ph)):
+        m.load_state_dict(synth.seeded_state_dict(m.state_dict(), seed + i, 0.1))
+    dist = lf.recon.utils.optimal_camera_dist(615.4991, 256, 0.5, slack=0.5)
+    model = LatentFusionModel(sc, fu, ph, dist, 'cpu')
+    ref_obs, target = synth_obs(lf, V, seed + 10), synth_obs(lf, 1, seed + 20)
+    for o, sd_ in ((ref_obs, seed + 10), (target, seed + 20)):           # the product's generator yields the same tensors
+        d = synth.make_observation_data(len(o), sd_)
+        assert torch.equal(d['color'], o.color) and torch.equal(d['depth'], o.depth) and torch.equal(d['mask'], o.mask)
+        assert torch.allclose(d['extrinsic'], o.camera.extrinsic, atol=1e-6)      # (the camera re-derives it from log_q, t)
+    with torch.no_grad():
+        z_obj = model.build_latent_object(ref_obs)
+        torch.manual_seed(seed + 30)
+        cams = pu.sample_cameras_with_estimate(4, target.camera, hemisphere=True, upright=True)
+        w = {'depth': 1.0, 'ov_depth': 0.0, 'iou': 0.0, 'mask': 0.0}     # configs/cross_entropy_linemod.toml
+        ce = estimation.CrossEntropyPoseEstimator(model=model, num_samples=16, num_elites=6, num_iters=1, num_gmm_components=2,
+                                                  learning_rate=0.9, sample_flipped=True, ranking_size=4, loss_weights=w)
+        allc = Camera.cat([cams, pu.flip_camera(cams, axis=(0.0, 0.0, 1.0)), pu.flip_camera(cams, axis=(0.0, 1.0, 0.0)),
+                           pu.flip_camera(cams, axis=(1.0, 0.0, 0.0))])
+        zd, zl, _, zc = ce._render_observation(z_obj, allc)
+        ld = ce.loss_func(target, zd, zl, zc)
+        loss = sum(estimation.weigh_losses(ld, w).values())
+    n_par = sum(p.numel() for m in (sc, fu, ph) for p in m.parameters())
+    save('g25_released_arch', {
+        'seed': seed, 'views': V, 'camera_dist': dist, 'params': n_par,
+        'z_obj_sub': z_obj[..., ::2, ::2, ::2].clone(), 'z_obj_absmax': z_obj.abs().max(), 'z_obj_mean': z_obj.mean(),
+        'z_obj_channel_mean': z_obj.mean(dim=(0, 1, 3, 4, 5)).clone(), 'z_obj_channel_sq': (z_obj ** 2).mean(dim=(0, 1, 3, 4, 5)).clone(),
+        'cams': cam_dict(cams), 'all_cams': cam_dict(allc), 'zoom_viewport': zc.viewport.clone(),
+        'depth_crop_sub': zd[..., ::4, ::4].clone(), 'mask_logits_crop_sub': zl[..., ::4, ::4].clone(),
+        'loss_terms': {k: v.clone() for k, v in ld.items()}, 'loss': loss.clone(), 'order': torch.argsort(loss), 'weights': w})
+    print('g25: params %.1f M, loss' % (n_par / 1e6), loss)
+
+
 def main():
     lf = refharness.load_reference()
     import latentfusion.recon.utils  # noqa
@@ -974,7 +1022,7 @@ def main():
     gens = [g0_preprocess, g1_camera, g2_resample, g3_block, g4_fusers, g5_decode, g6_loss, g7_g10_loop, g9_ibr,
             g11_released_like, g12_latent_code, g13_metrics, g14_initial_pose, g15_losses, g16_bop_reader, g17_api_helpers, g18_training_prep,
             g19_metropolis, g20_released_width, g21_bop_scene,
-            g22_photographer_skip, g23_ibr_generator, g24_tile_projection]
+            g22_photographer_skip, g23_ibr_generator, g24_tile_projection, g25_released_arch]
     only = sys.argv[1:]                                  # e.g. `python oracle/make_golden.py g13` regenerates one group
     for fn in gens:
         if not only or any(fn.__name__.startswith(o + '_') or fn.__name__ == o for o in only):

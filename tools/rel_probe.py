@@ -24,22 +24,8 @@ sys.path.insert(0, ROOT)
 
 
 def rel_model(device, seed=0):
-    from latentfusion_amd.recon import fusion, utils as ru
-    from latentfusion_amd.recon.inference import LatentFusionModel
-    from latentfusion_amd.recon.models import Photographer, Sculptor
-    torch.manual_seed(seed)
-    sc = Sculptor(in_size=256, image_config=[[64, 'D', 128, 'D', 196, 'D', 256, 'D', 512, 'D', 512, 'D', 512],
-                                              [512, 'U', 512, 'U', 256]],
-                  camera_config=[64, 128, 256], object_config=[256, 256], projection_type='factor',
-                  input_color=True, input_depth=False, input_mask=True, scale_mode='nearest')
-    ph = Photographer(in_size=sc.out_size,
-                      image_config=[[256, 'D', 512, 'D', 512],
-                                    [512, 'U', 512, 'U', 512, 'U', 256, 'U', 196, 'U', 128, 'U', 64]],
-                      camera_config=[256, 256], object_config=[], projection_type='factor',
-                      predict_depth=True, predict_mask=True, scale_mode='nearest')
-    fu = fusion.get_fuser('gru', 256, 1.0)
-    dist = ru.optimal_camera_dist(615.4991, 256, 0.5, slack=0.5)
-    return LatentFusionModel(sc.eval(), fu.eval(), ph.eval(), dist, device)
+    from latentfusion_amd import synth
+    return synth.build_released_model(device, seed)[0]
 
 
 def main():
