@@ -24,7 +24,8 @@ def needs_build():
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(HERE, s) for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
-    deps += [os.path.join(HERE, 'lf_common.h'), os.path.join(HERE, '..', '..', 'include', 'lf_hip.h')]
+    deps += [os.path.join(HERE, 'lf_common.h'), os.path.join(HERE, 'resample_staged.inc'),
+             os.path.join(HERE, '..', '..', 'include', 'lf_hip.h')]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

@@ -512,9 +512,18 @@ __global__ void __launch_bounds__(256, MINW) resample_bwd_coef_c16_kernel(
   }
 }
 
+#include "resample_staged.inc"
+
+#ifdef STAGED_TPW_OVERRIDE
+constexpr int STAGED_TPW = STAGED_TPW_OVERRIDE;
+#else
+constexpr int STAGED_TPW = 16;   // tiles per workgroup of the staged coefficient gradient
+#endif
+
 int g_bwd_coef_variant = 2;   // lean coefficient gradient: 1 = one sub-tile in flight (6 waves/SIMD), 2 = two (4 waves/SIMD; default),
                               // 3 = as 2 with a 128-register cap, 4 / 5 = one in flight capped at 6 / 8 waves/SIMD
-int g_resample_variant = 3;   // 1 = generic kernels, 2 = lean kernels, 3 = lean + 16-channel gather (lf_set_tuning)
+int g_resample_variant = 3;   // 1 = generic kernels, 2 = lean kernels, 3 = lean + 16-channel gather, 4 = LDS-staged footprint (16 channels;
+                              // other shapes as 3) (lf_set_tuning)
 
 // Sample evaluation for the deterministic splats with floating-point contraction OFF: every operation is rounded on its own,
 // so the kernels that must agree with each other -- the bounding-box pass and the tile pass of the tiled form (a corner voxel
@@ -818,7 +827,17 @@ extern "C" int lf_resample3d_fwd(const float* vol, int vol_n, const float* coef,
   dim3 grid((unsigned)((W + (1 << tlx) - 1) >> tlx), (unsigned)((H + (1 << tly) - 1) >> tly), (unsigned)(nbz * N)), block(256);
   const Steps st = make_steps(D, H, W);
   hipStream_t s = (hipStream_t)stream;
-  if (g_resample_variant == 3 && vec && C == 16 && (long)D * H * W * 64 < 0xffffffffL) {
+  if (g_resample_variant == 4 && vec && C == 16 && (long)D * H * W * 64 < 0xffffffffL && W <= 65535) {
+    const int ntx = (W + LT_X - 1) / LT_X, nty = (H + LT_Y - 1) / LT_Y, ntz = (D + LT_Z - 1) / LT_Z;
+    const long nwg = (long)ntx * nty * ntz * N;
+    if (nwg > 0x7fffffffL) return LF_EINVAL;
+    if (kind == LF_MAP_O2C)
+      hipLaunchKernelGGL((resample_fwd_staged_kernel<LF_MAP_O2C>), dim3((unsigned)nwg), block, 0, s, vol, bstride, coef, out, D, H, W, ntx, nty, ntz, st);
+    else
+      hipLaunchKernelGGL((resample_fwd_staged_kernel<LF_MAP_C2O>), dim3((unsigned)nwg), block, 0, s, vol, bstride, coef, out, D, H, W, ntx, nty, ntz, st);
+    return lf_launch_status();
+  }
+  if (g_resample_variant >= 3 && vec && C == 16 && (long)D * H * W * 64 < 0xffffffffL) {
     const int nbz4 = (D + 3) >> 2;
     if ((long)nbz4 * N > 65535 || ((H + 3) >> 2) > 65535) return LF_EINVAL;
     dim3 g4((unsigned)((W + 3) >> 2), (unsigned)((H + 3) >> 2), (unsigned)(nbz4 * N));
@@ -842,12 +861,18 @@ extern "C" int lf_resample3d_fwd(const float* vol, int vol_n, const float* coef,
   return lf_launch_status();
 }
 
+static long staged_bwd_blocks(int D, int H, int W) {
+  const long nt = (long)((W + LT_X - 1) / LT_X) * ((H + LT_Y - 1) / LT_Y) * ((D + LT_Z - 1) / LT_Z);
+  return (nt + STAGED_TPW - 1) / STAGED_TPW;
+}
+
 extern "C" size_t lf_resample3d_bwd_coef_scratch_bytes(int N, int D, int H, int W) {
   const long nvox = (long)D * H * W;
   const int vpb = bwd_vox_per_block(nvox, N);
   const BwdTile bt = bwd_tile(vpb, D, H, W);
   const long nblk = (long)bt.ntx * bt.nty * bt.ntz;
-  return (size_t)N * nblk * 18 * sizeof(float);
+  const long nblk_staged = staged_bwd_blocks(D, H, W);             // whichever form runs (lf_set_tuning) must fit
+  return (size_t)N * (nblk > nblk_staged ? nblk : nblk_staged) * 18 * sizeof(float);
 }
 
 extern "C" int lf_resample3d_bwd_coef(const float* gout, const float* vol, int vol_n, const float* coef,
@@ -874,6 +899,17 @@ extern "C" int lf_resample3d_bwd_coef(const float* gout, const float* vol, int v
   int lpv = 1;
   while (lpv < groups) lpv <<= 1;
   if (lpv > 64) return LF_EINVAL;                       // C > 256 (vec) / C > 64 (scalar)
+  if (g_resample_variant == 4 && vec && C == 16 && nvox * 64 < 0xffffffffL && W <= 65535) {
+    const int ntx = (W + LT_X - 1) / LT_X, nty = (H + LT_Y - 1) / LT_Y, ntz = (D + LT_Z - 1) / LT_Z;
+    const long nb = staged_bwd_blocks(D, H, W);
+    if (nb * N > 0x7fffffffL) return LF_EINVAL;
+    hipLaunchKernelGGL((resample_bwd_coef_staged_kernel<STAGED_TPW>), dim3((unsigned)(nb * N)), block, 0, s, gout, vol, bstride, coef,
+                       partial, (int)nb, D, H, W, ntx, nty, ntz, make_steps(D, H, W));
+    int st4 = lf_launch_status();
+    if (st4) return st4;
+    hipLaunchKernelGGL(resample_bwd_coef_reduce, dim3(N), dim3(256), 0, s, partial, (int)nb, gcoef);
+    return lf_launch_status();
+  }
   if (g_resample_variant >= 2 && vec && C == 16 && vpb >= 64 && nvox * 64 < 0xffffffffL) {
     const Steps stp = make_steps(D, H, W);
     if (g_bwd_coef_variant == 1)
@@ -919,12 +955,18 @@ extern "C" int lf_resample3d_bwd_vol(const float* gout, const float* coef, int k
   return lf_launch_status();
 }
 
+#ifdef STAGE_TS
+extern "C" int lf_debug_stage_ts(void* dst) {                      // experimental builds only (tools/stage_timeline.py)
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stage_ts), sizeof(unsigned long long) * 256 * 16, 0, hipMemcpyDeviceToHost);
+}
+#endif
+
 // Tuning / A-B switch (not part of the functional interface): key 1 = resampler variant (1 generic, 2 lean, 3 lean + 16-channel gather).
 // Returns the previous value, or LF_EINVAL for an unknown key.
 extern "C" int lf_set_tuning(int key, int value) {
   if (key == 1) {
     const int prev = g_resample_variant;
-    if (value >= 1 && value <= 3) g_resample_variant = value;
+    if (value >= 1 && value <= 4) g_resample_variant = value;
     return prev;
   }
   if (key == 4) {

@@ -54,3 +54,20 @@ def oracle_loss_grad(dt, case):
     finally:
         torch.Tensor.float = keep_float
         torch.set_default_dtype(keep_default)
+
+
+def in_fp64(fn):
+    """Runs fn() with the oracle in double precision: default dtype fp64 and the reference's explicit .float() up-casts
+    (which the oracle keeps) turned into .double()."""
+    keep_float, keep_default = torch.Tensor.float, torch.get_default_dtype()
+    try:
+        torch.set_default_dtype(torch.float64)
+        torch.Tensor.float = lambda self, *a, **k: self.double()
+        return fn()
+    finally:
+        torch.Tensor.float = keep_float
+        torch.set_default_dtype(keep_default)
+
+
+def cast(o, dt):
+    return _cast(o, dt)

@@ -205,7 +205,25 @@ def test_g24_tile_projection_on_hip(golden):
     z, _ = sc.encode(fu, prod_camera(g['cam']), color, None, g['mask'].to(DEV))
     close(z, g['z_obj'], atol=1e-4, rtol=1e-3)
     (z * g['wz'].to(DEV)).sum().backward()
-    close(color.grad, g['grad_color'], atol=5e-4, rtol=5e-3)
+    # The network is piecewise linear: the reference's own fp32 gradient has a pre-activation within rounding of 0 on the
+    # other LeakyReLU slope than an exact evaluation (6.8 % of its elements differ from the oracle in fp64 by up to 0.2;
+    # tests/test_oracle_golden.py pins oracle == reference bit for bit in fp32).  So the gradient is judged against the fp64
+    # evaluation: the HIP path must be at least as close to it as the fp32 reference is, and within 1e-2 of the reference.
+    from oracle_util import cast, in_fp64
+
+    def exact():
+        c64 = cast(g['color'][0], torch.float64).requires_grad_(True)
+        sck = {'args': g['sculptor']['args'], 'state_dict': cast(g['sculptor']['state_dict'], torch.float64)}
+        z64 = nets.encode(sck, g['fuser'], O.cam_from_dict(cast(g['cam'], torch.float64)), c64, None, cast(g['mask'][0], torch.float64))
+        (z64 * cast(g['wz'], torch.float64)).sum().backward()
+        return c64.grad
+    g64 = in_fp64(exact)
+
+    def rel(a):
+        return ((a.detach().cpu().double() - g64).norm() / g64.norm()).item()
+    err_hip, err_ref = rel(color.grad[0]), rel(g['grad_color'][0])
+    assert err_hip <= max(1e-4, 1.2 * err_ref), (err_hip, err_ref)
+    assert ((color.grad.cpu() - g['grad_color']).norm() / g['grad_color'].norm()).item() < 1e-2
 
 
 def test_g12_latent_code_on_hip(golden):
