@@ -50,6 +50,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-iters', type=int, default=3, help='timed oracle iterations of the CPU baseline (after 1 warm-up)')
     ap.add_argument('--no-alt', action='store_true', help='skip the secondary f16x3 measurement')
+    ap.add_argument('--engine-streams', type=int, default=1,
+                    help='hypothesis groups of the render-loop engine evaluated concurrently on separate HIP streams')
     ap.add_argument('--repeats', type=int, default=5,
                     help='the timed region (exactly --steps iterations between barriers) is run this many times back to back; '
                          '`value` is steps / MEDIAN block time, every block time is reported (box-to-box and run-to-run '
@@ -165,7 +167,7 @@ def main():
     cfg = estimation._load_toml(os.path.join(ROOT, 'configs', 'adam_quick.toml'))
     cfg['args']['num_samples'] = N
     cfg['args']['ranking_size'] = N
-    est = estimation.load_from_config(cfg, model, converge_patience=10 ** 6, conv_mode=a.conv_mode)
+    est = estimation.load_from_config(cfg, model, converge_patience=10 ** 6, conv_mode=a.conv_mode, engine_streams=a.engine_streams)
     torch.manual_seed(300 + rank)
     init = pu.sample_cameras_with_estimate(N, target.camera.to('cpu'))
     init_rec = {'K': init.intrinsic.clone(), 'log_q': init.log_quaternion.clone(), 't': init.translation.clone()}
@@ -214,7 +216,7 @@ def main():
         # secondary line (never `value`): the same loop with the split-precision conv3d kernels
         del est, st
         torch.cuda.empty_cache()
-        est2 = estimation.load_from_config(cfg, model, converge_patience=10 ** 6, conv_mode='f16x3')
+        est2 = estimation.load_from_config(cfg, model, converge_patience=10 ** 6, conv_mode='f16x3', engine_streams=a.engine_streams)
         st2 = est2.start(z_obj, target, init.zoom(None, model.input_size, model.camera_dist).to(dev))
         with torch.no_grad():
             l2, g2 = st2['engine'].forward_backward(st2['cam'], need_grad=True)
@@ -371,7 +373,7 @@ def main():
         'dtype': 'f32' if a.conv_mode in ('fp32', 'winograd') else 'f32 (conv3d products split into 3 f16 MFMAs, fp32 accumulate)', 'data': 'synthetic (SYN(S,C) random-init weights, synthetic observations)',
         'config': {'workload': f'SYN({S},{C}) latent volume, {V} reference views, adam_quick pose loop, '
                                f'{N} pose samples per iteration, one object per GPU',
-                   'fuser': a.fuser, 'pose_samples': N, 'ref_views': V, 'volume': S, 'channels': C,
+                   'engine_streams': a.engine_streams, 'fuser': a.fuser, 'pose_samples': N, 'ref_views': V, 'volume': S, 'channels': C,
                    'parallelism': f'objects x{world} (no data-path collective in the loop)'},
         't_build_s': t_build, 't_build_warm_s': t_build_warm,
         'e2e_100_iters_per_s': 100.0 / (t_build_warm + 100.0 * elapsed / a.steps),

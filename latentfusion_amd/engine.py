@@ -180,6 +180,7 @@ class RenderLoopEngine:
                      ops.pack_conv1x1(pw.reshape(cout, C, D).permute(0, 2, 1).reshape(cout, D * C)),
                      ops.pack_conv1x1(pw.reshape(cout, C, D).permute(2, 1, 0).reshape(D * C, cout)))
         self.dev = dev
+        self.streams, self._side_streams = 1, []
 
     def set_weights(self, loss_weights):
         self.weights = torch.tensor([loss_weights.get(k, 0.0) for k in self.LOSS_KEYS], dtype=torch.float32,
@@ -187,15 +188,62 @@ class RenderLoopEngine:
 
     # -----------------------------------------------------------------------------------------
     def forward_backward(self, camera, need_grad=True):
-        """Returns (losses (N,8): depth, ov_depth, iou, mask, weighted total ..., gparams (N,10) or None)."""
+        """Returns (losses (N,8): depth, ov_depth, iou, mask, weighted total ..., gparams (N,10) or None).
+
+        With `streams` = k > 1 (set_streams) the N hypotheses are evaluated as k independent groups on k HIP streams:
+        hypotheses do not interact (the reference optimises N separate cameras, estimation.py:580-594), so while one
+        group is in its latency-bound stretch (2-D decoder, loss, camera algebra: ~40 small launches that leave most of the
+        chip idle) another group's volume kernels run.  Same kernels, same per-hypothesis arithmetic: the results are
+        bit-identical to the single-stream evaluation (tests/test_engine_gpu.py)."""
+        params = camera_params(camera).detach().contiguous()
+        intr = camera_intrinsics(camera)
+        n = params.shape[0]
+        k = min(self.streams, n)
+        if k <= 1:
+            return self._forward_backward_group(params, intr, float(camera.z_span), need_grad, 1.0)
+        main = torch.cuda.current_stream()
+        ready = torch.cuda.Event()
+        ready.record(main)
+        bounds = [(n * i) // k for i in range(k + 1)]
+        outs = []
+        for i in range(k):
+            b, e = bounds[i], bounds[i + 1]
+            st = self._side_streams[i]
+            st.wait_event(ready)
+            params.record_stream(st)                               # (made on the main stream, read on the side streams)
+            intr.record_stream(st)
+            with torch.cuda.stream(st):
+                # d(mean over all N) = (group size / N) x d(mean over the group): an exact power-of-two factor for the
+                # usual sizes, applied to the 10 numbers per hypothesis at the end
+                lo, gp = self._forward_backward_group(params[b:e], intr[b:e], float(camera.z_span), need_grad, (e - b) / n)
+                done = torch.cuda.Event()
+                done.record(st)
+            outs.append((lo, gp, done))
+        for lo, gp, done in outs:
+            main.wait_event(done)
+            lo.record_stream(main)
+            if gp is not None:
+                gp.record_stream(main)
+        losses = torch.cat([o[0] for o in outs], dim=0)
+        gparams = torch.cat([o[1] for o in outs], dim=0) if need_grad else None
+        return losses, gparams
+
+    def set_streams(self, k):
+        """Number of hypothesis groups evaluated concurrently on separate HIP streams (1 = everything on the current stream)."""
+        self.streams = max(1, int(k))
+        while len(self._side_streams) < self.streams:
+            self._side_streams.append(torch.cuda.Stream(device=self.dev))
+        return self
+
+    def _forward_backward_group(self, params, intr, z_span, need_grad, grad_scale):
         L = _lib.lib()
         dev, S, s = self.dev, self.S, _s()
-        params = camera_params(camera).detach().contiguous()
+        params = params.contiguous()
+        intr = intr.contiguous()
         n = params.shape[0]
-        intr = camera_intrinsics(camera)
         coefs = torch.empty(n, NCOEF, device=dev, dtype=torch.float32)
         jac = torch.empty(n, NCOEF, NPAR, device=dev, dtype=torch.float32)
-        check(L.lf_camera_coefs(params.data_ptr(), intr.data_ptr(), float(self.cube), float(camera.z_span), self.crop,
+        check(L.lf_camera_coefs(params.data_ptr(), intr.data_ptr(), float(self.cube), z_span, self.crop,
                                 self.crop, coefs.data_ptr(), jac.data_ptr(), n, s), 'lf_camera_coefs')
         # O2C coefficient block padded to the resampler's stride (LF_MAP_COEFS = 20)
         cf20 = torch.zeros(n, 20, device=dev, dtype=torch.float32)
@@ -290,4 +338,6 @@ class RenderLoopEngine:
         gcoefs[:, :18] = gcoef18
         gparams = torch.empty(n, NPAR, device=dev, dtype=torch.float32)
         check(L.lf_camera_coefs_bwd(gcoefs.data_ptr(), jac.data_ptr(), gparams.data_ptr(), n, s), 'lf_camera_coefs_bwd')
+        if grad_scale != 1.0:
+            gparams *= grad_scale
         return losses, gparams

@@ -515,3 +515,54 @@ def test_winograd_sliding_halo_and_addend(shape):
     full, nfull = ops.conv3d_c16_wino(x, up, b, he, flags, prev=(addend, None, LF_EPI_ADD))
     assert (full - act / norm).abs().max().item() < 5e-5
     assert (nfull.view(norm.shape) - norm).abs().max().item() < 5e-5
+
+
+def test_engine_hypothesis_groups_on_streams_are_bit_identical(golden):
+    """RenderLoopEngine.set_streams(k): the N hypotheses evaluated as k groups on k HIP streams (the small-kernel stretch of
+    one group overlaps the volume kernels of another): the SAME losses bit for bit as one group on one stream, gradients equal
+    to rounding (the deterministic reductions partition by group size), run-to-run identical; a whole adam loop ranks alike."""
+    from latentfusion_amd import synth
+    from latentfusion_amd.engine import RenderLoopEngine
+    from latentfusion_amd.pose import estimation
+    model, _ = synth.build_model(32, 16, 'pool:mean', seed=4, device=DEV, bias_std=0.05)
+    g = golden('g7_adam_trace')
+    target = _target(g)
+    weights = {'depth': 1.0, 'ov_depth': 0.3, 'iou': 0.2, 'mask': 0.4}
+    gen = torch.Generator().manual_seed(9)
+    z_obj = torch.randn(1, 1, 16, 32, 32, 32, generator=gen).to(DEV)
+    cam0 = prod_camera(g['init']).zoom(None, model.input_size, model.camera_dist)          # 8 hypotheses
+    eng = RenderLoopEngine(model.photographer, z_obj, target, weights)
+    l1, g1 = eng.forward_backward(cam0)
+    for k in (2, 4):
+        eng.set_streams(k)
+        for _ in range(3):                                       # repeated: stream hand-offs, allocator reuse across streams
+            lk, gk = eng.forward_backward(cam0)
+            torch.cuda.synchronize()
+            assert torch.equal(lk, l1), k
+            # (the coefficient gradient's block partition follows the group size: its fixed-order sums associate differently)
+            close(gk, g1, atol=0.0, rtol=2e-5)
+    eng.set_streams(3)                                           # 8 -> 2 + 3 + 3: factors 2/8, 3/8
+    l3, g3 = eng.forward_backward(cam0)
+    assert torch.equal(l3, l1)
+    close(g3, g1, atol=0.0, rtol=2e-5)
+    cam5 = cam0[:5]
+    eng.set_streams(1)
+    l5, g5 = eng.forward_backward(cam5)
+    eng.set_streams(2)                                           # 5 -> 2 + 3
+    l52, g52 = eng.forward_backward(cam5)
+    assert torch.equal(l52, l5)
+    close(g52, g5, atol=0.0, rtol=2e-5)
+    runs = []
+    for k in (1, 2):
+        est = estimation.GradientPoseEstimator(model=model, learning_rate=0.01, num_samples=8, num_iters=6, ranking_size=8,
+                                               converge_threshold=1e-9, converge_patience=100, optimizer='adam',
+                                               loss_weights=weights, engine_streams=k, return_camera_history=True)
+        best, hist = est.estimate(z_obj, target, camera=prod_camera(g['init']))
+        runs.append((torch.cat((best.log_quaternion, best.translation), dim=1).cpu(), torch.stack([h[0] for h in hist])))
+    # iteration 0 is the same evaluation; later iterations drift apart at the rate any last-bit gradient difference does
+    # (Adam turns ~1e-5-sized viewport gradients into lr-sized steps: SURVEY 7 "chaotic sensitivity") -- within one
+    # optimiser step (lr = 0.01) per iteration, and the same best hypothesis at the end
+    assert torch.equal(runs[0][1][0], runs[1][1][0])
+    close(runs[0][1], runs[1][1], atol=0.0, rtol=2e-2)
+    close(runs[0][0], runs[1][0], atol=6 * 0.01, rtol=0.0)
+    assert int(torch.argmin(runs[0][1][-1])) == int(torch.argmin(runs[1][1][-1]))

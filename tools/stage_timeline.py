@@ -49,7 +49,7 @@ out = torch.empty_like(gout)
 nb = L.lf_resample3d_bwd_coef_scratch_bytes(N, S, S, S)
 scratch = torch.empty(nb // 4 + 1, device=dev)
 gc = torch.empty(N, 18, device=dev)
-NAMES = ['tap->', 'origin', 'atomics', 'barrier1', 'scan', 'barrier2a', 'alloc+recmap', 'barrier2', 'load', 'barrier3', 'compute']
+NAMES = ['tap->', 'origin', 'atomics', 'barrier1', 'scan', 'barrier2a+offsets+recmap', 'barrier2', 'load', 'barrier3', 'compute']
 
 
 def stamps():
@@ -70,4 +70,4 @@ for name, fn in (('gather', lambda: L.lf_resample3d_fwd(z.data_ptr(), 1, cf20.da
     print(f'{name}: {ok.sum()} stamped workgroups; median cycles per phase (tile start -> end of compute: '
           f'{int(np.median(ts[ok][:, 9] - ts[ok][:, 0]))})')
     for i in range(9):
-        print(f'   {NAMES[i + 1]:>14s}: median {int(np.median(d[:, i])):6d}   p90 {int(np.percentile(d[:, i], 90)):6d}')
+        print(f'   {NAMES[i + 1]:>24s}: median {int(np.median(d[:, i])):6d}   p90 {int(np.percentile(d[:, i], 90)):6d}')
