@@ -61,7 +61,7 @@ typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
 #define SPLIT_PF 2                                       // operand reads issued this many operands ahead of their MFMAs
 #endif
 #ifndef SPLIT_ABL
-#define SPLIT_ABL 0                                      // ablations (tools/split_ab.py): 1 no MFMAs, 2 no operand reads, 4 no halo fetch, 8 no stores, 16 no commit; 32 = cycle stamps (tools/split_timeline.py)
+#define SPLIT_ABL 0                                      // ablations (tools/split_ab.py; 64 = every MFMA twice): 1 no MFMAs, 2 no operand reads, 4 no halo fetch, 8 no stores, 16 no commit; 32 = cycle stamps (tools/split_timeline.py)
 #endif
 #ifndef SPLIT_E0
 #define SPLIT_E0 1                                       // operand step at which the previous tile's epilogue starts (8 steps)
@@ -454,6 +454,11 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_f16x3_kernel(
               if constexpr (term == 0 && NP != 1) acc[r] = mfma_k32(whi[p], vl, acc[r]);
               if constexpr (term == 1 && NP != 1) acc[r] = mfma_k32(wlo[NP == 1 ? 0 : p], vh, acc[r]);
               if constexpr (term == 2) acc[r] = mfma_k32(whi[p], vh, acc[r]);
+              if constexpr ((SPLIT_ABL & 64) != 0) {         // every product twice: the MFMA count of a bf16 x 3 (six-product) split
+                if constexpr (term == 0 && NP != 1) acc[r] = mfma_k32(whi[p], vl, acc[r]);
+                if constexpr (term == 1 && NP != 1) acc[r] = mfma_k32(wlo[NP == 1 ? 0 : p], vh, acc[r]);
+                if constexpr (term == 2) acc[r] = mfma_k32(whi[p], vh, acc[r]);
+              }
             }
           });
         }

@@ -31,8 +31,10 @@
 // (SQ_LDS_BANK_CONFLICT = 0).
 #include "lf_common.h"
 #ifndef WINO_ABL
-#define WINO_ABL 0
-#endif
+#define WINO_ABL 0      // ablations for tools/wino_ab.py (results are WRONG, timings only): 1 = no epilogue arithmetic (upper bound on
+#endif                  // what moving the epilogue to other waves could give: they would still issue it on the shared pipe);
+                        // 2 = no z-frequency exchange / z output transform (each wave stores from its own partials); 4 = every MFMA
+                        // chain 1.5x as long (the MFMA count of F(2,3) in y,x with direct z taps); 16 / 32 = cycle stamps
 // wave priorities (s_setprio) of the three phases of a tile: halo reads + input transforms (latency-bound: LDS),
 // the MFMA chains (throughput-bound) and the exchange / epilogue / halo fetch (latency-bound: LDS, HBM)
 #ifndef WINO_PL
@@ -176,14 +178,24 @@ __device__ __forceinline__ void wino_compute(const unsigned char* __restrict__ b
 #pragma unroll
             for (int h = 0; h < 2; ++h)
               m[cp + h] = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[(b * 4 + cp + h) * 4 + i], v[h][i], m[cp + h], 0, 0, 0);
+          if constexpr ((WINO_ABL & 4) != 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int h = 0; h < 2; ++h)
+                m[cp + h] = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[(b * 4 + cp + h) * 4 + i], v[h][i], m[cp + h], 0, 0, 0);
+          }
         } else {
           // fp32 Winograd-domain value -> f16 hi + lo (exact to 22 bits), three product terms
-          f16x4 vhi[2], vlo[2];
+          f16x4 vhi[2], vlo[2], vl2[2];
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             const f32x4 vs = v[h] * in_scale;
             vhi[h] = __builtin_convertvector(vs, f16x4);
-            vlo[h] = __builtin_convertvector(vs - __builtin_convertvector(vhi[h], f32x4), f16x4);
+            const f32x4 r1 = vs - __builtin_convertvector(vhi[h], f32x4);
+            vlo[h] = __builtin_convertvector(r1, f16x4);
+            if constexpr ((WINO_ABL & 8) != 0)                  // timing proxy of a THREE-piece split: third piece + 6 products
+              vl2[h] = __builtin_convertvector(r1 - __builtin_convertvector(vlo[h], f32x4), f16x4);
           }
 #pragma unroll
           for (int h = 0; h < 2; ++h) m[cp + h] = __builtin_amdgcn_mfma_f32_16x16x16f16(whi[b * 4 + cp + h], vlo[h], m[cp + h], 0, 0, 0);
@@ -191,6 +203,14 @@ __device__ __forceinline__ void wino_compute(const unsigned char* __restrict__ b
           for (int h = 0; h < 2; ++h) m[cp + h] = __builtin_amdgcn_mfma_f32_16x16x16f16(wlo[b * 4 + cp + h], vhi[h], m[cp + h], 0, 0, 0);
 #pragma unroll
           for (int h = 0; h < 2; ++h) m[cp + h] = __builtin_amdgcn_mfma_f32_16x16x16f16(whi[b * 4 + cp + h], vhi[h], m[cp + h], 0, 0, 0);
+          if constexpr ((WINO_ABL & 8) != 0) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) m[cp + h] = __builtin_amdgcn_mfma_f32_16x16x16f16(wlo[b * 4 + cp + h], vlo[h], m[cp + h], 0, 0, 0);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) m[cp + h] = __builtin_amdgcn_mfma_f32_16x16x16f16(whi[b * 4 + cp + h], vl2[h], m[cp + h], 0, 0, 0);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) m[cp + h] = __builtin_amdgcn_mfma_f32_16x16x16f16(wlo[b * 4 + cp + h], vl2[h], m[cp + h], 0, 0, 0);
+          }
         }
       }
       // x output transform, then accumulate the y output transform
@@ -452,11 +472,16 @@ __device__ __forceinline__ void conv3d_c16_wino_body(
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       f32x4 p[4];
+      if constexpr ((WINO_ABL & 2) != 0) {
+        o[j * 2 + 0] = *(const f32x4*)(px + fa * 8192 + fa * 2048 + j * 1024 + pr);
+        o[j * 2 + 1] = *(const f32x4*)(px + fa * 8192 + ((fa + 1) & 3) * 2048 + j * 1024 + pr);
+      } else {
 #pragma unroll
-      for (int a2 = 0; a2 < 4; ++a2)
-        p[a2] = *(const f32x4*)(px + a2 * 8192 + fa * 2048 + j * 1024 + pr);
-      o[j * 2 + 0] = p[0] + p[1] + p[2];                        // z output transform
-      o[j * 2 + 1] = pk_sub(pk_sub(p[1], p[2]), p[3]);
+        for (int a2 = 0; a2 < 4; ++a2)
+          p[a2] = *(const f32x4*)(px + a2 * 8192 + fa * 2048 + j * 1024 + pr);
+        o[j * 2 + 0] = p[0] + p[1] + p[2];                        // z output transform
+        o[j * 2 + 1] = pk_sub(pk_sub(p[1], p[2]), p[3]);
+      }
     }
 
     unsigned char* ybase = (unsigned char*)(y + (long)tt * nvox * 16) + eq * 16;
@@ -466,6 +491,7 @@ __device__ __forceinline__ void conv3d_c16_wino_body(
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       rn[k] = 1.f;
+      if constexpr ((WINO_ABL & 1) != 0) { v[k] = o[k]; continue; }
       if (prev_y == nullptr || addmode) {
         float ss = 0.f;
 #pragma unroll
@@ -492,7 +518,7 @@ __device__ __forceinline__ void conv3d_c16_wino_body(
     TS(7);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      if (prev_y != nullptr && !addmode) {
+      if (!(WINO_ABL & 1) && prev_y != nullptr && !addmode) {
         const f32x4 yp = pyv[k];
         v[k] = o[k] * out_scale;
         if (prev_flags & LF_EPI_PIXELNORM) {
