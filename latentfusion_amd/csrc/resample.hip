@@ -512,6 +512,127 @@ __global__ void __launch_bounds__(256, MINW) resample_bwd_coef_c16_kernel(
   }
 }
 
+// coefficient gradient, C == 16, per-voxel arithmetic done ONCE per voxel (variant 6 of lf_set_tuning key 2).
+// The kernel above spends most of its VALU issue on work that is identical in the four lanes sharing a voxel (map, taps,
+// derivative algebra: ~3/4 of its ~200 instructions per lane and voxel), and VALU issue is what bounds it.
+// Here a WAVE owns a 4x4x4 sub-tile and works on it in three phases that only meet through 3 KB of wave-private LDS:
+//   A  lane = voxel (64 voxels per instruction): map, clip, corner offsets -> one 16-byte record per voxel in LDS
+//      (fractions, clip masks and lattice coordinates stay in the lane's registers for phase C);
+//   B  four passes of 16 voxels, lane = (voxel, channel quarter) as before: the gathers stay coalesced 64-byte records
+//      through L1 (a lane-per-voxel gather would quadruple the L1 look-ups), contraction with the gradient, quad sums;
+//      the 8 per-corner scalars of a voxel go back to LDS;
+//   C  lane = voxel again: spatial derivatives, clip masks, the 18 basis sums.
+// No workgroup barrier; waves walk their own sub-tiles.  Same value as the kernel above, different summation order.
+template <int PIF, int MINW>
+__global__ void __launch_bounds__(256, MINW) resample_bwd_coef_c16_dedup_kernel(
+    const float* __restrict__ gout, const float* __restrict__ vol, long vol_bstride,
+    const float* __restrict__ coef, float* __restrict__ partial, int nblk, int vpb, BwdTile bt,
+    int D, int H, int W, Steps st) {
+  __shared__ u32x4_t tapbuf[4][64];                             // per wave: o000 | dead, x / y / z corner strides (bytes, 0 if clamped)
+  __shared__ float pbuf[4][64 * 8];                             // per wave: p[corner] of every voxel
+  __shared__ double red[4][18];
+  const unsigned fb = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int n = fb / nblk, blk = fb - n * nblk;
+  const float* cf = coef + n * LF_MAP_COEFS;
+  const u32 rec = 64u;
+  const u32 sample_bytes = (u32)D * (u32)H * (u32)W * rec;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(vol + (long)n * vol_bstride), 0, sample_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)(gout + (long)n * D * H * W * 16), 0, sample_bytes, 0x00020000);
+  const int tx = blk % bt.ntx, ty = (blk / bt.ntx) % bt.nty, tz = blk / (bt.ntx * bt.nty);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int px = lane & 3, py = (lane >> 2) & 3, pz = lane >> 4;  // phase A / C: lane = voxel of the sub-tile
+  const int q = lane & 3, vq = lane >> 2;                         // phase B: lane = (voxel 16 i + vq, quarter q)
+  const int sbx = bt.lx - 2, sby = bt.ly - 2;
+  const int nsub = vpb >> 6;
+  const u32 co = (u32)q * 16u;
+  float acc[18];
+#pragma unroll
+  for (int i = 0; i < 18; ++i) acc[i] = 0.f;
+  u32x4_t* tb = tapbuf[wave];
+  float* pb = pbuf[wave];
+  for (int sub = wave; sub < nsub; sub += 4) {                    // wave-uniform
+    const int x0 = (tx << bt.lx) + ((sub & ((1 << sbx) - 1)) << 2);
+    const int y0 = (ty << bt.ly) + (((sub >> sbx) & ((1 << sby) - 1)) << 2);
+    const int z0 = (tz << bt.lz) + ((sub >> (sbx + sby)) << 2);
+    // ---- A ----
+    const int x = x0 + px, y = y0 + py, z = z0 + pz;
+    const bool live = x < W && y < H && z < D;
+    float gx, gy, gz, a, b, k;
+    eval_grid<LF_MAP_O2C>(cf, live ? x : 0, live ? y : 0, live ? z : 0, W, H, D, st, gx, gy, gz, a, b, k);
+    u32 ox, dx, oy, dy, oz, dz;
+    float tx_, ty_, tz_, mx, my, mz;
+    axis_tap(gx, W, rec, ox, dx, tx_, mx);
+    axis_tap(gy, H, rec * (u32)W, oy, dy, ty_, my);
+    axis_tap(gz, D, rec * (u32)W * (u32)H, oz, dz, tz_, mz);
+    u32x4_t tr;
+    tr[0] = live ? (oz + oy + ox) : 0xffffffffu;                  // dead voxels: every offset out of range -> zeros
+    tr[1] = live ? dx : 0u; tr[2] = live ? dy : 0u; tr[3] = live ? dz : 0u;
+    tb[lane] = tr;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // ---- B ---- (PIF passes in flight; a real loop, so that no more than PIF x 9 loads are live)
+#pragma unroll 1
+    for (int i0 = 0; i0 < 4; i0 += PIF) {
+      f32x4 go[PIF], v[PIF][8];
+#pragma unroll
+      for (int u = 0; u < PIF; ++u) {
+        const int vi = 16 * (i0 + u) + vq;                        // voxel of the sub-tile: same numbering as phase A's lane
+        const u32x4_t t = tb[vi];
+        const int vx = x0 + (vi & 3), vy = y0 + ((vi >> 2) & 3), vz = z0 + (vi >> 4);
+        const u32 dead = t[0] == 0xffffffffu ? 0xffffffffu : 0u;
+        go[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+            rg, (int)(((u32)((vz * H + vy) * W + vx) * rec + co) | dead), 0, 2));        // streamed once (nt)
+        const u32 b00 = (t[0] + co) | dead, b01 = b00 + t[2], b10 = b00 + t[3], b11 = b01 + t[3];
+        v[u][0] = ldrec(rs, b00); v[u][1] = ldrec(rs, b00 + t[1]);
+        v[u][2] = ldrec(rs, b01); v[u][3] = ldrec(rs, b01 + t[1]);
+        v[u][4] = ldrec(rs, b10); v[u][5] = ldrec(rs, b10 + t[1]);
+        v[u][6] = ldrec(rs, b11); v[u][7] = ldrec(rs, b11 + t[1]);
+      }
+#pragma unroll
+      for (int u = 0; u < PIF; ++u) {
+        float p[8];
+#pragma unroll
+        for (int c8 = 0; c8 < 8; ++c8)
+          p[c8] = quad_sum4((go[u][0] * v[u][c8][0] + go[u][1] * v[u][c8][1]) + (go[u][2] * v[u][c8][2] + go[u][3] * v[u][c8][3]));
+        // every lane of a quad holds the voxel's 8 sums; lane q stores corners 2q, 2q+1 (one contiguous 32 bytes per voxel)
+        const float e0 = q == 0 ? p[0] : (q == 1 ? p[2] : (q == 2 ? p[4] : p[6]));
+        const float e1 = q == 0 ? p[1] : (q == 1 ? p[3] : (q == 2 ? p[5] : p[7]));
+        *(float2*)(pb + (16 * (i0 + u) + vq) * 8 + 2 * q) = make_float2(e0, e1);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // ---- C ----
+    {
+      const f32x4 pa = *(const f32x4*)(pb + lane * 8), pc = *(const f32x4*)(pb + lane * 8 + 4);
+      const float wx1 = tx_, wx0 = 1.f - wx1, wy1 = ty_, wy0 = 1.f - wy1, wz1 = tz_, wz0 = 1.f - wz1;
+      // corner index = z*4 + y*2 + x: pa = corners 0..3 (z0), pc = corners 4..7 (z1)
+      const float dxv = (pa[1] - pa[0]) * (wy0 * wz0) + (pa[3] - pa[2]) * (wy1 * wz0) + (pc[1] - pc[0]) * (wy0 * wz1) + (pc[3] - pc[2]) * (wy1 * wz1);
+      const float dyv = (pa[2] - pa[0]) * (wx0 * wz0) + (pa[3] - pa[1]) * (wx1 * wz0) + (pc[2] - pc[0]) * (wx0 * wz1) + (pc[3] - pc[1]) * (wx1 * wz1);
+      const float dzv = (pc[0] - pa[0]) * (wx0 * wy0) + (pc[1] - pa[1]) * (wx1 * wy0) + (pc[2] - pa[2]) * (wx0 * wy1) + (pc[3] - pa[3]) * (wx1 * wy1);
+      const float hx = live ? dxv * mx : 0.f, hy = live ? dyv * my : 0.f, hz = live ? dzv * mz : 0.f;
+      const float ak = a * k, bk = b * k;
+      acc[0] += hx;       acc[1] += hy;       acc[2] += hz;
+      acc[3] += hx * a;   acc[4] += hy * a;   acc[5] += hz * a;
+      acc[6] += hx * b;   acc[7] += hy * b;   acc[8] += hz * b;
+      acc[9] += hx * k;   acc[10] += hy * k;  acc[11] += hz * k;
+      acc[12] += hx * ak; acc[13] += hy * ak; acc[14] += hz * ak;
+      acc[15] += hx * bk; acc[16] += hy * bk; acc[17] += hz * bk;
+    }
+    asm volatile("" ::: "memory");                               // the next sub-tile's phase A overwrites tb after phase B's reads (program order)
+  }
+#pragma unroll
+  for (int i = 0; i < 18; ++i) {
+    double s = (double)acc[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) red[wave][i] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 18) {
+    const double s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    partial[((long)n * nblk + blk) * 18 + threadIdx.x] = (float)s;
+  }
+}
+
 #include "resample_staged.inc"
 
 #ifdef STAGED_TPW_OVERRIDE
@@ -520,7 +641,7 @@ constexpr int STAGED_TPW = STAGED_TPW_OVERRIDE;
 constexpr int STAGED_TPW = 16;   // tiles per workgroup of the staged coefficient gradient
 #endif
 
-int g_bwd_coef_variant = 2;   // lean coefficient gradient: 1 = one sub-tile in flight (6 waves/SIMD), 2 = two (4 waves/SIMD; default),
+int g_bwd_coef_variant = 6;   // lean coefficient gradient: 1 = one sub-tile in flight (6 waves/SIMD), 2 = two (4 waves/SIMD; r02 default),
                               // 3 = as 2 with a 128-register cap, 4 / 5 = one in flight capped at 6 / 8 waves/SIMD
 int g_resample_variant = 3;   // 1 = generic kernels, 2 = lean kernels, 3 = lean + 16-channel gather, 4 = LDS-staged footprint (16 channels;
                               // other shapes as 3) (lf_set_tuning)
@@ -918,6 +1039,14 @@ extern "C" int lf_resample3d_bwd_coef(const float* gout, const float* vol, int v
       hipLaunchKernelGGL((resample_bwd_coef_c16_kernel<1, 2>), grid, block, 0, s, gout, vol, bstride, coef, partial, nblk, vpb, bt, D, H, W, stp);
     else if (g_bwd_coef_variant == 3)
       hipLaunchKernelGGL((resample_bwd_coef_c16_kernel<4, 2>), grid, block, 0, s, gout, vol, bstride, coef, partial, nblk, vpb, bt, D, H, W, stp);
+    else if (g_bwd_coef_variant == 6 && vpb >= 256)
+      hipLaunchKernelGGL((resample_bwd_coef_c16_dedup_kernel<2, 1>), grid, block, 0, s, gout, vol, bstride, coef, partial, nblk, vpb, bt, D, H, W, stp);
+    else if (g_bwd_coef_variant == 7 && vpb >= 256)
+      hipLaunchKernelGGL((resample_bwd_coef_c16_dedup_kernel<1, 1>), grid, block, 0, s, gout, vol, bstride, coef, partial, nblk, vpb, bt, D, H, W, stp);
+    else if (g_bwd_coef_variant == 8 && vpb >= 256)
+      hipLaunchKernelGGL((resample_bwd_coef_c16_dedup_kernel<2, 4>), grid, block, 0, s, gout, vol, bstride, coef, partial, nblk, vpb, bt, D, H, W, stp);
+    else if (g_bwd_coef_variant == 9 && vpb >= 256)
+      hipLaunchKernelGGL((resample_bwd_coef_c16_dedup_kernel<1, 5>), grid, block, 0, s, gout, vol, bstride, coef, partial, nblk, vpb, bt, D, H, W, stp);
     else if (g_bwd_coef_variant == 4)
       hipLaunchKernelGGL((resample_bwd_coef_c16_kernel<6, 1>), grid, block, 0, s, gout, vol, bstride, coef, partial, nblk, vpb, bt, D, H, W, stp);
     else
@@ -978,7 +1107,7 @@ extern "C" int lf_set_tuning(int key, int value) {
   if (key == 5) return lf_internal_ring_bf16_set_wgs(value);        // bf16 ring convolution: resident workgroups per CU
   if (key == 2) {
     const int prev = g_bwd_coef_variant;
-    if (value >= 1 && value <= 5) g_bwd_coef_variant = value;
+    if (value >= 1 && value <= 9) g_bwd_coef_variant = value;
     return prev;
   }
   return LF_EINVAL;

@@ -121,7 +121,6 @@ class RenderLoopEngine:
                 and not photographer.skip_connections and len(photographer.object_blocks) == 0
                 and all(b.interpolate is None for b in photographer.camera_blocks)
                 and photographer.predict_depth and photographer.predict_mask and not photographer.predict_color
-                and loss_weights.get('latent', 0.0) == 0.0
                 and photographer.camera_config[-1] % 4 == 0)
 
     def __init__(self, photographer, z_obj, target_obs, loss_weights, conv_mode='auto'):
@@ -185,10 +184,15 @@ class RenderLoopEngine:
     def set_weights(self, loss_weights):
         self.weights = torch.tensor([loss_weights.get(k, 0.0) for k in self.LOSS_KEYS], dtype=torch.float32,
                                     device=self.z.device)
+        self.w_latent = float(loss_weights.get('latent', 0.0))
 
     # -----------------------------------------------------------------------------------------
-    def forward_backward(self, camera, need_grad=True):
-        """Returns (losses (N,8): depth, ov_depth, iou, mask, weighted total ..., gparams (N,10) or None).
+    def forward_backward(self, camera, need_grad=True, z_target_latent=None):
+        """Returns (losses (N,8): depth, ov_depth, iou, mask, weighted total, latent, 0, 0; gparams (N,10) or None).
+
+        z_target_latent (N or 1, C2, h, w): the latent code of the target under every hypothesis
+        (LatentFusionModel.compute_latent_code); with a non-zero 'latent' weight the cosine distance between it and the
+        renderer's projected latent joins the loss (reference pose/estimation.py:112-116), column 5 of `losses`.
 
         With `streams` = k > 1 (set_streams) the N hypotheses are evaluated as k independent groups on k HIP streams:
         hypotheses do not interact (the reference optimises N separate cameras, estimation.py:580-594), so while one
@@ -199,8 +203,11 @@ class RenderLoopEngine:
         intr = camera_intrinsics(camera)
         n = params.shape[0]
         k = min(self.streams, n)
+        zt = z_target_latent if (z_target_latent is not None and self.w_latent != 0.0) else None
+        if zt is not None and zt.shape[0] == 1 and n > 1:
+            zt = zt.expand(n, *zt.shape[1:])
         if k <= 1:
-            return self._forward_backward_group(params, intr, float(camera.z_span), need_grad, 1.0)
+            return self._forward_backward_group(params, intr, float(camera.z_span), need_grad, 1.0, zt)
         main = torch.cuda.current_stream()
         ready = torch.cuda.Event()
         ready.record(main)
@@ -212,10 +219,13 @@ class RenderLoopEngine:
             st.wait_event(ready)
             params.record_stream(st)                               # (made on the main stream, read on the side streams)
             intr.record_stream(st)
+            if zt is not None:
+                zt.record_stream(st)
             with torch.cuda.stream(st):
                 # d(mean over all N) = (group size / N) x d(mean over the group): an exact power-of-two factor for the
                 # usual sizes, applied to the 10 numbers per hypothesis at the end
-                lo, gp = self._forward_backward_group(params[b:e], intr[b:e], float(camera.z_span), need_grad, (e - b) / n)
+                lo, gp = self._forward_backward_group(params[b:e], intr[b:e], float(camera.z_span), need_grad, (e - b) / n,
+                                                      zt[b:e] if zt is not None else None)
                 done = torch.cuda.Event()
                 done.record(st)
             outs.append((lo, gp, done))
@@ -235,7 +245,7 @@ class RenderLoopEngine:
             self._side_streams.append(torch.cuda.Stream(device=self.dev))
         return self
 
-    def _forward_backward_group(self, params, intr, z_span, need_grad, grad_scale):
+    def _forward_backward_group(self, params, intr, z_span, need_grad, grad_scale, zt=None):
         L = _lib.lib()
         dev, S, s = self.dev, self.S, _s()
         params = params.contiguous()
@@ -284,6 +294,13 @@ class RenderLoopEngine:
             yimg = self.ph.image_decoder(zp_leaf)
             logits = torch.cat([ob(yimg) for ob in self.ph.output_blocks], dim=1)
             total, losses = pose_loss(logits, cf_leaf, self.tdepth, self.tmask, self.weights, self.H, self.W)
+            if zt is not None:
+                # latent term: cosine distance of the projected latent (what Photographer.forward returns as its latent)
+                lat = 1.0 - torch.cosine_similarity(zp_leaf.reshape(n, -1), zt.reshape(n, -1).to(zp_leaf.dtype), 1, 1e-8)
+                total = total + self.w_latent * lat
+                losses = losses.clone()
+                losses[:, 5] = lat.detach()
+                losses[:, 4] += self.w_latent * lat.detach()
             objective = total.mean()                     # the optimised quantity (estimation.py:616-617)
         if not need_grad:
             return losses, None

@@ -461,7 +461,7 @@ class GradientPoseEstimator(PoseEstimator):
             return None
         # a scheduled term the fused loss does not evaluate (e.g. [loss_schedules.latent] with loss_weights.latent = 0)
         # must not be dropped silently: the reference applies every scheduled weight (estimation.py:612-617)
-        if any(k not in RenderLoopEngine.LOSS_KEYS for k in self.loss_schedules):
+        if any(k not in RenderLoopEngine.LOSS_KEYS + ('latent',) for k in self.loss_schedules):
             return None
         return RenderLoopEngine(ph, z_obj, target_obs, self.loss_weights, conv_mode=self.conv_mode).set_streams(self.engine_streams)
 
@@ -585,8 +585,12 @@ class GradientPoseEstimator(PoseEstimator):
         eng, P = st['engine'], st['P']
         optim_weights = self._engine_weights(st, step)
         with torch.no_grad():
-            losses, gparams = eng.forward_backward(st['cam'], need_grad=True)
-            dev = torch.cat((losses[:, :5], P.detach()), dim=1)
+            z_target_latent = None
+            if optim_weights.get('latent', 0.0) != 0.0 or self.loss_weights.get('latent', 0.0) != 0.0:
+                # the target's latent code under every hypothesis (reference :606-608): encoder + renderer, no gradient
+                z_target_latent = self.model.compute_latent_code(st['target'], st['cam'])
+            losses, gparams = eng.forward_backward(st['cam'], need_grad=True, z_target_latent=z_target_latent)
+            dev = torch.cat((losses[:, :6], P.detach()), dim=1)
             if st.get('shard') is not None:                           # (N_local,15) -> (N,15) over the ranks
                 from .. import parallel
                 dev = parallel.gather_rows(dev.contiguous(), st['shard'][2])
@@ -618,11 +622,13 @@ class GradientPoseEstimator(PoseEstimator):
         host = cur['host'].clone()
         optim_weights = cur['weights']
         comp = {k: host[:, i] for i, k in enumerate(eng.LOSS_KEYS)}
-        rank = sum(self.loss_weights.get(k, 0.0) * comp[k] for k in eng.LOSS_KEYS)
+        if self.loss_weights.get('latent', 0.0) != 0.0 or 'latent' in self.loss_schedules:
+            comp['latent'] = host[:, 5]
+        rank = sum(self.loss_weights.get(k, 0.0) * v for k, v in comp.items())
         rank_host = rank.tolist()
         shard = st.get('shard')
         tpl = st['template_cpu'] if shard is None else st['template_full_cpu']
-        detached = tpl._like(log_quaternion=host[:, 5:8].clone(), translation=host[:, 8:11].clone(), viewport=None)
+        detached = tpl._like(log_quaternion=host[:, 6:9].clone(), translation=host[:, 9:12].clone(), viewport=None)
         if self.return_camera_history:
             st['camera_history'].append((rank.clone(), detached))
         delta = self._track_best_items(st['ranking'], step, list(detached), rank_host)

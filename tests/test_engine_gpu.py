@@ -566,3 +566,47 @@ def test_engine_hypothesis_groups_on_streams_are_bit_identical(golden):
     close(runs[0][1], runs[1][1], atol=0.0, rtol=2e-2)
     close(runs[0][0], runs[1][0], atol=6 * 0.01, rtol=0.0)
     assert int(torch.argmin(runs[0][1][-1])) == int(torch.argmin(runs[1][1][-1]))
+
+
+def test_engine_latent_term_matches_module_path(golden):
+    """adam_latent-style weights (latent = 0.2): the fused engine with the latent term (cosine distance between the projected
+    latent of every hypothesis and the target's latent code under that hypothesis, reference pose/estimation.py:112-116,606-608)
+    == Photographer.decode + default_pose_loss through the autograd modules: every loss term, the ranking loss, the camera
+    gradients; the estimator takes the engine for this preset and its first iterations follow the module path's."""
+    from latentfusion_amd.observation import Observation
+    from latentfusion_amd.pose import estimation
+    from latentfusion_amd.recon import fusion
+    from latentfusion_amd.recon.inference import LatentFusionModel
+    from latentfusion_amd.recon.models import Photographer, Sculptor
+    g = golden('g12_latent_code')
+    model = LatentFusionModel(Sculptor.from_checkpoint(g['sculptor']), fusion.from_checkpoint(g['fuser']),
+                              Photographer.from_checkpoint(g['photographer']), g['camera_dist'], DEV)
+    tg = g['target']
+    target = Observation(tg['color_u8'].float() / 255.0, tg['depth'], tg['mask'].float(), prod_camera(tg['cam'], 'cpu')).to(DEV)
+    z_obj = g['z_obj'].to(DEV)
+    cam0 = prod_camera(g['cams'])
+    weights = {'depth': 1.0, 'ov_depth': 0.3, 'iou': 0.0, 'mask': 0.0, 'latent': 0.2}
+    kw = dict(model=model, learning_rate=0.01, num_samples=len(cam0), num_iters=3, ranking_size=len(cam0), converge_threshold=1e-9,
+              converge_patience=100, optimizer='adam', loss_weights=weights, return_camera_history=True)
+    ref = estimation.GradientPoseEstimator(use_engine=False, **kw)
+    with model.frozen():
+        st = ref.start(z_obj, target, cam0)
+        with torch.no_grad():                                    # as the estimators do (reference :606-608)
+            zt = model.compute_latent_code(target, st['cam'])
+        ld, _, rank, _ = ref.loss_and_grad(z_obj, target, st['cam'], 0, zt)
+        want_g = torch.cat((st['cam'].log_quaternion.grad, st['cam'].translation.grad, st['cam'].viewport.grad), dim=1)
+        eng_est = estimation.GradientPoseEstimator(**kw)
+        st2 = eng_est.start(z_obj, target, cam0)
+        assert 'engine' in st2 and st2['engine'].w_latent == 0.2
+        losses, gparams = st2['engine'].forward_backward(st2['cam'], z_target_latent=zt)
+    for i, k in enumerate(('depth', 'ov_depth', 'iou', 'mask')):
+        close(losses[:, i], ld[k], atol=5e-6, rtol=1e-4)
+    close(losses[:, 5], ld['latent'], atol=2e-6, rtol=1e-4)
+    close(losses[:, 4], rank, atol=5e-6, rtol=1e-4)
+    rel = ((gparams - want_g).norm(dim=1) / want_g.norm(dim=1)).max().item()
+    assert rel < 5e-3, rel
+    a, ha = ref.estimate(z_obj, target, camera=prod_camera(g['cams']))
+    b, hb = eng_est.estimate(z_obj, target, camera=prod_camera(g['cams']))
+    la, lb = torch.stack([h[0] for h in ha]), torch.stack([h[0] for h in hb])
+    close(lb[0], la[0], atol=5e-6, rtol=1e-4)
+    close(lb, la, atol=0.0, rtol=2e-2)

@@ -224,3 +224,28 @@ def test_staged_forms_at_the_headline_size():
     e3 = ((g3[:M].cpu().double() - want).abs() / sc).max().item()
     e4 = ((g4[:M].cpu().double() - want).abs() / sc).max().item()
     assert e4 < max(2e-3, 1.5 * e3) and e4 < 2e-2, (e4, e3)
+
+
+@pytest.mark.parametrize('case', CASES[:5], ids=[c[0] for c in CASES[:5]])
+def test_deduplicated_coefficient_gradient(case):
+    """lf_set_tuning(2, 6): the gather form of the coefficient gradient with the per-voxel arithmetic done once per voxel
+    (lane-per-voxel phases around the lane-per-quarter gather, wave-private LDS hand-over) == the default form up to the
+    summation order, run-to-run identical, and as close to fp64 autograd."""
+    from latentfusion_amd import ops
+    name, (D, H, W), N, vol_n, scales = case
+    L = _lib()
+    gen = torch.Generator().manual_seed(sum(map(ord, name)) + 29)
+    cf = o2c_coefs(N, gen, scales).float().to(DEV).contiguous()
+    vol = ops.cl(torch.randn(vol_n, 16, D, H, W, generator=gen).to(DEV))
+    gout = ops.cl(torch.randn(N, 16, D, H, W, generator=gen).to(DEV))
+    prev = L.lf_set_tuning(2, 2)
+    try:
+        ref = run_bwd(L, 3, gout, vol, cf, N, D, H, W)
+        L.lf_set_tuning(2, 6)
+        got = run_bwd(L, 3, gout, vol, cf, N, D, H, W)
+        again = run_bwd(L, 3, gout, vol, cf, N, D, H, W)
+    finally:
+        L.lf_set_tuning(2, prev)
+    assert torch.equal(got, again)
+    scale = ref.abs().amax(dim=1, keepdim=True).clamp_min(1e-6)
+    assert ((got - ref).abs() / scale).max().item() < 2e-4, ((got - ref).abs() / scale).max().item()

@@ -82,6 +82,19 @@ def main():
             est.estimate(z_obj, target, camera=init8.to(dev))
             torch.cuda.synchronize(); el = time.perf_counter() - t0
             out['adam_it_per_s' if rep else 'adam_cold_it_per_s'] = a.adam_iters / el
+        # adam_latent (the notebook's fine stage: depth + overlap depth + latent term, 16 hypotheses): on the fused engine
+        # (latent term included since round 3) and on the autograd-module path
+        cfg = estimation._load_toml(os.path.join(ROOT, 'configs', 'adam_latent.toml'))
+        cfg['args']['num_iters'] = max(4, a.adam_iters // 2)
+        torch.manual_seed(303)
+        init16 = pu.sample_cameras_with_estimate(cfg['args']['num_samples'], target.camera.to('cpu'))
+        for tag, use_engine in (('adam_latent_engine_it_per_s', True), ('adam_latent_modules_it_per_s', False)):
+            est = estimation.load_from_config(cfg, model, converge_patience=10 ** 6, use_engine=use_engine)
+            for rep in range(2):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                est.estimate(z_obj, target, camera=init16.to(dev))
+                torch.cuda.synchronize(); el = time.perf_counter() - t0
+            out[tag] = cfg['args']['num_iters'] / el
         res[mode] = out
     ops.WIDE_CONV_MODE = 'fused'
     if len(check) == 2:
