@@ -50,8 +50,11 @@ int lf_device_name(char* buf, int buflen);
 /* Kernel-variant switch for in-process A/B measurements (tools/, profiles/); results are equivalent within the test
  * tolerances for every value.  key 1: 3-D resampler kernels, 1 = generic (64-bit addressing, any C), 2 = lean
  * (32-bit buffer addressing, C % 4 == 0, volumes < 4 GB per sample; other shapes take the generic ones),
- * 3 = lean + the 16-channel specialisation of the gather (default).  key 2: lean coefficient-gradient kernel, sub-tiles in
- * flight per workgroup iteration: 1 = one, 2 = two (default), 3-5 = register-capped forms of 2 / 1.  key 3: workgroup
+ * 3 = lean + the 16-channel specialisation of the gather (default), 4 = LDS-staged source footprint (16 channels; measured
+ * slower, profiles/r03_resample_staged_ab.txt).  key 2: lean coefficient-gradient kernel, sub-tiles in
+ * flight per workgroup iteration: 1 = one, 2 = two (round-2 default), 3-5 = register-capped forms of 2 / 1, 6-11 = forms that do the
+ * per-voxel arithmetic once per voxel instead of once per lane (10 = default: two gather passes in flight, gradient records
+ * requested one sub-tile ahead).  key 3: workgroup
  * shape of lf_wino_fused_gemm (output channels x Winograd tiles): 0 = 64 x 64, 1 = 128 x 64, 2 = 64 x 128, 3 = 128 x 128,
  * 4 = 64 x 256 (3, 4: 2-D only), -1 = chosen from the problem shape (default).  key 4: lf_resample3d_bwd_vol_det, 1 = global
  * 64-bit atomics, 2 = source tiles accumulated in LDS (default; C == 16; bit-identical results).  key 5: resident workgroups

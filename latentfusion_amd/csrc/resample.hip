@@ -523,7 +523,7 @@ __global__ void __launch_bounds__(256, MINW) resample_bwd_coef_c16_kernel(
 //      the 8 per-corner scalars of a voxel go back to LDS;
 //   C  lane = voxel again: spatial derivatives, clip masks, the 18 basis sums.
 // No workgroup barrier; waves walk their own sub-tiles.  Same value as the kernel above, different summation order.
-template <int PIF, int MINW>
+template <int PIF, int MINW, bool GOPF = false>
 __global__ void __launch_bounds__(256, MINW) resample_bwd_coef_c16_dedup_kernel(
     const float* __restrict__ gout, const float* __restrict__ vol, long vol_bstride,
     const float* __restrict__ coef, float* __restrict__ partial, int nblk, int vpb, BwdTile bt,
@@ -550,10 +550,33 @@ __global__ void __launch_bounds__(256, MINW) resample_bwd_coef_c16_dedup_kernel(
   for (int i = 0; i < 18; ++i) acc[i] = 0.f;
   u32x4_t* tb = tapbuf[wave];
   float* pb = pbuf[wave];
+  // GOPF: the gradient records (streamed from HBM: the longest latency of an iteration; the gathered volume sits in the
+  // Infinity Cache) are requested one sub-tile ahead
+  f32x4 gnext[4];
+  auto load_go = [&](int sub_, f32x4 (&dst)[4]) {
+    const int bx0 = (tx << bt.lx) + ((sub_ & ((1 << sbx) - 1)) << 2);
+    const int by0 = (ty << bt.ly) + (((sub_ >> sbx) & ((1 << sby) - 1)) << 2);
+    const int bz0 = (tz << bt.lz) + ((sub_ >> (sbx + sby)) << 2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int vi = 16 * i + vq;
+      const int vx = bx0 + (vi & 3), vy = by0 + ((vi >> 2) & 3), vz = bz0 + (vi >> 4);
+      const u32 dead = (sub_ < nsub && vx < W && vy < H && vz < D) ? 0u : 0xffffffffu;
+      dst[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+          rg, (int)(((u32)((vz * H + vy) * W + vx) * rec + co) | dead), 0, 2));
+    }
+  };
+  if (GOPF) load_go(wave, gnext);
   for (int sub = wave; sub < nsub; sub += 4) {                    // wave-uniform
     const int x0 = (tx << bt.lx) + ((sub & ((1 << sbx) - 1)) << 2);
     const int y0 = (ty << bt.ly) + (((sub >> sbx) & ((1 << sby) - 1)) << 2);
     const int z0 = (tz << bt.lz) + ((sub >> (sbx + sby)) << 2);
+    f32x4 gcur[4];
+    if (GOPF) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) gcur[i] = gnext[i];
+      load_go(sub + 4, gnext);
+    }
     // ---- A ----
     const int x = x0 + px, y = y0 + py, z = z0 + pz;
     const bool live = x < W && y < H && z < D;
@@ -571,7 +594,37 @@ __global__ void __launch_bounds__(256, MINW) resample_bwd_coef_c16_dedup_kernel(
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // ---- B ---- (PIF passes in flight; a real loop, so that no more than PIF x 9 loads are live)
 #pragma unroll 1
-    for (int i0 = 0; i0 < 4; i0 += PIF) {
+    for (int i0 = 0; i0 < 4; i0 += (GOPF ? 4 : PIF)) {
+      if (GOPF) {
+        // passes unrolled (static indices into gcur), PIF gathers in flight
+#pragma unroll
+        for (int j0 = 0; j0 < 4; j0 += PIF) {
+          f32x4 v[PIF][8];
+#pragma unroll
+          for (int u = 0; u < PIF; ++u) {
+            const u32x4_t t = tb[16 * (j0 + u) + vq];
+            const u32 dead = t[0] == 0xffffffffu ? 0xffffffffu : 0u;
+            const u32 b00 = (t[0] + co) | dead, b01 = b00 + t[2], b10 = b00 + t[3], b11 = b01 + t[3];
+            v[u][0] = ldrec(rs, b00); v[u][1] = ldrec(rs, b00 + t[1]);
+            v[u][2] = ldrec(rs, b01); v[u][3] = ldrec(rs, b01 + t[1]);
+            v[u][4] = ldrec(rs, b10); v[u][5] = ldrec(rs, b10 + t[1]);
+            v[u][6] = ldrec(rs, b11); v[u][7] = ldrec(rs, b11 + t[1]);
+          }
+#pragma unroll
+          for (int u = 0; u < PIF; ++u) {
+            const f32x4 go = gcur[j0 + u];
+            float p[8];
+#pragma unroll
+            for (int c8 = 0; c8 < 8; ++c8)
+              p[c8] = quad_sum4((go[0] * v[u][c8][0] + go[1] * v[u][c8][1]) + (go[2] * v[u][c8][2] + go[3] * v[u][c8][3]));
+            const float e0 = q == 0 ? p[0] : (q == 1 ? p[2] : (q == 2 ? p[4] : p[6]));
+            const float e1 = q == 0 ? p[1] : (q == 1 ? p[3] : (q == 2 ? p[5] : p[7]));
+            *(float2*)(pb + (16 * (j0 + u) + vq) * 8 + 2 * q) = make_float2(e0, e1);
+          }
+          __builtin_amdgcn_sched_barrier(0);                      // keep at most PIF x 8 gathers live
+        }
+        continue;
+      }
       f32x4 go[PIF], v[PIF][8];
 #pragma unroll
       for (int u = 0; u < PIF; ++u) {
@@ -641,7 +694,7 @@ constexpr int STAGED_TPW = STAGED_TPW_OVERRIDE;
 constexpr int STAGED_TPW = 16;   // tiles per workgroup of the staged coefficient gradient
 #endif
 
-int g_bwd_coef_variant = 6;   // lean coefficient gradient: 1 = one sub-tile in flight (6 waves/SIMD), 2 = two (4 waves/SIMD; r02 default),
+int g_bwd_coef_variant = 10;   // lean coefficient gradient: 1 = one sub-tile in flight (6 waves/SIMD), 2 = two (4 waves/SIMD; r02 default),
                               // 3 = as 2 with a 128-register cap, 4 / 5 = one in flight capped at 6 / 8 waves/SIMD
 int g_resample_variant = 3;   // 1 = generic kernels, 2 = lean kernels, 3 = lean + 16-channel gather, 4 = LDS-staged footprint (16 channels;
                               // other shapes as 3) (lf_set_tuning)
@@ -1047,6 +1100,10 @@ extern "C" int lf_resample3d_bwd_coef(const float* gout, const float* vol, int v
       hipLaunchKernelGGL((resample_bwd_coef_c16_dedup_kernel<2, 4>), grid, block, 0, s, gout, vol, bstride, coef, partial, nblk, vpb, bt, D, H, W, stp);
     else if (g_bwd_coef_variant == 9 && vpb >= 256)
       hipLaunchKernelGGL((resample_bwd_coef_c16_dedup_kernel<1, 5>), grid, block, 0, s, gout, vol, bstride, coef, partial, nblk, vpb, bt, D, H, W, stp);
+    else if (g_bwd_coef_variant == 10 && vpb >= 256)
+      hipLaunchKernelGGL((resample_bwd_coef_c16_dedup_kernel<2, 1, true>), grid, block, 0, s, gout, vol, bstride, coef, partial, nblk, vpb, bt, D, H, W, stp);
+    else if (g_bwd_coef_variant == 11 && vpb >= 256)
+      hipLaunchKernelGGL((resample_bwd_coef_c16_dedup_kernel<1, 1, true>), grid, block, 0, s, gout, vol, bstride, coef, partial, nblk, vpb, bt, D, H, W, stp);
     else if (g_bwd_coef_variant == 4)
       hipLaunchKernelGGL((resample_bwd_coef_c16_kernel<6, 1>), grid, block, 0, s, gout, vol, bstride, coef, partial, nblk, vpb, bt, D, H, W, stp);
     else
@@ -1107,7 +1164,7 @@ extern "C" int lf_set_tuning(int key, int value) {
   if (key == 5) return lf_internal_ring_bf16_set_wgs(value);        // bf16 ring convolution: resident workgroups per CU
   if (key == 2) {
     const int prev = g_bwd_coef_variant;
-    if (value >= 1 && value <= 9) g_bwd_coef_variant = value;
+    if (value >= 1 && value <= 11) g_bwd_coef_variant = value;
     return prev;
   }
   return LF_EINVAL;

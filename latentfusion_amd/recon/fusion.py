@@ -8,6 +8,7 @@ import abc
 import torch
 from torch import nn
 
+from ..functional import absolute_max_pool  # noqa: F401  (reference functional.py:47-49; re-exported here)
 from ..modules import EqualizedConv2d, EqualizedConv3d, unet
 from ..modules.geometry import CameraToObjectTransform
 from ..three.batchview import b2bv, bv2b
@@ -30,12 +31,6 @@ def get_fuser(fuser_type, in_channels, cube_size, block_config=None, conv_module
 
 def from_checkpoint(checkpoint):
     return globals()[checkpoint['type']].from_checkpoint(checkpoint)
-
-
-def absolute_max_pool(tensor, dim):
-    """Signed value of largest magnitude along `dim` (reference functional.py:47-49)."""
-    idx = tensor.abs().max(dim=dim, keepdim=True)[1]
-    return torch.gather(tensor, dim, idx)
 
 
 def pool_tensor(tensor, pool_type, dim=0):

@@ -226,11 +226,12 @@ def test_staged_forms_at_the_headline_size():
     assert e4 < max(2e-3, 1.5 * e3) and e4 < 2e-2, (e4, e3)
 
 
+@pytest.mark.parametrize('variant', [6, 10])
 @pytest.mark.parametrize('case', CASES[:5], ids=[c[0] for c in CASES[:5]])
-def test_deduplicated_coefficient_gradient(case):
-    """lf_set_tuning(2, 6): the gather form of the coefficient gradient with the per-voxel arithmetic done once per voxel
-    (lane-per-voxel phases around the lane-per-quarter gather, wave-private LDS hand-over) == the default form up to the
-    summation order, run-to-run identical, and as close to fp64 autograd."""
+def test_deduplicated_coefficient_gradient(case, variant):
+    """lf_set_tuning(2, 6 | 10): the gather form of the coefficient gradient with the per-voxel arithmetic done once per voxel
+    (lane-per-voxel phases around the lane-per-quarter gather, wave-private LDS hand-over; 10 = the default: gradient records
+    requested one sub-tile ahead) == the round-2 form (2) up to the summation order, and run-to-run identical."""
     from latentfusion_amd import ops
     name, (D, H, W), N, vol_n, scales = case
     L = _lib()
@@ -241,7 +242,7 @@ def test_deduplicated_coefficient_gradient(case):
     prev = L.lf_set_tuning(2, 2)
     try:
         ref = run_bwd(L, 3, gout, vol, cf, N, D, H, W)
-        L.lf_set_tuning(2, 6)
+        assert L.lf_set_tuning(2, variant) == 2
         got = run_bwd(L, 3, gout, vol, cf, N, D, H, W)
         again = run_bwd(L, 3, gout, vol, cf, N, D, H, W)
     finally:
