@@ -614,7 +614,7 @@ __global__ void __launch_bounds__(256) conv1x1_kernel(
 
   const int K = ksl * Cin;
   const int nchunks = Kp >> 4;
-  for (int kc = 0; kc < nchunks; ++kc) {
+  auto load_b = [&](int kc) -> f32x4 {
     const int k0 = kc * 16 + cq * 4;
     f32x4 bfrag = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (live && k0 < K) {
@@ -628,6 +628,9 @@ __global__ void __launch_bounds__(256) conv1x1_kernel(
           if (k0 + e < K) bfrag[e] = src[e];
       }
     }
+    return bfrag;
+  };
+  auto mac = [&](int kc, const f32x4& bfrag) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const f32x4 afrag = *(const f32x4*)(wrow + (long)t * 16 * Kp + kc * 16);
@@ -635,7 +638,21 @@ __global__ void __launch_bounds__(256) conv1x1_kernel(
       for (int st = 0; st < 4; ++st)
         acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[st], bfrag[st], acc[t][0], 0, 0, 0);
     }
+  };
+  int kc = 0;
+  if (NT == 1) {
+    // long contractions (the factor projection: K = C * D = 2048) stream their activations from HBM with one load per
+    // wave in flight; four chunks are requested before the first is consumed (same accumulation order: same bits;
+    // measured 0.218 -> 0.209 ms per 8 x 128^3 x 16 launch -- occupancy already covered most of the latency)
+    for (; kc + 4 <= nchunks; kc += 4) {
+      f32x4 b4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) b4[u] = load_b(kc + u);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) mac(kc + u, b4[u]);
+    }
   }
+  for (; kc < nchunks; ++kc) mac(kc, load_b(kc));
   long rowidx[1] = {live ? ((long)n * P + p) : -1};
   long rowoff[1] = {live ? ((long)n * y_batch_stride + p * y_row_stride) : -1};
   const bool vec_out = ((y_row_stride | y_slice_channels) & 3) == 0 && ((y_batch_stride | y_slice_stride) & 3) == 0;
