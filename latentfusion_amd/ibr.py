@@ -6,7 +6,6 @@ renderer, the 2-D warps are served by the device grid sampler.
 import math
 
 import torch
-from torch.nn import functional as F
 
 from . import image_ops, three
 from .three.batchview import b2bv, bv2b

@@ -2,7 +2,6 @@
 of the large-size tests.  Everything is generated on the CPU generator (device independent)
 and returned as plain data -- reference-format checkpoints and tensors -- so that the same
 inputs can be fed to the HIP path and to the CPU oracle."""
-import math
 
 import torch
 

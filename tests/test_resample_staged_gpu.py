@@ -6,7 +6,6 @@
     memory), on clamped-out and NaN maps, on ragged volume sizes, with one shared and with per-sample volumes;
   * coefficient gradient: against the gather form (same value, different summation order) and against autograd through an
     fp64 evaluation of the same map."""
-import math
 
 import pytest
 import torch
