@@ -112,6 +112,42 @@ def cpu_baseline(cks, z_obj_gpu_cpu, ref_data, target_data, init, cfg, iters, bu
     return iters / dt, torch.get_num_threads(), ref0, dt, build_info, z_obj_cpu
 
 
+def sharded_build_report(a, S, C, V, dev, world, barrier):
+    """The north-star collective (reported as `sharded_build`): every rank builds the SAME pool:mean model and observation;
+    the reference views are split over the ranks and the per-view volumes meet in ONE RCCL all-reduce of the C*S^3 volume."""
+    import torch.distributed as dist
+    from latentfusion_amd import synth
+    # the north-star collective: every rank builds the SAME pool:mean model and observation; the reference views are
+    # split over the ranks and the per-view volumes meet in ONE RCCL all-reduce of the C*S^3 latent volume
+    from latentfusion_amd import parallel
+    sh_fuser = 'pool:mean'
+    model0, _ = synth.build_model(S, C, sh_fuser, seed=12345, device=dev)
+    obs0 = synth.make_observation(V, seed=54321, device=dev)
+    for rep in range(2):                                       # second pass = warm
+        barrier()
+        t0 = time.perf_counter()
+        z_sh = parallel.build_latent_object_sharded(model0, obs0)
+        barrier()
+        t_sh = time.perf_counter() - t0
+    z_full = model0.build_latent_object(obs0)                  # local full build for comparison
+    err = (z_sh - z_full).abs().max().item()
+    # the collective alone: all-reduce of one latent volume, timed with barriers on both sides
+    ar_ms = None
+    if world > 1:
+        buf = torch.empty_like(z_full)
+        for rep in range(3):
+            barrier()
+            t0 = time.perf_counter()
+            dist.all_reduce(buf)
+            barrier()
+            ar_ms = (time.perf_counter() - t0) * 1e3
+    sharded = {'t_s': t_sh, 'fuser': sh_fuser, 'views': V, 'ranks': world, 'max_abs_diff_vs_local_build': err,
+               'volume_MB': z_full.numel() * 4 / 1e6, 'allreduce_ms': ar_ms,
+               'allreduce_algbw_GBps': (z_full.numel() * 4 / 1e9) / (ar_ms * 1e-3) if ar_ms else None}
+
+    return sharded
+
+
 def main():
     a = parse()
     rank = int(os.environ.get('RANK', 0))
@@ -125,6 +161,8 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = f'cuda:{local}'
+    if world > 1:                                              # the ranks share the host: no 8 x all-cores thread pools
+        torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))
     import torch.distributed as dist
     launched = 'RANK' in os.environ and 'MASTER_ADDR' in os.environ          # torchrun / torch.distributed.run
     if world > 1 or launched:
@@ -306,34 +344,11 @@ def main():
 
     sharded = None
     if a.sharded_build or (world > 1 and not a.no_sharded_build):
-        # the north-star collective: every rank builds the SAME pool:mean model and observation; the reference views are
-        # split over the ranks and the per-view volumes meet in ONE RCCL all-reduce of the C*S^3 latent volume
-        from latentfusion_amd import parallel
-        sh_fuser = 'pool:mean'
-        model0, _ = synth.build_model(S, C, sh_fuser, seed=12345, device=dev)
-        obs0 = synth.make_observation(V, seed=54321, device=dev)
-        for rep in range(2):                                       # second pass = warm
-            barrier()
-            t0 = time.perf_counter()
-            z_sh = parallel.build_latent_object_sharded(model0, obs0)
-            barrier()
-            t_sh = time.perf_counter() - t0
-        z_full = model0.build_latent_object(obs0)                  # local full build for comparison
-        err = (z_sh - z_full).abs().max().item()
-        # the collective alone: all-reduce of one latent volume, timed with barriers on both sides
-        ar_ms = None
-        if world > 1:
-            buf = torch.empty_like(z_full)
-            for rep in range(3):
-                barrier()
-                t0 = time.perf_counter()
-                dist.all_reduce(buf)
-                barrier()
-                ar_ms = (time.perf_counter() - t0) * 1e3
-        sharded = {'t_s': t_sh, 'fuser': sh_fuser, 'views': V, 'ranks': world, 'max_abs_diff_vs_local_build': err,
-                   'volume_MB': z_full.numel() * 4 / 1e6, 'allreduce_ms': ar_ms,
-                   'allreduce_algbw_GBps': (z_full.numel() * 4 / 1e9) / (ar_ms * 1e-3) if ar_ms else None}
-        del model0, obs0, z_sh, z_full
+        # auxiliary measurement: whatever happens here must not lose the headline line of an N-GPU run
+        try:
+            sharded = sharded_build_report(a, S, C, V, dev, world, barrier)
+        except Exception as e:                                       # noqa: BLE001
+            sharded = {'error': f'{type(e).__name__}: {e}'[:300]}
 
     # RCCL on this box: under a launcher the process group above IS an RCCL communicator; a plain `python bench.py` run
     # initialises a world-size-1 group here (after the timed regions, so it cannot touch the number) and runs one
