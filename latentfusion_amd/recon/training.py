@@ -107,6 +107,10 @@ class GeneratorStep:
         self.generator_input_depth, self.depth_noise_std = generator_input_depth, depth_noise_std
         self.group = process_group
         self.use_amp = bool(use_amp)
+        # data-parallel ranks: gradient buckets are all-reduced while backward is still running (parallel.GradientBuckets)
+        self.buckets = None
+        if parallel.world()[1] > 1:
+            self.buckets = parallel.GradientBuckets(self.flat.grad, self.flat.params, self.flat.offsets, process_group)
 
     def losses(self, batch):
         """Forward of the generator and the loss terms of train_reconstruct.py:456-516."""
@@ -138,11 +142,17 @@ class GeneratorStep:
         them on every stepping micro-batch, so only the last group is applied there)."""
         if train and zero_grad:
             self.flat.zero_grad()
+        if self.buckets is not None:
+            self.buckets.arm(train and is_step)
         with torch.set_grad_enabled(train):
             out, _ = self.losses(batch)
             if train:
                 out['total'].backward()
         if train and is_step:
-            parallel.allreduce_flat_(self.flat.grad, self.group)
+            if self.buckets is not None:
+                self.buckets.finish()                      # most buckets were launched from the backward hooks
+            else:
+                parallel.allreduce_flat_(self.flat.grad, self.group)
             self.optim.step()
+
         return {k: v.detach() for k, v in out.items()}

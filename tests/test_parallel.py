@@ -258,3 +258,62 @@ def test_estimators_with_sharded_hypotheses_world2():
     # the sharded cross-entropy search: both ranks end with rank 0's ranking, which is the one-rank result for rank 0's seed
     torch.testing.assert_close(res[1][('ce', True)][0], res[0][('ce', True)][0], atol=0, rtol=0)
     torch.testing.assert_close(res[0][('ce', True)][0], res[0][('ce', False)][0], atol=1e-6, rtol=1e-6)
+
+
+def _bucket_worker(rank, size, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=size)
+    try:
+        from latentfusion_amd import parallel
+        from latentfusion_amd.recon.training import FlatParameters
+
+        def net():
+            torch.manual_seed(0)
+            return torch.nn.Sequential(torch.nn.Linear(37, 53), torch.nn.Tanh(), torch.nn.Linear(53, 29), torch.nn.Tanh(),
+                                       torch.nn.Linear(29, 5))
+        g = torch.Generator().manual_seed(10 + rank)                 # every rank its own micro-batches
+        xs = [torch.randn(11, 37, generator=g) for _ in range(2)]
+        out = {}
+        for mode in ('after_backward', 'overlapped'):
+            m = net()
+            flat = FlatParameters([m])
+            bk = parallel.GradientBuckets(flat.grad, flat.params, flat.offsets, bucket_bytes=1024) if mode == 'overlapped' else None
+            res = []
+            for accumulate in (False, True):
+                flat.zero_grad()
+                steps = xs if accumulate else xs[:1]                 # accumulate: two micro-batches, ONE reduction
+                for i, x in enumerate(steps):
+                    if bk is not None:
+                        bk.arm(i == len(steps) - 1)
+                    m(x).square().sum().backward()
+                if bk is not None:
+                    assert len(bk.handles) > 1                        # buckets really left during the backward
+                    bk.finish()
+                else:
+                    parallel.allreduce_flat_(flat.grad, bucket_bytes=1024)
+                res.append(flat.grad.clone().numpy())
+            out[mode] = res
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_gradient_buckets_world2():
+    """parallel.GradientBuckets (all-reduce of a bucket as soon as its parameters have their gradients, during backward) ==
+    parallel.allreduce_flat_ after backward, bit for bit, with and without gradient accumulation; identical on both ranks."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        for a, b in zip(got[r]['after_backward'], got[r]['overlapped']):
+            assert (a == b).all() and abs(a).max() > 0
+    for a, b in zip(got[0]['overlapped'], got[1]['overlapped']):
+        assert (a == b).all()
