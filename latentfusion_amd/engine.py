@@ -180,6 +180,16 @@ class RenderLoopEngine:
                      ops.pack_conv1x1(pw.reshape(cout, C, D).permute(2, 1, 0).reshape(D * C, cout)))
         self.dev = dev
         self.streams, self._side_streams = 1, []
+        self._intr = None                                            # (key, tensor): the intrinsics do not change during a loop
+        # the output heads (1x1 convolutions without activation, reference blocks.py:108-119) as ONE pointwise convolution
+        # with their weights stacked along the output channels: same arithmetic per channel, one launch each way instead
+        # of a launch per head plus a concatenation
+        self.heads = None
+        obs = list(photographer.output_blocks)
+        if len(obs) > 1 and all(getattr(ob, 'activation', None) is None and getattr(ob.conv, 'kernel_size', 0) == 1
+                                and ob.conv.bias is not None for ob in obs):
+            self.heads = (torch.cat([ob.conv.module.weight.detach() for ob in obs], dim=0).contiguous(),
+                          torch.cat([ob.conv.bias.detach() for ob in obs], dim=0).contiguous())
 
     def set_weights(self, loss_weights):
         self.weights = torch.tensor([loss_weights.get(k, 0.0) for k in self.LOSS_KEYS], dtype=torch.float32,
@@ -187,7 +197,7 @@ class RenderLoopEngine:
         self.w_latent = float(loss_weights.get('latent', 0.0))
 
     # -----------------------------------------------------------------------------------------
-    def forward_backward(self, camera, need_grad=True, z_target_latent=None):
+    def forward_backward(self, camera, need_grad=True, z_target_latent=None, params=None):
         """Returns (losses (N,8): depth, ov_depth, iou, mask, weighted total, latent, 0, 0; gparams (N,10) or None).
 
         z_target_latent (N or 1, C2, h, w): the latent code of the target under every hypothesis
@@ -199,8 +209,14 @@ class RenderLoopEngine:
         group is in its latency-bound stretch (2-D decoder, loss, camera algebra: ~40 small launches that leave most of the
         chip idle) another group's volume kernels run.  Same kernels, same per-hypothesis arithmetic: the results are
         bit-identical to the single-stream evaluation (tests/test_engine_gpu.py)."""
-        params = camera_params(camera).detach().contiguous()
-        intr = camera_intrinsics(camera)
+        # `params`: the (N,10) block [log_quaternion | translation | viewport] when the caller already holds it (the estimators'
+        # cameras are views of one such tensor), else it is gathered from the camera; the intrinsics are gathered once
+        params = (camera_params(camera) if params is None else params).detach().contiguous()
+        K = camera.intrinsic
+        key = (K.data_ptr(), K._version, tuple(K.shape))
+        if self._intr is None or self._intr[0] != key:
+            self._intr = (key, camera_intrinsics(camera))
+        intr = self._intr[1]
         n = params.shape[0]
         k = min(self.streams, n)
         zt = z_target_latent if (z_target_latent is not None and self.w_latent != 0.0) else None
@@ -287,24 +303,50 @@ class RenderLoopEngine:
         with ops._timed('factor_project_fwd'):
             pnorm = ops._conv1x1_raw(acts[-1], ppack, pb, n, S * S, Cl, S, S * S * S * Cl, S * S * Cl, cout, zp, phe, flags)
 
-        # ---- 2-D decoder + heads + fused loss (autograd over small maps) ----
+        # ---- 2-D decoder + heads (autograd over small maps) + fused loss ----
         zp_leaf = zp.detach().requires_grad_(need_grad)
-        cf_leaf = coefs.detach().requires_grad_(need_grad)
         with torch.set_grad_enabled(need_grad):
             yimg = self.ph.image_decoder(zp_leaf)
-            logits = torch.cat([ob(yimg) for ob in self.ph.output_blocks], dim=1)
-            total, losses = pose_loss(logits, cf_leaf, self.tdepth, self.tmask, self.weights, self.H, self.W)
-            if zt is not None:
+            if self.heads is not None:
+                logits = ops.conv1x1(yimg, self.heads[0], self.heads[1])
+            else:
+                logits = torch.cat([ob(yimg) for ob in self.ph.output_blocks], dim=1)
+        if zt is None:
+            # the optimised quantity is mean_n(total) (estimation.py:616-617): lf_pose_loss_fwd already leaves the sums'
+            # gradients for exactly that, so the loss needs no autograd node -- logits -> loss -> d/d(logits, coefficients)
+            # are two kernel calls, and autograd only carries d(logits) back through the decoder
+            lg = ops.cl(logits.detach())                          # (n,2,h,w) channels-last == [n][h*w][2]
+            h_, w_ = lg.shape[-2:]
+            nbytes = L.lf_pose_loss_scratch_bytes(n, h_, w_, self.H, self.W)
+            scratch_l = torch.empty(nbytes // 4 + 1, device=dev, dtype=torch.float32)
+            sums = torch.empty(n, 8, device=dev, dtype=torch.float32)
+            losses = torch.empty(n, 8, device=dev, dtype=torch.float32)
+            gsums = torch.empty(n, 8, device=dev, dtype=torch.float32)
+            check(L.lf_pose_loss_fwd(lg.data_ptr(), coefs.data_ptr(), self.tdepth.data_ptr(), self.tmask.data_ptr(),
+                                     self.weights.data_ptr(), sums.data_ptr(), losses.data_ptr(), gsums.data_ptr(),
+                                     scratch_l.data_ptr(), scratch_l.numel() * 4, n, h_, w_, self.H, self.W, s), 'lf_pose_loss_fwd')
+            if not need_grad:
+                return losses, None
+            glogits = torch.empty_like(lg)
+            g_cf = torch.zeros(n, NCOEF, device=dev, dtype=torch.float32)
+            check(L.lf_pose_loss_bwd(lg.data_ptr(), coefs.data_ptr(), self.tdepth.data_ptr(), self.tmask.data_ptr(), gsums.data_ptr(),
+                                     glogits.data_ptr(), g_cf.data_ptr(), scratch_l.data_ptr(), scratch_l.numel() * 4,
+                                     n, h_, w_, self.H, self.W, s), 'lf_pose_loss_bwd')
+            g_zp, = torch.autograd.grad(logits, [zp_leaf], grad_outputs=[glogits])
+        else:
+            cf_leaf = coefs.detach().requires_grad_(need_grad)
+            with torch.set_grad_enabled(need_grad):
+                total, losses = pose_loss(logits, cf_leaf, self.tdepth, self.tmask, self.weights, self.H, self.W)
                 # latent term: cosine distance of the projected latent (what Photographer.forward returns as its latent)
                 lat = 1.0 - torch.cosine_similarity(zp_leaf.reshape(n, -1), zt.reshape(n, -1).to(zp_leaf.dtype), 1, 1e-8)
                 total = total + self.w_latent * lat
                 losses = losses.clone()
                 losses[:, 5] = lat.detach()
                 losses[:, 4] += self.w_latent * lat.detach()
-            objective = total.mean()                     # the optimised quantity (estimation.py:616-617)
-        if not need_grad:
-            return losses, None
-        g_zp, g_cf = torch.autograd.grad(objective, [zp_leaf, cf_leaf])
+                objective = total.mean()                     # the optimised quantity (estimation.py:616-617)
+            if not need_grad:
+                return losses, None
+            g_zp, g_cf = torch.autograd.grad(objective, [zp_leaf, cf_leaf])
 
         # ---- 3-D backward (data gradients only) ----
         gp = ops._epilogue_bwd(ops.cl(g_zp), zp, pnorm, flags)

@@ -589,7 +589,7 @@ class GradientPoseEstimator(PoseEstimator):
             if optim_weights.get('latent', 0.0) != 0.0 or self.loss_weights.get('latent', 0.0) != 0.0:
                 # the target's latent code under every hypothesis (reference :606-608): encoder + renderer, no gradient
                 z_target_latent = self.model.compute_latent_code(st['target'], st['cam'])
-            losses, gparams = eng.forward_backward(st['cam'], need_grad=True, z_target_latent=z_target_latent)
+            losses, gparams = eng.forward_backward(st['cam'], need_grad=True, z_target_latent=z_target_latent, params=P)
             dev = torch.cat((losses[:, :6], P.detach()), dim=1)
             if st.get('shard') is not None:                           # (N_local,15) -> (N,15) over the ranks
                 from .. import parallel
