@@ -214,11 +214,18 @@ __global__ void pose_loss_finish_kernel(const float* __restrict__ partial, int n
                                         float* __restrict__ gsums) {
   const int n = blockIdx.x;
   __shared__ double S[NSUM];
-  if (threadIdx.x < NSUM) {
+  // one wave: lane l adds the partials of blocks l, l + 64, ... in fp64, then a fixed butterfly over the lanes (a serial walk
+  // over the 240 blocks by one lane per component was 240 dependent global loads = 28 us of pure latency)
+#pragma unroll
+  for (int c = 0; c < NSUM; ++c) {
     double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += (double)partial[((long)n * nblk + b) * NSUM + threadIdx.x];
-    S[threadIdx.x] = s;
-    sums[n * NSUM + threadIdx.x] = (float)s;
+    for (int b = threadIdx.x; b < nblk; b += 64) s += (double)partial[((long)n * nblk + b) * NSUM + c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (threadIdx.x == 0) {
+      S[c] = s;
+      sums[n * NSUM + c] = (float)s;
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -358,10 +365,12 @@ __global__ void __launch_bounds__(256) pose_loss_bwd_cols_kernel(
 __global__ void reduce_partials_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ out, int ncomp,
                                        int out_stride, int out_offset) {
   const int n = blockIdx.x;
-  if (threadIdx.x < ncomp) {
+  for (int c = 0; c < ncomp; ++c) {                               // (one wave; lanes over the blocks, fixed butterfly: see above)
     double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += (double)partial[((long)n * nblk + b) * NSUM + threadIdx.x];
-    out[n * out_stride + out_offset + threadIdx.x] = (float)s;
+    for (int b = threadIdx.x; b < nblk; b += 64) s += (double)partial[((long)n * nblk + b) * NSUM + c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (threadIdx.x == 0) out[n * out_stride + out_offset + c] = (float)s;
   }
 }
 

@@ -272,7 +272,8 @@ class RenderLoopEngine:
         check(L.lf_camera_coefs(params.data_ptr(), intr.data_ptr(), float(self.cube), z_span, self.crop,
                                 self.crop, coefs.data_ptr(), jac.data_ptr(), n, s), 'lf_camera_coefs')
         # O2C coefficient block padded to the resampler's stride (LF_MAP_COEFS = 20)
-        cf20 = torch.zeros(n, 20, device=dev, dtype=torch.float32)
+        # (the object->camera map reads 18 of the 20 floats of a block; the two pad floats are never read: no fill launch)
+        cf20 = torch.empty(n, 20, device=dev, dtype=torch.float32)
         cf20[:, :18] = coefs[:, :18]
 
         # ---- 3-D forward ----
@@ -328,7 +329,8 @@ class RenderLoopEngine:
             if not need_grad:
                 return losses, None
             glogits = torch.empty_like(lg)
-            g_cf = torch.zeros(n, NCOEF, device=dev, dtype=torch.float32)
+            # (lf_pose_loss_bwd writes entries 18..23; 0..17 come from the resampler's coefficient gradient below)
+            g_cf = torch.empty(n, NCOEF, device=dev, dtype=torch.float32)
             check(L.lf_pose_loss_bwd(lg.data_ptr(), coefs.data_ptr(), self.tdepth.data_ptr(), self.tmask.data_ptr(), gsums.data_ptr(),
                                      glogits.data_ptr(), g_cf.data_ptr(), scratch_l.data_ptr(), scratch_l.numel() * 4,
                                      n, h_, w_, self.H, self.W, s), 'lf_pose_loss_bwd')
