@@ -180,7 +180,7 @@ class RenderLoopEngine:
                      ops.pack_conv1x1(pw.reshape(cout, C, D).permute(2, 1, 0).reshape(D * C, cout)))
         self.dev = dev
         self.streams, self._side_streams = 1, []
-        self._intr = None                                            # (key, tensor): the intrinsics do not change during a loop
+        self._intr = None                                            # (K, version, gathered): the intrinsics do not change during a loop
         # the output heads (1x1 convolutions without activation, reference blocks.py:108-119) as ONE pointwise convolution
         # with their weights stacked along the output channels: same arithmetic per channel, one launch each way instead
         # of a launch per head plus a concatenation
@@ -213,10 +213,11 @@ class RenderLoopEngine:
         # cameras are views of one such tensor), else it is gathered from the camera; the intrinsics are gathered once
         params = (camera_params(camera) if params is None else params).detach().contiguous()
         K = camera.intrinsic
-        key = (K.data_ptr(), K._version, tuple(K.shape))
-        if self._intr is None or self._intr[0] != key:
-            self._intr = (key, camera_intrinsics(camera))
-        intr = self._intr[1]
+        # (keyed on the tensor OBJECT, which the cache keeps alive, and its version counter: an address alone could be
+        # reused by another camera's intrinsics)
+        if self._intr is None or self._intr[0] is not K or self._intr[1] != K._version:
+            self._intr = (K, K._version, camera_intrinsics(camera))
+        intr = self._intr[2]
         n = params.shape[0]
         k = min(self.streams, n)
         zt = z_target_latent if (z_target_latent is not None and self.w_latent != 0.0) else None
