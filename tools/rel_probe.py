@@ -95,6 +95,17 @@ def main():
                 est.estimate(z_obj, target, camera=init16.to(dev))
                 torch.cuda.synchronize(); el = time.perf_counter() - t0
             out[tag] = cfg['args']['num_iters'] / el
+        # cross_entropy_latent (the notebook's coarse stage: latent term only, 96 = 24 x 4 flips renders per iteration, plus the
+        # target's latent code under every sample): module path (the fused loss implements the gradient estimator's form)
+        cfg = estimation._load_toml(os.path.join(ROOT, 'configs', 'cross_entropy_latent.toml'))
+        cfg['args']['num_iters'] = max(3, a.ce_iters // 3)
+        est = estimation.load_from_config(cfg, model)
+        for rep in range(2):
+            torch.manual_seed(304)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            est.estimate(z_obj, target, camera=target.camera)
+            torch.cuda.synchronize(); el = time.perf_counter() - t0
+        out['ce_latent_it_per_s'] = cfg['args']['num_iters'] / el
         res[mode] = out
     ops.WIDE_CONV_MODE = 'fused'
     if len(check) == 2:
