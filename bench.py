@@ -227,6 +227,9 @@ def main():
         for _ in range(a.warmup):
             est_.iterate(st_)
         blocks, timer_ = [], []
+        # HIP events only around the kernels the roofline fields report (an event pair costs a few us of dispatch gap)
+        ops.KERNEL_TIMER_TAGS = {'conv3d_c16_wino', 'conv3d_c16_split', 'conv3d_c16_wino_split', f'conv3x3_3d_{C}x{C}',
+                                 'resample_fwd', 'resample_bwd_coef', 'factor_project_fwd', 'factor_project_bwd'}
         for _rep in range(max(1, a.repeats)):
             barrier()
             ops.KERNEL_TIMER = []

@@ -65,21 +65,26 @@ def _ac_in(t):
 # Optional per-kernel timing with HIP events on the launch stream (used by bench.py for the
 # roofline of the dominant kernel).  Set to a list to collect (name, start_event, end_event).
 KERNEL_TIMER = None
+# Restrict the events to these kernel tags (None = every tagged launch).  An event pair costs ~4-5 us of dispatch gap
+# around its kernel: bench.py times only the kernels its roofline fields report.
+KERNEL_TIMER_TAGS = None
 
 
 class _timed:
     def __init__(self, name):
         self.name = name
+        self.on = False
 
     def __enter__(self):
-        if KERNEL_TIMER is not None:
+        self.on = KERNEL_TIMER is not None and (KERNEL_TIMER_TAGS is None or self.name in KERNEL_TIMER_TAGS)
+        if self.on:
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e1 = torch.cuda.Event(enable_timing=True)
             self.e0.record()                    # current stream == the stream the kernel is launched on
         return self
 
     def __exit__(self, *exc):
-        if KERNEL_TIMER is not None:
+        if self.on and KERNEL_TIMER is not None:
             self.e1.record()
             KERNEL_TIMER.append((self.name, self.e0, self.e1))
         return False
