@@ -17,41 +17,54 @@ namespace {
 // forward-mode duals over the 10 camera parameters (log_q 3, t 3, viewport 4)
 // ---------------------------------------------------------------------------------------------
 constexpr int NP = 10;
-struct Dual {
+// forward-mode dual number carrying ND derivative components: ND = NP (one thread per camera, all ten derivatives) or
+// ND = 1 (one thread per (camera, parameter): the same operations per component, ten times the parallelism -- the kernel is
+// a serial fp64 dependency chain, 22 us for N = 8 in the first form)
+template <int ND>
+struct DualT {
   double v;
-  double d[NP];
+  double d[ND];
 };
-__device__ inline Dual dconst(double c) { Dual r; r.v = c; for (int i = 0; i < NP; ++i) r.d[i] = 0.0; return r; }
-__device__ inline Dual dvar(double c, int idx) { Dual r = dconst(c); r.d[idx] = 1.0; return r; }
-__device__ inline Dual operator+(const Dual& a, const Dual& b) { Dual r; r.v = a.v + b.v; for (int i = 0; i < NP; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
-__device__ inline Dual operator-(const Dual& a, const Dual& b) { Dual r; r.v = a.v - b.v; for (int i = 0; i < NP; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
-__device__ inline Dual operator-(const Dual& a) { Dual r; r.v = -a.v; for (int i = 0; i < NP; ++i) r.d[i] = -a.d[i]; return r; }
-__device__ inline Dual operator*(const Dual& a, const Dual& b) { Dual r; r.v = a.v * b.v; for (int i = 0; i < NP; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
-__device__ inline Dual operator*(const Dual& a, double s) { Dual r; r.v = a.v * s; for (int i = 0; i < NP; ++i) r.d[i] = a.d[i] * s; return r; }
-__device__ inline Dual operator+(const Dual& a, double s) { Dual r = a; r.v += s; return r; }
-__device__ inline Dual operator-(const Dual& a, double s) { Dual r = a; r.v -= s; return r; }
-__device__ inline Dual operator/(const Dual& a, const Dual& b) {
-  Dual r; const double inv = 1.0 / b.v; r.v = a.v * inv;
-  for (int i = 0; i < NP; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * inv;
+template <int ND> __device__ inline DualT<ND> dconst_(double c) { DualT<ND> r; r.v = c; for (int i = 0; i < ND; ++i) r.d[i] = 0.0; return r; }
+template <int ND> __device__ inline DualT<ND> dvar_(double c, int idx, int mine) {
+  DualT<ND> r = dconst_<ND>(c);
+  if (ND == 1) r.d[0] = (idx == mine) ? 1.0 : 0.0; else r.d[idx % ND] = 1.0;
   return r;
 }
-__device__ inline Dual dsqrt(const Dual& a) {
-  Dual r; r.v = sqrt(a.v); const double k = r.v > 0.0 ? 0.5 / r.v : 0.0;      // subgradient 0 at 0 (torch.norm)
-  for (int i = 0; i < NP; ++i) r.d[i] = a.d[i] * k;
+template <int ND> __device__ inline DualT<ND> operator+(const DualT<ND>& a, const DualT<ND>& b) { DualT<ND> r; r.v = a.v + b.v; for (int i = 0; i < ND; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
+template <int ND> __device__ inline DualT<ND> operator-(const DualT<ND>& a, const DualT<ND>& b) { DualT<ND> r; r.v = a.v - b.v; for (int i = 0; i < ND; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
+template <int ND> __device__ inline DualT<ND> operator-(const DualT<ND>& a) { DualT<ND> r; r.v = -a.v; for (int i = 0; i < ND; ++i) r.d[i] = -a.d[i]; return r; }
+template <int ND> __device__ inline DualT<ND> operator*(const DualT<ND>& a, const DualT<ND>& b) { DualT<ND> r; r.v = a.v * b.v; for (int i = 0; i < ND; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+template <int ND> __device__ inline DualT<ND> operator*(const DualT<ND>& a, double s) { DualT<ND> r; r.v = a.v * s; for (int i = 0; i < ND; ++i) r.d[i] = a.d[i] * s; return r; }
+template <int ND> __device__ inline DualT<ND> operator+(const DualT<ND>& a, double s) { DualT<ND> r = a; r.v += s; return r; }
+template <int ND> __device__ inline DualT<ND> operator-(const DualT<ND>& a, double s) { DualT<ND> r = a; r.v -= s; return r; }
+template <int ND> __device__ inline DualT<ND> operator/(const DualT<ND>& a, const DualT<ND>& b) {
+  DualT<ND> r; const double inv = 1.0 / b.v; r.v = a.v * inv;
+  for (int i = 0; i < ND; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * inv;
   return r;
 }
-__device__ inline Dual dsin(const Dual& a) { Dual r; r.v = sin(a.v); const double c = cos(a.v); for (int i = 0; i < NP; ++i) r.d[i] = a.d[i] * c; return r; }
-__device__ inline Dual dcos(const Dual& a) { Dual r; r.v = cos(a.v); const double s = -sin(a.v); for (int i = 0; i < NP; ++i) r.d[i] = a.d[i] * s; return r; }
+template <int ND> __device__ inline DualT<ND> dsqrt(const DualT<ND>& a) {
+  DualT<ND> r; r.v = sqrt(a.v); const double k = r.v > 0.0 ? 0.5 / r.v : 0.0;      // subgradient 0 at 0 (torch.norm)
+  for (int i = 0; i < ND; ++i) r.d[i] = a.d[i] * k;
+  return r;
+}
+template <int ND> __device__ inline DualT<ND> dsin(const DualT<ND>& a) { DualT<ND> r; r.v = sin(a.v); const double c = cos(a.v); for (int i = 0; i < ND; ++i) r.d[i] = a.d[i] * c; return r; }
+template <int ND> __device__ inline DualT<ND> dcos(const DualT<ND>& a) { DualT<ND> r; r.v = cos(a.v); const double s = -sin(a.v); for (int i = 0; i < ND; ++i) r.d[i] = a.d[i] * s; return r; }
 // max(a, floor): derivative passes only where a is the active branch (torch.clamp(min=))
-__device__ inline Dual dclamp_min(const Dual& a, double lo) { return a.v >= lo ? a : dconst(lo); }
+template <int ND> __device__ inline DualT<ND> dclamp_min(const DualT<ND>& a, double lo) { return a.v >= lo ? a : dconst_<ND>(lo); }
 
 constexpr int NOUT = 24;   // 18 O2C coefficients + (ax, bx, ay, by) of the crop->frame map + (a_depth, b_depth)
 
+template <int ND>
 __global__ void camera_coefs_kernel(const float* __restrict__ params, const float* __restrict__ intr,
                                     float cube, float z_span, int crop_h, int crop_w,
                                     float* __restrict__ out, float* __restrict__ jac, int N) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  typedef DualT<ND> Dual;
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = ND == 1 ? tid / NP : tid, mine = ND == 1 ? tid % NP : 0;
   if (n >= N) return;
+  auto dconst = [](double c) { return dconst_<ND>(c); };
+  auto dvar = [&](double c, int idx) { return dvar_<ND>(c, idx, mine); };
   const float* p = params + n * NP;
   Dual w[3], t[3], vp[4];
   for (int i = 0; i < 3; ++i) w[i] = dvar((double)p[i], i);
@@ -102,8 +115,9 @@ __global__ void camera_coefs_kernel(const float* __restrict__ params, const floa
   o[22] = dconst((double)z_span + 0.01);
   o[23] = t[2];
   for (int j = 0; j < NOUT; ++j) {
-    out[n * NOUT + j] = (float)o[j].v;
-    for (int i = 0; i < NP; ++i) jac[(n * NOUT + j) * NP + i] = (float)o[j].d[i];
+    if (ND != 1 || mine == 0) out[n * NOUT + j] = (float)o[j].v;
+    if (ND == 1) jac[(n * NOUT + j) * NP + mine] = (float)o[j].d[0];
+    else for (int i = 0; i < ND; ++i) jac[(n * NOUT + j) * NP + i] = (float)o[j].d[i];
   }
 }
 
@@ -382,7 +396,8 @@ extern "C" int lf_camera_coefs(const float* params, const float* intrinsics, flo
                                int crop_h, int crop_w, float* coefs, float* jac, int N, void* stream) {
   lf_clear_error();
   if (N <= 0 || crop_h <= 0 || crop_w <= 0 || cube_size <= 0.f) return LF_EINVAL;
-  hipLaunchKernelGGL(camera_coefs_kernel, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, params, intrinsics,
+  // one thread per (camera, parameter)
+  hipLaunchKernelGGL((camera_coefs_kernel<1>), dim3((N * NP + 63) / 64), dim3(64), 0, (hipStream_t)stream, params, intrinsics,
                      cube_size, z_span, crop_h, crop_w, coefs, jac, N);
   return lf_launch_status();
 }
