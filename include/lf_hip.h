@@ -51,7 +51,7 @@ int lf_device_name(char* buf, int buflen);
  * tolerances for every value.  key 1: 3-D resampler kernels, 1 = generic (64-bit addressing, any C), 2 = lean
  * (32-bit buffer addressing, C % 4 == 0, volumes < 4 GB per sample; other shapes take the generic ones),
  * 3 = lean + the 16-channel specialisation of the gather (default), 4 = LDS-staged source footprint (16 channels; measured
- * slower, profiles/r03_resample_staged_ab.txt).  key 2: lean coefficient-gradient kernel, sub-tiles in
+ * slower, profiles/r03_resample_staged_ab.txt), 5 = gather with the map evaluated once per voxel (bit-identical to 3, 6 % slower).  key 2: lean coefficient-gradient kernel, sub-tiles in
  * flight per workgroup iteration: 1 = one, 2 = two (round-2 default), 3-5 = register-capped forms of 2 / 1, 6-11 = forms that do the
  * per-voxel arithmetic once per voxel instead of once per lane (10 = default: two gather passes in flight, gradient records
  * requested one sub-tile ahead).  key 3: workgroup

@@ -415,6 +415,72 @@ __global__ void __launch_bounds__(256) resample_fwd_c16_kernel(
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, r), ro, (int)((u32)((z * H + y) * W + x) * 64u + co), 0, 2);
 }
 
+// 16-channel gather with the per-voxel arithmetic done once per voxel (variant 5 of lf_set_tuning key 1).  The gather above
+// is bound by VALU issue as much as by the L1 (PMC: VALU busy 93 % of its run time): map, clip and corner offsets are
+// evaluated in all four lanes of a voxel.  Here a wave owns a 4x4x4 tile: phase A, lane = voxel, evaluates the 64 maps with
+// one instruction stream and leaves (offset of corner 000, the three corner strides, the three fractions) in 2 KB of
+// wave-private LDS; phase B, four passes of 16 voxels with lane = (voxel, channel quarter) as before, reads them back (one
+// broadcast read per quad), forms the 8 weights and fetches the coalesced 64-byte records.  Same operations per voxel in the
+// same order: bit-identical to resample_fwd_c16_kernel.
+template <int KIND>
+__global__ void __launch_bounds__(256) resample_fwd_c16_dedup_kernel(
+    const float* __restrict__ vol, long vol_bstride, const float* __restrict__ coef,
+    float* __restrict__ out, int D, int H, int W, int nbx, int nby, int nbz, Steps st) {
+  __shared__ u32x4_t tapo[4][64];                                 // o000 | dead, dx, dy, dz (bytes; 0 if clamped)
+  __shared__ f32x4 tapf[4][64];                                   // tx, ty, tz, -
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // tile index: 4 x-adjacent 4^3 tiles per workgroup (one per wave)
+  const int n = blockIdx.z / nbz, bz = blockIdx.z - n * nbz;
+  const int x0 = ((blockIdx.x << 2) + wave) << 2, y0 = blockIdx.y << 2, z0 = bz << 2;
+  const u32 sample_bytes = (u32)D * (u32)H * (u32)W * 64u;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(vol + (long)n * vol_bstride), 0, sample_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (long)n * D * H * W * 16), 0, sample_bytes, 0x00020000);
+  const float* cf = coef + n * LF_MAP_COEFS;
+  {
+    const int x = x0 + (lane & 3), y = y0 + ((lane >> 2) & 3), z = z0 + (lane >> 4);
+    const bool live = x < W && y < H && z < D;
+    float gx, gy, gz, a, b, k;
+    eval_grid<KIND>(cf, live ? x : 0, live ? y : 0, live ? z : 0, W, H, D, st, gx, gy, gz, a, b, k);
+    const Tap32 t = make_tap32(gx, gy, gz, W, H, D, 64u);
+    u32x4_t o;
+    o[0] = live ? t.o000 : 0xffffffffu;
+    o[1] = t.o001 - t.o000; o[2] = t.o010 - t.o000; o[3] = t.o100 - t.o000;
+    tapo[wave][lane] = o;
+    tapf[wave][lane] = (f32x4){t.tx, t.ty, t.tz, 0.f};
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const int q = lane & 3, vq = lane >> 2;
+  const u32 co = (u32)q * 16u;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int vi = 16 * i + vq;
+    const u32x4_t o = tapo[wave][vi];
+    const f32x4 f = tapf[wave][vi];
+    if (o[0] == 0xffffffffu) continue;                            // voxel outside the volume (ragged tiles)
+    const u32 b00 = o[0] + co, b01 = b00 + o[2], b10 = b00 + o[3], b11 = b01 + o[3];
+    const f32x4 v000 = ldrec(rs, b00), v001 = ldrec(rs, b00 + o[1]), v010 = ldrec(rs, b01), v011 = ldrec(rs, b01 + o[1]);
+    const f32x4 v100 = ldrec(rs, b10), v101 = ldrec(rs, b10 + o[1]), v110 = ldrec(rs, b11), v111 = ldrec(rs, b11 + o[1]);
+    const float wx1 = f[0], wx0 = 1.f - f[0], wy1 = f[1], wy0 = 1.f - f[1], wz1 = f[2], wz0 = 1.f - f[2];
+    const float w000 = wx0 * wy0 * wz0, w001 = wx1 * wy0 * wz0, w010 = wx0 * wy1 * wz0, w011 = wx1 * wy1 * wz0;
+    const float w100 = wx0 * wy0 * wz1, w101 = wx1 * wy0 * wz1, w110 = wx0 * wy1 * wz1, w111 = wx1 * wy1 * wz1;
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float acc = v000[e] * w000;
+      asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "v"(v001[e]), "v"(w001));
+      asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "v"(v010[e]), "v"(w010));
+      asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "v"(v011[e]), "v"(w011));
+      asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "v"(v100[e]), "v"(w100));
+      asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "v"(v101[e]), "v"(w101));
+      asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "v"(v110[e]), "v"(w110));
+      asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "v"(v111[e]), "v"(w111));
+      r[e] = acc;
+    }
+    const int x = x0 + (vi & 3), y = y0 + ((vi >> 2) & 3), z = z0 + (vi >> 4);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, r), ro, (int)((u32)((z * H + y) * W + x) * 64u + co), 0, 2);
+  }
+}
+
 // sum over the 4 lanes of a quad (all four receive it)
 __device__ __forceinline__ float quad_sum4(float v) {
   const float a = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));   // [1,0,3,2]
@@ -1011,6 +1077,16 @@ extern "C" int lf_resample3d_fwd(const float* vol, int vol_n, const float* coef,
       hipLaunchKernelGGL((resample_fwd_staged_kernel<LF_MAP_C2O>), dim3((unsigned)nwg), block, 0, s, vol, bstride, coef, out, D, H, W, ntx, nty, ntz, st);
     return lf_launch_status();
   }
+  if (g_resample_variant == 5 && vec && C == 16 && (long)D * H * W * 64 < 0xffffffffL) {
+    const int nbz4 = (D + 3) >> 2, nbx16 = (W + 15) >> 4, nby4 = (H + 3) >> 2;
+    if ((long)nbz4 * N > 65535 || nby4 > 65535) return LF_EINVAL;
+    dim3 g5((unsigned)nbx16, (unsigned)nby4, (unsigned)(nbz4 * N));
+    if (kind == LF_MAP_O2C)
+      hipLaunchKernelGGL((resample_fwd_c16_dedup_kernel<LF_MAP_O2C>), g5, block, 0, s, vol, bstride, coef, out, D, H, W, nbx16, nby4, nbz4, st);
+    else
+      hipLaunchKernelGGL((resample_fwd_c16_dedup_kernel<LF_MAP_C2O>), g5, block, 0, s, vol, bstride, coef, out, D, H, W, nbx16, nby4, nbz4, st);
+    return lf_launch_status();
+  }
   if (g_resample_variant >= 3 && vec && C == 16 && (long)D * H * W * 64 < 0xffffffffL) {
     const int nbz4 = (D + 3) >> 2;
     if ((long)nbz4 * N > 65535 || ((H + 3) >> 2) > 65535) return LF_EINVAL;
@@ -1152,7 +1228,7 @@ extern "C" int lf_debug_stage_ts(void* dst) {                      // experiment
 extern "C" int lf_set_tuning(int key, int value) {
   if (key == 1) {
     const int prev = g_resample_variant;
-    if (value >= 1 && value <= 4) g_resample_variant = value;
+    if (value >= 1 && value <= 5) g_resample_variant = value;
     return prev;
   }
   if (key == 4) {

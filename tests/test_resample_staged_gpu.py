@@ -127,6 +127,12 @@ def test_staged_gather_is_bit_identical_to_the_gather_form(case, kind):
     vol = ops.cl(torch.randn(vol_n, 16, D, H, W, generator=gen).to(DEV))
     ref = run_fwd(L, 3, vol, cf, kind, N, D, H, W)
     got = run_fwd(L, 4, vol, cf, kind, N, D, H, W)
+    # variant 5: the gather form with the map evaluated once per voxel (lane-per-voxel phase + wave-private LDS hand-over)
+    ded = run_fwd(L, 5, vol, cf, kind, N, D, H, W)
+    if kind == O2C:
+        assert torch.equal(ded, ref), (name, (ded - ref).abs().max().item(), int((ded != ref).sum()))
+    else:
+        assert (ded - ref).abs().max().item() < 1e-4 * max(1.0, max(scales))
     if kind == O2C:
         assert torch.equal(got, ref), (name, (got - ref).abs().max().item(), int((got != ref).sum()))
     else:
