@@ -10,7 +10,13 @@ parameters of every sample, batched Adam + plateau step, ranking.  Workload: SYN
 (SURVEY 8d), V=16 reference views, fp32, synthetic data, random-init weights.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N ...                      # bench.py starts the N ranks itself (launch_ranks below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+`--gpus N` IS the number of ranks: without a launcher environment bench.py spawns N processes (one per GPU, RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_* set, RCCL process group); under a launcher it checks WORLD_SIZE == N and fails
+loudly otherwise.  This replaces the reference's single-command multi-GPU path (latentfusion/torchutils.py:133-170
+MyDataParallel, `--data-parallel` in tools/train/train.sh:66).
 
 Multi-GPU (weak scaling): every rank owns one object (its own latent volume, target and pose
 samples; BASELINE cfg 4) -- the pose loop has no data-path collective; value = total
@@ -20,6 +26,8 @@ Prints ONE JSON line on rank 0.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -37,7 +45,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 den
 F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF dense
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
@@ -67,7 +75,83 @@ def parse():
     ap.add_argument('--conv-mode', default='winograd', choices=['fp32', 'winograd', 'f16x3', 'winograd_f16x3'],
                     help="conv3d kernels of the engine: 'winograd' (default; F(2^3,3^3) minimal filtering, all-fp32 "
                          "arithmetic), 'fp32' (direct implicit GEMM on the fp32 MFMA) or 'f16x3' (split precision)")
-    return ap.parse_args()
+    ap.add_argument('--launcher-selftest', action='store_true',
+                    help='run only the rank plumbing (spawn / process group / one all-reduce on HOST tensors over gloo) and '
+                         'print a JSON line with n_gpus and ranks_seen: the CPU test of the N-rank path (tests/test_parallel.py)')
+    ap.add_argument('--no-hypothesis-sharding', action='store_true',
+                    help='skip the strong-scaling section at N > 1 (ONE object, its pose hypotheses sharded over the ranks)')
+    ap.add_argument('--no-pipelined-build', action='store_true',
+                    help='skip the GRU view-sharded build (hidden state handed rank to rank) at N > 1')
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(a, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start the N ranks from here -- one process per
+    GPU, the environment torch.distributed.run would give them (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT on
+    127.0.0.1), the same command line.  Rank 0's stdout (the ONE JSON line) is this process's stdout; the other ranks'
+    output goes to stderr.  A rank that fails takes the run down: the others are terminated (by their own PIDs) and the exit
+    code is the failing rank's -- a silent N = 1 run under an `--gpus N` label cannot happen."""
+    n = a.gpus
+    port = _free_port()
+    script = os.path.abspath(__file__)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), LF_BENCH_SPAWNED='1')
+        env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // n)))
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+
+    def forward():
+        # rank 0's JSON line(s) -> stdout; anything a library prints on stdout (gloo's connection banner) -> stderr
+        for line in procs[0].stdout:
+            (sys.stdout if line.lstrip().startswith('{') else sys.stderr).write(line)
+            sys.stdout.flush()
+    import threading
+    fwd = threading.Thread(target=forward, daemon=True)
+    fwd.start()
+    code = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            alive.discard(r)
+            if rc != 0 and code == 0:
+                code = rc if rc > 0 else 1
+                sys.stderr.write(f'bench.py: rank {r} of {n} exited with {rc}; stopping the other ranks\n')
+                for o in alive:
+                    procs[o].terminate()
+        if alive:
+            time.sleep(0.05)
+    fwd.join(timeout=10)
+    return code
+
+
+def launcher_selftest(a, rank, world):
+    """The rank plumbing alone, on host tensors over gloo (no GPU): what tests/test_parallel.py runs here."""
+    import torch.distributed as dist
+    if world > 1 or ('RANK' in os.environ and 'MASTER_ADDR' in os.environ):
+        dist.init_process_group('gloo')
+    seen = dist.get_world_size() if dist.is_initialized() else 1
+    t = torch.tensor([float(rank + 1)])
+    if dist.is_initialized():
+        dist.all_reduce(t)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({'selftest': True, 'n_gpus': world, 'gpus_flag': a.gpus, 'ranks_seen': seen,
+                          'allreduce_sum': t.item(), 'spawned_by_bench': os.environ.get('LF_BENCH_SPAWNED') == '1'}))
 
 
 def cpu_baseline(cks, z_obj_gpu_cpu, ref_data, target_data, init, cfg, iters, build):
@@ -148,17 +232,134 @@ def sharded_build_report(a, S, C, V, dev, world, barrier):
     return sharded
 
 
+def pipelined_build_report(a, S, C, V, dev, world, barrier):
+    """The released recipe's fuser is a ConvGRU over the views: an order-dependent recurrence, so a view-sharded build hands
+    the hidden state from rank to rank (parallel._fuse_recurrent_pipelined: one send/recv of the C*S^3 state per hop, one
+    broadcast of the result).  Every rank builds the SAME model and observation; reported: the time of the sharded build,
+    the difference to the local build (the arithmetic is the same in the same order: 0.0 expected) and the time of ONE hop
+    (point-to-point transfer of one latent volume, rank 0 -> rank 1) measured alone.  Returns (report, the fused volume,
+    the model) -- the volume is the ONE object the hypothesis-sharded loop below runs on."""
+    import torch.distributed as dist
+    from latentfusion_amd import parallel, synth
+    model0, _ = synth.build_model(S, C, 'gru', seed=777, device=dev)
+    model0.freeze()
+    obs0 = synth.make_observation(V, seed=778, device=dev)
+    for rep in range(2):                                       # second pass = warm
+        barrier()
+        t0 = time.perf_counter()
+        z_sh = parallel.build_latent_object_sharded(model0, obs0)
+        barrier()
+        t_sh = time.perf_counter() - t0
+    barrier()
+    t0 = time.perf_counter()
+    z_full = model0.build_latent_object(obs0)
+    barrier()
+    t_local = time.perf_counter() - t0
+    err = (z_sh - z_full).abs().max().item()
+    hop_ms = None
+    if world > 1:
+        buf = torch.empty_like(z_full)
+        for rep in range(3):
+            barrier()
+            t0 = time.perf_counter()
+            if dist.get_rank() == 0:
+                parallel._send(buf, 1, None)
+            elif dist.get_rank() == 1:
+                parallel._recv(buf, 0, None)
+            barrier()
+            hop_ms = (time.perf_counter() - t0) * 1e3
+    rep = {'fuser': 'gru', 'views': V, 'ranks': world, 't_s': t_sh, 't_local_build_s': t_local,
+           'max_abs_diff_vs_local_build': err, 'state_MB': z_full.numel() * 4 / 1e6, 'hops': max(0, min(world, V) - 1),
+           'hop_ms': hop_ms, 'hop_GBps': (z_full.numel() * 4 / 1e9) / (hop_ms * 1e-3) if hop_ms else None,
+           'what': 'ConvGRU recurrence over the views continued rank to rank: one send/recv of the hidden state per hop + one '
+                   'broadcast of the result (reference recon/fusion.py:180-201 is a single-process loop)'}
+    return rep, z_full, model0
+
+
+def hypothesis_sharding_report(a, S, C, N, dev, world, rank, barrier, z_one, model_one, cfg):
+    """STRONG scaling of ONE object ("shard N samples, 8 GPUs x 1 sample for adam_quick"): every rank holds the
+    same latent volume, renders / scores / differentiates its contiguous slice of the N pose hypotheses and the per-hypothesis
+    rows (loss terms + camera parameters) meet in ONE all-gather per iteration (parallel.gather_rows); every rank ranks the
+    full set.  Replaces the reference's single-process loop over N optimisers (pose/estimation.py:580-594, 602-617).
+    Reported: iterations/s of the sharded loop (max over ranks, barriers on both sides), the same loop on ONE rank's GPU
+    with all N hypotheses for comparison (rank 0's headline number is per OBJECT, this one is for ONE object), and the time
+    of the all-gather alone."""
+    import torch.distributed as dist
+    from latentfusion_amd import parallel
+    from latentfusion_amd.modules.geometry import Camera
+    from latentfusion_amd.observation import Observation
+    from latentfusion_amd.pose import estimation, utils as pu
+    from latentfusion_amd import synth
+    if N < world:
+        return {'skipped': f'{N} hypotheses cannot be split over {world} ranks'}
+    tdata = synth.make_observation_data(1, seed=779)
+    target = Observation(tdata['color'], tdata['depth'], tdata['mask'], Camera(tdata['intrinsic'], tdata['extrinsic'])).to(dev)
+    torch.manual_seed(780)                                      # same draws on every rank (and broadcast from rank 0 anyway)
+    init = pu.sample_cameras_with_estimate(N, target.camera.to('cpu'))
+    cams = init.zoom(None, model_one.input_size, model_one.camera_dist).to(dev)
+    est = estimation.load_from_config(cfg, model_one, converge_patience=10 ** 6, conv_mode=a.conv_mode, shard_hypotheses=True)
+    cams = est._sync_cameras_from_rank0(cams)
+    st = est.start(z_one, target, cams)
+    for _ in range(a.warmup):
+        est.iterate(st)
+    blocks = []
+    for _rep in range(max(1, min(a.repeats, 3))):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            est.iterate(st)
+        barrier()
+        tt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        blocks.append(tt.item())
+    el = sorted(blocks)[len(blocks) // 2]
+    # ranking agreement: every rank holds the same top entry (rows were all-gathered)
+    top = torch.tensor([st['ranking'][0][1]], device=dev, dtype=torch.float64)
+    lo, hi = top.clone(), top.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    # the collective alone: (N_local,15) rows -> (N,15) on every rank
+    b, e = parallel.shard_range(N, rank, world)
+    rows = torch.zeros(e - b, 15, device=dev)
+    ag = []
+    for rep in range(20):
+        barrier()
+        t0 = time.perf_counter()
+        parallel.gather_rows(rows, N)
+        torch.cuda.synchronize()
+        ag.append((time.perf_counter() - t0) * 1e3)
+    return {'value': a.steps / el, 'unit': 'iters/s of ONE object', 'ms_per_step': el / a.steps * 1e3,
+            'ms_per_step_blocks': [x / a.steps * 1e3 for x in blocks], 'hypotheses': N, 'ranks': world,
+            'hypotheses_per_rank': [parallel.shard_range(N, r, world)[1] - parallel.shard_range(N, r, world)[0] for r in range(world)],
+            'allgather_rows_ms': sorted(ag)[len(ag) // 2], 'allgather_payload_bytes': N * 15 * 4,
+            'best_loss_identical_on_all_ranks': bool(lo.item() == hi.item()), 'scaling': 'strong'}
+
+
 def main():
-    a = parse()
+    argv = sys.argv[1:]
+    a = parse(argv)
+    if a.gpus < 1:
+        raise SystemExit('bench.py: --gpus must be >= 1')
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # no launcher: bench.py IS the launcher
+        sys.exit(launch_ranks(a, argv))
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
+    if world != a.gpus:
+        raise SystemExit(f'bench.py: --gpus {a.gpus} but the launcher started {world} rank(s) (WORLD_SIZE): refusing to print a '
+                         f'line whose n_gpus is not what was asked for')
+    if a.launcher_selftest:
+        return launcher_selftest(a, rank, world)
     # Test hook for boxes with ONE GPU (the multi-rank code path cannot be exercised there with RCCL, which refuses two
     # ranks on one device): LF_BENCH_SINGLE_DEVICE=1 puts every rank on cuda:0 and uses gloo for the collectives.  The
     # numbers of such a run mean nothing (the ranks share the GPU); it only proves that the N > 1 path runs and agrees.
     single = os.environ.get('LF_BENCH_SINGLE_DEVICE') == '1'
     if single:
         local = 0
+    elif torch.cuda.device_count() < world:
+        raise SystemExit(f'bench.py: --gpus {a.gpus} needs {world} visible devices, found {torch.cuda.device_count()} '
+                         '(LF_BENCH_SINGLE_DEVICE=1 runs the N-rank code path on one device over gloo, for testing only)')
     torch.cuda.set_device(local)
     dev = f'cuda:{local}'
     if world > 1:                                              # the ranks share the host: no 8 x all-cores thread pools
@@ -255,7 +456,7 @@ def main():
     alt = None
     if a.conv_mode in ('fp32', 'winograd') and not a.no_alt and C == 16:
         # secondary line (never `value`): the same loop with the split-precision conv3d kernels
-        del est, st
+        st = est = None
         torch.cuda.empty_cache()
         est2 = estimation.load_from_config(cfg, model, converge_patience=10 ** 6, conv_mode='f16x3', engine_streams=a.engine_streams)
         st2 = est2.start(z_obj, target, init.zoom(None, model.input_size, model.camera_dist).to(dev))
@@ -353,10 +554,27 @@ def main():
         except Exception as e:                                       # noqa: BLE001
             sharded = {'error': f'{type(e).__name__}: {e}'[:300]}
 
+    # N > 1: the other two sharding axes of SURVEY 8(e), on ONE object (auxiliary: never allowed to lose the headline line)
+    pipelined, hyp = None, None
+    if world > 1 and not (a.no_pipelined_build and a.no_hypothesis_sharding):
+        try:
+            st = est = st2 = est2 = None                             # release the per-rank loop states
+            torch.cuda.empty_cache()
+            pipelined, z_one, model_one = pipelined_build_report(a, S, C, V, dev, world, barrier)
+            if a.no_pipelined_build:
+                pipelined = None
+            if not a.no_hypothesis_sharding:
+                try:
+                    hyp = hypothesis_sharding_report(a, S, C, N, dev, world, rank, barrier, z_one, model_one, cfg)
+                except Exception as e:                               # noqa: BLE001
+                    hyp = {'error': f'{type(e).__name__}: {e}'[:300]}
+        except Exception as e:                                       # noqa: BLE001
+            pipelined = {'error': f'{type(e).__name__}: {e}'[:300]}
+
     # RCCL on this box: under a launcher the process group above IS an RCCL communicator; a plain `python bench.py` run
     # initialises a world-size-1 group here (after the timed regions, so it cannot touch the number) and runs one
     # all-reduce of a latent-volume-sized tensor through it
-    rccl = {'backend': None, 'ranks_seen': world}
+    rccl = {'backend': None, 'ranks_seen': dist.get_world_size() if dist.is_initialized() else 1}
     try:
         if not dist.is_initialized():
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -440,7 +658,11 @@ def main():
         out['alt'] = alt
     if sharded is not None:
         out['sharded_build'] = sharded
-    print(json.dumps(out))
+    if pipelined is not None:
+        out['pipelined_gru_build'] = pipelined
+    if hyp is not None:
+        out['hypothesis_sharded_one_object'] = hyp
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':

@@ -317,3 +317,45 @@ def test_overlapped_gradient_buckets_world2():
             assert (a == b).all() and abs(a).max() > 0
     for a, b in zip(got[0]['overlapped'], got[1]['overlapped']):
         assert (a == b).all()
+
+
+# ---------------------------------------------------------------------------------------------
+# bench.py --gpus N is an N-rank run by itself: the spawn path on host tensors over gloo
+# ---------------------------------------------------------------------------------------------
+def _run_bench(args, env_extra=None, drop=('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + args, env=env, capture_output=True, text=True,
+                       timeout=600)
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    return r, [json.loads(l) for l in lines]
+
+
+def test_bench_gpus_flag_spawns_that_many_ranks():
+    """`python bench.py --gpus 2` with NO launcher environment starts two ranks itself, they form one process group and
+    rank 0 prints exactly one JSON line whose n_gpus / ranks_seen are 2 (the reference's single-command multi-GPU path is
+    torchutils.py:133-170)."""
+    r, out = _run_bench(['--gpus', '2', '--launcher-selftest'])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(out) == 1 and r.stdout.strip().count('\n') == 0, r.stdout        # ONE line on stdout, nothing else
+    assert out[0]['n_gpus'] == 2 and out[0]['ranks_seen'] == 2 and out[0]['spawned_by_bench'] is True
+    assert out[0]['allreduce_sum'] == 3.0                                        # ranks 0 and 1 both took part
+    r3, out3 = _run_bench(['--gpus', '3', '--launcher-selftest'])
+    assert r3.returncode == 0 and out3[0]['ranks_seen'] == 3 and out3[0]['allreduce_sum'] == 6.0
+
+
+def test_bench_refuses_a_world_size_that_is_not_the_gpus_flag():
+    """Under a launcher (WORLD_SIZE present) the flag is CHECKED, not ignored: a mismatch is an error, never a mislabelled line."""
+    r, out = _run_bench(['--gpus', '2', '--launcher-selftest'], env_extra={'WORLD_SIZE': '1', 'RANK': '0'})
+    assert r.returncode != 0 and not out and 'refusing' in r.stderr
+    r, out = _run_bench(['--gpus', '1', '--launcher-selftest'])
+    assert r.returncode == 0 and out[0]['n_gpus'] == 1 and out[0]['spawned_by_bench'] is False
+
+
+def test_bench_launcher_propagates_a_failing_rank():
+    r, out = _run_bench(['--gpus', '2', '--launcher-selftest', '--steps', 'not-a-number'])
+    assert r.returncode != 0 and not out
