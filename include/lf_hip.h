@@ -192,6 +192,33 @@ int lf_conv3d_c16_wino(const float* x, const float* upack, const float* bias, fl
                        const float* prev_y, const float* prev_norm, unsigned prev_flags,
                        float* amax_out, void* stream);
 
+/* The renderer's factor projection fused into the Winograd kernel of the LAST camera block (round 4).
+ * Reference: Photographer.decode runs camera_blocks then FactorProjection3d2d (recon/models.py:417-437,
+ * modules/geometry.py:731-749: view (N, C*D, H, W) -> 1x1 conv -> LeakyReLU -> PixelNorm); a workgroup of
+ * lf_conv3d_c16_wino walks exactly the axis that projection contracts.
+ *
+ * lf_conv3d_c16_wino_projfwd = lf_conv3d_c16_wino (forward form, prev_y = NULL) followed by
+ *   lf_conv1x1_fwd(y as (N, H*W, K = D*16), ..., Cout = 16, proj_he, proj_flags)  ->  zp (N, H, W, 16), pnorm (N*H*W or NULL)
+ * in ONE launch: same operands, same accumulation order, bit-identical zp; y / norm_out are still written (the backward
+ * pass needs them).  proj_wA: lf_conv3d_c16_wino_proj_pack_floats(D) floats, [D][64 lanes l][4 i]
+ *   = Wp[cout = l & 15][k = d*16 + (l >> 4)*4 + i]   (Wp = the (16, D*16) matrix lf_conv1x1_fwd takes, depth-major K).
+ *
+ * lf_conv3d_c16_wino_projbwd = lf_conv1x1_bwd_data(gp (N, H*W, 16), ..., prev = (act, act_norm, act_flags)) followed by
+ *   lf_conv3d_c16_wino(data-gradient form on that volume, prev = (prev_y, prev_norm, prev_flags))
+ * in ONE launch: the (N, 16, D, H, W) gradient volume between the two never exists; its halo planes are formed on chip
+ * from `act` (the last camera block's saved output), `act_norm`, gp and the depth slices of the transposed projection.
+ * proj_wtA: [D][64 lanes l][4 i] = Wp[cout = (l >> 4)*4 + i][k = d*16 + (l & 15)].  upack = the TRANSPOSED Winograd pack of
+ * the block's convolution.  Differs from the two-launch form only by the reciprocal used for 1 / act_norm (<= 1 ulp). */
+size_t lf_conv3d_c16_wino_proj_pack_floats(int D);
+int lf_conv3d_c16_wino_projfwd(const float* x, const float* upack, const float* bias, float* y, float* norm_out,
+                               int N, int D, int H, int W, float he, unsigned flags, float slope, float eps,
+                               const float* proj_wA, const float* proj_bias, float* zp, float* pnorm,
+                               float proj_he, unsigned proj_flags, void* stream);
+int lf_conv3d_c16_wino_projbwd(const float* gp, const float* proj_wtA, float proj_he, const float* act,
+                               const float* act_norm, unsigned act_flags, const float* upack, float* y,
+                               int N, int D, int H, int W, float he, float slope, const float* prev_y,
+                               const float* prev_norm, unsigned prev_flags, void* stream);
+
 /* Winograd F(2x2x2,3x3x3) with split-precision products: transforms in fp32, every Winograd-domain product
  * from three v_mfma_f32_16x16x16_f16 (U_hi.V_hi + U_hi.V_lo + U_lo.V_hi, fp32 accumulate).  Same semantics
  * as lf_conv3d_c16_wino; amax_in / amax_out as in lf_conv3d_c16_split.

@@ -48,6 +48,11 @@ SIGNATURES = {
     'lf_conv3d_c16_wino_upack_floats': (c_size_t, []),
     'lf_conv3d_c16_wino': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint, c_float, c_float, P, P,
                                    c_uint, P, P]),
+    'lf_conv3d_c16_wino_proj_pack_floats': (c_size_t, [c_int]),
+    'lf_conv3d_c16_wino_projfwd': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint, c_float, c_float,
+                                           P, P, P, P, c_float, c_uint, P]),
+    'lf_conv3d_c16_wino_projbwd': (c_int, [P, P, c_float, P, P, c_uint, P, P, c_int, c_int, c_int, c_int, c_float, c_float,
+                                           P, P, c_uint, P]),
     'lf_conv3d_c16_wino_split_upack_halfs': (c_size_t, []),
     'lf_conv3d_c16_wino_split': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint, c_float, c_float, P, P,
                                          c_uint, P, P, P]),

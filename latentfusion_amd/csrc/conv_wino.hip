@@ -104,7 +104,9 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 // SPLIT = true : every Winograd-domain product U.V from three v_mfma_f32_16x16x16_f16 accumulating in fp32,
 //                U_hi.V_hi + U_hi.V_lo + U_lo.V_hi  (x = x_hi + x_lo, both f16; dropped term <= 2^-22 |U||V|);
 //                whi / wlo = the two halves of U, V is split on the fly after scaling by the power of two in_scale.
-template <int A, bool SPLIT>
+// OFFX (the fused forms, which have no registers to spare): only off[r][0] is kept; the rows dy = 2, 3, whose quarter
+// swizzle differs in bit 0, derive their offset with one v_xor per read instead of a second register per residue.
+template <int A, bool SPLIT, bool OFFX = false>
 __device__ __forceinline__ void wino_compute(const unsigned char* __restrict__ buf, const int (&off)[8][2],
                                               const float (&wt)[64], const f16x4 (&whi)[16], const f16x4 (&wlo)[16],
                                               float in_scale, unsigned char* __restrict__ pdst,
@@ -128,8 +130,19 @@ __device__ __forceinline__ void wino_compute(const unsigned char* __restrict__ b
         const int dx = (hh & 1) * 2 + e;
         const int ca = ((DZ0 * 10 + 4 * g + dy) * 18 + (dx & 1) * 9 + (dx >> 1));
         const int cb = ((DZ1 * 10 + 4 * g + dy) * 18 + (dx & 1) * 9 + (dx >> 1));
-        r[2 * e] = *(const f32x4*)(buf + off[ca & 7][dy >> 1] + ca * 64);
-        r[2 * e + 1] = *(const f32x4*)(buf + off[cb & 7][dy >> 1] + cb * 64);
+        if constexpr (OFFX) {
+          int oa = off[ca & 7][0], ob = off[cb & 7][0];
+          if (dy >> 1) {
+            asm volatile("" : "+v"(oa), "+v"(ob));               // (opaque: or the xor-ed copies are hoisted back into registers)
+            oa ^= 16;
+            ob ^= 16;
+          }
+          r[2 * e] = *(const f32x4*)(buf + oa + ca * 64);
+          r[2 * e + 1] = *(const f32x4*)(buf + ob + cb * 64);
+        } else {
+          r[2 * e] = *(const f32x4*)(buf + off[ca & 7][dy >> 1] + ca * 64);
+          r[2 * e + 1] = *(const f32x4*)(buf + off[cb & 7][dy >> 1] + cb * 64);
+        }
       }
     };
     __builtin_amdgcn_s_setprio(WINO_PL);
@@ -232,14 +245,44 @@ __device__ __forceinline__ void wino_compute(const unsigned char* __restrict__ b
 #undef CTS
 }
 
-template <bool SPLIT>
+// The renderer's factor projection (reference modules/geometry.py:731-749: the depth axis folded into the channels of a
+// 1x1 convolution, C*D -> 16) sits directly behind the last camera block and contracts exactly the axis a workgroup of
+// this kernel walks (a column of tiles along z).  Two fused forms remove its HBM round trips (round 4):
+//   FUSE = 1 (forward): the finished output records of a tile (after LeakyReLU / PixelNorm) are also contracted with the
+//     projection weights of their two depth planes into a per-wave 2 rows x 16 x x 16 cout accumulator (16 extra MFMAs per
+//     wave and tile; the records cross from the epilogue's lane = (x, quarter) order to the MFMA's B-operand order
+//     through the wave's own, already consumed slices of the exchange region); at the top of the column the projection's
+//     own epilogue (He, bias, LeakyReLU, PixelNorm) runs and the (H, W, 16) latent image rows are stored.  Same
+//     operands in the same accumulation order as lf_conv1x1_fwd on the stored volume: bit-identical.
+//   FUSE = 2 (backward): the input gradient volume of the first data-gradient convolution never exists in HBM.  It is
+//     g(z, y, x, :) = LReLU'/PixelNorm'[ he_p * Wt_p(z) . gp(y, x, :) ] with the saved activation / norm of the last
+//     camera block; a workgroup forms the two new z planes of its halo per tile from the block's activation record
+//     (same bytes the gradient volume would have cost), the 16-float projection gradient of the pixel (resident in
+//     registers for the whole column) and the plane's 16 x 16 weight slice: 24 extra MFMAs per wave and tile instead of a
+//     2.1 GB kernel.  Same arithmetic as lf_conv1x1_bwd_data's epilogue.
+struct WinoProj {
+  const float* wA;        // FUSE 1: [D][64 lanes][4] = Wp[cout = lane & 15][d][c = 4 (lane >> 4) + i]; FUSE 2: the transposed slices
+  const float* bias;      // FUSE 1: projection bias (16) or null
+  float* zp;              // FUSE 1: out, (N, H, W, 16) projected latent image
+  float* pnorm;           // FUSE 1: out, (N * H * W) PixelNorm denominators of zp (or null)
+  const float* gp;        // FUSE 2: in, (N, H, W, 16) gradient w.r.t. the projection's pre-activation
+  const float* xnorm;     // FUSE 2: in, (N * D * H * W) PixelNorm denominators saved with the activation passed as `x`
+  float he;               // the projection's He constant
+  unsigned flags;         // FUSE 1: the projection's epilogue; FUSE 2: the epilogue of the layer that produced `x`
+};
+
+// 2-bit table p = (0, 2, 3, 1): a 16-byte quarter q of record v (16 records of 64 B) stored at position q ^ p(v >> 2) is read
+// conflict-free by ds_read_b128 with lane = q * 16 + v (the hardware's lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ...)
+__device__ __forceinline__ int tr_swz(int v) { return (0x78 >> (2 * ((v >> 2) & 3))) & 3; }
+
+template <bool SPLIT, int FUSE = 0>
 __device__ __forceinline__ void conv3d_c16_wino_body(
     const float* __restrict__ x, const float* __restrict__ upack, const float* __restrict__ bias,
     float* __restrict__ y, float* __restrict__ norm_out,
     int N, int D, int H, int W, int tiles_x, int tiles_y, int tiles_z, int ntiles,
     float he, unsigned flags, float slope, float eps,
     const float* __restrict__ prev_y, const float* __restrict__ prev_norm, unsigned prev_flags,
-    const float* __restrict__ amax_in, float* __restrict__ amax_out) {
+    const float* __restrict__ amax_in, float* __restrict__ amax_out, const WinoProj pj = WinoProj()) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const buf = smem;                              // halo
   unsigned char* const px = smem + BUFw;                        // partial exchange
@@ -253,7 +296,8 @@ __device__ __forceinline__ void conv3d_c16_wino_body(
   // that the z-halo planes shared by neighbouring ranges are fetched from HBM once
   const int nb = gridDim.x;
   const int lb = (nb % 8 == 0) ? (blockIdx.x % 8) * (nb / 8) + blockIdx.x / 8 : blockIdx.x;
-  const int per = (ntiles + nb - 1) / nb;
+  // (the fused forms keep per-column state: their ranges are whole columns of tiles)
+  const int per = (FUSE != 0) ? ((ntiles / tiles_z + nb - 1) / nb) * tiles_z : (ntiles + nb - 1) / nb;
   const int t_begin = lb * per;
   const int t_end = min(t_begin + per, ntiles);
   if (t_begin >= t_end) return;
@@ -395,8 +439,146 @@ __device__ __forceinline__ void conv3d_c16_wino_body(
   const bool addmode = prev_y != nullptr && (prev_flags & LF_EPI_ADD);      // prev_y is an addend, not a saved activation
   float wave_amax = 0.f;
 
-  halo_fetch(cx, cy, cz, cn, true, false);
-  halo_commit();
+  // ---- FUSE = 2: the halo is COMPUTED, not fetched.  A z plane of the halo (180 voxel slots) is cut into 12 groups of 16
+  // consecutive slots (the last one holds 4); wave fa owns groups fa, fa + 4, fa + 8 of both planes of a half: lane =
+  // kg * 16 + n is (channel quarter kg, slot 16 * group + n) -- the D-operand order of the MFMA that forms the record and
+  // the order of lf_conv1x1_bwd_data's epilogue.  Every LDS byte of a group region (1 KiB per plane) is read (slide) and
+  // written by its owner wave only, so the slide needs no barrier of its own. ----
+  int pj_lo[3];                                                // LDS byte offset of (slot, quarter) in plane 0 of a half
+  int pj_pix[3];                                               // per column: pixel index gy * W + gx of the slot, -1 = outside
+  f32x4 pj_b[3];                                               // per tile: B operands = gp(pixel, 4 kg .. 4 kg + 3)
+  f32x4 pj_aw[2], pj_yp[6];
+  float pj_nr[6];
+  const bool pj_last_ok = n < 4;                               // group 11 = slots 176 .. 179
+  auto pj_column = [&](int bx, int by, int bn) {
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+      const int sl = (fa + 4 * it) * 16 + n;
+      const int ly = sl / HXw, rem = sl - ly * HXw;
+      const int xl = rem / 9, xa = rem - xl * 9;
+      const int gy = by * TYw - 1 + ly, gx = bx * TXw - 1 + 2 * xa + xl;
+      const bool ok = sl < HYw * HXw && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      pj_pix[it] = ok ? gy * W + gx : -1;
+    }
+  };
+  // the loads of a half in two parts: the HBM streams (activation records, norms) are requested early, under the
+  // exchange / epilogue arithmetic; the L2-resident operands (the pixels' gradient records, the planes' weight slices)
+  // late, behind that arithmetic, when its registers are free
+  auto pj_issue_hot = [&](int z0, int bn) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(pj_pix[i]));
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)(pj.gp + (long)bn * H * W * 16), 0,
+                                                                        (unsigned)(H * W * 64), 0x00020000);
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+      const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rg, pj_pix[it] >= 0 ? pj_pix[it] * 64 + kg * 16 : 0x7fffffff, 0, 0);
+      pj_b[it] = (f32x4){__uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]), __uint_as_float(r[3])};
+    }
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+      const int gz = z0 + pl;                                    // wave-uniform
+      const bool pok = gz >= 0 && gz < D;
+      pj_aw[pl] = *(const f32x4*)(pj.wA + ((long)(pok ? gz : 0) * 64 + lane) * 4);
+      if (!pok) pj_aw[pl] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto pj_issue = [&](int z0, int bn) {
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long)bn * nvox * 16), 0, sample_bytes, 0x00020000);
+    const bool has_norm = pj.xnorm != nullptr;                   // (wave-uniform)
+    const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc((void*)(has_norm ? pj.xnorm + (long)bn * nvox : x), 0,
+                                                                        has_norm ? (unsigned)(nvox * 4) : 0u, 0x00020000);
+    // (the pixels' gradient records are re-read per tile -- 11.5 KB per workgroup, L1 / L2 hits -- rather than held in 12
+    // registers across the MFMA phase, where the kernel has none to spare)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(pj_pix[i]));
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+      const int gz = z0 + pl;                                    // wave-uniform
+      const bool pok = gz >= 0 && gz < D;
+#pragma unroll
+      for (int it = 0; it < 3; ++it) {
+        const bool ok = pok && pj_pix[it] >= 0;
+        const int vox = gz * H * W + pj_pix[it];
+        const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(ra, ok ? vox * 64 + kg * 16 : 0x7fffffff, 0, 0);
+        pj_yp[pl * 3 + it] = (f32x4){__uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]), __uint_as_float(r[3])};
+        const float nv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rn, (ok && has_norm) ? vox * 4 : 0x7fffffff, 0, 0));
+        pj_nr[pl * 3 + it] = (ok && has_norm) ? nv : 1.f;
+      }
+    }
+  };
+  auto pj_finish = [&](int half_base) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(pj_lo[i]));
+#pragma unroll
+   for (int pl0 = 0; pl0 < 2; ++pl0) {
+    f32x4 g[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) g[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        g[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(pj_aw[pl0][i], pj_b[k][i], g[k], 0, 0, 0);
+#pragma unroll
+    for (int k = pl0 * 3; k < pl0 * 3 + 3; ++k) {
+      const f32x4 yp = pj_yp[k];
+      f32x4 v = g[k - pl0 * 3] * pj.he;
+      if (pj.flags & LF_EPI_PIXELNORM) {
+        float dot = v[0] * yp[0] + v[1] * yp[1] + v[2] * yp[2] + v[3] * yp[3];
+        dot += __shfl_xor(dot, 16, 64);
+        dot += __shfl_xor(dot, 32, 64);
+        dot *= (1.f / 16.f);
+        const float rinv = fast_rcp(pj_nr[k]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (v[e] - yp[e] * dot) * rinv;
+      }
+      if (pj.flags & LF_EPI_LRELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = yp[e] > 0.f ? v[e] : v[e] * slope;
+      }
+      const int pl = k / 3, it = k % 3;
+      if (it < 2 || fa < 3 || pj_last_ok)
+        *(f32x4*)(buf + half_base + pl * (HYw * HXw * 64) + (pj_lo[it] ^ (pl * 32))) = v;
+    }
+   }
+  };
+  // slide: the upper half's group regions of this wave -> the lower half, LDS -> LDS through three registers at a time (the
+  // buffer is free once the tile's first barrier has passed, and the regions are this wave's own)
+  auto pj_slide = [&]() {
+    int sbase = fa * 1024 + lane * 16;
+    asm volatile("" : "+v"(sbase));
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+      u32x4 tmp[3];
+#pragma unroll
+      for (int it = 0; it < 3; ++it) tmp[it] = *(const u32x4*)(buf + HALFBw + pl * (HYw * HXw * 64) + it * 4096 + sbase);
+#pragma unroll
+      for (int it = 0; it < 3; ++it)
+        if (it < 2 || fa < 3 || lane < 16) *(u32x4*)(buf + pl * (HYw * HXw * 64) + it * 4096 + sbase) = tmp[it];
+    }
+  };
+  // FUSE = 1: per-wave projection accumulators (2 output rows x 16 x x 16 cout) and the A operands of the tile's two planes
+  f32x4 pacc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+
+  if constexpr (FUSE == 2) {
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+      const int sl = (fa + 4 * it) * 16 + n;
+      const int ly = sl / HXw;
+      const int q0 = kg ^ ((((sl >> 2) & 1) << 1) | ((ly >> 1) & 1));
+      pj_lo[it] = sl * 64 + q0 * 16;
+    }
+    pj_column(cx, cy, cn);
+    pj_issue(cz * TZw - 1, cn);
+    pj_issue_hot(cz * TZw - 1, cn);
+    pj_finish(0);
+    pj_issue(cz * TZw + 1, cn);
+    pj_issue_hot(cz * TZw + 1, cn);
+    pj_finish(HALFBw);
+  } else {
+    halo_fetch(cx, cy, cz, cn, true, false);
+    halo_commit();
+  }
   lds_barrier();
 
 #if WINO_ABL & 16
@@ -412,10 +594,10 @@ __device__ __forceinline__ void conv3d_c16_wino_body(
     unsigned* const tsp = nullptr;
 #endif
     switch (fa) {
-      case 0: wino_compute<0, SPLIT>(buf, off, wt, whi, wlo, in_scale, px + fa * 8192, pw, tsp); break;
-      case 1: wino_compute<1, SPLIT>(buf, off, wt, whi, wlo, in_scale, px + fa * 8192, pw, tsp); break;
-      case 2: wino_compute<2, SPLIT>(buf, off, wt, whi, wlo, in_scale, px + fa * 8192, pw, tsp); break;
-      default: wino_compute<3, SPLIT>(buf, off, wt, whi, wlo, in_scale, px + fa * 8192, pw, tsp); break;
+      case 0: wino_compute<0, SPLIT, FUSE != 0>(buf, off, wt, whi, wlo, in_scale, px + fa * 8192, pw, tsp); break;
+      case 1: wino_compute<1, SPLIT, FUSE != 0>(buf, off, wt, whi, wlo, in_scale, px + fa * 8192, pw, tsp); break;
+      case 2: wino_compute<2, SPLIT, FUSE != 0>(buf, off, wt, whi, wlo, in_scale, px + fa * 8192, pw, tsp); break;
+      default: wino_compute<3, SPLIT, FUSE != 0>(buf, off, wt, whi, wlo, in_scale, px + fa * 8192, pw, tsp); break;
     }
     TS(1);
     lds_barrier();                                  // every wave is done reading the halo; all partials are in LDS
@@ -465,7 +647,11 @@ __device__ __forceinline__ void conv3d_c16_wino_body(
       if (bp != nullptr) bv4 = *(const f32x4*)(bp + eq * 4);
     }
     TS(4);
-    halo_fetch(nx, ny, nz, nn, t + 1 < t_end, nz != 0);
+    if constexpr (FUSE == 2) {
+      // (the next halo is formed behind the epilogue, below)
+    } else {
+      halo_fetch(nx, ny, nz, nn, t + 1 < t_end, nz != 0);
+    }
     TS(5);
 
     f32x4 o[4];
@@ -514,7 +700,7 @@ __device__ __forceinline__ void conv3d_c16_wino_body(
     // before the tile's last barrier; this tile's stores are issued after the wait so they stay out of it
     // and drain behind the next tile's MFMAs
     TS(6);
-    halo_commit();
+    if constexpr (FUSE != 2) halo_commit();                       // (FUSE = 2 forms its planes after the stores, below)
     TS(7);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -539,9 +725,96 @@ __device__ __forceinline__ void conv3d_c16_wino_body(
           wave_amax = fmaxf(wave_amax, fmaxf(fmaxf(fabsf(v[k][0]), fabsf(v[k][1])), fmaxf(fabsf(v[k][2]), fabsf(v[k][3]))));
       }
     }
+    if constexpr (FUSE == 2) {
+      // the next tile's two new planes, in a phase of their own behind this tile's stores: the kernel sits at the register
+      // limit (254 of 256, no spills) and every placement that keeps the plane loads in flight under the exchange /
+      // epilogue arithmetic spills 11 - 115 registers into the MFMA phase (measured, round 4); here nothing else is
+      // live.  The loads' latency is exposed to this wave -- the SIMD's other wave (the CU's second workgroup) issues
+      // its MFMAs meanwhile, which is what the two-workgroup organisation is for.
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 1 < t_end && nz != 0) {
+        pj_slide();
+        pj_issue(nz * TZw + 1, nn);
+        pj_issue_hot(nz * TZw + 1, nn);
+        __builtin_amdgcn_sched_barrier(0);
+        pj_finish(HALFBw);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (FUSE == 1) {
+      // finished records -> B-operand order through this wave's own (consumed) slices of the exchange region
+      __builtin_amdgcn_sched_barrier(0);
+      int lop = lane;
+      asm volatile("" : "+v"(lop));                               // (opaque: or per-lane 64-bit addresses are hoisted out of the loop and spilled)
+      const int trn = lop & 15, trk = lop >> 4;
+      f32x4 pw_a[2];                                             // L2-resident weight slices of the tile's two planes
+#pragma unroll
+      for (int zo = 0; zo < 2; ++zo)
+        pw_a[zo] = *(const f32x4*)((const char*)pj.wA + (long)min(bz * TZw + zo, D - 1) * 1024 + (unsigned)(lop * 16));
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const f32x4 vz = okv[k] ? v[k] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        *(f32x4*)(px + (k >> 1) * 8192 + fa * 2048 + (k & 1) * 1024 + (lop >> 2) * 64 + (((lop & 3) ^ tr_swz(lop >> 2)) * 16)) = vz;
+      }
+      f32x4 bq[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        bq[k] = *(const f32x4*)(px + (k >> 1) * 8192 + fa * 2048 + (k & 1) * 1024 + trn * 64 + ((trk ^ tr_swz(trn)) * 16));
+#pragma unroll
+      for (int zo = 0; zo < 2; ++zo)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            pacc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(pw_a[zo][i], bq[j * 2 + zo][i], pacc[j], 0, 0, 0);
+      if (bz == tiles_z - 1) {                                   // top of the column: the projection's own epilogue
+        f32x4 pb = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (pj.bias != nullptr) pb = *(const f32x4*)(pj.bias + trk * 4);
+        const int pgx = bx * TXw + trn;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int pgy = by * TYw + 2 * fa + j;
+          float ss = 0.f;
+          f32x4 u;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float q = pacc[j][e] * pj.he + pb[e];
+            if (pj.flags & LF_EPI_LRELU) q = lf_lrelu(q, slope);
+            u[e] = q;
+            ss += q * q;
+          }
+          float r = 1.f, rinv = 1.f;
+          if (pj.flags & LF_EPI_PIXELNORM) {
+            ss += __shfl_xor(ss, 16, 64);
+            ss += __shfl_xor(ss, 32, 64);
+            r = sqrtf(ss / 16.f + eps);
+            rinv = 1.0f / r;
+          }
+          if (pgy < H && pgx < W) {
+            const long pix = ((long)tt * H + pgy) * W + pgx;
+            if (pj.flags & LF_EPI_PIXELNORM) { u[0] *= rinv; u[1] *= rinv; u[2] *= rinv; u[3] *= rinv; }
+            *(f32x4*)(pj.zp + pix * 16 + trk * 4) = u;
+            if ((pj.flags & LF_EPI_PIXELNORM) && pj.pnorm != nullptr && trk == 0) pj.pnorm[pix] = r;
+          }
+          pacc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    }
     TS(8);
     lds_barrier();                                              // next halo visible to all; partials consumed
     cx = nx; cy = ny; cz = nz; cn = nn;
+    if constexpr (FUSE == 2) {
+      if (t + 1 < t_end && nz == 0) {                            // bottom of a new column: its pixels, all four halo planes
+        pj_column(cx, cy, cn);
+        pj_issue(-1, cn);
+        pj_issue_hot(-1, cn);
+        pj_finish(0);
+        pj_issue(1, cn);
+        pj_issue_hot(1, cn);
+        pj_finish(HALFBw);
+        lds_barrier();
+      }
+    }
   }
   if (amax_out != nullptr) {
     float m = wave_amax;
@@ -570,7 +843,25 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_wino_f16x3_kernel(
                              prev_y, prev_norm, prev_flags, amax_in, amax_out);
 }
 
-template <typename K, typename... Extra>
+__global__ void __launch_bounds__(256, 2) conv3d_c16_wino_projfwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ upack, const float* __restrict__ bias,
+    float* __restrict__ y, float* __restrict__ norm_out, int N, int D, int H, int W, int tiles_x, int tiles_y, int tiles_z,
+    int ntiles, float he, unsigned flags, float slope, float eps, const float* __restrict__ prev_y,
+    const float* __restrict__ prev_norm, unsigned prev_flags, WinoProj pj) {
+  conv3d_c16_wino_body<false, 1>(x, upack, bias, y, norm_out, N, D, H, W, tiles_x, tiles_y, tiles_z, ntiles, he, flags, slope,
+                                 eps, prev_y, prev_norm, prev_flags, nullptr, nullptr, pj);
+}
+
+__global__ void __launch_bounds__(256, 2) conv3d_c16_wino_projbwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ upack, const float* __restrict__ bias,
+    float* __restrict__ y, float* __restrict__ norm_out, int N, int D, int H, int W, int tiles_x, int tiles_y, int tiles_z,
+    int ntiles, float he, unsigned flags, float slope, float eps, const float* __restrict__ prev_y,
+    const float* __restrict__ prev_norm, unsigned prev_flags, WinoProj pj) {
+  conv3d_c16_wino_body<false, 2>(x, upack, bias, y, norm_out, N, D, H, W, tiles_x, tiles_y, tiles_z, ntiles, he, flags, slope,
+                                 eps, prev_y, prev_norm, prev_flags, nullptr, nullptr, pj);
+}
+
+template <bool COLUMNS = false, typename K, typename... Extra>
 int launch_wino(K kernel, const float* x, const void* upack, const float* bias, float* y, float* norm_out, int N, int D,
                 int H, int W, float he, unsigned flags, float slope, float eps, const float* prev_y, const float* prev_norm,
                 unsigned prev_flags, void* stream, Extra... extra) {
@@ -598,7 +889,8 @@ int launch_wino(K kernel, const float* x, const void* upack, const float* bias, 
     attr_set = true;
   }
   const long want = 2L * cus;                                     // two resident workgroups per CU
-  const unsigned grid = (unsigned)(pt < want ? pt : want);
+  const long units = COLUMNS ? pt / ptz : pt;                     // (the fused forms hand out whole columns of tiles)
+  const unsigned grid = (unsigned)(units < want ? units : want);
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), shmem, (hipStream_t)stream, x, (const float*)upack, bias, y, norm_out, N, D,
                      H, W, ptx, pty, ptz, (int)pt, he, flags, slope, eps, prev_y, prev_norm, prev_flags, extra...);
   return lf_launch_status();
@@ -628,4 +920,35 @@ extern "C" int lf_conv3d_c16_wino_split(const float* x, const void* upack, const
   lf_clear_error();
   return launch_wino(conv3d_c16_wino_f16x3_kernel, x, upack, bias, y, norm_out, N, D, H, W, he, flags, slope, eps, prev_y,
                      prev_norm, prev_flags, stream, amax_in, amax_out);
+}
+
+// floats of a projection slice pack of the fused forms: [D][64 lanes][4]
+extern "C" size_t lf_conv3d_c16_wino_proj_pack_floats(int D) { return (size_t)(D > 0 ? D : 0) * 64 * 4; }
+
+extern "C" int lf_conv3d_c16_wino_projfwd(const float* x, const float* upack, const float* bias, float* y, float* norm_out,
+                                          int N, int D, int H, int W, float he, unsigned flags, float slope, float eps,
+                                          const float* proj_wA, const float* proj_bias, float* zp, float* pnorm,
+                                          float proj_he, unsigned proj_flags, void* stream) {
+  lf_clear_error();
+  if (proj_wA == nullptr || zp == nullptr) return LF_EINVAL;
+  if (!lf_aligned16(proj_wA) || !lf_aligned16(zp) || (proj_bias && !lf_aligned16(proj_bias))) return LF_EALIGN;
+  if ((proj_flags & ~(LF_EPI_LRELU | LF_EPI_PIXELNORM)) != 0) return LF_EINVAL;
+  WinoProj pj = {proj_wA, proj_bias, zp, pnorm, nullptr, nullptr, proj_he, proj_flags};
+  return launch_wino<true>(conv3d_c16_wino_projfwd_kernel, x, upack, bias, y, norm_out, N, D, H, W, he, flags, slope, eps,
+                           nullptr, nullptr, 0u, stream, pj);
+}
+
+extern "C" int lf_conv3d_c16_wino_projbwd(const float* gp, const float* proj_wtA, float proj_he, const float* act,
+                                          const float* act_norm, unsigned act_flags, const float* upack, float* y,
+                                          int N, int D, int H, int W, float he, float slope, const float* prev_y,
+                                          const float* prev_norm, unsigned prev_flags, void* stream) {
+  lf_clear_error();
+  if (gp == nullptr || proj_wtA == nullptr || act == nullptr) return LF_EINVAL;
+  if ((act_flags & LF_EPI_PIXELNORM) && act_norm == nullptr) return LF_EINVAL;
+  if ((act_flags & ~(LF_EPI_LRELU | LF_EPI_PIXELNORM)) != 0) return LF_EINVAL;
+  if (!lf_aligned16(gp) || !lf_aligned16(proj_wtA) || (prev_y && !lf_aligned16(prev_y))) return LF_EALIGN;
+  if (prev_y != nullptr && (prev_flags & LF_EPI_ADD)) return LF_EINVAL;
+  WinoProj pj = {proj_wtA, nullptr, nullptr, nullptr, gp, act_norm, proj_he, act_flags};
+  return launch_wino<true>(conv3d_c16_wino_projbwd_kernel, act, upack, nullptr, y, nullptr, N, D, H, W, he, 0u, slope, 0.f,
+                           prev_y, prev_norm, prev_flags, stream, pj);
 }

@@ -123,7 +123,7 @@ class RenderLoopEngine:
                 and photographer.predict_depth and photographer.predict_mask and not photographer.predict_color
                 and photographer.camera_config[-1] % 4 == 0)
 
-    def __init__(self, photographer, z_obj, target_obs, loss_weights, conv_mode='auto'):
+    def __init__(self, photographer, z_obj, target_obs, loss_weights, conv_mode='auto', fuse_projection=None):
         """conv_mode selects the kernels of the 16->16 camera-block convolutions:
         'fp32'     direct implicit-GEMM on the fp32 MFMA (works for every channel count);
         'winograd' F(2x2x2,3x3x3) minimal filtering, all-fp32 arithmetic (fp32 MFMA + fp32 transforms);
@@ -178,6 +178,23 @@ class RenderLoopEngine:
         self.proj = (pw, photographer.projection_block.conv.bias, ops.he_constant(pw),
                      ops.pack_conv1x1(pw.reshape(cout, C, D).permute(0, 2, 1).reshape(cout, D * C)),
                      ops.pack_conv1x1(pw.reshape(cout, C, D).permute(2, 1, 0).reshape(D * C, cout)))
+        # factor projection fused into the Winograd kernel of the last camera block (lf_conv3d_c16_wino_projfwd / _projbwd;
+        # round 4): forward bit-identical to the two-launch form, backward to the reciprocal of the saved norm.
+        # fuse_projection: None = both where the shapes allow, or a subset of {'fwd', 'bwd'} / False for A/B runs
+        can_fuse = self.wino is not None and cout == 16 and C == 16
+        if fuse_projection is None:
+            fuse_projection = ('fwd', 'bwd') if can_fuse else ()
+        elif fuse_projection is False:
+            fuse_projection = ()
+        elif fuse_projection is True:
+            fuse_projection = ('fwd', 'bwd')
+        if fuse_projection and not can_fuse:
+            raise NotImplementedError("fuse_projection needs conv_mode 'winograd' on 16-channel blocks and a 16-channel projection")
+        self.fuse_projection = tuple(fuse_projection)
+        self.proj_fused = None
+        if self.fuse_projection:
+            wdm = pw.reshape(cout, C, D).permute(0, 2, 1).reshape(cout, D * C)        # depth-major K, as ppack
+            self.proj_fused = (ops.pack_wino_proj(wdm), ops.pack_wino_proj(wdm, transpose=True))
         self.dev = dev
         self.streams, self._side_streams = 1, []
         self._intr = None                                            # (K, version, gathered): the intrinsics do not change during a loop
@@ -290,6 +307,10 @@ class RenderLoopEngine:
                                                    amax_in=self.z_amax if li_ == 0 else None)
             elif self.split is not None:
                 y, nrm = ops.conv3d_c16_split(acts[-1], self.split[li_][0], b, he, flags)
+            elif self.wino is not None and li_ == len(self.convs) - 1 and 'fwd' in self.fuse_projection:
+                pw, pb, phe, _ppack, _ppack_t = self.proj
+                y, nrm, zp, pnorm = ops.conv3d_c16_wino_projfwd(acts[-1], self.wino[li_][0], b, he, flags, self.proj_fused[0],
+                                                                  pb, phe, flags)
             elif self.wino is not None:
                 y, nrm = ops.conv3d_c16_wino(acts[-1], self.wino[li_][0], b, he, flags)
             elif self.wgemm is not None:
@@ -301,9 +322,10 @@ class RenderLoopEngine:
         pw, pb, phe, ppack, ppack_t = self.proj
         cout = pw.shape[0]
         Cl = acts[-1].shape[1]
-        zp = ops.empty_cl((n, cout, S, S), dev)
-        with ops._timed('factor_project_fwd'):
-            pnorm = ops._conv1x1_raw(acts[-1], ppack, pb, n, S * S, Cl, S, S * S * S * Cl, S * S * Cl, cout, zp, phe, flags)
+        if 'fwd' not in self.fuse_projection:
+            zp = ops.empty_cl((n, cout, S, S), dev)
+            with ops._timed('factor_project_fwd'):
+                pnorm = ops._conv1x1_raw(acts[-1], ppack, pb, n, S * S, Cl, S, S * S * S * Cl, S * S * Cl, cout, zp, phe, flags)
 
         # ---- 2-D decoder + heads (autograd over small maps) + fused loss ----
         zp_leaf = zp.detach().requires_grad_(need_grad)
@@ -353,10 +375,20 @@ class RenderLoopEngine:
 
         # ---- 3-D backward (data gradients only) ----
         gp = ops._epilogue_bwd(ops.cl(g_zp), zp, pnorm, flags)
-        g = ops.empty_cl((n, Cl, S, S, S), dev)
         fuse = (Cl == 16 and self.C == 16 and all(w.shape[0] == 16 and w.shape[1] == 16 for w, *_ in self.convs))
         nconv = len(self.convs)
-        if fuse and nconv:
+        fuse_pb = fuse and nconv and 'bwd' in self.fuse_projection
+        g = None if fuse_pb else ops.empty_cl((n, Cl, S, S, S), dev)
+        if fuse_pb:
+            # projection backward + first data-gradient convolution in one launch; then the remaining layers
+            i = nconv - 1
+            prev = (acts[i], norms[i - 1], flags) if i > 0 else None
+            g = ops.conv3d_c16_wino_projbwd(gp, self.proj_fused[1], phe, acts[nconv], norms[nconv - 1], flags,
+                                            self.wino[i][1], self.convs[i][2], prev=prev)
+            for i in range(nconv - 2, -1, -1):
+                prev = (acts[i], norms[i - 1], flags) if i > 0 else None
+                g, _ = ops.conv3d_c16_wino(g, self.wino[i][1], None, self.convs[i][2], 0, prev=prev)
+        elif fuse and nconv:
             # every data-gradient kernel also applies the LeakyReLU'/PixelNorm' of the layer feeding it,
             # so no separate epilogue-backward pass touches the (N,16,S,S,S) volumes
             # max-abs of each gradient volume (order-independent atomic max inside the producing kernel):

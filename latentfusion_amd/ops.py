@@ -386,6 +386,57 @@ def conv3d_c16_wino(x, upack, bias, he, flags, prev=None, amax_out=None):
     return y, norm
 
 
+def pack_wino_proj(wp_dmajor, transpose=False):
+    """Depth slices of the factor projection for the fused forms of lf_conv3d_c16_wino (include/lf_hip.h):
+    wp_dmajor = the (16, D*16) matrix lf_conv1x1_fwd takes (K = d*16 + c) -> [D][64 lanes][4].
+    transpose=False: A operands of the forward projection, [d][l][i] = Wp[l & 15][d*16 + (l >> 4)*4 + i];
+    transpose=True : A operands of its data gradient,      [d][l][i] = Wp[(l >> 4)*4 + i][d*16 + (l & 15)]."""
+    w = wp_dmajor.detach()
+    cout, K = w.shape
+    assert cout == 16 and K % 16 == 0
+    D = K // 16
+    if not transpose:
+        out = w.reshape(16, D, 4, 4).permute(1, 2, 0, 3)          # [m][d][kg][i] -> [d][kg][m][i]
+    else:
+        out = w.reshape(4, 4, D, 16).permute(2, 0, 3, 1)          # [kg][i][d][m] -> [d][kg][m][i]
+    return out.reshape(D, 64, 4).float().contiguous()
+
+
+def conv3d_c16_wino_projfwd(x, upack, bias, he, flags, proj_wA, proj_bias, proj_he, proj_flags):
+    """lf_conv3d_c16_wino_projfwd: the last camera block's convolution AND the factor projection behind it in one launch.
+    Returns (y, norm, zp (N,16,H,W) channels-last, pnorm)."""
+    L = _lib.lib()
+    N, _, D, H, W = x.shape
+    y = empty_cl((N, 16, D, H, W), x.device)
+    norm = torch.empty(N * D * H * W, device=x.device, dtype=torch.float32) if (flags & LF_EPI_PIXELNORM) else None
+    zp = empty_cl((N, 16, H, W), x.device)
+    pnorm = torch.empty(N * H * W, device=x.device, dtype=torch.float32) if (proj_flags & LF_EPI_PIXELNORM) else None
+    with _timed('conv3d_c16_wino_projfwd'):
+        check(L.lf_conv3d_c16_wino_projfwd(_ptr(x), _ptr(upack), _ptr(bias) if bias is not None else None, _ptr(y),
+                                           _ptr(norm) if norm is not None else None, N, D, H, W, he, flags, SLOPE, PN_EPS,
+                                           _ptr(proj_wA), _ptr(proj_bias) if proj_bias is not None else None, _ptr(zp),
+                                           _ptr(pnorm) if pnorm is not None else None, proj_he, proj_flags, _stream()),
+              'lf_conv3d_c16_wino_projfwd')
+    return y, norm, zp, pnorm
+
+
+def conv3d_c16_wino_projbwd(gp, proj_wtA, proj_he, act, act_norm, act_flags, upack_t, he, prev=None):
+    """lf_conv3d_c16_wino_projbwd: data gradient of the factor projection AND of the last camera block's convolution in one
+    launch (the gradient volume between them is formed on chip).  gp: (N,16,H,W) channels-last gradient w.r.t. the
+    projection's pre-activation; act / act_norm: the block's saved output; prev: (y, norm, flags) of the layer feeding the
+    block.  Returns the (N,16,D,H,W) gradient w.r.t. that layer's pre-activation (or the block's input if prev is None)."""
+    L = _lib.lib()
+    N, _, D, H, W = act.shape
+    g = empty_cl((N, 16, D, H, W), act.device)
+    py, pn, pf = (prev[0], prev[1], prev[2]) if prev is not None else (None, None, 0)
+    with _timed('conv3d_c16_wino_projbwd'):
+        check(L.lf_conv3d_c16_wino_projbwd(_ptr(gp), _ptr(proj_wtA), proj_he, _ptr(act),
+                                           _ptr(act_norm) if act_norm is not None else None, act_flags, _ptr(upack_t), _ptr(g),
+                                           N, D, H, W, he, SLOPE, _ptr(py) if py is not None else None,
+                                           _ptr(pn) if pn is not None else None, pf, _stream()), 'lf_conv3d_c16_wino_projbwd')
+    return g
+
+
 def pack_conv3d_wino_gemm(weight, transpose=False):
     """[Cout,Cin,3,3(,3)] -> U [64 | 16 f][Cin][Cout], f = (a*4+b)*4+c (3-D) or b*4+c (2-D), for the three-stage
     Winograd path (lf_wino3d_* / lf_wino2d_*): U[f][ci][co] = ((G x ..) w)[co][ci][f], evaluated in fp64."""

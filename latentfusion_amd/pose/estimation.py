@@ -406,11 +406,13 @@ class GradientPoseEstimator(PoseEstimator):
 
     def __init__(self, *, learning_rate, num_samples, num_iters, converge_threshold, converge_patience,
                  lr_reduce_patience=25, lr_reduce_threshold=1e-5, lr_reduce_factor=0.5, track_stats=False,
-                 loss_schedules=None, optimizer='adamw', use_engine=True, conv_mode='auto', engine_streams=1, **kwargs):
+                 loss_schedules=None, optimizer='adamw', use_engine=True, conv_mode='auto', engine_streams=1,
+                 fuse_projection=None, **kwargs):
         super().__init__(**kwargs)
         self.use_engine = use_engine
         self.conv_mode = conv_mode
         self.engine_streams = engine_streams     # hypothesis groups evaluated concurrently on separate HIP streams (engine.py)
+        self.fuse_projection = fuse_projection   # engine.py: None = fused projection kernels where the shapes allow; False / subset for A/B
         self.learning_rate, self.num_samples, self.num_iters = learning_rate, num_samples, num_iters
         self.optimizer = optimizer
         self.lr_reduce_patience, self.lr_reduce_threshold = lr_reduce_patience, lr_reduce_threshold
@@ -463,7 +465,8 @@ class GradientPoseEstimator(PoseEstimator):
         # must not be dropped silently: the reference applies every scheduled weight (estimation.py:612-617)
         if any(k not in RenderLoopEngine.LOSS_KEYS + ('latent',) for k in self.loss_schedules):
             return None
-        return RenderLoopEngine(ph, z_obj, target_obs, self.loss_weights, conv_mode=self.conv_mode).set_streams(self.engine_streams)
+        return RenderLoopEngine(ph, z_obj, target_obs, self.loss_weights, conv_mode=self.conv_mode,
+                                fuse_projection=self.fuse_projection).set_streams(self.engine_streams)
 
     @classmethod
     def get_optimizer(cls, name, *args, **kwargs):

@@ -143,6 +143,68 @@ def test_cfg2_build_at_full_size_vs_oracle():
     gerr = ((g0.cpu() - ref_grad).norm(dim=1) / ref_grad.norm(dim=1).clamp_min(1e-30)).max().item()
     assert gerr < 1e-2, gerr                      # the fp32 noise floor of these gradients at 128^3 (test_oracle_golden)
 
+    # what the north star states: the RENDERED depth / mask of the N = 8 hypotheses, pixel by pixel at the headline size
+    # (reference recon/models.py:455-484: logits -> tanh / sigmoid, thresholded mask applied to the depth), within 1e-3 rel
+    ocam = O.Cam(init.intrinsic.clone(), init.log_quaternion.clone(), init.translation.clone()).zoom(None, om.input_size, om.camera_dist)
+    with torch.no_grad():
+        yo, _ = om.render_latent_object(z_ora, ocam, apply_mask=True)
+        pred, _ = model.render_latent_object(z_ora.to(DEV), st['cam'], return_latent=True, apply_mask=True)
+    for key in ('depth_logits', 'mask_logits'):
+        a, b = pred[key].squeeze(0).cpu(), yo[key].squeeze(0)
+        assert a.shape == b.shape == (N, 1, S, S)
+        close(a, b, atol=1e-4 * max(1.0, b.abs().max().item()), rtol=1e-3)
+    # thresholded outputs: identical wherever the oracle's mask logit is not within fp32 noise of the threshold
+    mo, mh = yo['mask'].squeeze(0), pred['mask'].squeeze(0).cpu()
+    clear = yo['mask_logits'].squeeze(0).abs() > 1e-3
+    assert clear.float().mean().item() > 0.99
+    assert torch.equal((mh > 0.5)[clear], (mo > 0.5)[clear])
+    close(mh, mo, atol=1e-4, rtol=1e-3)
+    same = ((mh > 0.5) == (mo > 0.5))
+    close(pred['depth'].squeeze(0).cpu()[same], yo['depth'].squeeze(0)[same], atol=1e-4, rtol=1e-3)
+    # the four terms of default_pose_loss, not only their weighted sum (reference pose/estimation.py:70-118)
+    ld = opose.pose_loss(otarget, ocam.denormalize_depth(yo['depth'].squeeze(0)), yo['mask_logits'].squeeze(0), ocam)
+    for i, k in enumerate(('depth', 'ov_depth', 'iou', 'mask')):
+        close(l0[:, i], ld[k], atol=1e-5, rtol=1e-3)
+
+
+def test_mid_size_loop_trace_vs_oracle():
+    """adam_quick on SYN(32,16), 4 views, N = 8, TWENTY iterations against the CPU oracle (reference pose/estimation.py:
+    618-632, the per-iteration ranking): identical argmin pose index at every iteration, the first iterations' losses to
+    1e-4, the rest within the envelope of the 16^3 golden trace (g7) -- Adam turns 1e-5-sized viewport gradients into
+    lr-sized steps, so fp32 noise moves late iterations by ~one optimiser step."""
+    from lf_oracle import pose as opose
+    import lf_oracle as O
+    from latentfusion_amd import synth
+    from latentfusion_amd.pose import estimation, utils as pu
+    S, C, V, N, IT = 32, 16, 4, 8, 20
+    model, cks = synth.build_model(S, C, 'gru', seed=2, device=DEV)
+    rd, td = synth.make_observation_data(V, seed=110), synth.make_observation_data(1, seed=210)
+    om = opose.Model(*cks)
+    z_ora = om.build_latent_object(opose.Obs(rd['color'], rd['depth'], rd['mask'], O.Cam.from_extrinsic(rd['intrinsic'], rd['extrinsic'])))
+    z_hip = model.build_latent_object(_observation(rd))
+    assert (z_hip.cpu() - z_ora).abs().max().item() <= 1e-3 * z_ora.abs().max().item()
+    target = _observation(td)
+    cfg = estimation._load_toml(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'configs', 'adam_quick.toml'))
+    cfg['args'].update(num_samples=N, ranking_size=N, num_iters=IT, converge_patience=10 ** 6)
+    torch.manual_seed(301)
+    init = pu.sample_cameras_with_estimate(N, target.camera.to('cpu'))
+    otarget = opose.Obs(None, td['depth'], td['mask'], O.Cam.from_extrinsic(td['intrinsic'], td['extrinsic']))
+    _, tr = opose.gradient_estimate(om, z_ora, otarget, O.Cam(init.intrinsic.clone(), init.log_quaternion.clone(),
+                                                              init.translation.clone()), cfg)
+    ref = tr['rank_loss']                                         # (IT, N)
+    assert ref.shape == (IT, N)
+    for z in (z_ora.to(DEV), z_hip):                               # render parity alone, then end to end
+        est = estimation.load_from_config(cfg, model, track_stats=True)
+        _, stats = est.estimate(z, target, camera=init)
+        got = stats['rank_loss']
+        assert got.shape == (IT, N)
+        close(got[:3], ref[:3], atol=1e-5, rtol=1e-4)
+        close(got, ref, atol=3e-2, rtol=0)
+        top2 = torch.sort(ref, dim=1).values[:, :2]
+        clear = (top2[:, 1] - top2[:, 0]) > 1e-3 * top2[:, 0].abs()
+        assert clear.sum().item() >= IT - 2, clear
+        assert torch.equal(torch.argmin(got, dim=1)[clear], torch.argmin(ref, dim=1)[clear])
+
 
 # ----------------------------------------------------------------------------------------------------------------------
 # cfg 5: the training step at its stated shape
