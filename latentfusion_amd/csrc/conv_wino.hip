@@ -37,6 +37,10 @@
                         // chain 1.5x as long (the MFMA count of F(2,3) in y,x with direct z taps); 16 / 32 = cycle stamps
 // wave priorities (s_setprio) of the three phases of a tile: halo reads + input transforms (latency-bound: LDS),
 // the MFMA chains (throughput-bound) and the exchange / epilogue / halo fetch (latency-bound: LDS, HBM)
+#ifndef WINO_PJ_ABL
+#define WINO_PJ_ABL 0   // ablations of the fused projection backward (tools/proj_fuse_ab.py --variants; results WRONG, timings only):
+#endif                  // 1 = no activation / norm loads (the HBM streams of the halo phase), 2 = no MFMAs / epilogue arithmetic,
+                        // 4 = no slide copy
 #ifndef WINO_PL
 #define WINO_PL 2
 #endif
@@ -497,7 +501,7 @@ __device__ __forceinline__ void conv3d_c16_wino_body(
       const bool pok = gz >= 0 && gz < D;
 #pragma unroll
       for (int it = 0; it < 3; ++it) {
-        const bool ok = pok && pj_pix[it] >= 0;
+        const bool ok = pok && pj_pix[it] >= 0 && !(WINO_PJ_ABL & 1);
         const int vox = gz * H * W + pj_pix[it];
         const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(ra, ok ? vox * 64 + kg * 16 : 0x7fffffff, 0, 0);
         pj_yp[pl * 3 + it] = (f32x4){__uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]), __uint_as_float(r[3])};
@@ -514,16 +518,21 @@ __device__ __forceinline__ void conv3d_c16_wino_body(
     f32x4 g[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) g[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr ((WINO_PJ_ABL & 2) == 0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int k = 0; k < 3; ++k)
         g[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(pj_aw[pl0][i], pj_b[k][i], g[k], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) g[k] = pj_b[k] + pj_aw[pl0];
+    }
 #pragma unroll
     for (int k = pl0 * 3; k < pl0 * 3 + 3; ++k) {
       const f32x4 yp = pj_yp[k];
       f32x4 v = g[k - pl0 * 3] * pj.he;
-      if (pj.flags & LF_EPI_PIXELNORM) {
+      if ((pj.flags & LF_EPI_PIXELNORM) && !(WINO_PJ_ABL & 2)) {
         float dot = v[0] * yp[0] + v[1] * yp[1] + v[2] * yp[2] + v[3] * yp[3];
         dot += __shfl_xor(dot, 16, 64);
         dot += __shfl_xor(dot, 32, 64);
@@ -733,7 +742,7 @@ __device__ __forceinline__ void conv3d_c16_wino_body(
       // its MFMAs meanwhile, which is what the two-workgroup organisation is for.
       __builtin_amdgcn_sched_barrier(0);
       if (t + 1 < t_end && nz != 0) {
-        pj_slide();
+        if constexpr ((WINO_PJ_ABL & 4) == 0) pj_slide();
         pj_issue(nz * TZw + 1, nn);
         pj_issue_hot(nz * TZw + 1, nn);
         __builtin_amdgcn_sched_barrier(0);

@@ -180,10 +180,12 @@ class RenderLoopEngine:
                      ops.pack_conv1x1(pw.reshape(cout, C, D).permute(2, 1, 0).reshape(D * C, cout)))
         # factor projection fused into the Winograd kernel of the last camera block (lf_conv3d_c16_wino_projfwd / _projbwd;
         # round 4): forward bit-identical to the two-launch form, backward to the reciprocal of the saved norm.
-        # fuse_projection: None = both where the shapes allow, or a subset of {'fwd', 'bwd'} / False for A/B runs
+        # fuse_projection: None = the default ('fwd' where the shapes allow: measured -0.07 ms per iteration; the backward
+        # form is correct but trades its 2.1 GB of HBM traffic for +19 % MFMAs on the pipe-bound kernel and comes out even
+        # or behind -- profiles/r04_proj_fuse_ab.txt), True = both, or a subset of {'fwd', 'bwd'} / False for A/B runs
         can_fuse = self.wino is not None and cout == 16 and C == 16
         if fuse_projection is None:
-            fuse_projection = ('fwd', 'bwd') if can_fuse else ()
+            fuse_projection = ('fwd',) if can_fuse else ()
         elif fuse_projection is False:
             fuse_projection = ()
         elif fuse_projection is True:

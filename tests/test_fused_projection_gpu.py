@@ -144,8 +144,9 @@ def test_projbwd_is_run_to_run_identical_and_refuses_bad_arguments():
 
 @pytest.mark.parametrize('S', [16, 32])
 def test_engine_with_fused_projection_equals_the_unfused_engine(S):
-    """RenderLoopEngine with the projection fused into the last camera block's kernels (default) against the same engine with
-    the separate projection launches: identical losses (the forward is bit-identical), camera gradients to the last bits."""
+    """RenderLoopEngine with the projection fused into the last camera block's kernels (forward: the default; backward:
+    opt-in) against the same engine with the separate projection launches: identical losses (the forward is bit-identical),
+    camera gradients to the last bits."""
     from latentfusion_amd import synth
     from latentfusion_amd.engine import RenderLoopEngine
     from latentfusion_amd.modules.geometry import Camera
@@ -163,14 +164,15 @@ def test_engine_with_fused_projection_equals_the_unfused_engine(S):
     plain = RenderLoopEngine(model.photographer, z_obj, target, weights, fuse_projection=False)
     assert plain.fuse_projection == ()
     l0, g0 = plain.forward_backward(cam)
-    for sel in (None, ('fwd',), ('bwd',)):
+    for sel in (None, True, ('fwd',), ('bwd',)):
         eng = RenderLoopEngine(model.photographer, z_obj, target, weights, fuse_projection=sel)
-        assert eng.conv_mode == 'winograd' and eng.fuse_projection == (('fwd', 'bwd') if sel is None else sel)
+        assert eng.conv_mode == 'winograd'
+        assert eng.fuse_projection == {None: ('fwd',), True: ('fwd', 'bwd')}.get(sel, sel)
         l1, g1 = eng.forward_backward(cam)
         assert torch.equal(l1, l0), sel
         rel = ((g1 - g0).norm(dim=1) / g0.norm(dim=1)).max().item()
         assert rel < 1e-5, (sel, rel)
-        if sel == ('fwd',):
+        if sel in (None, ('fwd',)):
             assert torch.equal(g1, g0)
     with pytest.raises(NotImplementedError):
         RenderLoopEngine(model.photographer, z_obj, target, weights, conv_mode='fp32', fuse_projection=True)

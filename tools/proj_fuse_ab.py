@@ -131,7 +131,7 @@ if not a.no_loop:
     torch.manual_seed(300)
     init = pu.sample_cameras_with_estimate(N, target.camera.to('cpu'))
     loop, first = {}, {}
-    sels = {'none': False, 'fwd': ('fwd',), 'bwd': ('bwd',), 'both': None}
+    sels = {'none': False, 'fwd': ('fwd',), 'bwd': ('bwd',), 'both': True}
     states = {}
     for name, sel in sels.items():
         est = estimation.load_from_config(cfg, model, converge_patience=10 ** 6, fuse_projection=sel)
