@@ -56,7 +56,9 @@ def parse(argv=None):
     ap.add_argument('--samples', type=int, default=8)
     ap.add_argument('--fuser', default='gru')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-iters', type=int, default=3, help='timed oracle iterations of the CPU baseline (after 1 warm-up)')
+    ap.add_argument('--cpu-iters', type=int, default=4,
+                    help='timed oracle iterations of the CPU baseline (after 1 warm-up); their per-iteration trace is compared with '
+                         'the HIP loop from the same start (trace_parity_at_full_size)')
     ap.add_argument('--no-alt', action='store_true', help='skip the secondary f16x3 measurement')
     ap.add_argument('--engine-streams', type=int, default=1,
                     help='hypothesis groups of the render-loop engine evaluated concurrently on separate HIP streams')
@@ -75,6 +77,10 @@ def parse(argv=None):
     ap.add_argument('--conv-mode', default='winograd', choices=['fp32', 'winograd', 'f16x3', 'winograd_f16x3'],
                     help="conv3d kernels of the engine: 'winograd' (default; F(2^3,3^3) minimal filtering, all-fp32 "
                          "arithmetic), 'fp32' (direct implicit GEMM on the fp32 MFMA) or 'f16x3' (split precision)")
+    ap.add_argument('--no-cfg3', action='store_true',
+                    help='skip the secondary cfg 3 block (released architecture, 8 views, cross_entropy_linemod: 128 renders per '
+                         'iteration on the fused engine)')
+    ap.add_argument('--cfg3-iters', type=int, default=10)
     ap.add_argument('--launcher-selftest', action='store_true',
                     help='run only the rank plumbing (spawn / process group / one all-reduce on HOST tensors over gloo) and '
                          'print a JSON line with n_gpus and ranks_seen: the CPU test of the N-rank path (tests/test_parallel.py)')
@@ -188,11 +194,13 @@ def cpu_baseline(cks, z_obj_gpu_cpu, ref_data, target_data, init, cfg, iters, bu
     _, first = opose.gradient_estimate(model, z_obj_cpu, target, cam0, c)   # warm-up (page-in, thread pools)
     c['args']['num_iters'] = iters
     t0 = time.perf_counter()
-    opose.gradient_estimate(model, z_obj_cpu, target, cam0, c)
+    _, trace = opose.gradient_estimate(model, z_obj_cpu, target, cam0, c)
     dt = time.perf_counter() - t0
-    # iteration 0 of the oracle on ITS volume / the same target / initial cameras: the full-size parity check
+    # iteration 0 of the oracle on ITS volume / the same target / initial cameras: the full-size parity check;
+    # `trace`: the timed iterations 0 .. iters-1 from the same start (per-iteration rank losses, parameters)
     ref0 = {'rank_loss': first['rank_loss'][0],
-            'grad': torch.cat((first['grad_log_q'][0], first['grad_t'][0], first['grad_viewport'][0]), dim=1)}
+            'grad': torch.cat((first['grad_log_q'][0], first['grad_t'][0], first['grad_viewport'][0]), dim=1),
+            'trace_rank_loss': trace['rank_loss'], 'trace_log_q': trace['log_q'], 'trace_t': trace['t']}
     return iters / dt, torch.get_num_threads(), ref0, dt, build_info, z_obj_cpu
 
 
@@ -230,6 +238,74 @@ def sharded_build_report(a, S, C, V, dev, world, barrier):
                'allreduce_algbw_GBps': (z_full.numel() * 4 / 1e9) / (ar_ms * 1e-3) if ar_ms else None}
 
     return sharded
+
+
+def cfg3_report(a, dev):
+    """BASELINE cfg 3 (secondary block, never `value`): the RELEASED architecture (tools/train/train.sh:28-66: 256^2 inputs, 16^3 x
+    256-channel volume, 512-channel U-Net levels, GRU fuser; 68 M seeded random parameters -- the public checkpoint and LINEMOD
+    are not obtainable offline), 8 reference views, the cross_entropy_linemod preset: 32 samples x 4 flips = 128 renders per
+    iteration, ranked without gradients (reference pose/estimation.py:298-497).  The hypotheses are scored on the fused
+    engine (forward only, lf_pose_loss_fwd_masked).  Reported: iterations/s and renders/s of the warm loop (host GMM fits
+    included, as in the reference), and the launch time / fp32-MFMA fraction of the dominant kernel of this model,
+    wino_fused_kernel<3> (the 256 -> 256 camera-block convolutions as Winograd GEMMs with the output transform folded in)."""
+    import numpy as np
+    from latentfusion_amd import ops, synth
+    from latentfusion_amd.modules.geometry import Camera
+    from latentfusion_amd.observation import Observation
+    from latentfusion_amd.pose import estimation
+    t0 = time.perf_counter()
+    model, _ = synth.build_released_model(dev, seed=0)
+    model.freeze()
+    t_model = time.perf_counter() - t0
+    V3 = 8
+    ref = synth.make_observation(V3, seed=100, device=dev)
+    td = synth.make_observation_data(1, seed=200)
+    target = Observation(td['color'], td['depth'], td['mask'], Camera(td['intrinsic'], td['extrinsic'])).to(dev)
+    builds = []
+    for rep in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        z_obj = model.build_latent_object(ref)
+        torch.cuda.synchronize()
+        builds.append(time.perf_counter() - t0)
+    cfg = estimation._load_toml(os.path.join(ROOT, 'configs', 'cross_entropy_linemod.toml'))
+    cfg['args']['num_iters'] = a.cfg3_iters
+    n_r = cfg['args']['num_samples']
+    est = estimation.load_from_config(cfg, model)
+    runs, timer = [], []
+    for rep in range(3):
+        torch.manual_seed(300)
+        np.random.seed(300)
+        if rep == 2:
+            ops.KERNEL_TIMER_TAGS = {'wino3d_fused'}
+            ops.KERNEL_TIMER = []
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        best = est.estimate(z_obj, target, camera=target.camera)
+        torch.cuda.synchronize()
+        runs.append(time.perf_counter() - t0)
+        if rep == 2:
+            timer, ops.KERNEL_TIMER = ops.KERNEL_TIMER, None
+    on_engine = est._engine_cache is not None and est._engine_cache[2] is not None
+    el = min(runs[1:2])                                            # the un-instrumented warm run
+    d3 = [e0.elapsed_time(e1) for n_, e0, e1 in timer if n_ == 'wino3d_fused']
+    Cw, Sw = 256, 16
+    tiles = n_r * (Sw // 2) ** 3
+    fl = 2.0 * 64 * tiles * Cw * Cw                                # executed: 64 Winograd frequencies x tiles x Cin x Cout
+    out = {'workload': f'released architecture (68 M seeded random parameters), {V3} reference views, cross_entropy_linemod: '
+                       f'{n_r} renders per iteration, no gradient; synthetic observation',
+           'value': a.cfg3_iters / el, 'unit': 'iters/s', 'renders_per_s': a.cfg3_iters * n_r / el, 'iterations': a.cfg3_iters,
+           'run_s': runs, 't_build_s': builds[0], 't_build_warm_s': builds[1], 't_model_setup_s': t_model,
+           'scored_on_fused_engine': bool(on_engine), 'ranking_size_returned': len(best)}
+    if d3:
+        ms = sum(d3) / len(d3)
+        out['roofline'] = {'bound': 'mfma', 'kernel': 'wino_fused_kernel<3> (3-D 256 -> 256 @ 16^3, N = %d: per-frequency fp32-MFMA GEMM '
+                                                      '+ output transform + He + bias + LeakyReLU)' % n_r,
+                           'achieved': fl / (ms * 1e-3) / 1e12, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                           'frac': fl / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 'avg_launch_ms': ms, 'launches_timed': len(d3),
+                           'executed_flops_per_launch': fl,
+                           'algorithmic_flops_per_launch': 2.0 * 27 * Cw * Cw * n_r * Sw ** 3, 'traffic': None}
+    return out
 
 
 def pipelined_build_report(a, S, C, V, dev, world, barrier):
@@ -571,6 +647,15 @@ def main():
         except Exception as e:                                       # noqa: BLE001
             pipelined = {'error': f'{type(e).__name__}: {e}'[:300]}
 
+    cfg3 = None
+    if world == 1 and not a.no_cfg3:
+        try:
+            st = est = st2 = est2 = None
+            torch.cuda.empty_cache()
+            cfg3 = cfg3_report(a, dev)
+        except Exception as e:                                       # noqa: BLE001  (auxiliary: never loses the headline)
+            cfg3 = {'error': f'{type(e).__name__}: {e}'[:300]}
+
     # RCCL on this box: under a launcher the process group above IS an RCCL communicator; a plain `python bench.py` run
     # initialises a world-size-1 group here (after the timed regions, so it cannot touch the number) and runs one
     # all-reduce of a latent-volume-sized tensor through it
@@ -629,6 +714,33 @@ def main():
                 l3, g3 = st3['engine'].forward_backward(st3['cam'], need_grad=True)
             hip_on_oracle = {'rank_loss': l3[:, 4].cpu(), 'grad': g3.cpu()}
 
+        def hip_trace(z_):
+            """`cpu_iters` iterations of the HIP loop from the same start, per-iteration rank losses and parameters."""
+            e_ = estimation.load_from_config(cfg, model, converge_patience=10 ** 6, conv_mode=a.conv_mode, return_camera_history=True)
+            s_ = e_.start(z_, target, init.zoom(None, model.input_size, model.camera_dist).to(dev))
+            s_['max_steps'] = a.cpu_iters
+            for _ in range(a.cpu_iters):
+                e_.iterate(s_)
+            rl = torch.stack([h_[0] for h_ in s_['camera_history']]).cpu()
+            lq = torch.stack([h_[1].log_quaternion for h_ in s_['camera_history']]).cpu()
+            return rl, lq
+
+        def trace_parity(z_):
+            rl, lq = hip_trace(z_)
+            ref = ref0['trace_rank_loss']
+            k = min(len(rl), len(ref))
+            rows = []
+            for i in range(k):
+                rows.append({'iteration': i,
+                             'rank_loss_max_rel_diff': ((rl[i] - ref[i]).abs() / ref[i].abs().clamp_min(1e-30)).max().item(),
+                             'argmin_equal': bool(torch.argmin(rl[i]) == torch.argmin(ref[i])),
+                             'ranking_equal': bool(torch.equal(torch.argsort(rl[i]), torch.argsort(ref[i])))})
+            return {'iterations': k, 'per_iteration': rows,
+                    'argmin_equal_all': all(r['argmin_equal'] for r in rows),
+                    'ranking_equal_all': all(r['ranking_equal'] for r in rows),
+                    'what': 'the HIP adam_quick loop vs the oracle loop from the same initial cameras, iteration by iteration '
+                            '(rank loss of every hypothesis, index of the best, order of all N)'}
+
         def parity(h):
             gerr = (h['grad'] - ref0['grad']).norm(dim=1) / ref0['grad'].norm(dim=1).clamp_min(1e-30)
             return {'rank_loss_max_abs_diff': (h['rank_loss'] - ref0['rank_loss']).abs().max().item(),
@@ -648,9 +760,13 @@ def main():
                                # (same reference views, target, initial cameras): per-hypothesis ranking loss and
                                # camera-parameter gradients
                                'parity_at_full_size': parity(hip0)}
+        # iterations 0 .. cpu_iters-1: end to end (HIP build + HIP loop vs oracle build + oracle loop) and, when the oracle
+        # built its own volume, the HIP loop on THAT volume (render / loss / optimiser parity alone)
+        out['cpu_baseline']['trace_parity_at_full_size'] = trace_parity(z_obj)
         if build_info is not None:
             out['cpu_baseline']['build_parity_at_full_size'] = build_info
             out['cpu_baseline']['render_parity_on_oracle_built_volume'] = parity(hip_on_oracle)
+            out['cpu_baseline']['trace_parity_on_oracle_built_volume'] = trace_parity(z_ora.to(dev))
             out['cpu_baseline']['e2e_100_iters_per_s'] = 100.0 / (build_info['t_oracle_build_s'] + 100.0 / v)
         if alt is not None:
             alt['parity_at_full_size'] = parity(alt0)
@@ -658,6 +774,8 @@ def main():
         out['alt'] = alt
     if sharded is not None:
         out['sharded_build'] = sharded
+    if cfg3 is not None:
+        out['cfg3'] = cfg3
     if pipelined is not None:
         out['pipelined_gru_build'] = pipelined
     if hyp is not None:

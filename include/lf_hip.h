@@ -451,6 +451,13 @@ int lf_pose_loss_fwd(const float* logits, const float* coefs, const float* targe
 int lf_pose_loss_bwd(const float* logits, const float* coefs, const float* target_depth,
                      const float* target_mask, const float* gsums, float* glogits, float* gcoefs,
                      void* scratch, size_t scratch_bytes, int N, int h, int w, int H, int W, void* stream);
+/* The loss as the cross-entropy and Metropolis estimators evaluate it (PoseEstimator._render_observation,
+ * pose/estimation.py:207-216): the de-normalised crop depth is multiplied by the crop's own sigmoid mask before it is
+ * uncropped, z_depth = denormalize(depth) * mask; everything else as lf_pose_loss_fwd.  Forward only (those estimators
+ * rank hypotheses, they do not differentiate); same scratch size. */
+int lf_pose_loss_fwd_masked(const float* logits, const float* coefs, const float* target_depth,
+                            const float* target_mask, const float* weights, float* sums, float* losses,
+                            void* scratch, size_t scratch_bytes, int N, int h, int w, int H, int W, void* stream);
 
 /* Batched Adam / AdamW step over N independent rows of P parameters (pose/estimation.py:579-594,
  * 664-666).  step_size[n] = lr[n] / (1 - beta1^t) and bias_correction2_sqrt = sqrt(1 - beta2^t)

@@ -156,6 +156,10 @@ __device__ __forceinline__ void clip_pos(float p, int size, float& pos, float& m
 }
 
 // logits: [N][h*w][2] = (depth_logit, mask_logit) per crop pixel (channels-last head output)
+// MASKED: the form the cross-entropy / Metropolis estimators feed the loss (reference pose/estimation.py:207-216): the
+// de-normalised crop depth is multiplied by the crop's own sigmoid mask BEFORE it is uncropped (the gradient estimator
+// passes the depth without that factor, :703-713)
+template <bool MASKED = false>
 __device__ __forceinline__ PixelFwd pixel_forward(const float* __restrict__ lg, const float* __restrict__ cf,
                                                   int h, int w, int x, int y, float td_raw, float mt) {
   PixelFwd r;
@@ -174,6 +178,7 @@ __device__ __forceinline__ PixelFwd pixel_forward(const float* __restrict__ lg, 
   r.mask_on = sigmoidf_(ml) > 0.5f;
   r.dn = r.mask_on ? tanhf(dl) : -1.f;                               // (tanh+1)*(mask>0.5)-1
   r.dhat = r.dn * cf[4] + cf[5];
+  if constexpr (MASKED) r.dhat *= sigmoidf_(ml);
   r.pd = r.dhat * r.sig;
   r.mt = mt;
   r.valid = (td_raw == 0.f && mt > 0.1f) ? 0.f : 1.f;
@@ -198,6 +203,7 @@ __device__ __forceinline__ void block_reduce_store(float (&acc)[NSUM], float* __
   }
 }
 
+template <bool MASKED>
 __global__ void __launch_bounds__(LOSS_BLOCK) pose_loss_fwd_kernel(
     const float* __restrict__ logits, const float* __restrict__ coef, const float* __restrict__ tdepth,
     const float* __restrict__ tmask, float* __restrict__ partial, int nblk, int h, int w, int H, int W) {
@@ -209,7 +215,7 @@ __global__ void __launch_bounds__(LOSS_BLOCK) pose_loss_fwd_kernel(
   for (int i = 0; i < NSUM; ++i) acc[i] = 0.f;
   for (int p = blockIdx.x * LOSS_BLOCK + threadIdx.x; p < H * W; p += nblk * LOSS_BLOCK) {
     const int y = p / W, x = p - y * W;
-    const PixelFwd f = pixel_forward(lg, cf, h, w, x, y, tdepth[p], tmask[p]);
+    const PixelFwd f = pixel_forward<MASKED>(lg, cf, h, w, x, y, tdepth[p], tmask[p]);
     acc[0] += f.l1;
     acc[1] += f.l1 * (f.sig * f.mt);
     acc[2] += f.sig * f.mt;
@@ -415,7 +421,7 @@ extern "C" size_t lf_pose_loss_scratch_bytes(int N, int h, int w, int H, int W) 
   return ((size_t)N * LOSS_NBLK * NSUM + 2 * (size_t)N * H * W + 2 * (size_t)N * H * w) * sizeof(float);
 }
 
-extern "C" int lf_pose_loss_fwd(const float* logits, const float* coefs, const float* target_depth,
+static int pose_loss_fwd_launch(bool masked, const float* logits, const float* coefs, const float* target_depth,
                                 const float* target_mask, const float* weights, float* sums, float* losses,
                                 float* gsums, void* scratch, size_t scratch_bytes,
                                 int N, int h, int w, int H, int W, void* stream) {
@@ -424,13 +430,35 @@ extern "C" int lf_pose_loss_fwd(const float* logits, const float* coefs, const f
   if (scratch_bytes < lf_pose_loss_scratch_bytes(N, h, w, H, W)) return LF_ENOSPC;
   hipStream_t s = (hipStream_t)stream;
   float* partial = (float*)scratch;
-  hipLaunchKernelGGL(pose_loss_fwd_kernel, dim3(LOSS_NBLK, N), dim3(LOSS_BLOCK), 0, s, logits, coefs, target_depth,
-                     target_mask, partial, LOSS_NBLK, h, w, H, W);
+  if (masked)
+    hipLaunchKernelGGL(pose_loss_fwd_kernel<true>, dim3(LOSS_NBLK, N), dim3(LOSS_BLOCK), 0, s, logits, coefs, target_depth,
+                       target_mask, partial, LOSS_NBLK, h, w, H, W);
+  else
+    hipLaunchKernelGGL(pose_loss_fwd_kernel<false>, dim3(LOSS_NBLK, N), dim3(LOSS_BLOCK), 0, s, logits, coefs, target_depth,
+                       target_mask, partial, LOSS_NBLK, h, w, H, W);
   int st = lf_launch_status();
   if (st) return st;
   hipLaunchKernelGGL(pose_loss_finish_kernel, dim3(N), dim3(64), 0, s, partial, LOSS_NBLK, weights, N, H * W, sums, losses,
                      gsums);
   return lf_launch_status();
+}
+
+extern "C" int lf_pose_loss_fwd(const float* logits, const float* coefs, const float* target_depth,
+                                const float* target_mask, const float* weights, float* sums, float* losses,
+                                float* gsums, void* scratch, size_t scratch_bytes,
+                                int N, int h, int w, int H, int W, void* stream) {
+  return pose_loss_fwd_launch(false, logits, coefs, target_depth, target_mask, weights, sums, losses, gsums, scratch,
+                              scratch_bytes, N, h, w, H, W, stream);
+}
+
+extern "C" int lf_pose_loss_fwd_masked(const float* logits, const float* coefs, const float* target_depth,
+                                       const float* target_mask, const float* weights, float* sums, float* losses,
+                                       void* scratch, size_t scratch_bytes,
+                                       int N, int h, int w, int H, int W, void* stream) {
+  // forward only (the estimators that use this form do not differentiate): gsums lands in the scratch tail
+  float* gs = (float*)scratch + (size_t)N * LOSS_NBLK * NSUM;
+  return pose_loss_fwd_launch(true, logits, coefs, target_depth, target_mask, weights, sums, losses, gs, scratch,
+                              scratch_bytes, N, h, w, H, W, stream);
 }
 
 extern "C" int lf_pose_loss_bwd(const float* logits, const float* coefs, const float* target_depth,

@@ -117,8 +117,11 @@ class RenderLoopEngine:
 
     @staticmethod
     def supports(photographer, loss_weights):
-        return (photographer.projection_type == 'factor' and photographer.occlusion_module is None
-                and not photographer.skip_connections and len(photographer.object_blocks) == 0
+        """Renderers the engine sequences: the 'factor' projection (explicit kernels end to end) and -- through the
+        depth-column kernels lf_column_softmax_* / lf_column_scale_* / lf_column_reduce_sum_* -- the 'sum' projection and the
+        occlusion module (reference recon/models.py:378-395,427-437)."""
+        return (photographer.projection_type in ('factor', 'sum')
+                and not photographer.skip_connections
                 and all(b.interpolate is None for b in photographer.camera_blocks)
                 and photographer.predict_depth and photographer.predict_mask and not photographer.predict_color
                 and photographer.camera_config[-1] % 4 == 0)
@@ -137,6 +140,14 @@ class RenderLoopEngine:
         self.cube = photographer.cube_size
         dev = z_obj.device
         self.z = ops.cl(z_obj.reshape(1, *z_obj.shape[-4:]))              # (1,C,S,S,S) channels-last, resident
+        if len(photographer.object_blocks):
+            # object-frame blocks act on the volume BEFORE the camera transform (reference recon/models.py:410-415): every
+            # hypothesis sees the same input, so they are evaluated once per object here, not once per hypothesis per call
+            with torch.no_grad():
+                zo = self.z
+                for blk in photographer.object_blocks:
+                    zo = blk(zo)
+            self.z = ops.cl(zo.detach())
         self.S = self.z.shape[-1]
         self.C = self.z.shape[1]
         self.crop = photographer.out_size
@@ -173,17 +184,26 @@ class RenderLoopEngine:
             self.z_amax = ops.amax_buffer(self.z.abs().max(), dev)
         elif conv_mode == 'winograd' and c16:
             self.wino = [(ops.pack_conv3d_c16_wino(w), ops.pack_conv3d_c16_wino(w, transpose=True)) for w, *_ in self.convs]
-        pw = photographer.projection_block.conv.module.weight
-        cout, C, D = pw.shape[0], self.convs[-1][0].shape[0] if self.convs else self.C, self.S
-        self.proj = (pw, photographer.projection_block.conv.bias, ops.he_constant(pw),
-                     ops.pack_conv1x1(pw.reshape(cout, C, D).permute(0, 2, 1).reshape(cout, D * C)),
-                     ops.pack_conv1x1(pw.reshape(cout, C, D).permute(2, 1, 0).reshape(D * C, cout)))
+        # 'sum' projection / occlusion module: the tail between the camera blocks and the 2-D decoder runs through the
+        # depth-column ops (autograd functions over lf_column_*), the rest of the iteration stays explicit
+        self.generic_tail = photographer.projection_type != 'factor' or photographer.occlusion_module is not None
+        if self.generic_tail and self.split is not None:
+            raise NotImplementedError("the split-precision conv modes drive the plain 'factor' renderer only")
+        C, D = (self.convs[-1][0].shape[0] if self.convs else self.C), self.S
+        cout, pw = C, None
+        self.proj = None
+        if photographer.projection_type == 'factor':
+            pw = photographer.projection_block.conv.module.weight
+            cout = pw.shape[0]
+            self.proj = (pw, photographer.projection_block.conv.bias, ops.he_constant(pw),
+                         ops.pack_conv1x1(pw.reshape(cout, C, D).permute(0, 2, 1).reshape(cout, D * C)),
+                         ops.pack_conv1x1(pw.reshape(cout, C, D).permute(2, 1, 0).reshape(D * C, cout)))
         # factor projection fused into the Winograd kernel of the last camera block (lf_conv3d_c16_wino_projfwd / _projbwd;
         # round 4): forward bit-identical to the two-launch form, backward to the reciprocal of the saved norm.
         # fuse_projection: None = the default ('fwd' where the shapes allow: measured -0.07 ms per iteration; the backward
         # form is correct but trades its 2.1 GB of HBM traffic for +19 % MFMAs on the pipe-bound kernel and comes out even
         # or behind -- profiles/r04_proj_fuse_ab.txt), True = both, or a subset of {'fwd', 'bwd'} / False for A/B runs
-        can_fuse = self.wino is not None and cout == 16 and C == 16
+        can_fuse = self.wino is not None and cout == 16 and C == 16 and not self.generic_tail
         if fuse_projection is None:
             fuse_projection = ('fwd',) if can_fuse else ()
         elif fuse_projection is False:
@@ -199,6 +219,8 @@ class RenderLoopEngine:
             self.proj_fused = (ops.pack_wino_proj(wdm), ops.pack_wino_proj(wdm, transpose=True))
         self.dev = dev
         self.streams, self._side_streams = 1, []
+        self._packs_built = False
+        self._params = list(photographer.parameters())
         self._intr = None                                            # (K, version, gathered): the intrinsics do not change during a loop
         # the output heads (1x1 convolutions without activation, reference blocks.py:108-119) as ONE pointwise convolution
         # with their weights stacked along the output channels: same arithmetic per channel, one launch each way instead
@@ -216,12 +238,15 @@ class RenderLoopEngine:
         self.w_latent = float(loss_weights.get('latent', 0.0))
 
     # -----------------------------------------------------------------------------------------
-    def forward_backward(self, camera, need_grad=True, z_target_latent=None, params=None):
+    def forward_backward(self, camera, need_grad=True, z_target_latent=None, params=None, masked_depth=False):
         """Returns (losses (N,8): depth, ov_depth, iou, mask, weighted total, latent, 0, 0; gparams (N,10) or None).
 
         z_target_latent (N or 1, C2, h, w): the latent code of the target under every hypothesis
         (LatentFusionModel.compute_latent_code); with a non-zero 'latent' weight the cosine distance between it and the
         renderer's projected latent joins the loss (reference pose/estimation.py:112-116), column 5 of `losses`.
+
+        masked_depth (forward only): the loss as the cross-entropy / Metropolis estimators evaluate it -- the crop depth
+        times the crop's sigmoid mask before the uncrop (reference pose/estimation.py:207-216; lf_pose_loss_fwd_masked).
 
         With `streams` = k > 1 (set_streams) the N hypotheses are evaluated as k independent groups on k HIP streams:
         hypotheses do not interact (the reference optimises N separate cameras, estimation.py:580-594), so while one
@@ -230,6 +255,22 @@ class RenderLoopEngine:
         bit-identical to the single-stream evaluation (tests/test_engine_gpu.py)."""
         # `params`: the (N,10) block [log_quaternion | translation | viewport] when the caller already holds it (the estimators'
         # cameras are views of one such tensor), else it is gathered from the camera; the intrinsics are gathered once
+        # the engine differentiates w.r.t. the cameras only: with trainable parameters (the default of a model that was not
+        # frozen: eval() is a pure mode switch, as in the reference) the autograd pieces would save activations for, and
+        # launch, weight-gradient kernels nobody reads -- freeze them for the duration of the call (ADVICE r03)
+        if any(p.requires_grad for p in self._params):
+            live = [p for p in self._params if p.requires_grad]
+            for p in live:
+                p.requires_grad_(False)
+            try:
+                return self.forward_backward(camera, need_grad, z_target_latent, params, masked_depth)
+            finally:
+                for p in live:
+                    p.requires_grad_(True)
+        if masked_depth and need_grad:
+            raise ValueError('masked_depth is the forward-only loss form of the ranking estimators (no gradient is defined here)')
+        if self.w_latent != 0.0 and z_target_latent is None:
+            raise ValueError("the loss weights carry a 'latent' term: pass z_target_latent (LatentFusionModel.compute_latent_code)")
         params = (camera_params(camera) if params is None else params).detach().contiguous()
         K = camera.intrinsic
         # (keyed on the tensor OBJECT, which the cache keeps alive, and its version counter: an address alone could be
@@ -242,8 +283,14 @@ class RenderLoopEngine:
         zt = z_target_latent if (z_target_latent is not None and self.w_latent != 0.0) else None
         if zt is not None and zt.shape[0] == 1 and n > 1:
             zt = zt.expand(n, *zt.shape[1:])
+        if k > 1 and not self._packs_built:
+            # weight packs are memoised on the parameters when the HOST enqueues the packing kernels (ops._cached), with no
+            # stream attached: built inside one group's side stream they could be read by another group's stream before they
+            # are written.  The first evaluation therefore runs on the current stream alone
+            k = 1
+        self._packs_built = True
         if k <= 1:
-            return self._forward_backward_group(params, intr, float(camera.z_span), need_grad, 1.0, zt)
+            return self._forward_backward_group(params, intr, float(camera.z_span), need_grad, 1.0, zt, masked_depth)
         main = torch.cuda.current_stream()
         ready = torch.cuda.Event()
         ready.record(main)
@@ -261,7 +308,7 @@ class RenderLoopEngine:
                 # d(mean over all N) = (group size / N) x d(mean over the group): an exact power-of-two factor for the
                 # usual sizes, applied to the 10 numbers per hypothesis at the end
                 lo, gp = self._forward_backward_group(params[b:e], intr[b:e], float(camera.z_span), need_grad, (e - b) / n,
-                                                      zt[b:e] if zt is not None else None)
+                                                      zt[b:e] if zt is not None else None, masked_depth)
                 done = torch.cuda.Event()
                 done.record(st)
             outs.append((lo, gp, done))
@@ -281,7 +328,7 @@ class RenderLoopEngine:
             self._side_streams.append(torch.cuda.Stream(device=self.dev))
         return self
 
-    def _forward_backward_group(self, params, intr, z_span, need_grad, grad_scale, zt=None):
+    def _forward_backward_group(self, params, intr, z_span, need_grad, grad_scale, zt=None, masked_depth=False):
         L = _lib.lib()
         dev, S, s = self.dev, self.S, _s()
         params = params.contiguous()
@@ -321,23 +368,41 @@ class RenderLoopEngine:
                 y, nrm = ops._conv3x3_raw(acts[-1], wp, b, w.shape[0], he, flags, True)
             acts.append(y)
             norms.append(nrm)
-        pw, pb, phe, ppack, ppack_t = self.proj
-        cout = pw.shape[0]
         Cl = acts[-1].shape[1]
-        if 'fwd' not in self.fuse_projection:
-            zp = ops.empty_cl((n, cout, S, S), dev)
-            with ops._timed('factor_project_fwd'):
-                pnorm = ops._conv1x1_raw(acts[-1], ppack, pb, n, S * S, Cl, S, S * S * S * Cl, S * S * Cl, cout, zp, phe, flags)
+        act_leaf = None
+        if self.generic_tail:
+            # occlusion weights (3-D U-Net logits -> softmax over the depth column -> scale) and / or the 'sum' composite
+            # (reference recon/models.py:378-395,427-437), as in Photographer.forward, differentiated by autograd up to the
+            # last camera block's output
+            from .recon.utils import get_normalized_voxel_depth
+            act_leaf = acts[-1].detach().requires_grad_(need_grad)
+            with torch.set_grad_enabled(need_grad):
+                zt_ = act_leaf
+                if self.ph.occlusion_module is not None:
+                    occ = self.ph.occlusion_module(torch.cat((zt_, get_normalized_voxel_depth(zt_)), dim=1))
+                    wocc = ops.column_softmax(occ)[0]
+                    if tuple(occ.shape[-3:]) != tuple(zt_.shape[-3:]):
+                        wocc = ops.column_softmax(torch.nn.functional.interpolate(occ, zt_.size(-1)))[0]
+                    zt_ = ops.column_scale(zt_, wocc)
+                zp_leaf = ops.column_sum(zt_) if self.ph.projection_type == 'sum' else self.ph.projection_block(zt_)
+            zp = zp_leaf
+        else:
+            pw, pb, phe, ppack, ppack_t = self.proj
+            cout = pw.shape[0]
+            if 'fwd' not in self.fuse_projection:
+                zp = ops.empty_cl((n, cout, S, S), dev)
+                with ops._timed('factor_project_fwd'):
+                    pnorm = ops._conv1x1_raw(acts[-1], ppack, pb, n, S * S, Cl, S, S * S * S * Cl, S * S * Cl, cout, zp, phe, flags)
+            zp_leaf = zp.detach().requires_grad_(need_grad)
 
         # ---- 2-D decoder + heads (autograd over small maps) + fused loss ----
-        zp_leaf = zp.detach().requires_grad_(need_grad)
         with torch.set_grad_enabled(need_grad):
             yimg = self.ph.image_decoder(zp_leaf)
             if self.heads is not None:
                 logits = ops.conv1x1(yimg, self.heads[0], self.heads[1])
             else:
                 logits = torch.cat([ob(yimg) for ob in self.ph.output_blocks], dim=1)
-        if zt is None:
+        if zt is None or not need_grad:
             # the optimised quantity is mean_n(total) (estimation.py:616-617): lf_pose_loss_fwd already leaves the sums'
             # gradients for exactly that, so the loss needs no autograd node -- logits -> loss -> d/d(logits, coefficients)
             # are two kernel calls, and autograd only carries d(logits) back through the decoder
@@ -348,10 +413,20 @@ class RenderLoopEngine:
             sums = torch.empty(n, 8, device=dev, dtype=torch.float32)
             losses = torch.empty(n, 8, device=dev, dtype=torch.float32)
             gsums = torch.empty(n, 8, device=dev, dtype=torch.float32)
-            check(L.lf_pose_loss_fwd(lg.data_ptr(), coefs.data_ptr(), self.tdepth.data_ptr(), self.tmask.data_ptr(),
-                                     self.weights.data_ptr(), sums.data_ptr(), losses.data_ptr(), gsums.data_ptr(),
-                                     scratch_l.data_ptr(), scratch_l.numel() * 4, n, h_, w_, self.H, self.W, s), 'lf_pose_loss_fwd')
+            if masked_depth:
+                check(L.lf_pose_loss_fwd_masked(lg.data_ptr(), coefs.data_ptr(), self.tdepth.data_ptr(), self.tmask.data_ptr(),
+                                                self.weights.data_ptr(), sums.data_ptr(), losses.data_ptr(), scratch_l.data_ptr(),
+                                                scratch_l.numel() * 4, n, h_, w_, self.H, self.W, s), 'lf_pose_loss_fwd_masked')
+            else:
+                check(L.lf_pose_loss_fwd(lg.data_ptr(), coefs.data_ptr(), self.tdepth.data_ptr(), self.tmask.data_ptr(),
+                                         self.weights.data_ptr(), sums.data_ptr(), losses.data_ptr(), gsums.data_ptr(),
+                                         scratch_l.data_ptr(), scratch_l.numel() * 4, n, h_, w_, self.H, self.W, s), 'lf_pose_loss_fwd')
             if not need_grad:
+                if zt is not None:
+                    # latent term of a ranking-only evaluation: cosine distance of the projected latent (estimation.py:112-116)
+                    lat = 1.0 - torch.cosine_similarity(zp.reshape(n, -1), zt.reshape(n, -1).to(zp.dtype), 1, 1e-8)
+                    losses[:, 5] = lat
+                    losses[:, 4] += self.w_latent * lat
                 return losses, None
             glogits = torch.empty_like(lg)
             # (lf_pose_loss_bwd writes entries 18..23; 0..17 come from the resampler's coefficient gradient below)
@@ -359,7 +434,7 @@ class RenderLoopEngine:
             check(L.lf_pose_loss_bwd(lg.data_ptr(), coefs.data_ptr(), self.tdepth.data_ptr(), self.tmask.data_ptr(), gsums.data_ptr(),
                                      glogits.data_ptr(), g_cf.data_ptr(), scratch_l.data_ptr(), scratch_l.numel() * 4,
                                      n, h_, w_, self.H, self.W, s), 'lf_pose_loss_bwd')
-            g_zp, = torch.autograd.grad(logits, [zp_leaf], grad_outputs=[glogits])
+            g_zp, = torch.autograd.grad(logits, [act_leaf if self.generic_tail else zp_leaf], grad_outputs=[glogits])
         else:
             cf_leaf = coefs.detach().requires_grad_(need_grad)
             with torch.set_grad_enabled(need_grad):
@@ -373,12 +448,35 @@ class RenderLoopEngine:
                 objective = total.mean()                     # the optimised quantity (estimation.py:616-617)
             if not need_grad:
                 return losses, None
-            g_zp, g_cf = torch.autograd.grad(objective, [zp_leaf, cf_leaf])
+            g_zp, g_cf = torch.autograd.grad(objective, [act_leaf if self.generic_tail else zp_leaf, cf_leaf])
 
         # ---- 3-D backward (data gradients only) ----
-        gp = ops._epilogue_bwd(ops.cl(g_zp), zp, pnorm, flags)
         fuse = (Cl == 16 and self.C == 16 and all(w.shape[0] == 16 and w.shape[1] == 16 for w, *_ in self.convs))
         nconv = len(self.convs)
+        if self.generic_tail:
+            # g_zp is d/d(output of the last camera block); from here the explicit data-gradient chain
+            g = ops.cl(g_zp)
+            if fuse and nconv:
+                g = ops._epilogue_bwd(g, acts[nconv], norms[nconv - 1], flags)
+                for i in range(nconv - 1, -1, -1):
+                    w, b, he, _wp, wt = self.convs[i]
+                    prev = (acts[i], norms[i - 1], flags) if i > 0 else None
+                    if self.wino is not None:
+                        g, _ = ops.conv3d_c16_wino(g, self.wino[i][1], None, he, 0, prev=prev)
+                    elif self.split is not None:
+                        raise NotImplementedError('split-precision kernels drive the factor renderer only')
+                    else:
+                        g = ops.conv3x3_bwd_data(g, wt, w.shape[1], he, prev)
+            else:
+                for i in range(nconv - 1, -1, -1):
+                    w, b, he, _wp, wt = self.convs[i]
+                    gpre = ops._epilogue_bwd(g, acts[i + 1], norms[i], flags)
+                    if self.wgemm is not None:
+                        g, _ = ops.wide_conv(gpre, self.wgemm[i], None, he, 0, transpose=True)
+                    else:
+                        g, _ = ops._conv3x3_raw(gpre, wt, None, w.shape[1], he, 0, False)
+            return self._finish_backward(g, g_cf, cf20, jac, n, grad_scale, losses)
+        gp = ops._epilogue_bwd(ops.cl(g_zp), zp, pnorm, flags)
         fuse_pb = fuse and nconv and 'bwd' in self.fuse_projection
         g = None if fuse_pb else ops.empty_cl((n, Cl, S, S, S), dev)
         if fuse_pb:
@@ -424,6 +522,12 @@ class RenderLoopEngine:
                     g, _ = ops.wide_conv(gpre, self.wgemm[i], None, he, 0, transpose=True)
                 else:
                     g, _ = ops._conv3x3_raw(gpre, wt, None, w.shape[1], he, 0, False)
+        return self._finish_backward(g, g_cf, cf20, jac, n, grad_scale, losses)
+
+    def _finish_backward(self, g, g_cf, cf20, jac, n, grad_scale, losses):
+        """d/d(O2C output) -> coefficient gradient -> camera parameters (lf_resample3d_bwd_coef, lf_camera_coefs_bwd)."""
+        L = _lib.lib()
+        dev, S, s = self.dev, self.S, _s()
         gcoef18 = torch.empty(n, 18, device=dev, dtype=torch.float32)
         nbytes = L.lf_resample3d_bwd_coef_scratch_bytes(n, S, S, S)
         scratch = torch.empty(nbytes // 4 + 1, device=dev, dtype=torch.float32)

@@ -18,10 +18,16 @@ import torch
 import torch.distributed as dist
 
 
-def world():
+def world(group=None):
+    """(rank, size) within `group` (the default group when None); (0, 1) outside torch.distributed."""
     if dist.is_available() and dist.is_initialized():
-        return dist.get_rank(), dist.get_world_size()
+        return dist.get_rank(group), dist.get_world_size(group)
     return 0, 1
+
+
+def _global(group, r):
+    """Global rank of group-rank r (send / recv / broadcast address peers by GLOBAL rank even when given a group)."""
+    return r if group is None else dist.get_global_rank(group, r)
 
 
 def shard_range(n, rank, size):
@@ -75,7 +81,7 @@ def fuse_sharded(fuser, z_local, num_views_total, group=None, z_cam_mid_local=No
     median        all-gather of the per-view volumes in rank (= view) order (the median needs every view), then the
                   fuser runs replicated on the full, ordered view list.
     """
-    rank, size = world()
+    rank, size = world(group)
     kind = type(fuser).__name__
     pool = getattr(fuser, 'pool_type', None)
     if size == 1:
@@ -171,31 +177,34 @@ def _fuse_recurrent_pipelined(fuser, z_local, counts, rank, size, group, recurre
     have = z_local.shape[1] > 0
     vol = (1, 1) + tuple(z_local.shape[2:])
     nstate = 2 if recurrence == 'lstm' else 1
-    out = z_local.new_empty(vol)
-    if have:
-        state = None
-        if rank > 0:
-            state = z_local.new_empty((nstate,) + vol)
-            _recv(state, rank - 1, group)
-        if recurrence == 'gru':
-            stack = z_local if state is None else torch.cat((state[0], z_local), dim=1)
-            out = fuser(stack, None, None, None)[0].contiguous()
-            nxt = out.unsqueeze(0)
-        else:
-            init = None if state is None else (state[0][:, 0], state[1][:, 0])
-            out, extra = fuser(z_local, None, None, None, initial_state=init)
-            out = out.contiguous()
-            nxt = torch.stack((out, extra['state'][1].unsqueeze(1)), dim=0)
-        if rank < last:
-            _send(nxt, rank + 1, group)
-    dist.broadcast(out, src=last, group=group)
+    # (rank / size / counts are GROUP ranks; the point-to-point calls and the broadcast source take global ranks.  Inference
+    # only: the result is broadcast in place, so nothing here may be an autograd output)
+    with torch.no_grad():
+        out = z_local.new_empty(vol)
+        if have:
+            state = None
+            if rank > 0:
+                state = z_local.new_empty((nstate,) + vol)
+                _recv(state, _global(group, rank - 1), group)
+            if recurrence == 'gru':
+                stack = z_local if state is None else torch.cat((state[0], z_local), dim=1)
+                out = fuser(stack, None, None, None)[0].contiguous()
+                nxt = out.unsqueeze(0)
+            else:
+                init = None if state is None else (state[0][:, 0], state[1][:, 0])
+                out, extra = fuser(z_local, None, None, None, initial_state=init)
+                out = out.contiguous()
+                nxt = torch.stack((out, extra['state'][1].unsqueeze(1)), dim=0)
+            if rank < last:
+                _send(nxt, _global(group, rank + 1), group)
+        dist.broadcast(out, src=_global(group, last), group=group)
     return out
 
 
 def build_latent_object_sharded(model, observation, group=None):
     """LatentFusionModel.build_latent_object with the reference views sharded over the ranks of
     `group`.  Every rank passes the SAME full observation; each encodes only its slice."""
-    rank, size = world()
+    rank, size = world(group)
     obs = model.preprocess_observation(observation.to(model.device))
     total = len(obs)
     local, (b, e) = shard_views(obs, rank, size)
@@ -310,6 +319,7 @@ class GradientBuckets:
     def reset(self):
         self.left = list(self.members)
         self.launched = [False] * self.nb
+        self.next = self.nb - 1                            # buckets leave in ONE order on every rank: nb-1, nb-2, ..., 0
         self.handles = []
 
     def _launch(self, b):
@@ -318,6 +328,15 @@ class GradientBuckets:
             piece = self.grad[b * self.step:(b + 1) * self.step]
             self.handles.append(dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
+    def _drain(self, force=False):
+        """Launches the ready buckets in descending index order (gradients arrive last layer first, i.e. from the end of the flat
+        buffer): c10d needs every rank to issue its collectives in the same order, and the order in which hooks happen to
+        complete buckets may differ between ranks (a parameter unused on one rank, data-dependent branches) -- a bucket
+        therefore waits for every bucket above it, as torch's DDP does."""
+        while self.next >= 0 and (force or self.left[self.next] <= 0):
+            self._launch(self.next)
+            self.next -= 1
+
     def _hook(self, i):
         def fire(_param):
             if not self.armed:                             # gradient-accumulation micro-batch: nothing leaves the rank yet
@@ -325,8 +344,7 @@ class GradientBuckets:
             b0, b1 = self.of_param[i]
             for b in range(b0, b1 + 1):
                 self.left[b] -= 1
-                if self.left[b] == 0:
-                    self._launch(b)
+            self._drain()
         return fire
 
     def arm(self, on=True):
@@ -339,8 +357,7 @@ class GradientBuckets:
         self.armed = False
         rank, size = world()
         if size > 1:
-            for b in range(self.nb):
-                self._launch(b)
+            self._drain(force=True)
             for h in self.handles:
                 h.wait()
             self.grad.div_(size)

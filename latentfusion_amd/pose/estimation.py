@@ -65,13 +65,17 @@ def load_schedules_from_config(config):
 
 class PoseEstimator:
     def __init__(self, *, model, ranking_size, loss_weights, loss_func=None, return_camera_history=False,
-                 verbose=False, shard_hypotheses=False):
+                 verbose=False, shard_hypotheses=False, use_engine=True, conv_mode='auto', fuse_projection=None):
         """shard_hypotheses (an addition; the reference is single-process): under torch.distributed every rank
         renders and scores only its contiguous slice of the pose hypotheses; the per-hypothesis rows (loss
         [+ camera parameters]) are all-gathered once per iteration (parallel.gather_rows) and every rank ranks the
         full set, so the returned ranking is identical on all ranks and to a one-rank run.  Host-random draws
         (initial hypotheses, GMM samples) are taken from rank 0."""
         self.model = model
+        # use_engine / conv_mode / fuse_projection (additions): the fused render-and-score engine (engine.py) evaluates the
+        # hypotheses when the renderer and the loss are of the kind it sequences; False selects the generic module path
+        self.use_engine, self.conv_mode, self.fuse_projection = use_engine, conv_mode, fuse_projection
+        self._engine_cache = None
         self.shard_hypotheses = bool(shard_hypotheses)
         self.ranking_size = ranking_size
         self.loss_func = default_pose_loss if loss_func is None else loss_func
@@ -129,6 +133,43 @@ class PoseEstimator:
         del ranking[self.ranking_size:]
         best = ranking[0][1]
         return prev_best - best if best < prev_best else 0.0
+
+    def _engine_for(self, z_obj, target_obs, schedules=()):
+        """The fused HIP engine when the configuration allows it (default loss, factor-projection renderer); None selects
+        the generic autograd-module path."""
+        if not self.use_engine or self.loss_func is not default_pose_loss or not z_obj.is_cuda:
+            return None
+        from ..engine import RenderLoopEngine
+        ph = getattr(self.model, 'photographer', None)
+        if ph is None or not RenderLoopEngine.supports(ph, self.loss_weights):
+            return None
+        # a scheduled term the fused loss does not evaluate (e.g. [loss_schedules.latent] with loss_weights.latent = 0)
+        # must not be dropped silently: the reference applies every scheduled weight (estimation.py:612-617)
+        if any(k not in RenderLoopEngine.LOSS_KEYS + ('latent',) for k in schedules):
+            return None
+        return RenderLoopEngine(ph, z_obj, target_obs, self.loss_weights, conv_mode=self.conv_mode,
+                                fuse_projection=self.fuse_projection)
+
+    def _ranking_engine(self, z_obj, target_obs):
+        """One engine per (object, target) for the ranking-only estimators; the cache keeps both alive, so an address
+        cannot be reused by another volume while the entry exists."""
+        c = self._engine_cache
+        if c is None or c[0] is not z_obj or c[1] is not target_obs:
+            self._engine_cache = c = (z_obj, target_obs, self._engine_for(z_obj, target_obs))
+        return c[2]
+
+    def _score_samples(self, z_obj, target_obs, cameras, z_target_latent=None):
+        """Weighted pose loss of every hypothesis, no gradient: zoom, render, denormalise, multiply by the mask, loss
+        (reference :207-216 + :383-401).  On the fused engine when it supports the renderer (lf_pose_loss_fwd_masked)."""
+        eng = self._ranking_engine(z_obj, target_obs)
+        with torch.no_grad():
+            if eng is not None:
+                z_camera = cameras.zoom(None, self.model.input_size, self.model.camera_dist).to(self.device)
+                losses, _ = eng.forward_backward(z_camera, need_grad=False, z_target_latent=z_target_latent, masked_depth=True)
+                return losses[:, 4].clone()
+            zd, zl, z_lat, z_camera = self._render_observation(z_obj, cameras)
+            ld = self.loss_func(target_obs, zd, zl, z_camera, z_pred_latent=z_lat, z_target_latent=z_target_latent)
+            return sum(weigh_losses(ld, self.loss_weights).values())
 
     def _render_observation(self, z_obj, camera, **kwargs):
         """Zoom, render without grad, denormalise, multiply by the mask (reference :207-216)."""
@@ -252,9 +293,7 @@ class CrossEntropyPoseEstimator(PoseEstimator):
             local = cameras[b:e]
         with torch.no_grad():
             if len(local):
-                zd, zl, z_lat, z_camera = self._render_observation(z_obj, local)
-                ld = self.loss_func(target_obs, zd, zl, z_camera, z_pred_latent=z_lat, z_target_latent=z_target_latent)
-                loss = sum(weigh_losses(ld, self.loss_weights).values())
+                loss = self._score_samples(z_obj, target_obs, local, z_target_latent)
             else:
                 loss = torch.zeros(0, device=cameras.device)
             if size > 1:
@@ -408,11 +447,8 @@ class GradientPoseEstimator(PoseEstimator):
                  lr_reduce_patience=25, lr_reduce_threshold=1e-5, lr_reduce_factor=0.5, track_stats=False,
                  loss_schedules=None, optimizer='adamw', use_engine=True, conv_mode='auto', engine_streams=1,
                  fuse_projection=None, **kwargs):
-        super().__init__(**kwargs)
-        self.use_engine = use_engine
-        self.conv_mode = conv_mode
+        super().__init__(use_engine=use_engine, conv_mode=conv_mode, fuse_projection=fuse_projection, **kwargs)
         self.engine_streams = engine_streams     # hypothesis groups evaluated concurrently on separate HIP streams (engine.py)
-        self.fuse_projection = fuse_projection   # engine.py: None = fused projection kernels where the shapes allow; False / subset for A/B
         self.learning_rate, self.num_samples, self.num_iters = learning_rate, num_samples, num_iters
         self.optimizer = optimizer
         self.lr_reduce_patience, self.lr_reduce_threshold = lr_reduce_patience, lr_reduce_threshold
@@ -452,21 +488,9 @@ class GradientPoseEstimator(PoseEstimator):
         rank_loss = sum(weigh_losses(loss_dict, self.loss_weights).values()).detach()
         return loss_dict, optim_loss.detach(), rank_loss, optim_weights
 
-    def _engine_for(self, z_obj, target_obs):
-        """The fused HIP engine when the configuration allows it (default loss, factor-projection
-        renderer, no latent term); None selects the generic autograd-module path."""
-        if not self.use_engine or self.loss_func is not default_pose_loss or not z_obj.is_cuda:
-            return None
-        from ..engine import RenderLoopEngine
-        ph = getattr(self.model, 'photographer', None)
-        if ph is None or not RenderLoopEngine.supports(ph, self.loss_weights):
-            return None
-        # a scheduled term the fused loss does not evaluate (e.g. [loss_schedules.latent] with loss_weights.latent = 0)
-        # must not be dropped silently: the reference applies every scheduled weight (estimation.py:612-617)
-        if any(k not in RenderLoopEngine.LOSS_KEYS + ('latent',) for k in self.loss_schedules):
-            return None
-        return RenderLoopEngine(ph, z_obj, target_obs, self.loss_weights, conv_mode=self.conv_mode,
-                                fuse_projection=self.fuse_projection).set_streams(self.engine_streams)
+    def _engine_for(self, z_obj, target_obs, schedules=()):
+        eng = super()._engine_for(z_obj, target_obs, schedules=self.loss_schedules)
+        return eng.set_streams(self.engine_streams) if eng is not None else None
 
     @classmethod
     def get_optimizer(cls, name, *args, **kwargs):

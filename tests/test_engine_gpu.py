@@ -611,3 +611,133 @@ def test_engine_latent_term_matches_module_path(golden):
     la, lb = torch.stack([h[0] for h in ha]), torch.stack([h[0] for h in hb])
     close(lb[0], la[0], atol=5e-6, rtol=1e-4)
     close(lb, la, atol=0.0, rtol=2e-2)
+
+
+def test_cross_entropy_scoring_runs_on_the_engine_and_matches_the_module_path(golden):
+    """CrossEntropyPoseEstimator.evaluate_samples on the fused engine (forward only, lf_pose_loss_fwd_masked: the crop depth is
+    multiplied by the crop's sigmoid mask before the uncrop, reference pose/estimation.py:207-216) against the same estimator
+    on the generic module path and against the reference's golden losses / order (g8); then with a latent term."""
+    from latentfusion_amd import synth
+    from latentfusion_amd.engine import RenderLoopEngine
+    from latentfusion_amd.observation import Observation
+    from latentfusion_amd.pose import estimation
+    from latentfusion_amd.recon import fusion
+    from latentfusion_amd.recon.inference import LatentFusionModel
+    from latentfusion_amd.recon.models import Photographer, Sculptor
+    g, t7 = golden('g8_ce_step'), golden('g7_adam_trace')
+    model = LatentFusionModel(Sculptor.from_checkpoint(t7['sculptor']), fusion.from_checkpoint(t7['fuser']),
+                              Photographer.from_checkpoint(t7['photographer']), t7['camera_dist'], DEV)
+    tg = t7['target']
+    target = Observation(None, tg['depth'], tg['mask'].float(), prod_camera(tg['cam'], 'cpu')).to(DEV)
+    z_obj = t7['z_obj'].to(DEV)
+    kw = dict(model=model, num_samples=24, num_elites=5, num_iters=3, num_gmm_components=2, learning_rate=0.9,
+              sample_flipped=True, ranking_size=4, loss_weights=g['weights'])
+    on, off = estimation.CrossEntropyPoseEstimator(**kw), estimation.CrossEntropyPoseEstimator(use_engine=False, **kw)
+    _, l_on = on.evaluate_samples(z_obj, target, prod_camera(g['cams']))
+    _, l_off = off.evaluate_samples(z_obj, target, prod_camera(g['cams']))
+    assert isinstance(on._ranking_engine(z_obj, target), RenderLoopEngine) and off._ranking_engine(z_obj, target) is None
+    close(l_on, l_off, atol=2e-6, rtol=2e-5)
+    close(l_on, g['loss'], atol=1e-4, rtol=1e-3)
+    assert torch.argsort(l_on).cpu().tolist() == g['order'].tolist()
+    # the masked form is NOT the gradient estimator's form: the two must differ where the mask is soft
+    eng = on._ranking_engine(z_obj, target)
+    zc = prod_camera(g['cams']).zoom(None, model.input_size, model.camera_dist).to(DEV)
+    plain, _ = eng.forward_backward(zc, need_grad=False)
+    masked, _ = eng.forward_backward(zc, need_grad=False, masked_depth=True)
+    assert not torch.equal(plain[:, 0], masked[:, 0]) and torch.equal(plain[:, 2:4], masked[:, 2:4])
+    with pytest.raises(ValueError):
+        eng.forward_backward(zc, need_grad=True, masked_depth=True)
+
+    # SYN(16,16) (Winograd kernels, fused projection) with a latent term: engine == modules, per sample and in order
+    model2, _ = synth.build_model(16, 16, 'pool:mean', seed=4, device=DEV, bias_std=0.05)
+    gen = torch.Generator().manual_seed(9)
+    z2 = torch.randn(1, 1, 16, 16, 16, 16, generator=gen).to(DEV)
+    tcol = _target_with_color(t7).to(DEV)
+    w2 = {'depth': 1.0, 'ov_depth': 0.3, 'iou': 0.2, 'mask': 0.4, 'latent': 0.5}
+    kw2 = dict(model=model2, num_samples=16, num_elites=4, num_iters=2, num_gmm_components=2, learning_rate=0.9,
+               sample_flipped=True, ranking_size=4, loss_weights=w2)
+    cams = prod_camera(t7['init'])[:4]
+    a_ = estimation.CrossEntropyPoseEstimator(**kw2).evaluate_samples(z2, tcol, cams)[1]
+    b_ = estimation.CrossEntropyPoseEstimator(use_engine=False, **kw2).evaluate_samples(z2, tcol, cams)[1]
+    assert a_.shape == (16,)
+    close(a_, b_, atol=5e-6, rtol=5e-5)
+    assert torch.equal(torch.argsort(a_), torch.argsort(b_))
+    # a latent weight without the target's code is an error, not a silently shorter loss (ADVICE r03)
+    eng2 = RenderLoopEngine(model2.photographer, z2, tcol, w2)
+    with pytest.raises(ValueError):
+        eng2.forward_backward(cams.zoom(None, model2.input_size, model2.camera_dist).to(DEV), need_grad=False)
+
+
+@pytest.mark.parametrize('variant', ['factor', 'sum', 'occlusion'])
+def test_engine_renders_the_sum_and_occlusion_variants(golden, variant):
+    """RenderLoopEngine on the three renderer variants of the reference (recon/models.py:378-395,427-437: 'factor' projection,
+    'sum' composite, occlusion softmax over the depth column) against Photographer.decode + default_pose_loss through the
+    generic modules on the golden fixture's network (g5): the four loss terms, their weighted sum and the camera gradients;
+    the forward-only ranking form as well."""
+    from latentfusion_amd.engine import RenderLoopEngine
+    from latentfusion_amd.pose import estimation
+    from latentfusion_amd.recon.models import Photographer
+    r = golden('g5_decode')[variant]
+    ph = Photographer.from_checkpoint(r['ck']).to(DEV)
+    for p in ph.parameters():
+        p.requires_grad_(False)
+    weights = {'depth': 1.0, 'ov_depth': 0.3, 'iou': 0.2, 'mask': 0.4}
+    assert RenderLoopEngine.supports(ph, weights)
+    target = _target(golden('g7_adam_trace'))
+    z_obj = r['z_obj'].to(DEV)
+
+    class _M:                                                     # the facade surface the estimator touches
+        photographer, device, input_size, camera_dist = ph, torch.device(DEV), ph.in_size, 1.0
+
+        @staticmethod
+        def render_latent_object(z, cam, return_latent=True, apply_mask=True):
+            y, zl, _ = ph.decode(z, cam, return_latent=return_latent, apply_mask=apply_mask)
+            return y, (zl.squeeze(0) if return_latent else zl)
+    cam0 = prod_camera(r['cam'])
+    est = estimation.GradientPoseEstimator(model=_M, learning_rate=0.01, num_samples=len(cam0), num_iters=1, ranking_size=len(cam0),
+                                           converge_threshold=1e-6, converge_patience=10, optimizer='adam', loss_weights=weights,
+                                           use_engine=False)
+    st = est.start(z_obj, target, cam0)
+    assert 'engine' not in st
+    ld, _, rank, _ = est.loss_and_grad(z_obj, target, st['cam'])
+    want_g = torch.cat((st['cam'].log_quaternion.grad, st['cam'].translation.grad, st['cam'].viewport.grad), dim=1)
+    eng = RenderLoopEngine(ph, z_obj, target, weights)
+    assert eng.generic_tail == (variant != 'factor')
+    losses, gparams = eng.forward_backward(cam0)
+    for i, k in enumerate(eng.LOSS_KEYS):
+        close(losses[:, i], ld[k], atol=5e-6, rtol=5e-5)
+    close(losses[:, 4], rank, atol=5e-6, rtol=5e-5)
+    rel = ((gparams - want_g).norm(dim=1) / want_g.norm(dim=1)).max().item()
+    assert rel < 2e-3, (variant, rel)
+    fwd_only, none = eng.forward_backward(cam0, need_grad=False)
+    assert none is None and torch.equal(fwd_only, losses)
+    # the estimator now takes the engine for these renderers
+    est2 = estimation.GradientPoseEstimator(model=_M, learning_rate=0.01, num_samples=len(cam0), num_iters=1, ranking_size=len(cam0),
+                                            converge_threshold=1e-6, converge_patience=10, optimizer='adam', loss_weights=weights)
+    assert 'engine' in est2.start(z_obj, target, cam0)
+
+
+def test_engine_first_call_on_several_streams(golden):
+    """a FRESH engine (fresh model: no weight pack exists yet) whose very first evaluation is multi-stream must give
+    the single-stream result -- the packs are built on the current stream before any side stream reads them."""
+    from latentfusion_amd import synth
+    from latentfusion_amd.engine import RenderLoopEngine
+    g = golden('g7_adam_trace')
+    target = _target(g)
+    weights = {'depth': 1.0, 'ov_depth': 0.3, 'iou': 0.2, 'mask': 0.4}
+    gen = torch.Generator().manual_seed(9)
+    z_obj = torch.randn(1, 1, 16, 32, 32, 32, generator=gen).to(DEV)
+    outs = []
+    for k in (1, 4, 2):
+        model, _ = synth.build_model(32, 16, 'pool:mean', seed=4, device=DEV, bias_std=0.05)     # new parameters: no cached packs
+        model.freeze()
+        cam0 = prod_camera(g['init']).zoom(None, model.input_size, model.camera_dist)
+        eng = RenderLoopEngine(model.photographer, z_obj, target, weights).set_streams(k)
+        first = eng.forward_backward(cam0)
+        second = eng.forward_backward(cam0)                       # this one IS multi-stream
+        torch.cuda.synchronize()
+        outs.append((first, second))
+    for first, second in outs:
+        assert torch.equal(first[0], outs[0][0][0]) and torch.equal(second[0], outs[0][0][0])
+        close(first[1], outs[0][0][1], atol=0.0, rtol=2e-5)
+        close(second[1], outs[0][0][1], atol=0.0, rtol=2e-5)
