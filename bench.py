@@ -74,6 +74,8 @@ def parse(argv=None):
                          'RCCL all-reduce of the latent volume (parallel.build_latent_object_sharded); reported as '
                          '`sharded_build`.  ON by default when N > 1 (the north-star collective); this flag forces it at N = 1')
     ap.add_argument('--no-sharded-build', action='store_true', help='skip the view-sharded build at N > 1')
+    ap.add_argument('--fuse-projection', default='default', choices=['default', 'none', 'fwd', 'bwd', 'both'],
+                    help="factor projection fused into the last camera block's Winograd kernels (engine.py): 'default' = forward form")
     ap.add_argument('--conv-mode', default='winograd', choices=['fp32', 'winograd', 'f16x3', 'winograd_f16x3'],
                     help="conv3d kernels of the engine: 'winograd' (default; F(2^3,3^3) minimal filtering, all-fp32 "
                          "arithmetic), 'fp32' (direct implicit GEMM on the fp32 MFMA) or 'f16x3' (split precision)")
@@ -482,7 +484,9 @@ def main():
     cfg = estimation._load_toml(os.path.join(ROOT, 'configs', 'adam_quick.toml'))
     cfg['args']['num_samples'] = N
     cfg['args']['ranking_size'] = N
-    est = estimation.load_from_config(cfg, model, converge_patience=10 ** 6, conv_mode=a.conv_mode, engine_streams=a.engine_streams)
+    fuse_sel = {'default': None, 'none': False, 'fwd': ('fwd',), 'bwd': ('bwd',), 'both': True}[a.fuse_projection]
+    est = estimation.load_from_config(cfg, model, converge_patience=10 ** 6, conv_mode=a.conv_mode, engine_streams=a.engine_streams,
+                                      fuse_projection=fuse_sel)
     torch.manual_seed(300 + rank)
     init = pu.sample_cameras_with_estimate(N, target.camera.to('cpu'))
     init_rec = {'K': init.intrinsic.clone(), 'log_q': init.log_quaternion.clone(), 't': init.translation.clone()}
@@ -506,6 +510,7 @@ def main():
         blocks, timer_ = [], []
         # HIP events only around the kernels the roofline fields report (an event pair costs a few us of dispatch gap)
         ops.KERNEL_TIMER_TAGS = {'conv3d_c16_wino', 'conv3d_c16_split', 'conv3d_c16_wino_split', f'conv3x3_3d_{C}x{C}',
+                                 'conv3d_c16_wino_projfwd', 'conv3d_c16_wino_projbwd',
                                  'resample_fwd', 'resample_bwd_coef', 'factor_project_fwd', 'factor_project_bwd'}
         for _rep in range(max(1, a.repeats)):
             barrier()
@@ -618,6 +623,20 @@ def main():
         if cnt_:
             others[tag] = {'avg_launch_ms': ms_, 'launches_timed': cnt_, 'algorithmic_bytes': nbytes,
                            'hbm_frac': nbytes / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    # round 4: the last camera block's convolution with the factor projection fused in (one launch instead of two): its own
+    # executed flops (Winograd products + the projection's 2 * 16 * 16 per voxel) and algorithmic bytes
+    for tag, extra_fl, nbytes, what in (
+            ('conv3d_c16_wino_projfwd', 2.0 * 16 * 16 * nvox, alg_bytes + N * 17 * S * S * 4,
+             'conv3d_c16_wino_projfwd_kernel: camera-block conv 2 + factor projection forward'),
+            ('conv3d_c16_wino_projbwd', 2.0 * 16 * 16 * nvox * (10 * 18) / (8 * 16), alg_bytes + (C + 1) * nvox * 4 + N * 16 * S * S * 4,
+             'conv3d_c16_wino_projbwd_kernel: factor projection backward + first data-gradient conv')):
+        ms_, cnt_ = avg_ms(tag)
+        if cnt_ and wino:
+            fl_ = alg_flops * 64.0 / 216.0 + extra_fl
+            tr_, trs_ = pmc_traffic(tag + '_kernel')
+            others[tag] = {'kernel': what, 'avg_launch_ms': ms_, 'launches_timed': cnt_, 'executed_flops': fl_,
+                           'mfma_frac': fl_ / (ms_ * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 'algorithmic_bytes': nbytes,
+                           'hbm_frac': nbytes / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': tr_, 'traffic_source': trs_}
     # whole iteration vs its HBM floor (~2.2 GB per pose sample forward + backward)
     iter_bytes = 2.2e9 * N * (S / 128.0) ** 3 * (C / 16.0)
     iter_floor_ms = iter_bytes / (HBM_PEAK_GBS * 1e9) * 1e3

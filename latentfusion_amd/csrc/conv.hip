@@ -30,7 +30,7 @@ template <> struct TileGeom<2> { static constexpr int TY = 16, TZ = 1, HY = 18, 
 // rowidx[j] = flat voxel index (for norm_out).  Output channel co lands at
 // rowoff + (co / ysc) * yss + (co % ysc): ysc >= Cout gives the plain channels-last record,
 // smaller ysc scatters channel slices (depth-unfolded outputs).
-template <int NT, int NR>
+template <int NT, int NR, bool WHOLE = false>
 __device__ __forceinline__ void epilogue_store(f32x4 (&acc)[NT][NR], const long (&rowoff)[NR], const long (&rowidx)[NR],
                                                const float* __restrict__ bias, float* __restrict__ y,
                                                float* __restrict__ norm_out, int Cout, int co_base,
@@ -76,6 +76,12 @@ __device__ __forceinline__ void epilogue_store(f32x4 (&acc)[NT][NR], const long 
       // records; fold that layer's LeakyReLU' * PixelNorm' in here (saves one HBM round trip):
       //   g <- lrelu'(y_prev) * (g - y_prev * mean_c(g * y_prev)) / norm_prev      (C == 16 per tile)
       // All NT loads are issued before the first use so they overlap each other.
+      // Two record shapes: 16-channel slices (ysc == 16: the unfolding factor projection, every tile its own voxel and norm)
+      // and -- round 4 -- WHOLE rows of Cout channels (ysc >= Cout, all of them in this workgroup's NT tiles: the 2-D decoder's
+      // 32-channel layers), whose PixelNorm' dot product runs over all tiles of the row and whose norm is indexed by the row.
+      // (compile-time: the multi-tile 3x3 kernels only -- the sliced pointwise kernel must not pay registers for it, and a
+      // single 16-channel tile is the same arithmetic either way)
+      constexpr bool whole = WHOLE;
       f32x4 ypv[NT];
       float nrv[NT];
 #pragma unroll
@@ -84,17 +90,29 @@ __device__ __forceinline__ void epilogue_store(f32x4 (&acc)[NT][NR], const long 
         const bool ok = rowoff[j] >= 0 && co < Cout;
         const long off = ok ? rowoff[j] + (long)(co / ysc) * yss + (co % ysc) : 0;
         ypv[t] = ok ? *(const f32x4*)(prev_y + off) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        nrv[t] = (ok && (prev_flags & LF_EPI_PIXELNORM)) ? prev_norm[off >> 4] : 1.f;
+        nrv[t] = (ok && (prev_flags & LF_EPI_PIXELNORM)) ? prev_norm[whole ? rowidx[j] : (off >> 4)] : 1.f;
+      }
+      float dot_row = 0.f;
+      if (whole && (prev_flags & LF_EPI_PIXELNORM)) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          dot_row += acc[t][j][0] * ypv[t][0] + acc[t][j][1] * ypv[t][1] + acc[t][j][2] * ypv[t][2] + acc[t][j][3] * ypv[t][3];
+        dot_row += __shfl_xor(dot_row, 16, 64);
+        dot_row += __shfl_xor(dot_row, 32, 64);
+        dot_row *= 1.f / (float)Cout;
       }
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const f32x4 yp = ypv[t];
         f32x4 g = acc[t][j];
         if (prev_flags & LF_EPI_PIXELNORM) {
-          float dot = g[0] * yp[0] + g[1] * yp[1] + g[2] * yp[2] + g[3] * yp[3];
-          dot += __shfl_xor(dot, 16, 64);
-          dot += __shfl_xor(dot, 32, 64);
-          dot *= (1.f / 16.f);
+          float dot = dot_row;
+          if (!whole) {
+            dot = g[0] * yp[0] + g[1] * yp[1] + g[2] * yp[2] + g[3] * yp[3];
+            dot += __shfl_xor(dot, 16, 64);
+            dot += __shfl_xor(dot, 32, 64);
+            dot *= (1.f / 16.f);
+          }
           const float rinv = 1.0f / nrv[t];
 #pragma unroll
           for (int e = 0; e < 4; ++e) g[e] = (g[e] - yp[e] * dot) * rinv;
@@ -257,8 +275,8 @@ __global__ void __launch_bounds__(256) conv3x3_kernel(
     rowidx[j] = (gx < W && gy < H && gz < D) ? ((((long)n * D + gz) * H + gy) * W + gx) : -1;
     rowoff[j] = rowidx[j] < 0 ? -1 : rowidx[j] * Cout;
   }
-  epilogue_store<NT, 4>(acc, rowoff, rowidx, bias, y, norm_out, Cout, co_base, 1 << 30, 0, (Cout & 3) == 0,
-                        he, flags, slope, eps, prev_y, prev_norm, prev_flags);
+  epilogue_store<NT, 4, (NT > 1)>(acc, rowoff, rowidx, bias, y, norm_out, Cout, co_base, 1 << 30, 0, (Cout & 3) == 0,
+                                  he, flags, slope, eps, prev_y, prev_norm, prev_flags);
 }
 
 // ---- C = 16 specialisation of the 3x3(x3) kernel (the SYN(S,16) hot path) ---------------------
@@ -685,8 +703,9 @@ static int conv3x3_launch(const float* x, const float* wpack, const float* bias,
                           const float* prev_y, const float* prev_norm, unsigned prev_flags) {
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return LF_EINVAL;
   if (prev_y != nullptr) {
-    // fused previous-layer epilogue backward: plain data-gradient launch onto 16-channel records
-    if (flags != 0 || bias != nullptr || Cout != 16 || !lf_aligned16(prev_y)) return LF_EINVAL;
+    // fused previous-layer epilogue backward: plain data-gradient launch onto whole records of 16, 32 or 64 channels
+    // (all channels of a voxel in one workgroup's tiles: the PixelNorm' dot product does not cross workgroups)
+    if (flags != 0 || bias != nullptr || (Cout != 16 && Cout != 32 && Cout != 64) || !lf_aligned16(prev_y)) return LF_EINVAL;
     if ((prev_flags & LF_EPI_PIXELNORM) && prev_norm == nullptr) return LF_EINVAL;
   }
   if (dims != 2 && dims != 3) return LF_EINVAL;

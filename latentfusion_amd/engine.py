@@ -9,8 +9,10 @@ d(mean weighted loss)/d(log_quaternion, translation, viewport).
 Compared with driving the same kernels through the generic autograd modules this removes the
 ~600 tiny ATen launches per iteration of the camera algebra and of the loss (they become
 lf_camera_coefs, lf_pose_loss_fwd/bwd and lf_camera_coefs_bwd), keeps the 3-D activations in
-preallocated buffers and sequences the heavy kernels explicitly.  The 2-D decoder (a generic
-U-Net in the released model) still runs through the autograd ops on its (N,C,h,w) maps.
+preallocated buffers and sequences the heavy kernels explicitly.  A PLAIN 2-D decoder (blocks without rescaling or skip
+concatenations: the SYN family) is sequenced explicitly as well since round 4 -- every data-gradient kernel applies the
+LeakyReLU' / PixelNorm' of the layer feeding it, so no separate epilogue-backward pass runs; a generic U-Net (the released
+model) runs through the autograd ops on its (N,C,h,w) maps.
 
 Numerically it is the same computation as Photographer.decode + default_pose_loss
 (reference recon/models.py:397-505, pose/estimation.py:70-118); tests/test_engine_gpu.py checks it
@@ -114,6 +116,7 @@ class RenderLoopEngine:
     no occlusion / skip connections) and the fused pose loss."""
 
     LOSS_KEYS = ('depth', 'ov_depth', 'iou', 'mask')
+    EXPLICIT_DECODER = True          # A/B switch (tools/engine_ab.py): False runs a plain 2-D decoder through autograd like a generic one
 
     @staticmethod
     def supports(photographer, loss_weights):
@@ -231,6 +234,24 @@ class RenderLoopEngine:
                                 and ob.conv.bias is not None for ob in obs):
             self.heads = (torch.cat([ob.conv.module.weight.detach() for ob in obs], dim=0).contiguous(),
                           torch.cat([ob.conv.bias.detach() for ob in obs], dim=0).contiguous())
+        # a plain 2-D decoder is sequenced by the engine itself (no autograd graph, fused epilogue backward)
+        self.dec = None
+        dec = photographer.image_decoder
+        blocks2d = list(dec.down_blocks) + list(dec.up_blocks)
+        plain = (dec.input_block is None and dec.output_block is None and self.heads is not None and not self.generic_tail
+                 and (len(dec.up_blocks) < 2 or len(dec.down_blocks) < 2)               # no skip concatenation happens
+                 and all(getattr(b, 'interpolate', True) is None for b in blocks2d) and len(blocks2d) > 0
+                 and all(c.module.weight.dim() == 4 and tuple(c.module.weight.shape[2:]) == (3, 3) and c.module.weight.shape[0] <= 64
+                         for b in blocks2d for c in (b.conv1, b.conv2)))
+        if plain and RenderLoopEngine.EXPLICIT_DECODER:
+            self.dec = []
+            for blk in blocks2d:
+                for conv in (blk.conv1, blk.conv2):
+                    w = conv.module.weight
+                    self.dec.append((w, conv.bias, ops.he_constant(w), ops.pack_conv3x3(w), ops.pack_conv3x3(w, transpose=True)))
+            hw = self.heads[0]
+            self.heads_pack = (ops.he_constant(hw), ops.pack_conv1x1(hw.reshape(hw.shape[0], hw.shape[1])),
+                               ops.pack_conv1x1(hw.reshape(hw.shape[0], hw.shape[1]).t()))
 
     def set_weights(self, loss_weights):
         self.weights = torch.tensor([loss_weights.get(k, 0.0) for k in self.LOSS_KEYS], dtype=torch.float32,
@@ -395,13 +416,27 @@ class RenderLoopEngine:
                     pnorm = ops._conv1x1_raw(acts[-1], ppack, pb, n, S * S, Cl, S, S * S * S * Cl, S * S * Cl, cout, zp, phe, flags)
             zp_leaf = zp.detach().requires_grad_(need_grad)
 
-        # ---- 2-D decoder + heads (autograd over small maps) + fused loss ----
-        with torch.set_grad_enabled(need_grad):
-            yimg = self.ph.image_decoder(zp_leaf)
-            if self.heads is not None:
-                logits = ops.conv1x1(yimg, self.heads[0], self.heads[1])
-            else:
-                logits = torch.cat([ob(yimg) for ob in self.ph.output_blocks], dim=1)
+        # ---- 2-D decoder + heads + fused loss ----
+        explicit = self.dec is not None and (zt is None or not need_grad)
+        if explicit:
+            # plain decoder, sequenced here: conv + He + bias + LeakyReLU + PixelNorm per launch, then the stacked heads
+            dacts, dnorms = [zp], [pnorm]
+            for (w2, b2, he2, pk2, _pkt2) in self.dec:
+                y2, n2 = ops._conv3x3_raw(dacts[-1], pk2, b2, w2.shape[0], he2, flags, True)
+                dacts.append(y2)
+                dnorms.append(n2)
+            hw, hb = self.heads
+            hhe, hpk, _hpkt = self.heads_pack
+            hh, ww = dacts[-1].shape[-2:]
+            logits = ops.empty_cl((n, hw.shape[0], hh, ww), dev)
+            ops._conv1x1_raw(dacts[-1], hpk, hb, n, hh * ww, hw.shape[1], 1, hh * ww * hw.shape[1], 0, hw.shape[0], logits, hhe, 0)
+        else:
+            with torch.set_grad_enabled(need_grad):
+                yimg = self.ph.image_decoder(zp_leaf)
+                if self.heads is not None:
+                    logits = ops.conv1x1(yimg, self.heads[0], self.heads[1])
+                else:
+                    logits = torch.cat([ob(yimg) for ob in self.ph.output_blocks], dim=1)
         if zt is None or not need_grad:
             # the optimised quantity is mean_n(total) (estimation.py:616-617): lf_pose_loss_fwd already leaves the sums'
             # gradients for exactly that, so the loss needs no autograd node -- logits -> loss -> d/d(logits, coefficients)
@@ -434,7 +469,33 @@ class RenderLoopEngine:
             check(L.lf_pose_loss_bwd(lg.data_ptr(), coefs.data_ptr(), self.tdepth.data_ptr(), self.tmask.data_ptr(), gsums.data_ptr(),
                                      glogits.data_ptr(), g_cf.data_ptr(), scratch_l.data_ptr(), scratch_l.numel() * 4,
                                      n, h_, w_, self.H, self.W, s), 'lf_pose_loss_bwd')
-            g_zp, = torch.autograd.grad(logits, [act_leaf if self.generic_tail else zp_leaf], grad_outputs=[glogits])
+            gp_explicit = None
+            if explicit:
+                # heads, then the decoder's data gradients in reverse; each launch folds in the LeakyReLU' / PixelNorm' of the
+                # activation it lands on (whole records of 16 / 32 / 64 channels; otherwise a separate pass)
+                def landed(gx, i):
+                    return ops._epilogue_bwd(gx, dacts[i], dnorms[i], flags)
+                hw = self.heads[0]
+                cin_h = hw.shape[1]
+                g2 = ops.empty_cl((n, cin_h, hh, ww), dev)
+                fuse_h = cin_h == 16
+                check(L.lf_conv1x1_bwd_data(glogits.data_ptr(), self.heads_pack[2].data_ptr(), g2.data_ptr(), n, hh * ww, hw.shape[0],
+                                            cin_h, hh * ww * cin_h, cin_h, cin_h if fuse_h else (1 << 30), 0, self.heads_pack[0],
+                                            dacts[-1].data_ptr() if fuse_h else None, dnorms[-1].data_ptr() if fuse_h else None,
+                                            flags if fuse_h else 0, ops.SLOPE, None, s), 'lf_conv1x1_bwd_data')
+                if not fuse_h:
+                    g2 = landed(g2, len(self.dec))
+                for i in range(len(self.dec) - 1, -1, -1):
+                    w2, _b2, he2, _pk2, pkt2 = self.dec[i]
+                    cin2 = w2.shape[1]
+                    if cin2 in (16, 32, 64):
+                        g2 = ops.conv3x3_bwd_data(g2, pkt2, cin2, he2, (dacts[i], dnorms[i], flags))
+                    else:
+                        g2 = landed(ops.conv3x3_bwd_data(g2, pkt2, cin2, he2, None), i)
+                gp_explicit = g2                                  # d/d(projection pre-activation): dacts[0] is zp itself
+                g_zp = None
+            else:
+                g_zp, = torch.autograd.grad(logits, [act_leaf if self.generic_tail else zp_leaf], grad_outputs=[glogits])
         else:
             cf_leaf = coefs.detach().requires_grad_(need_grad)
             with torch.set_grad_enabled(need_grad):
@@ -476,7 +537,7 @@ class RenderLoopEngine:
                     else:
                         g, _ = ops._conv3x3_raw(gpre, wt, None, w.shape[1], he, 0, False)
             return self._finish_backward(g, g_cf, cf20, jac, n, grad_scale, losses)
-        gp = ops._epilogue_bwd(ops.cl(g_zp), zp, pnorm, flags)
+        gp = gp_explicit if (explicit and gp_explicit is not None) else ops._epilogue_bwd(ops.cl(g_zp), zp, pnorm, flags)
         fuse_pb = fuse and nconv and 'bwd' in self.fuse_projection
         g = None if fuse_pb else ops.empty_cl((n, Cl, S, S, S), dev)
         if fuse_pb:

@@ -539,19 +539,20 @@ def test_engine_hypothesis_groups_on_streams_are_bit_identical(golden):
             lk, gk = eng.forward_backward(cam0)
             torch.cuda.synchronize()
             assert torch.equal(lk, l1), k
-            # (the coefficient gradient's block partition follows the group size: its fixed-order sums associate differently)
-            close(gk, g1, atol=0.0, rtol=2e-5)
+            # (the coefficient gradient's block partition follows the group size: its fixed-order sums associate differently;
+            # components that are small through cancellation move by a few 1e-7 absolute)
+            close(gk, g1, atol=1e-6 * g1.abs().max().item(), rtol=2e-5)
     eng.set_streams(3)                                           # 8 -> 2 + 3 + 3: factors 2/8, 3/8
     l3, g3 = eng.forward_backward(cam0)
     assert torch.equal(l3, l1)
-    close(g3, g1, atol=0.0, rtol=2e-5)
+    close(g3, g1, atol=1e-6 * g1.abs().max().item(), rtol=2e-5)
     cam5 = cam0[:5]
     eng.set_streams(1)
     l5, g5 = eng.forward_backward(cam5)
     eng.set_streams(2)                                           # 5 -> 2 + 3
     l52, g52 = eng.forward_backward(cam5)
     assert torch.equal(l52, l5)
-    close(g52, g5, atol=0.0, rtol=2e-5)
+    close(g52, g5, atol=1e-6 * g5.abs().max().item(), rtol=2e-5)
     runs = []
     for k in (1, 2):
         est = estimation.GradientPoseEstimator(model=model, learning_rate=0.01, num_samples=8, num_iters=6, ranking_size=8,
@@ -739,5 +740,5 @@ def test_engine_first_call_on_several_streams(golden):
         outs.append((first, second))
     for first, second in outs:
         assert torch.equal(first[0], outs[0][0][0]) and torch.equal(second[0], outs[0][0][0])
-        close(first[1], outs[0][0][1], atol=0.0, rtol=2e-5)
-        close(second[1], outs[0][0][1], atol=0.0, rtol=2e-5)
+        close(first[1], outs[0][0][1], atol=1e-6 * outs[0][0][1].abs().max().item(), rtol=2e-5)
+        close(second[1], outs[0][0][1], atol=1e-6 * outs[0][0][1].abs().max().item(), rtol=2e-5)

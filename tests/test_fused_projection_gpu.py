@@ -176,3 +176,31 @@ def test_engine_with_fused_projection_equals_the_unfused_engine(S):
             assert torch.equal(g1, g0)
     with pytest.raises(NotImplementedError):
         RenderLoopEngine(model.photographer, z_obj, target, weights, conv_mode='fp32', fuse_projection=True)
+
+
+@pytest.mark.parametrize('cin,cout', [(16, 32), (32, 32), (32, 16), (64, 32), (16, 64)])
+def test_conv2d_data_gradient_with_fused_epilogue_backward_on_wide_records(cin, cout):
+    """lf_conv3x3_bwd_data with the producer's LeakyReLU' / PixelNorm' folded in, on whole records of 16 / 32 / 64 channels
+    (round 4: the 2-D decoder's 32-channel layers; before, 16-channel records only) == the plain data gradient followed by
+    lf_epilogue_bwd, and fp64."""
+    from latentfusion_amd import ops
+    from latentfusion_amd._lib import LF_EPI_LRELU, LF_EPI_PIXELNORM
+    g = torch.Generator().manual_seed(cin * 100 + cout)
+    N, H, W = 3, 37, 29
+    flags = LF_EPI_LRELU | LF_EPI_PIXELNORM
+    w0 = torch.randn(cin, 8, 3, 3, generator=g).to(DEV)                  # producer: 8 -> cin, leaves (y, norm)
+    x0 = ops.cl(torch.randn(N, 8, H, W, generator=g).to(DEV))
+    y, nrm = ops._conv3x3_raw(x0, ops.pack_conv3x3(w0), None, cin, ops.he_constant(w0), flags, True)
+    w = torch.randn(cout, cin, 3, 3, generator=g).to(DEV)                # the layer whose data gradient lands on y
+    gy = ops.cl(torch.randn(N, cout, H, W, generator=g).to(DEV))
+    he = ops.he_constant(w)
+    wt = ops.pack_conv3x3(w, transpose=True)
+    fused = ops.conv3x3_bwd_data(gy, wt, cin, he, (y, nrm, flags))
+    plain = ops._epilogue_bwd(ops.conv3x3_bwd_data(gy, wt, cin, he, None), y, nrm, flags)
+    torch.cuda.synchronize()
+    assert (fused - plain).abs().max().item() <= 2e-6 * max(1.0, plain.abs().max().item())
+    gd = torch.nn.functional.conv_transpose2d(gy.double(), w.double(), padding=1) * he
+    yd = y.double()
+    want = (gd - yd * (gd * yd).mean(dim=1, keepdim=True)) / nrm.double().view(N, 1, H, W)
+    want = torch.where(yd > 0, want, want * 0.2)
+    assert (fused.double() - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())

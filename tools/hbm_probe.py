@@ -36,6 +36,20 @@ for _ in range(REP):                   # Winograd, data-gradient form with the p
     gx, _ = ops.conv3d_c16_wino(x, upt, None, he, 0, prev=(y, nrm, flags))
 torch.cuda.synchronize()
 
+# round 4: the factor projection fused into the last camera block's kernels (forward: default; backward: opt-in)
+pwf = torch.randn(16, C * S, 1, 1, generator=g).cuda()
+wdm = pwf.reshape(16, C, S).permute(0, 2, 1).reshape(16, S * C).contiguous()
+wA, wtA = ops.pack_wino_proj(wdm), ops.pack_wino_proj(wdm, transpose=True)
+phe = ops.he_constant(pwf)
+for _ in range(REP):
+    yf, nrmf, zpf, pnf = ops.conv3d_c16_wino_projfwd(x, up, b, he, flags, wA, None, phe, flags)
+torch.cuda.synchronize()
+gpf = ops.cl(torch.randn(N, 16, S, S, generator=g).cuda())
+for _ in range(REP):
+    gxf = ops.conv3d_c16_wino_projbwd(gpf, wtA, phe, yf, nrmf, flags, upt, he, prev=(y, nrm, flags))
+torch.cuda.synchronize()
+del yf, nrmf, gxf
+
 sp, spt = ops.pack_conv3d_c16_split(w), ops.pack_conv3d_c16_split(w, transpose=True)
 am = ops.amax_buffer(x.abs().max(), 'cuda')
 for _ in range(REP):                   # direct f16x3 kernel, forward form

@@ -22,6 +22,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNELS = collections.OrderedDict([
     # key -> (substring of the kernel name, algorithmic bytes per launch at N=8, C=16, S=128)
     ('conv3d_c16_wino_kernel', ('conv3d_c16_wino_kernel', 2 * 8 * 16 * 128 ** 3 * 4 + 8 * 128 ** 3 * 4)),
+    # round 4: conv + factor projection in one launch (forward: x, y, norm + the (8,16,128,128) latent image; backward: the
+    # block's activation + norm, the producer's activation + norm, the output gradient; the projection gradient is 8 MB)
+    ('conv3d_c16_wino_projfwd_kernel', ('conv3d_c16_wino_projfwd_kernel', 2 * 8 * 16 * 128 ** 3 * 4 + 8 * 128 ** 3 * 4 + 8 * 17 * 128 ** 2 * 4)),
+    ('conv3d_c16_wino_projbwd_kernel', ('conv3d_c16_wino_projbwd_kernel', 3 * 8 * 16 * 128 ** 3 * 4 + 2 * 8 * 128 ** 3 * 4 + 8 * 16 * 128 ** 2 * 4)),
     ('conv3d_c16_persistent_kernel', ('conv3d_c16_persistent_kernel', 2 * 8 * 16 * 128 ** 3 * 4 + 8 * 128 ** 3 * 4)),
     ('conv3d_c16_f16x3_kernel', (('conv3d_c16_f16x3_kernel<false, 3>', 'conv3d_c16_f16x3_kernel<false>', 'conv3d_c16_f16x3_kernelILb0ELi3E'), 2 * 8 * 16 * 128 ** 3 * 4 + 8 * 128 ** 3 * 4)),
     ('conv3d_c16_f16x3_kernel_bwd', (('conv3d_c16_f16x3_kernel<true, 3>', 'conv3d_c16_f16x3_kernel<true>', 'conv3d_c16_f16x3_kernelILb1ELi3E'), 3 * 8 * 16 * 128 ** 3 * 4 + 8 * 128 ** 3 * 4)),
