@@ -798,7 +798,12 @@ static int conv1x1_launch(const float* x, const float* wpack, const float* bias,
   const int K = ksl * Cin, Kp = (K + 15) & ~15;
   const int CoutP = lf_conv1x1_cout_padded(Cout);
   const int ntiles = CoutP / 16;
-  const int NT = ntiles >= 8 ? 8 : ntiles;          // 1, 2, 4 or 8 (CoutP is padded accordingly)
+  // 1, 2, 4 or 8 output tiles per workgroup (CoutP is padded accordingly).  The unfolding data gradient with a fused
+  // previous-layer backward (factor projection: one tile = one depth slice, 2.1 GB per launch) streams best at 4 slices per
+  // workgroup: 0.536 / 0.511 / 0.510 / 0.582 ms at 8 / 4 / 2 / 1 (round 4, standalone at 8 x 128^3 x 16); requesting the saved
+  // activation records AHEAD of the MFMA phase instead made it 0.82 ms (all waves of a CU then read, compute and write in
+  // step: the staggered phases of the plain form keep reads and writes mixed at the HBM) -- not kept
+  const int NT = ntiles >= 8 ? ((prev_y != nullptr && ntiles >= 16) ? 4 : 8) : ntiles;
   const int groups = ntiles / NT;
   dim3 grid((unsigned)((P + 63) / 64), groups, N), block(256);
   hipStream_t s = (hipStream_t)stream;
