@@ -631,3 +631,21 @@ def test_tap_pair_packs_match_the_kernel_table():
         assert torch.equal(sp[:, 0].float(), want.half().float())
         assert torch.equal(sp[:, 1].float(), (want - want.half().float()).half().float())
         assert bf.numel() == _lib.lib().lf_conv3d_c16_ring_bf16_wpack_elems()
+
+
+def test_torch_library_registration():
+    """the C-ABI replacements are registered with the dispatcher as ordinary operators (namespace `lf`).  Every
+    operator exists with the schema the module documents, and none has a CPU kernel behind it (LFHipError on host tensors)."""
+    import torch
+    import latentfusion_amd.torch_ops as T
+    from latentfusion_amd._lib import LFHipError
+    assert len(T.SCHEMAS) >= 19
+    for name, schema in T.SCHEMAS.items():
+        op = getattr(torch.ops.lf, name)
+        got = str(op.default._schema)
+        assert got.replace(' ', '') == ('lf::' + schema).replace(' ', ''), (got, schema)
+    import pytest
+    with pytest.raises(LFHipError):
+        torch.ops.lf.pixelnorm(torch.randn(2, 4, 3, 3))
+    with pytest.raises(LFHipError):
+        torch.ops.lf.conv_block(torch.randn(1, 4, 5, 5), torch.randn(4, 4, 3, 3), None, True, True)

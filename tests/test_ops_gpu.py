@@ -441,3 +441,36 @@ def test_volume_splat_is_deterministic(golden):
             # one contribution of size |gout| x weight ~ 1e-6 x scale -- 47 of 512,000 elements on this fixture)
             d = (grads[True][0] - grads[False][0]).abs()
             assert d.max().item() < 1e-5 * scale and (d > 2e-6 * scale).float().mean().item() < 1e-3
+
+
+def test_dispatcher_operators_equal_the_wrappers_and_differentiate():
+    """torch.ops.lf.* (latentfusion_amd/torch_ops.py) run the same kernels as the ops.py wrappers -- identical
+    values -- and autograd differentiates through them (camera-coefficient gradient of the O2C resampler, data / weight
+    gradients of a fused conv block)."""
+    import latentfusion_amd.torch_ops  # noqa: F401
+    from latentfusion_amd import ops
+    g = torch.Generator().manual_seed(4)
+    vol = torch.randn(1, 8, 12, 12, 12, generator=g).to(DEV)
+    coef = (torch.randn(3, 18, generator=g) * 0.2).to(DEV).requires_grad_(True)
+    a = torch.ops.lf.o2c(vol, coef)
+    b = ops.resample_o2c(vol, coef)
+    assert torch.equal(a, b)
+    ga, = torch.autograd.grad(a.square().sum(), coef)
+    gb, = torch.autograd.grad(b.square().sum(), coef)
+    assert torch.equal(ga, gb) and ga.abs().max().item() > 0
+    x = torch.randn(2, 8, 9, 10, 11, generator=g).to(DEV).requires_grad_(True)
+    w = torch.randn(12, 8, 3, 3, 3, generator=g).to(DEV).requires_grad_(True)
+    bias = (torch.randn(12, generator=g) * 0.1).to(DEV).requires_grad_(True)
+    y1 = torch.ops.lf.conv_block(x, w, bias, True, True)
+    y2 = ops.conv3x3(x, w, bias, True, True)
+    assert torch.equal(y1, y2)
+    g1 = torch.autograd.grad(y1.sum(), (x, w, bias))
+    g2 = torch.autograd.grad(y2.sum(), (x, w, bias))
+    for p, q in zip(g1, g2):
+        assert torch.equal(p, q)
+    z = torch.randn(2, 6, 8, 8, 8, generator=g).to(DEV)
+    assert torch.equal(torch.ops.lf.column_sum(z), ops.column_sum(z))
+    wgt, zd = torch.ops.lf.column_softmax(z[:, :1])
+    w2, zd2 = ops.column_softmax(z[:, :1])
+    assert torch.equal(wgt, w2) and torch.equal(zd, zd2)
+    assert torch.equal(torch.ops.lf.pixelnorm(z), ops.pixelnorm(z))
