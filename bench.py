@@ -307,6 +307,19 @@ def cfg3_report(a, dev):
                            'frac': fl / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 'avg_launch_ms': ms, 'launches_timed': len(d3),
                            'executed_flops_per_launch': fl,
                            'algorithmic_flops_per_launch': 2.0 * 27 * Cw * Cw * n_r * Sw ** 3, 'traffic': None}
+        # measured HBM bytes per launch (PMC passes over tools/cfg3_probe.py), refused when the kernel source changed since
+        import glob
+        import hashlib
+        for tpath in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_released_arch_hbm_bytes.json')), reverse=True):
+            try:
+                tj = json.load(open(tpath))
+                if n_r == 128 and all(hashlib.sha256(open(os.path.join(ROOT, 'latentfusion_amd', 'csrc', f), 'rb').read()).hexdigest() == h
+                                      for f, h in tj['source_sha256'].items()):
+                    out['roofline']['traffic'] = tj['kernels']['wino_fused_kernel<3>']['bytes_per_launch']
+                    out['roofline']['traffic_source'] = os.path.basename(tpath)
+                    break
+            except Exception:                                       # noqa: BLE001
+                continue
     return out
 
 
