@@ -1,3 +1,4 @@
+"""Prints the few numbers of a bench.py JSON line that are looked at between runs: `python bench.py ... | python tools/bench_brief.py`."""
 import sys, json
 for l in sys.stdin:
     if l.startswith("{"):
