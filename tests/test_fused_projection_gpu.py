@@ -9,8 +9,8 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda'
 
 # volumes with partial tiles on every axis (tile = 2 x 8 x 16), one with more columns of tiles than resident workgroups
-# (2 x 256 CUs: a workgroup then walks several columns), one tile-aligned
-SHAPES = [(2, 16, 16, 16), (1, 18, 12, 20), (3, 5, 9, 33), (5, 6, 128, 128), (1, 32, 32, 32)]
+# (2 x 256 CUs: a workgroup then walks several columns), one tile-aligned, two whose columns are a single tile (D <= 2)
+SHAPES = [(2, 16, 16, 16), (1, 18, 12, 20), (3, 5, 9, 33), (5, 6, 128, 128), (1, 32, 32, 32), (2, 2, 16, 16), (3, 1, 9, 17)]
 
 
 def _problem(shape, seed, bias=True):
