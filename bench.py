@@ -458,7 +458,10 @@ def main():
     import torch.distributed as dist
     launched = 'RANK' in os.environ and 'MASTER_ADDR' in os.environ          # torchrun / torch.distributed.run
     if world > 1 or launched:
-        dist.init_process_group('gloo' if single else 'nccl')                # "nccl" IS RCCL on ROCm
+        import datetime
+        # "nccl" IS RCCL on ROCm; a collective that does not complete within 5 minutes aborts the rank (and, through
+        # launch_ranks, the run) instead of hanging the node
+        dist.init_process_group('gloo' if single else 'nccl', timeout=datetime.timedelta(seconds=300))
 
     from latentfusion_amd import ops, synth
     from latentfusion_amd.modules.geometry import Camera
