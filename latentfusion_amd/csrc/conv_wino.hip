@@ -34,7 +34,8 @@
 #define WINO_ABL 0      // ablations for tools/wino_ab.py (results are WRONG, timings only): 1 = no epilogue arithmetic (upper bound on
 #endif                  // what moving the epilogue to other waves could give: they would still issue it on the shared pipe);
                         // 2 = no z-frequency exchange / z output transform (each wave stores from its own partials); 4 = every MFMA
-                        // chain 1.5x as long (the MFMA count of F(2,3) in y,x with direct z taps); 16 / 32 = cycle stamps
+                        // chain 1.5x as long (the MFMA count of F(2,3) in y,x with direct z taps); 16 / 32 = cycle stamps; 64 = one LDS read per
+                        // value and no z combination (upper bound on staging z-combined planes)
 // wave priorities (s_setprio) of the three phases of a tile: halo reads + input transforms (latency-bound: LDS),
 // the MFMA chains (throughput-bound) and the exchange / epilogue / halo fetch (latency-bound: LDS, HBM)
 #ifndef WINO_PJ_ABL
@@ -134,7 +135,10 @@ __device__ __forceinline__ void wino_compute(const unsigned char* __restrict__ b
         const int dx = (hh & 1) * 2 + e;
         const int ca = ((DZ0 * 10 + 4 * g + dy) * 18 + (dx & 1) * 9 + (dx >> 1));
         const int cb = ((DZ1 * 10 + 4 * g + dy) * 18 + (dx & 1) * 9 + (dx >> 1));
-        if constexpr (OFFX) {
+        if constexpr ((WINO_ABL & 64) != 0) {                  // ablation: ONE plane read per value, no z combination (an upper
+          r[2 * e] = *(const f32x4*)(buf + off[ca & 7][dy >> 1] + ca * 64);   // bound on staging z-COMBINED planes in LDS)
+          r[2 * e + 1] = r[2 * e];
+        } else if constexpr (OFFX) {
           int oa = off[ca & 7][0], ob = off[cb & 7][0];
           if (dy >> 1) {
             asm volatile("" : "+v"(oa), "+v"(ob));               // (opaque: or the xor-ed copies are hoisted back into registers)
@@ -160,7 +164,8 @@ __device__ __forceinline__ void wino_compute(const unsigned char* __restrict__ b
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const f32x4 va = raw[hh & 1][2 * e], vb = raw[hh & 1][2 * e + 1];
-        d[(hh & 1) * 2 + e] = (A == 1) ? (va + vb) : pk_sub(va, vb);
+        if constexpr ((WINO_ABL & 64) != 0) d[(hh & 1) * 2 + e] = va;
+        else d[(hh & 1) * 2 + e] = (A == 1) ? (va + vb) : pk_sub(va, vb);
       }
       if (hh & 1) {
         vx[dy][0] = pk_sub(d[0], d[2]);
