@@ -60,6 +60,7 @@ def parse(argv=None):
                     help='timed oracle iterations of the CPU baseline (after 1 warm-up); their per-iteration trace is compared with '
                          'the HIP loop from the same start (trace_parity_at_full_size)')
     ap.add_argument('--no-alt', action='store_true', help='skip the secondary f16x3 measurement')
+    ap.add_argument('--no-graph', action='store_true', help='skip the secondary hipGraph-replay measurement')
     ap.add_argument('--engine-streams', type=int, default=1,
                     help='hypothesis groups of the render-loop engine evaluated concurrently on separate HIP streams')
     ap.add_argument('--repeats', type=int, default=5,
@@ -518,7 +519,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def timed_loop(est_, st_):
+    def timed_loop(est_, st_, events=True):
         """W warm-up iterations, then `--repeats` blocks of EXACTLY K iterations, each bracketed by barrier + synchronize
         and reduced with MAX over the ranks.  Returns (median block time, all block times, the kernel events of all blocks)."""
         for _ in range(a.warmup):
@@ -531,19 +532,21 @@ def main():
         ops.KERNEL_TIMER_TAGS = dominant
         for _rep in range(max(1, a.repeats)):
             barrier()
-            ops.KERNEL_TIMER = []
+            ops.KERNEL_TIMER = [] if events else None
             t0_ = time.perf_counter()
             for _ in range(a.steps):
                 est_.iterate(st_)
             barrier()
             el = time.perf_counter() - t0_
-            timer_ += ops.KERNEL_TIMER
+            timer_ += ops.KERNEL_TIMER or []
             ops.KERNEL_TIMER = None
             if world > 1:
                 tt = torch.tensor([el], device=dev, dtype=torch.float64)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 el = tt.item()
             blocks.append(el)
+        if not events:
+            return sorted(blocks)[len(blocks) // 2], blocks, timer_
         ops.KERNEL_TIMER_TAGS = {'conv3d_c16_wino_projfwd', 'conv3d_c16_wino_projbwd', 'resample_fwd', 'resample_bwd_coef',
                                  'factor_project_fwd', 'factor_project_bwd'}
         ops.KERNEL_TIMER = []
@@ -584,6 +587,32 @@ def main():
             alt['roofline'] = {'bound': 'hbm', 'kernel': 'conv3d_c16_f16x3_kernel', 'achieved': ab2 / (ms2 * 1e-3) / 1e9,
                                'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ab2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                'f16_mfma_frac': fl2 / (ms2 * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS, 'launches_timed': len(d2)}
+
+    # secondary line (never `value`): the same all-fp32 loop with the engine's evaluation replayed from a captured hipGraph
+    # (RenderLoopEngine.forward_backward_graph) -- no HIP events can live inside a captured graph, so the headline above, which
+    # must time its dominant kernel inside the timed region, runs eagerly; this is what a user of the library gets
+    graph = None
+    if not a.no_graph and a.conv_mode in ('fp32', 'winograd'):
+        try:
+            st = est = st2 = est2 = None
+            torch.cuda.empty_cache()
+            est4 = estimation.load_from_config(cfg, model, converge_patience=10 ** 6, conv_mode=a.conv_mode, fuse_projection=fuse_sel,
+                                               engine_graph=True)
+            st4 = est4.start(z_obj, target, init.zoom(None, model.input_size, model.camera_dist).to(dev))
+            el4, blocks4, _ = timed_loop(est4, st4, events=False)
+            captured = st4['engine']._graph is not None
+            # the same estimator class without the graph and without events: what the capture itself is worth
+            est5 = estimation.load_from_config(cfg, model, converge_patience=10 ** 6, conv_mode=a.conv_mode, fuse_projection=fuse_sel)
+            st5 = est5.start(z_obj, target, init.zoom(None, model.input_size, model.camera_dist).to(dev))
+            el5, blocks5, _ = timed_loop(est5, st5, events=False)
+            graph = {'what': 'adam_quick loop, all-fp32, engine evaluation replayed from a captured hipGraph (no HIP events in the '
+                             'timed region); `eager_no_events` = the same loop launched eagerly, also without events',
+                     'value': world * a.steps / el4, 'unit': 'iters/s', 'ms_per_step': el4 / a.steps * 1e3,
+                     'ms_per_step_blocks': [b / a.steps * 1e3 for b in blocks4], 'graph_captured': bool(captured),
+                     'eager_no_events': {'value': world * a.steps / el5, 'ms_per_step': el5 / a.steps * 1e3}}
+            st4 = est4 = st5 = est5 = None
+        except Exception as e:                                       # noqa: BLE001  (auxiliary: never loses the headline)
+            graph = {'error': f'{type(e).__name__}: {e}'[:300]}
 
     # ---- roofline of the dominant kernel (fused conv3d 16->16 block step; 2 forward + 2 data-gradient launches per
     # iteration), from HIP events recorded on the launch stream inside the timed region -------------------------------
@@ -816,6 +845,8 @@ def main():
             alt['parity_at_full_size'] = parity(alt0)
     if alt is not None:
         out['alt'] = alt
+    if graph is not None:
+        out['graph'] = graph
     if sharded is not None:
         out['sharded_build'] = sharded
     if cfg3 is not None:

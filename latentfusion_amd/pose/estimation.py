@@ -446,8 +446,9 @@ class GradientPoseEstimator(PoseEstimator):
     def __init__(self, *, learning_rate, num_samples, num_iters, converge_threshold, converge_patience,
                  lr_reduce_patience=25, lr_reduce_threshold=1e-5, lr_reduce_factor=0.5, track_stats=False,
                  loss_schedules=None, optimizer='adamw', use_engine=True, conv_mode='auto', engine_streams=1,
-                 fuse_projection=None, **kwargs):
+                 fuse_projection=None, engine_graph=False, **kwargs):
         super().__init__(use_engine=use_engine, conv_mode=conv_mode, fuse_projection=fuse_projection, **kwargs)
+        self.engine_graph = engine_graph         # replay the engine's evaluation from a captured hipGraph (engine.forward_backward_graph)
         self.engine_streams = engine_streams     # hypothesis groups evaluated concurrently on separate HIP streams (engine.py)
         self.learning_rate, self.num_samples, self.num_iters = learning_rate, num_samples, num_iters
         self.optimizer = optimizer
@@ -616,7 +617,10 @@ class GradientPoseEstimator(PoseEstimator):
             if optim_weights.get('latent', 0.0) != 0.0 or self.loss_weights.get('latent', 0.0) != 0.0:
                 # the target's latent code under every hypothesis (reference :606-608): encoder + renderer, no gradient
                 z_target_latent = self.model.compute_latent_code(st['target'], st['cam'])
-            losses, gparams = eng.forward_backward(st['cam'], need_grad=True, z_target_latent=z_target_latent, params=P)
+            if self.engine_graph and z_target_latent is None and not self.loss_schedules:
+                losses, gparams = eng.forward_backward_graph(st['cam'], P)
+            else:
+                losses, gparams = eng.forward_backward(st['cam'], need_grad=True, z_target_latent=z_target_latent, params=P)
             dev = torch.cat((losses[:, :6], P.detach()), dim=1)
             if st.get('shard') is not None:                           # (N_local,15) -> (N,15) over the ranks
                 from .. import parallel

@@ -742,3 +742,37 @@ def test_engine_first_call_on_several_streams(golden):
         assert torch.equal(first[0], outs[0][0][0]) and torch.equal(second[0], outs[0][0][0])
         close(first[1], outs[0][0][1], atol=1e-6 * outs[0][0][1].abs().max().item(), rtol=2e-5)
         close(second[1], outs[0][0][1], atol=1e-6 * outs[0][0][1].abs().max().item(), rtol=2e-5)
+
+
+def test_engine_graph_replay_equals_eager(golden):
+    """RenderLoopEngine.forward_backward_graph (the evaluation captured once into a hipGraph and replayed) against the eager
+    evaluation: bit-identical losses and camera gradients at every replay, also after the parameters were updated in place;
+    and a whole adam loop with engine_graph=True ranks exactly like the eager loop."""
+    from latentfusion_amd import synth
+    from latentfusion_amd.engine import RenderLoopEngine, camera_params
+    from latentfusion_amd.pose import estimation
+    model, _ = synth.build_model(32, 16, 'pool:mean', seed=4, device=DEV, bias_std=0.05)
+    model.freeze()
+    g = golden('g7_adam_trace')
+    target = _target(g)
+    weights = {'depth': 1.0, 'ov_depth': 0.3, 'iou': 0.2, 'mask': 0.4}
+    gen = torch.Generator().manual_seed(9)
+    z_obj = torch.randn(1, 1, 16, 32, 32, 32, generator=gen).to(DEV)
+    cam0 = prod_camera(g['init']).zoom(None, model.input_size, model.camera_dist)
+    eng = RenderLoopEngine(model.photographer, z_obj, target, weights)
+    P = camera_params(cam0).detach().clone().contiguous()
+    cam = cam0._like(log_quaternion=P[:, 0:3], translation=P[:, 3:6], viewport=P[:, 6:10])
+    for it in range(4):
+        le, ge = eng.forward_backward(cam, params=P)
+        lg, gg = eng.forward_backward_graph(cam, P)
+        torch.cuda.synchronize()
+        assert torch.equal(lg, le) and torch.equal(gg, ge), it
+        P.sub_(0.01 * ge)                                          # in-place update, as the optimiser does
+    runs = []
+    for graph in (False, True):
+        est = estimation.GradientPoseEstimator(model=model, learning_rate=0.01, num_samples=8, num_iters=8, ranking_size=8,
+                                               converge_threshold=1e-9, converge_patience=100, optimizer='adam',
+                                               loss_weights=weights, engine_graph=graph, return_camera_history=True)
+        best, hist = est.estimate(z_obj, target, camera=prod_camera(g['init']))
+        runs.append((torch.cat((best.log_quaternion, best.translation), dim=1).cpu(), torch.stack([h[0] for h in hist])))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
