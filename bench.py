@@ -592,7 +592,9 @@ def main():
     # (RenderLoopEngine.forward_backward_graph) -- no HIP events can live inside a captured graph, so the headline above, which
     # must time its dominant kernel inside the timed region, runs eagerly; this is what a user of the library gets
     graph = None
-    if not a.no_graph and a.conv_mode in ('fp32', 'winograd'):
+    # (single-rank runs only: a capture in 'global' error mode next to a live RCCL communicator's watchdog thread is not worth
+    # risking the multi-rank sections for a number that does not depend on the rank count)
+    if not a.no_graph and world == 1 and a.conv_mode in ('fp32', 'winograd'):
         try:
             st = est = st2 = est2 = None
             torch.cuda.empty_cache()
