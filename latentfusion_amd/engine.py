@@ -363,8 +363,10 @@ class RenderLoopEngine:
         if self._intr is None or self._intr[0] is not K or self._intr[1] != K._version:
             self._intr = (K, K._version, camera_intrinsics(camera))
         intr = self._intr[2]
-        key = (pc.data_ptr(), tuple(pc.shape), id(self.weights), intr.data_ptr(), float(camera.z_span))
-        if self._graph is None or self._graph[0] != key:
+        # (the captured kernels hold raw pointers: the graph is valid for exactly these tensors -- compared by identity, and kept
+        # alive in the tuple below, so a freed buffer's address cannot come back as a false match)
+        key = (pc.data_ptr(), tuple(pc.shape), intr.data_ptr(), float(camera.z_span))
+        if self._graph is None or self._graph[0] != key or self._graph[6] is not self.weights or self._graph[7] is not params:
             cur = torch.cuda.current_stream()
             side = torch.cuda.Stream(device=self.dev)
             side.wait_stream(cur)
@@ -376,7 +378,7 @@ class RenderLoopEngine:
             g = torch.cuda.CUDAGraph()
             with torch.no_grad(), torch.cuda.graph(g):
                 lo, gp = self._forward_backward_group(pc, intr, float(camera.z_span), True, 1.0)
-            self._graph = (key, g, lo, gp, pc, intr)                  # (keeps the captured inputs alive)
+            self._graph = (key, g, lo, gp, pc, intr, self.weights, params)        # (keeps the captured inputs alive)
         self._graph[1].replay()
         return self._graph[2], self._graph[3]
 
