@@ -204,3 +204,36 @@ def test_conv2d_data_gradient_with_fused_epilogue_backward_on_wide_records(cin, 
     want = (gd - yd * (gd * yd).mean(dim=1, keepdim=True)) / nrm.double().view(N, 1, H, W)
     want = torch.where(yd > 0, want, want * 0.2)
     assert (fused.double() - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
+
+
+def test_fused_projection_kernels_at_the_headline_size():
+    """BASELINE cfg 2's shape (8 hypotheses x 128^3 x 16): the fused forward launch is the two-launch form bit for bit, the
+    fused backward launch agrees to the reciprocal's last place, and both are run-to-run identical (a workgroup walks two whole
+    columns of tiles here: the per-column state is re-armed correctly)."""
+    from latentfusion_amd import _lib, ops
+    from latentfusion_amd._lib import LF_EPI_LRELU, LF_EPI_PIXELNORM, check
+    N, D, H, W = 8, 128, 128, 128
+    x, w, b, wp, pb = _problem((N, D, H, W), 77)
+    flags = LF_EPI_LRELU | LF_EPI_PIXELNORM
+    he, phe = ops.he_constant(w), ops.he_constant(wp)
+    up, upt = ops.pack_conv3d_c16_wino(w), ops.pack_conv3d_c16_wino(w, transpose=True)
+    wdm = _proj_matrices(wp, D)
+    y0, n0 = ops.conv3d_c16_wino(x, up, b, he, flags)
+    zp0 = ops.empty_cl((N, 16, H, W), DEV)
+    pn0 = ops._conv1x1_raw(y0, ops.pack_conv1x1(wdm), pb, N, H * W, 16, D, D * H * W * 16, H * W * 16, 16, zp0, phe, flags)
+    wA = ops.pack_wino_proj(wdm)
+    for _ in range(2):
+        y1, n1, zp1, pn1 = ops.conv3d_c16_wino_projfwd(x, up, b, he, flags, wA, pb, phe, flags)
+        assert torch.equal(y1, y0) and torch.equal(n1, n0) and torch.equal(zp1, zp0) and torch.equal(pn1, pn0)
+    del y1, n1
+    gp = ops.cl(torch.randn(N, 16, H, W, generator=torch.Generator().manual_seed(3)).to(DEV))
+    gvol = ops.empty_cl((N, 16, D, H, W), DEV)
+    check(_lib.lib().lf_conv1x1_bwd_data(gp.data_ptr(), ops.pack_conv1x1(wdm.t().contiguous()).data_ptr(), gvol.data_ptr(), N, H * W, 16,
+                                         D * 16, D * H * W * 16, 16, 16, H * W * 16, phe, y0.data_ptr(), n0.data_ptr(), flags, ops.SLOPE,
+                                         None, torch.cuda.current_stream().cuda_stream), 'lf_conv1x1_bwd_data')
+    want, _ = ops.conv3d_c16_wino(gvol, upt, None, he, 0, prev=(x, n0, flags))      # (x / n0 stand in for a producer's record)
+    del gvol
+    wtA = ops.pack_wino_proj(wdm, transpose=True)
+    got = ops.conv3d_c16_wino_projbwd(gp, wtA, phe, y0, n0, flags, upt, he, prev=(x, n0, flags))
+    assert (got - want).abs().max().item() <= 2e-6 * want.abs().max().item()
+    assert torch.equal(ops.conv3d_c16_wino_projbwd(gp, wtA, phe, y0, n0, flags, upt, he, prev=(x, n0, flags)), got)
