@@ -63,7 +63,7 @@ def parse(argv=None):
     ap.add_argument('--no-graph', action='store_true', help='skip the secondary hipGraph-replay measurement')
     ap.add_argument('--engine-streams', type=int, default=1,
                     help='hypothesis groups of the render-loop engine evaluated concurrently on separate HIP streams')
-    ap.add_argument('--repeats', type=int, default=5,
+    ap.add_argument('--repeats', type=int, default=25,
                     help='the timed region (exactly --steps iterations between barriers) is run this many times back to back; '
                          '`value` is steps / MEDIAN block time, every block time is reported (box-to-box and run-to-run '
                          'spread of a 0.1 s region is a few per cent)')
@@ -84,6 +84,9 @@ def parse(argv=None):
                     help='skip the secondary cfg 3 block (released architecture, 8 views, cross_entropy_linemod: 128 renders per '
                          'iteration on the fused engine)')
     ap.add_argument('--cfg3-iters', type=int, default=10)
+    ap.add_argument('--no-cfg5', action='store_true',
+                    help='skip the secondary cfg 5 block (one bf16-autocast generator training step, 32 + 8 views, SYN(128,16))')
+    ap.add_argument('--cfg5-steps', type=int, default=3)
     ap.add_argument('--launcher-selftest', action='store_true',
                     help='run only the rank plumbing (spawn / process group / one all-reduce on HOST tensors over gloo) and '
                          'print a JSON line with n_gpus and ranks_seen: the CPU test of the N-rank path (tests/test_parallel.py)')
@@ -321,6 +324,110 @@ def cfg3_report(a, dev):
                     break
             except Exception:                                       # noqa: BLE001
                 continue
+    return out
+
+
+def cfg5_report(a, dev):
+    """BASELINE cfg 5 (secondary block, never `value`): ONE generator training step of the reference trainer
+    (tools/train/train_reconstruct.py:421-535, recon/utils.py:68-127, losses.py:33-57) on SYN(128,16) with the GRU fuser:
+    32 input views encoded and fused, 8 output views rendered, hard smooth-L1 depth + BCE mask losses, backward through every
+    kernel (data, weight and bias gradients, deterministic volume splat), flat Adam -- under the bf16 autocast policy
+    (ops.autocast; `--use-amp` of the reference).  One GPU: the data-parallel half (bucketed RCCL gradient all-reduce) needs
+    more devices.  Reported: wall time per step (mean of `--cfg5-steps` steps after one warm-up), peak device memory, the
+    launch time and HBM fraction of the dominant training kernel from HIP events in one extra step, and whether two fresh
+    runs of the same steps agree bit for bit."""
+    from latentfusion_amd import ops, synth
+    from latentfusion_amd.recon import training
+    S, C, Vi, Vo = a.size, a.channels, 32, 8
+
+    def fresh():
+        model, _ = synth.build_model(S, C, 'gru', seed=0, device=dev)
+        obs_in = model.preprocess_observation(synth.make_observation(Vi, seed=1, device=dev))
+        obs_out = model.preprocess_observation(synth.make_observation(Vo, seed=2, device=dev))
+        step = training.GeneratorStep(model.sculptor, model.fuser, model.photographer, g_depth_recon_loss_k=S * S // 4, use_amp=True)
+        batch = {'in': {'camera': obs_in.camera, 'image': obs_in.color.unsqueeze(0), 'mask': obs_in.mask.unsqueeze(0)},
+                 'out_gt': {'camera': obs_out.camera, 'depth': obs_out.depth.unsqueeze(0), 'mask': obs_out.mask.unsqueeze(0)}}
+        return step, batch
+
+    def run(step, batch, k):
+        times, losses = [], []
+        for _ in range(k):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            l_ = step.run_iteration(batch)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+            losses.append(float(l_['total']))
+        return times, losses
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
+    step, batch = fresh()
+    K = max(1, a.cfg5_steps)
+    times, losses = run(step, batch, 1 + K)
+    peak = torch.cuda.max_memory_allocated() / 2 ** 30
+    params_after = step.flat.data.clone()
+    # HIP events around the bf16 ring convolution (forward / data-gradient / ConvGRU addend forms) in one extra, untimed step
+    ops.KERNEL_TIMER_TAGS = {'conv3d_c16_ring_bf16'}
+    ops.KERNEL_TIMER = []
+    step.run_iteration(batch)
+    torch.cuda.synchronize()
+    timer, ops.KERNEL_TIMER, ops.KERNEL_TIMER_TAGS = ops.KERNEL_TIMER, None, None
+    n_par = sum(q.numel() for q in step.flat.params)
+    del step, batch
+    torch.cuda.empty_cache()
+    # the same 1 + K steps from a fresh model: identical losses and identical parameters, bit for bit
+    step2, batch2 = fresh()
+    _, losses2 = run(step2, batch2, 1 + K)
+    identical = losses == losses2 and bool(torch.equal(params_after, step2.flat.data))
+    del step2, batch2, params_after
+    torch.cuda.empty_cache()
+    ms = sum(times[1:]) / K * 1e3
+    out = {'workload': f'one generator training step (reference tools/train/train_reconstruct.py:421-535) on SYN({S},{C}), GRU fuser: '
+                       f'{Vi} input views + {Vo} output views, bf16 autocast policy, flat Adam; 1 GPU (no data-parallel all-reduce)',
+           'ms_per_step': ms, 'steps_per_s': 1e3 / ms, 'steps_timed': K, 'step_ms': [t * 1e3 for t in times[1:]],
+           'first_step_ms': times[0] * 1e3, 'peak_mem_GB': peak, 'params': n_par, 'loss': losses,
+           'run_to_run_identical': bool(identical), 'dtype': 'bf16 MFMA operands (autocast policy), fp32 accumulation / master weights / Adam'}
+    # roofline of the dominant training kernel: the bf16 ring convolution on ONE 128^3 x 16 volume (the ConvGRU recurrence
+    # launches it ~370 times per step); algorithmic bytes = input + output (+ the addend of the gates' sum form), fp32
+    vol = C * S ** 3 * 4
+    forms = {}
+    for n_, e0, e1 in timer:
+        form, nb, io = n_.detail.split(':')
+        forms.setdefault((form, int(nb), int(io[2:])), []).append(e0.elapsed_time(e1))
+    table = {}
+    for (form, nb, io), d in sorted(forms.items()):
+        # input + output (+ addend) records: 64 B per voxel in fp32 storage, 32 B in bf16 storage (io bits 0 / 1 / 2)
+        alg = nb * vol * ((0.5 if io & 1 else 1.0) + (0.5 if io & 2 else 1.0) + ((0.5 if io & 4 else 1.0) if form == 'add' else 0.0))
+        m_ = sum(d) / len(d)
+        table[f'{form}:io={io}:N={nb}'] = {'launches': len(d), 'avg_launch_ms': m_, 'total_ms': sum(d), 'algorithmic_bytes_per_launch': alg,
+                                   'hbm_frac': alg / (m_ * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    out['ring_conv_launches'] = table
+    dom = max(table.items(), key=lambda kv: kv[1]['total_ms']) if table else None
+    if dom is not None:
+        key, t_ = dom
+        tr, trs = None, None
+        import glob
+        import hashlib
+        for tpath in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_train_hbm_bytes.json')), reverse=True):
+            try:
+                tj = json.load(open(tpath))
+                fresh_ = all(hashlib.sha256(open(os.path.join(ROOT, 'latentfusion_amd', 'csrc', f), 'rb').read()).hexdigest() == h
+                             for f, h in tj['source_sha256'].items())
+                kk = 'conv3d_c16_ring_bf16_addend' if key.startswith('add') else 'conv3d_c16_ring_bf16'
+                if fresh_ and kk in tj['kernels']:
+                    # the PMC probe launches the kernel on 8 volumes: per-volume bytes x the volumes of this launch
+                    tr = tj['kernels'][kk]['bytes_per_launch'] / 8.0 * int(key.split('N=')[1])
+                    trs = os.path.basename(tpath)
+                    break
+            except Exception:                                       # noqa: BLE001
+                continue
+        out['roofline'] = {'bound': 'hbm', 'kernel': f'conv3d_c16_f16x3_kernel<{"true" if key.startswith("add") else "false"}, 1> '
+                                                     f'(bf16 ring convolution 16 -> 16, form {key})',
+                           'achieved': t_['algorithmic_bytes_per_launch'] / (t_['avg_launch_ms'] * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS,
+                           'unit': 'GB/s', 'frac': t_['hbm_frac'], 'traffic': tr, 'traffic_source': trs,
+                           'avg_launch_ms': t_['avg_launch_ms'], 'launches_timed': t_['launches'],
+                           'algorithmic_bytes_per_launch': t_['algorithmic_bytes_per_launch'],
+                           'share_of_step': t_['total_ms'] / ms}
     return out
 
 
@@ -731,6 +838,15 @@ def main():
         except Exception as e:                                       # noqa: BLE001  (auxiliary: never loses the headline)
             cfg3 = {'error': f'{type(e).__name__}: {e}'[:300]}
 
+    cfg5 = None
+    if world == 1 and not a.no_cfg5 and C == 16:
+        try:
+            st = est = st2 = est2 = None
+            torch.cuda.empty_cache()
+            cfg5 = cfg5_report(a, dev)
+        except Exception as e:                                       # noqa: BLE001  (auxiliary: never loses the headline)
+            cfg5 = {'error': f'{type(e).__name__}: {e}'[:300]}
+
     # RCCL on this box: under a launcher the process group above IS an RCCL communicator; a plain `python bench.py` run
     # initialises a world-size-1 group here (after the timed regions, so it cannot touch the number) and runs one
     # all-reduce of a latent-volume-sized tensor through it
@@ -764,6 +880,7 @@ def main():
         'timing': {'what': f'{len(blocks)} back-to-back blocks of exactly {a.steps} iterations, each between barrier + '
                            'synchronize, max over ranks; value = steps / MEDIAN block time',
                    'ms_per_step_blocks': [b / a.steps * 1e3 for b in blocks],
+                   'gpu_timed_total_s': sum(blocks),
                    'spread_pct': (max(blocks) - min(blocks)) / elapsed * 100.0},
         'rccl': rccl,
         'dtype': 'f32' if a.conv_mode in ('fp32', 'winograd') else 'f32 (conv3d products split into 3 f16 MFMAs, fp32 accumulate)', 'data': 'synthetic (SYN(S,C) random-init weights, synthetic observations)',
@@ -853,6 +970,8 @@ def main():
         out['sharded_build'] = sharded
     if cfg3 is not None:
         out['cfg3'] = cfg3
+    if cfg5 is not None:
+        out['cfg5'] = cfg5
     if pipelined is not None:
         out['pipelined_gru_build'] = pipelined
     if hyp is not None:

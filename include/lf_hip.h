@@ -256,6 +256,17 @@ size_t lf_conv3d_c16_ring_bf16_wpack_elems(void);
 int lf_conv3d_c16_ring_bf16(const float* x, const void* wpack, const float* bias, float* y, float* norm_out,
                             int N, int D, int H, int W, float he, unsigned flags, float slope, float eps,
                             const float* addend, int round_out, void* stream);
+/* The same launch with the STORAGE type of its three volumes selectable (round 5: the training step keeps the 16-channel
+ * tensors that only half-precision convolutions produce and consume as bf16 channels-last records, 32 B per voxel --
+ * half the HBM bytes of the same arithmetic: the staging rounds an fp32 input to bf16 anyway).  io = OR of LF_IO_*:
+ * LF_IO_IN_BF16: x is bf16; LF_IO_OUT_BF16: y is written as bf16 (RNE of the fp32 epilogue result);
+ * LF_IO_ADDEND_BF16: addend is bf16 (needs addend != NULL).  norm_out stays fp32.  io = 0 is lf_conv3d_c16_ring_bf16. */
+#define LF_IO_IN_BF16 1
+#define LF_IO_OUT_BF16 2
+#define LF_IO_ADDEND_BF16 4
+int lf_conv3d_c16_ring_bf16_io(const void* x, const void* wpack, const float* bias, void* y, float* norm_out,
+                               int N, int D, int H, int W, float he, unsigned flags, float slope, float eps,
+                               const void* addend, int round_out, int io, void* stream);
 
 /* Winograd F(2x2x2,3x3x3) for wide 3-D convolutions in three stages (input transform, 64 library GEMMs
  * M[f] = V[f] @ U[f] on the host side, output transform with the fused epilogue).  x, y channels-last;
@@ -311,6 +322,19 @@ int lf_gru_stage_b_bwd(const float* g, const float* h, const float* u, const flo
                        long n, void* stream);
 int lf_gru_stage_a_bwd(const float* gu, const float* grh, const float* u, const float* rpre, const float* h, float* gupre,
                        float* grpre, float* gh, long n, void* stream);
+/* The ConvGRU recurrence of the TRAINING step sequenced explicitly (ops._GruFuse; autograd of recon/fusion.py:188-197 over
+ * modules/gru.py:30-43): plain arrays of n values (n % 4 == 0, 16-byte aligned).  The state h, the gradient chain g / gh1 /
+ * gh12 and the accumulators are fp32; rpre, upre, cand, rh and the gate gradients are fp32 (bf16 = 0) or bf16 (bf16 = 1).
+ *   stage_a     rh = h sigmoid(rpre)
+ *   stage_b     h_out = h (1 - u) + cand u,  u = sigmoid(upre)
+ *   stage_b_bwd gh1 = g (1 - u); gupre = g (cand - h) u (1 - u); gc = g u; acc_u += gupre; acc_o += gc   (acc_* may be NULL)
+ *   stage_a_bwd grpre = grh h r (1 - r); gh12 = gh1 + grh r, r = sigmoid(rpre); acc_r += grpre            (acc_r may be NULL) */
+int lf_gru_train_stage_a(const void* rpre, const float* h, void* rh, long n, int bf16, void* stream);
+int lf_gru_train_stage_b(const float* h, const void* upre, const void* cand, float* h_out, long n, int bf16, void* stream);
+int lf_gru_train_stage_b_bwd(const float* g, const float* h, const void* upre, const void* cand, float* gh1, void* gupre,
+                             void* gc, float* acc_u, float* acc_o, long n, int bf16, void* stream);
+int lf_gru_train_stage_a_bwd(const void* grh, const void* rpre, const float* h, const float* gh1, void* grpre, float* gh12,
+                             float* acc_r, long n, int bf16, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Depth-column composites of the renderer (channels-last volumes [N][D][H][W][C], P = H*W pixels).
@@ -391,6 +415,9 @@ int lf_conv_bwd_weight(const float* x, const float* gpre, float* gw, void* scrat
  * keeps lf_conv_bwd_weight for the rest). */
 int lf_conv_bwd_weight_bf16(const float* x, const float* gpre, float* gw, void* scratch, size_t scratch_bytes,
                             int dims, int N, int D, int H, int W, int Cin, int Cout, float scale, void* stream);
+/* ... with x (io & 1) and / or gpre (io & 2) stored as bf16 channels-last records (see lf_conv3d_c16_ring_bf16_io). */
+int lf_conv_bwd_weight_bf16_io(const void* x, const void* gpre, float* gw, void* scratch, size_t scratch_bytes,
+                               int dims, int N, int D, int H, int W, int Cin, int Cout, float scale, int io, void* stream);
 
 /* Standalone PixelNorm over the last (channel) axis of [rows][C], in place allowed.
  * norm_out[rows] receives sqrt(mean+eps).  modules/__init__.py:14-15. */

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'liblf_hip.so')
 LF_EPI_LRELU = 1
 LF_EPI_PIXELNORM = 2
 LF_EPI_ADD = 4
+LF_IO_IN_BF16, LF_IO_OUT_BF16, LF_IO_ADDEND_BF16 = 1, 2, 4
 LF_MAP_O2C = 0
 LF_MAP_C2O = 1
 LF_MAP_COEFS = 20
@@ -61,6 +62,7 @@ SIGNATURES = {
     'lf_conv3d_c16_bf16': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint, c_float, c_float, c_int, P]),
     'lf_conv3d_c16_ring_bf16_wpack_elems': (c_size_t, []),
     'lf_conv3d_c16_ring_bf16': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint, c_float, c_float, P, c_int, P]),
+    'lf_conv3d_c16_ring_bf16_io': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint, c_float, c_float, P, c_int, c_int, P]),
     'lf_wino3d_tiles': (c_long, [c_int, c_int, c_int, c_int]),
     'lf_wino3d_input_transform': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'lf_wino3d_output_transform': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_uint, c_float, c_float, P]),
@@ -76,6 +78,10 @@ SIGNATURES = {
     'lf_lstm_cell_bwd': (c_int, [P, P, P, P, P, P, c_long, c_int, P]),
     'lf_gru_stage_b_bwd': (c_int, [P, P, P, P, P, P, P, c_long, P]),
     'lf_gru_stage_a_bwd': (c_int, [P, P, P, P, P, P, P, P, c_long, P]),
+    'lf_gru_train_stage_a': (c_int, [P, P, P, c_long, c_int, P]),
+    'lf_gru_train_stage_b': (c_int, [P, P, P, P, c_long, c_int, P]),
+    'lf_gru_train_stage_b_bwd': (c_int, [P, P, P, P, P, P, P, P, P, c_long, c_int, P]),
+    'lf_gru_train_stage_a_bwd': (c_int, [P, P, P, P, P, P, P, c_long, c_int, P]),
     'lf_column_reduce_sum_fwd': (c_int, [P, P, c_int, c_int, c_long, c_int, P]),
     'lf_column_reduce_sum_bwd': (c_int, [P, P, c_int, c_int, c_long, c_int, P]),
     'lf_column_softmax_fwd': (c_int, [P, P, P, c_int, c_int, c_long, P]),
@@ -91,6 +97,7 @@ SIGNATURES = {
     'lf_conv_bwd_weight_scratch_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     'lf_conv_bwd_weight': (c_int, [P, P, P, P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, P]),
     'lf_conv_bwd_weight_bf16': (c_int, [P, P, P, P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, P]),
+    'lf_conv_bwd_weight_bf16_io': (c_int, [P, P, P, P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, P]),
     'lf_pixelnorm_fwd': (c_int, [P, P, P, c_long, c_int, c_float, P]),
     'lf_epilogue_bwd': (c_int, [P, P, P, P, c_long, c_int, c_uint, c_float, P]),
     'lf_resize_fwd': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),

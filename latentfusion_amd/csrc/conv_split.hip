@@ -151,7 +151,10 @@ __device__ __forceinline__ int mod6(int v) { return v >= 6 ? v - 6 : v; }      /
 // (35 KB of LDS), no pre-scaling (bf16 has fp32's range); `round_out` = 1 rounds the result the way autocast's
 // half-precision convolution and `* he` do (conv_bf16.hip); GRAD with LF_EPI_ADD in prev_flags adds prev_y instead of
 // applying the previous layer's backward epilogue (the addend form of the ConvGRU gates).
-template <bool GRAD, int NP>
+// IO (NP = 1 only; round 5): storage type of the three volumes -- bit 0: the input x, bit 1: the output y, bit 2: prev_y
+// (the addend) are bf16 channels-last records of 32 B per voxel instead of fp32 records of 64 B.  An input that is only
+// ever read through this staging (which rounds to bf16) loses nothing by being stored rounded; half the bytes move.
+template <bool GRAD, int NP, int IO = 0>
 __global__ void __launch_bounds__(256, 2) conv3d_c16_f16x3_kernel(
     const float* __restrict__ x, const void* __restrict__ wsplit_v, const float* __restrict__ bias,
     float* __restrict__ y, float* __restrict__ norm_out,
@@ -163,6 +166,9 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_f16x3_kernel(
   using h8 = std::conditional_t<NP == 1, bf16x8s, f16x8>;
   using h1 = std::conditional_t<NP == 1, __bf16, _Float16>;
   constexpr int LDS_B = NP == 1 ? LO_OFF + GUARD_B : LDSs;
+  static_assert(IO == 0 || NP == 1, "bf16 storage is a property of the bf16 form");
+  constexpr bool IN16 = (IO & 1) != 0, OUT16 = (IO & 2) != 0, PREV16 = (IO & 4) != 0;
+  constexpr int IN_SH = IN16 ? 5 : 6;                     // log2 bytes per input voxel record
   const h1* wsplit = (const h1*)wsplit_v;
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -227,7 +233,9 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_f16x3_kernel(
   const int erow = frow0 + (lane >> 3), ecol = 16 + ((lane >> 2) & 1);
   const int eldso = (erow * HXs + ecol) * 32 + (lane & 3) * 8;
   const bool e_ok = lane < 40;
-  const int plane_bytes = H * W * 64;
+  const int plane_bytes = H * W * 64;                     // (fp32 records: the output side; halved per use for bf16 storage)
+  const int in_plane_bytes = (H * W) << IN_SH;
+  const unsigned in_sample_bytes = (unsigned)(nvox << IN_SH);
 
   int foff[NPIECE];
   const float* f_x = x;
@@ -237,25 +245,34 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_f16x3_kernel(
 #pragma unroll
     for (int it = 0; it < 5; ++it) {
       const int row = oy + frow0 + it;
-      foff[it] = ((unsigned)col < (unsigned)W && (unsigned)row < (unsigned)H) ? (row * W + col) * 64 + (lane & 3) * 16 : OOB;
+      foff[it] = ((unsigned)col < (unsigned)W && (unsigned)row < (unsigned)H) ? ((row * W + col) << IN_SH) + ((lane & 3) << (IN_SH - 2)) : OOB;
     }
     const int row = oy + erow, c2 = ox + ecol;
-    foff[5] = (e_ok && (unsigned)c2 < (unsigned)W && (unsigned)row < (unsigned)H) ? (row * W + c2) * 64 + (lane & 3) * 16 : OOB;
-    f_x = x + (long)bn * nvox * 16;
+    foff[5] = (e_ok && (unsigned)c2 < (unsigned)W && (unsigned)row < (unsigned)H) ? ((row * W + c2) << IN_SH) + ((lane & 3) << (IN_SH - 2)) : OOB;
+    f_x = x + (long)bn * nvox * (IN16 ? 8 : 16);          // (x is declared float*: a bf16 record is 8 floats' worth of bytes)
   };
   u32x4s stg[NPIECE];
   auto fetch_plane = [&](int z, bool on) {
     const bool v = on && (unsigned)z < (unsigned)D;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)f_x, 0, v ? sample_bytes : 0u, 0x00020000);
-    const int soff = v ? z * plane_bytes : 0;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)f_x, 0, v ? in_sample_bytes : 0u, 0x00020000);
+    const int soff = v ? z * in_plane_bytes : 0;
 #pragma unroll
-    for (int it = 0; it < NPIECE; ++it) stg[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, foff[it], soff, 0);
+    for (int it = 0; it < NPIECE; ++it) {
+      if constexpr (IN16) {
+        const u32x2s h = __builtin_amdgcn_raw_buffer_load_b64(rs, foff[it], soff, 0);
+        stg[it] = (u32x4s){h[0], h[1], 0u, 0u};
+      } else {
+        stg[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, foff[it], soff, 0);
+      }
+    }
   };
   // fp32 -> f16 hi / lo of staged piece `it`, into the plane slot at dst
   auto commit_piece = [&](unsigned char* dst, auto itc) {
     constexpr int it = decltype(itc)::v;
     if constexpr (NP == 1) {
-      const bf16x4s h = __builtin_convertvector(__builtin_bit_cast(f32x4, stg[it]), bf16x4s);
+      bf16x4s h;
+      if constexpr (IN16) h = __builtin_bit_cast(bf16x4s, (u32x2s){stg[it][0], stg[it][1]});
+      else h = __builtin_convertvector(__builtin_bit_cast(f32x4, stg[it]), bf16x4s);
       if constexpr (it < 5) *(bf16x4s*)(dst + (frow0 + it) * (HXs * 32) + lane * 8) = h;
       else if (e_ok) *(bf16x4s*)(dst + eldso) = h;
     } else {
@@ -311,10 +328,10 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_f16x3_kernel(
     const int gx = bx * TXs + n, gy0 = by * TYs + RYs * ry;
 #pragma unroll
     for (int r = 0; r < RYs; ++r) eoff[r] = (gx < W && gy0 + r < H) ? ((gy0 + r) * W + gx) * 64 + kg * 16 : OOB;
-    e_y = y + (long)bn * nvox * 16;
+    e_y = y + (long)bn * nvox * (OUT16 ? 8 : 16);
     e_n = norm_out ? norm_out + (long)bn * nvox : nullptr;
     if constexpr (GRAD) {
-      e_py = prev_y + (long)bn * nvox * 16;
+      e_py = prev_y + (long)bn * nvox * (PREV16 ? 8 : 16);
       e_pn = prev_norm ? prev_norm + (long)bn * nvox : nullptr;
     }
   };
@@ -328,14 +345,20 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_f16x3_kernel(
     E.zv = valid && gz < D;
     E.soff = E.zv ? gz * plane_bytes : 0;
     E.soff_n = E.zv ? gz * (plane_bytes >> 4) : 0;
-    E.rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)e_y, 0, E.zv ? sample_bytes : 0u, 0x00020000);
+    E.rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)e_y, 0, E.zv ? (OUT16 ? sample_bytes >> 1 : sample_bytes) : 0u, 0x00020000);
     E.rs_n = __builtin_amdgcn_make_buffer_rsrc((void*)e_n, 0, (E.zv && e_n != nullptr) ? (sample_bytes >> 4) : 0u, 0x00020000);
     if constexpr (GRAD) {
-      const __amdgpu_buffer_rsrc_t rs_py = __builtin_amdgcn_make_buffer_rsrc((void*)e_py, 0, E.zv ? sample_bytes : 0u, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rs_py = __builtin_amdgcn_make_buffer_rsrc((void*)e_py, 0, E.zv ? (PREV16 ? sample_bytes >> 1 : sample_bytes) : 0u, 0x00020000);
       const __amdgpu_buffer_rsrc_t rs_pn = __builtin_amdgcn_make_buffer_rsrc((void*)e_pn, 0, (E.zv && e_pn != nullptr) ? (sample_bytes >> 4) : 0u, 0x00020000);
 #pragma unroll
       for (int r = 0; r < RYs; ++r) {
-        pyv[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_py, eoff[r], E.soff, 0));
+        if constexpr (PREV16) {
+          // (an out-of-volume offset 0x80000000 shifts to 0xC0000000: still past every buffer)
+          const bf16x4s pb = __builtin_bit_cast(bf16x4s, __builtin_amdgcn_raw_buffer_load_b64(rs_py, eoff[r] >> 1, E.soff >> 1, 0));
+          pyv[r] = __builtin_convertvector(pb, f32x4);
+        } else {
+          pyv[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_py, eoff[r], E.soff, 0));
+        }
         pnv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_pn, (eoff[r] >> 4) & ~3, E.soff_n, 0));
       }
     }
@@ -380,7 +403,10 @@ __global__ void __launch_bounds__(256, 2) conv3d_c16_f16x3_kernel(
         v *= rinv;
       }
       if (!(SPLIT_ABL & 8) || v[0] == 123.456f) {
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, v), E.rs_y, eoff[r], E.soff, 2);   // nt: L2 is for halos
+        if constexpr (OUT16)
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2s, __builtin_convertvector(v, bf16x4s)), E.rs_y, eoff[r] >> 1, E.soff >> 1, 2);
+        else
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, v), E.rs_y, eoff[r], E.soff, 2);   // nt: L2 is for halos
         if (!(SPLIT_ABL & 32) && !GRAD && (flags & LF_EPI_PIXELNORM))
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, rn), E.rs_n, (eoff[r] >> 4) | kgmask, E.soff_n, 0);
       }
@@ -569,9 +595,26 @@ int lf_internal_ring_bf16_set_wgs(int v) {
 // bf16 elements of the weight pack of the bf16 form: [14 pairs][16 cout][32 = 2 taps x 16 cin] (pairs: lf_conv3d_c16_split_pairs)
 extern "C" size_t lf_conv3d_c16_ring_bf16_wpack_elems(void) { return (size_t)NPAIR * 16 * 32; }
 
+static int ring_bf16_launch(const void* x, const void* wpack, const float* bias, void* y, float* norm_out,
+                            int N, int D, int H, int W, float he, unsigned flags, float slope, float eps,
+                            const void* addend, int round_out, int io, void* stream);
+
 extern "C" int lf_conv3d_c16_ring_bf16(const float* x, const void* wpack, const float* bias, float* y, float* norm_out,
                                        int N, int D, int H, int W, float he, unsigned flags, float slope, float eps,
                                        const float* addend, int round_out, void* stream) {
+  return ring_bf16_launch(x, wpack, bias, y, norm_out, N, D, H, W, he, flags, slope, eps, addend, round_out, 0, stream);
+}
+
+extern "C" int lf_conv3d_c16_ring_bf16_io(const void* x, const void* wpack, const float* bias, void* y, float* norm_out,
+                                          int N, int D, int H, int W, float he, unsigned flags, float slope, float eps,
+                                          const void* addend, int round_out, int io, void* stream) {
+  if (io < 0 || io > 7 || (addend == nullptr && (io & LF_IO_ADDEND_BF16))) return LF_EINVAL;
+  return ring_bf16_launch(x, wpack, bias, y, norm_out, N, D, H, W, he, flags, slope, eps, addend, round_out, io, stream);
+}
+
+static int ring_bf16_launch(const void* x, const void* wpack, const float* bias, void* y, float* norm_out,
+                            int N, int D, int H, int W, float he, unsigned flags, float slope, float eps,
+                            const void* addend, int round_out, int io, void* stream) {
   lf_clear_error();
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || round_out < 0 || round_out > 1) return LF_EINVAL;
   if ((long)D * H * W * 64 >= 0x7fffffffL || !(slope > 0.f && slope < 1.f)) return LF_EINVAL;
@@ -590,11 +633,19 @@ extern "C" int lf_conv3d_c16_ring_bf16(const float* x, const void* wpack, const 
   const size_t shmem = (size_t)(LO_OFF + GUARD_B);
   typedef void (*kern_t)(const float*, const void*, const float*, float*, float*, int, int, int, int, int, int, int, int, float,
                          unsigned, float, float, const float*, const float*, unsigned, const float*, float*, int);
-  static const kern_t kerns[2] = {conv3d_c16_f16x3_kernel<false, 1>, conv3d_c16_f16x3_kernel<true, 1>};
+  // [addend form][io]: plain form = input / output storage (bits 0, 1); addend form = all three bits
+  static const kern_t kerns[2][8] = {
+      {conv3d_c16_f16x3_kernel<false, 1, 0>, conv3d_c16_f16x3_kernel<false, 1, 1>, conv3d_c16_f16x3_kernel<false, 1, 2>,
+       conv3d_c16_f16x3_kernel<false, 1, 3>, nullptr, nullptr, nullptr, nullptr},
+      {conv3d_c16_f16x3_kernel<true, 1, 0>, conv3d_c16_f16x3_kernel<true, 1, 1>, conv3d_c16_f16x3_kernel<true, 1, 2>,
+       conv3d_c16_f16x3_kernel<true, 1, 3>, conv3d_c16_f16x3_kernel<true, 1, 4>, conv3d_c16_f16x3_kernel<true, 1, 5>,
+       conv3d_c16_f16x3_kernel<true, 1, 6>, conv3d_c16_f16x3_kernel<true, 1, 7>}};
+  const kern_t kern = kerns[addend != nullptr ? 1 : 0][io];
+  if (kern == nullptr) return LF_EINVAL;
   const long want = (long)g_ring_bf16_wgs * cus;               // (35 KB of LDS and < 170 VGPRs: three fit)
   const unsigned grid = (unsigned)(pt < want ? pt : want);
-  hipLaunchKernelGGL(kerns[addend != nullptr ? 1 : 0], dim3(grid), dim3(256), shmem, (hipStream_t)stream, x, wpack, bias, y, norm_out,
-                     N, D, H, W, ptx, pty, ptz, (int)pt, he, flags, slope, eps, addend, (const float*)nullptr, (unsigned)LF_EPI_ADD,
-                     (const float*)nullptr, (float*)nullptr, round_out);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shmem, (hipStream_t)stream, (const float*)x, wpack, bias, (float*)y, norm_out,
+                     N, D, H, W, ptx, pty, ptz, (int)pt, he, flags, slope, eps, (const float*)addend, (const float*)nullptr,
+                     (unsigned)LF_EPI_ADD, (const float*)nullptr, (float*)nullptr, round_out);
   return lf_launch_status();
 }

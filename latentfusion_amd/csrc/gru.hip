@@ -110,6 +110,86 @@ __global__ void __launch_bounds__(256) lstm_cell_bwd_kernel(const float* __restr
   gc[idx] = dcn * f;
 }
 
+
+// ---- training path of the 16-channel ConvGRU fuser sequenced explicitly (round 5; ops._GruFuse): the recurrent state h, the
+// incoming gradient chain and the per-gate gradient accumulators stay fp32; the gate pre-activations, h*r, the candidate and
+// the gate gradients -- tensors that are produced and consumed once per step -- are stored as T = float or bf16 (the bf16
+// autocast policy: they are outputs / operands of half-precision convolutions).  u and r are recomputed from the saved
+// pre-activations, the two backward stages fold in what autograd ran as separate passes:
+//   stage A    rh = h s(rpre)
+//   stage B    h' = h (1 - u) + c u,                 u = s(upre)
+//   stage B'   gh1 = g (1 - u),  gupre = g (c - h) u (1 - u),  gc = g u;          acc_u += gupre, acc_o += gc
+//   stage A'   grpre = grh h r (1 - r),  gh12 = gh1 + grh r,  r = s(rpre);        acc_r += grpre
+// (the accumulators hold sum over the views of the gate gradients: bias and coordinate-channel weight gradients need only it)
+typedef __bf16 bf16x4g __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2g __attribute__((ext_vector_type(2)));
+template <typename T> struct Rec4;
+template <> struct Rec4<float> {
+  static __device__ __forceinline__ f32x4 ld(const void* p, long i) { return ((const f32x4*)p)[i]; }
+  static __device__ __forceinline__ void st(void* p, long i, f32x4 v) { ((f32x4*)p)[i] = v; }
+};
+template <> struct Rec4<__bf16> {
+  static __device__ __forceinline__ f32x4 ld(const void* p, long i) { return __builtin_convertvector(((const bf16x4g*)p)[i], f32x4); }
+  static __device__ __forceinline__ void st(void* p, long i, f32x4 v) { ((bf16x4g*)p)[i] = __builtin_convertvector(v, bf16x4g); }
+};
+__device__ __forceinline__ f32x4 sigmoid4(f32x4 v) {
+  f32x4 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) r[e] = sigmoidf_(v[e]);
+  return r;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) gru_train_a_kernel(const void* __restrict__ rpre, const f32x4* __restrict__ h,
+                                                          void* __restrict__ rh, long n4) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  Rec4<T>::st(rh, i, h[i] * sigmoid4(Rec4<T>::ld(rpre, i)));
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) gru_train_b_kernel(const f32x4* __restrict__ h, const void* __restrict__ upre,
+                                                          const void* __restrict__ cand, f32x4* __restrict__ h_out, long n4) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const f32x4 u = sigmoid4(Rec4<T>::ld(upre, i)), c = Rec4<T>::ld(cand, i), hh = h[i];
+  f32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = __fadd_rn(__fmul_rn(hh[e], __fsub_rn(1.f, u[e])), __fmul_rn(c[e], u[e]));
+  h_out[i] = o;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) gru_train_b_bwd_kernel(const f32x4* __restrict__ g, const f32x4* __restrict__ h,
+                                                              const void* __restrict__ upre, const void* __restrict__ cand,
+                                                              f32x4* __restrict__ gh1, void* __restrict__ gupre, void* __restrict__ gc,
+                                                              f32x4* __restrict__ acc_u, f32x4* __restrict__ acc_o, long n4) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const f32x4 gg = g[i], u = sigmoid4(Rec4<T>::ld(upre, i)), c = Rec4<T>::ld(cand, i), hh = h[i];
+  const f32x4 gu = gg * (c - hh);
+  const f32x4 gup = gu * u * (1.f - u), gcc = gg * u;
+  gh1[i] = gg * (1.f - u);
+  Rec4<T>::st(gupre, i, gup);
+  Rec4<T>::st(gc, i, gcc);
+  if (acc_u != nullptr) acc_u[i] += gup;
+  if (acc_o != nullptr) acc_o[i] += gcc;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) gru_train_a_bwd_kernel(const void* __restrict__ grh, const void* __restrict__ rpre,
+                                                              const f32x4* __restrict__ h, const f32x4* __restrict__ gh1,
+                                                              void* __restrict__ grpre, f32x4* __restrict__ gh12,
+                                                              f32x4* __restrict__ acc_r, long n4) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const f32x4 gr = Rec4<T>::ld(grh, i), r = sigmoid4(Rec4<T>::ld(rpre, i)), hh = h[i];
+  const f32x4 grp = gr * hh * r * (1.f - r);
+  Rec4<T>::st(grpre, i, grp);
+  gh12[i] = gh1[i] + gr * r;
+  if (acc_r != nullptr) acc_r[i] += grp;
+}
+
 }  // namespace
 
 extern "C" int lf_lstm_cell_fwd(const float* cc, const float* c_cur, float* h_next, float* c_next, long nvox, int Ch, void* stream) {
@@ -169,5 +249,56 @@ extern "C" int lf_gru_stage_b(const float* h, const float* u, const float* cand,
   if (rec != nullptr && (rec_stride < rec_off + Ch || rec_off < 0)) return LF_EINVAL;
   hipLaunchKernelGGL(gru_stage_b_kernel, dim3((unsigned)((nvox * Ch + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h, u, cand,
                      h_out, rec, nvox, Ch, rec_stride, rec_off);
+  return lf_launch_status();
+}
+
+// ---- training-path stages (see the kernels above); bf16 != 0: the T-typed tensors are bf16 ----
+static inline bool gru_train_ok(long n, const void* const* ptrs, int np) {
+  if (n <= 0 || (n & 3)) return false;
+  for (int i = 0; i < np; ++i)
+    if (ptrs[i] != nullptr && !lf_aligned16(ptrs[i])) return false;
+  return true;
+}
+#define GRU_GRID(n) dim3((unsigned)(((n) / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream
+
+extern "C" int lf_gru_train_stage_a(const void* rpre, const float* h, void* rh, long n, int bf16, void* stream) {
+  lf_clear_error();
+  const void* ps[] = {rpre, h, rh};
+  if (!gru_train_ok(n, ps, 3) || !rpre || !h || !rh) return LF_EINVAL;
+  if (bf16) hipLaunchKernelGGL(gru_train_a_kernel<__bf16>, GRU_GRID(n), rpre, (const f32x4*)h, rh, n / 4);
+  else hipLaunchKernelGGL(gru_train_a_kernel<float>, GRU_GRID(n), rpre, (const f32x4*)h, rh, n / 4);
+  return lf_launch_status();
+}
+
+extern "C" int lf_gru_train_stage_b(const float* h, const void* upre, const void* cand, float* h_out, long n, int bf16, void* stream) {
+  lf_clear_error();
+  const void* ps[] = {h, upre, cand, h_out};
+  if (!gru_train_ok(n, ps, 4) || !h || !upre || !cand || !h_out) return LF_EINVAL;
+  if (bf16) hipLaunchKernelGGL(gru_train_b_kernel<__bf16>, GRU_GRID(n), (const f32x4*)h, upre, cand, (f32x4*)h_out, n / 4);
+  else hipLaunchKernelGGL(gru_train_b_kernel<float>, GRU_GRID(n), (const f32x4*)h, upre, cand, (f32x4*)h_out, n / 4);
+  return lf_launch_status();
+}
+
+extern "C" int lf_gru_train_stage_b_bwd(const float* g, const float* h, const void* upre, const void* cand, float* gh1, void* gupre,
+                                        void* gc, float* acc_u, float* acc_o, long n, int bf16, void* stream) {
+  lf_clear_error();
+  const void* ps[] = {g, h, upre, cand, gh1, gupre, gc, acc_u, acc_o};
+  if (!gru_train_ok(n, ps, 9) || !g || !h || !upre || !cand || !gh1 || !gupre || !gc) return LF_EINVAL;
+  if (bf16) hipLaunchKernelGGL(gru_train_b_bwd_kernel<__bf16>, GRU_GRID(n), (const f32x4*)g, (const f32x4*)h, upre, cand, (f32x4*)gh1,
+                               gupre, gc, (f32x4*)acc_u, (f32x4*)acc_o, n / 4);
+  else hipLaunchKernelGGL(gru_train_b_bwd_kernel<float>, GRU_GRID(n), (const f32x4*)g, (const f32x4*)h, upre, cand, (f32x4*)gh1,
+                          gupre, gc, (f32x4*)acc_u, (f32x4*)acc_o, n / 4);
+  return lf_launch_status();
+}
+
+extern "C" int lf_gru_train_stage_a_bwd(const void* grh, const void* rpre, const float* h, const float* gh1, void* grpre, float* gh12,
+                                        float* acc_r, long n, int bf16, void* stream) {
+  lf_clear_error();
+  const void* ps[] = {grh, rpre, h, gh1, grpre, gh12, acc_r};
+  if (!gru_train_ok(n, ps, 7) || !grh || !rpre || !h || !gh1 || !grpre || !gh12) return LF_EINVAL;
+  if (bf16) hipLaunchKernelGGL(gru_train_a_bwd_kernel<__bf16>, GRU_GRID(n), grh, rpre, (const f32x4*)h, (const f32x4*)gh1, grpre,
+                               (f32x4*)gh12, (f32x4*)acc_r, n / 4);
+  else hipLaunchKernelGGL(gru_train_a_bwd_kernel<float>, GRU_GRID(n), grh, rpre, (const f32x4*)h, (const f32x4*)gh1, grpre,
+                          (f32x4*)gh12, (f32x4*)acc_r, n / 4);
   return lf_launch_status();
 }

@@ -230,6 +230,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 constexpr int BRING = 6;                                         // z-plane slots: 4 being read + 2 being filled
 constexpr int BRS = 48;                                          // bytes per halo row: 18 bf16 (+6)
 constexpr int BPL = WHY * BRS;                                   // 480 B per plane slot and channel
@@ -246,9 +247,14 @@ constexpr unsigned BOOB = 0x80000000u;
 
 __device__ __forceinline__ int bmod6(int v) { return v >= 6 ? v - 6 : v; }      // v in [0, 12)
 
+// IO (round 5): bit 0 -- x, bit 1 -- gpre are stored as bf16 channels-last records (32 B per voxel) instead of fp32 ones: the
+// staging rounds fp32 operands to bf16 anyway, so operands kept rounded in memory give the same products from half the bytes.
+template <int IO>
 __global__ void __launch_bounds__(256, 2) wgrad3d_c16_bf16_kernel(
     const float* __restrict__ x, const float* __restrict__ gp, float* __restrict__ partial,
     int N, int D, int H, int W, int tiles_x, int tiles_y, int tiles_z, int ntiles) {
+  constexpr bool X16 = (IO & 1) != 0, G16 = (IO & 2) != 0;
+  constexpr int XSH = X16 ? 5 : 6, GSH = G16 ? 5 : 6;                // log2 bytes per voxel record
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -259,8 +265,7 @@ __global__ void __launch_bounds__(256, 2) wgrad3d_c16_bf16_kernel(
   const int t_begin = lb * per;
   const int t_end = min(t_begin + per, ntiles);
   const long nvox = (long)D * H * W;
-  const unsigned sample_bytes = (unsigned)(nvox * 64);
-  const unsigned plane_bytes = (unsigned)(H * W * 64);
+  const unsigned plane_vox = (unsigned)(H * W);
 
   f32x4 acc[9];                                                  // rows 2w, 2w+1 (x 3 kx), then this wave's share of row 8
 #pragma unroll
@@ -299,25 +304,36 @@ __global__ void __launch_bounds__(256, 2) wgrad3d_c16_bf16_kernel(
       for (int it = 0; it < BNIT; ++it) {
         const int halo = it < BXIT ? 1 : 0;
         const int gx = bx * WTX - halo + (lxy[it] & 0xff), gy = by * WTY - halo + ((lxy[it] >> 8) & 0xff);
-        coff[it] = (unsigned)((gy * W + gx) * 64 + q * 16) + (unsigned)(lxy[it] >> 16) * plane_bytes;
+        const int sh = halo ? XSH : GSH;
+        coff[it] = (unsigned)(((gy * W + gx) << sh) + (q << (sh - 2))) + (((unsigned)(lxy[it] >> 16) * plane_vox) << sh);
         const bool oky = (unsigned)gy < (unsigned)H;
         okm |= ((oky && (unsigned)gx < (unsigned)W) ? 1u : 0u) << (2 * it);
         okm |= ((oky && (unsigned)(gx + 1) < (unsigned)W) ? 1u : 0u) << (2 * it + 1);
       }
-      cx_ptr = x + (long)bn * nvox * 16;
-      cg_ptr = gp + (long)bn * nvox * 16;
+      cx_ptr = x + (long)bn * nvox * (X16 ? 8 : 16);               // (declared float*: a bf16 record is 8 floats' worth of bytes)
+      cg_ptr = gp + (long)bn * nvox * (G16 ? 8 : 16);
     };
     u32x4 st[BNIT][2];
     // x planes zx, zx + 1 of the column (and, with_g, the gpre block of the tile at planes zg, zg + 1) -> registers
     auto issue = [&](int zx, int zg, bool with_g) {
-      const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)cx_ptr, 0, sample_bytes, 0x00020000);
-      const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)cg_ptr, 0, with_g ? sample_bytes : 0u, 0x00020000);
-      const unsigned zoffx = (unsigned)zx * plane_bytes, zoffg = (unsigned)zg * plane_bytes;
+      const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)cx_ptr, 0, (unsigned)(nvox << XSH), 0x00020000);
+      const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)cg_ptr, 0, with_g ? (unsigned)(nvox << GSH) : 0u, 0x00020000);
+      const unsigned zoffx = ((unsigned)zx * plane_vox) << XSH, zoffg = ((unsigned)zg * plane_vox) << GSH;
 #pragma unroll
       for (int it = 0; it < BNIT; ++it) {
         const unsigned o = coff[it] + (it < BXIT ? zoffx : zoffg);
-        st[it][0] = __builtin_amdgcn_raw_buffer_load_b128(it < BXIT ? rx : rg, (int)(((okm >> (2 * it)) & 1u) ? o : BOOB), 0, 0);
-        st[it][1] = __builtin_amdgcn_raw_buffer_load_b128(it < BXIT ? rx : rg, (int)(((okm >> (2 * it + 1)) & 1u) ? o + 64u : BOOB), 0, 0);
+        const int o0 = (int)(((okm >> (2 * it)) & 1u) ? o : BOOB);
+        if ((it < BXIT) ? X16 : G16) {                               // (folds after unrolling)
+          const int o1 = (int)(((okm >> (2 * it + 1)) & 1u) ? o + 32u : BOOB);
+          const u32x2 a = __builtin_amdgcn_raw_buffer_load_b64(it < BXIT ? rx : rg, o0, 0, 0);
+          const u32x2 b = __builtin_amdgcn_raw_buffer_load_b64(it < BXIT ? rx : rg, o1, 0, 0);
+          st[it][0] = (u32x4){a[0], a[1], 0u, 0u};
+          st[it][1] = (u32x4){b[0], b[1], 0u, 0u};
+        } else {
+          const int o1 = (int)(((okm >> (2 * it + 1)) & 1u) ? o + 64u : BOOB);
+          st[it][0] = __builtin_amdgcn_raw_buffer_load_b128(it < BXIT ? rx : rg, o0, 0, 0);
+          st[it][1] = __builtin_amdgcn_raw_buffer_load_b128(it < BXIT ? rx : rg, o1, 0, 0);
+        }
       }
     };
     // registers -> bf16 planes: x pieces into ring slots s0 (first plane) / s1, gpre pieces into buffer gsel
@@ -325,11 +341,16 @@ __global__ void __launch_bounds__(256, 2) wgrad3d_c16_bf16_kernel(
 #pragma unroll
       for (int it = 0; it < BNIT; ++it) {
         if (it >= BXIT && !with_g) continue;                       // (uniform)
-        const f32x4 e = __builtin_bit_cast(f32x4, st[it][0]), o = __builtin_bit_cast(f32x4, st[it][1]);
-        const unsigned e01 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){e[0], e[1]}, bf16x2));
-        const unsigned e23 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){e[2], e[3]}, bf16x2));
-        const unsigned o01 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){o[0], o[1]}, bf16x2));
-        const unsigned o23 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){o[2], o[3]}, bf16x2));
+        unsigned e01, e23, o01, o23;
+        if ((it < BXIT) ? X16 : G16) {                               // already bf16 pairs
+          e01 = st[it][0][0]; e23 = st[it][0][1]; o01 = st[it][1][0]; o23 = st[it][1][1];
+        } else {
+          const f32x4 e = __builtin_bit_cast(f32x4, st[it][0]), o = __builtin_bit_cast(f32x4, st[it][1]);
+          e01 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){e[0], e[1]}, bf16x2));
+          e23 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){e[2], e[3]}, bf16x2));
+          o01 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){o[0], o[1]}, bf16x2));
+          o23 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){o[2], o[3]}, bf16x2));
+        }
         const int cs = it < BXIT ? BXS : BGS;
         unsigned char* d = smem + dst[it] + (it < BXIT ? ((lxy[it] >> 16) ? s1 : s0) * BPL : gsel * BGB);
         // one dword per channel: [voxel x, voxel x + 1]
@@ -587,8 +608,22 @@ extern "C" int lf_conv_bwd_weight(const float* x, const float* gpre, float* gw, 
   return lf_launch_status();
 }
 
+static int wgrad_bf16_launch(const void* x, const void* gpre, float* gw, void* scratch, size_t scratch_bytes,
+                             int dims, int N, int D, int H, int W, int Cin, int Cout, float scale, int io, void* stream);
+
 extern "C" int lf_conv_bwd_weight_bf16(const float* x, const float* gpre, float* gw, void* scratch, size_t scratch_bytes,
                                        int dims, int N, int D, int H, int W, int Cin, int Cout, float scale, void* stream) {
+  return wgrad_bf16_launch(x, gpre, gw, scratch, scratch_bytes, dims, N, D, H, W, Cin, Cout, scale, 0, stream);
+}
+
+extern "C" int lf_conv_bwd_weight_bf16_io(const void* x, const void* gpre, float* gw, void* scratch, size_t scratch_bytes,
+                                          int dims, int N, int D, int H, int W, int Cin, int Cout, float scale, int io, void* stream) {
+  if (io < 0 || io > 3) return LF_EINVAL;
+  return wgrad_bf16_launch(x, gpre, gw, scratch, scratch_bytes, dims, N, D, H, W, Cin, Cout, scale, io, stream);
+}
+
+static int wgrad_bf16_launch(const void* x, const void* gpre, float* gw, void* scratch, size_t scratch_bytes,
+                             int dims, int N, int D, int H, int W, int Cin, int Cout, float scale, int io, void* stream) {
   lf_clear_error();
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || x == nullptr || gpre == nullptr || gw == nullptr) return LF_EINVAL;
   if (!wgrad_fast3d(dims, N, D, H, W, Cin, Cout) || !lf_aligned16(x) || !lf_aligned16(gpre)) return LF_EINVAL;
@@ -600,14 +635,18 @@ extern "C" int lf_conv_bwd_weight_bf16(const float* x, const float* gpre, float*
   const long pt = (long)ptx * pty * ptz * N;
   if (pt > 0x7fffffffL) return LF_EINVAL;
   const size_t shmem = (size_t)BLDS;
+  typedef void (*kern_t)(const float*, const float*, float*, int, int, int, int, int, int, int, int);
+  static const kern_t kerns[4] = {wgrad3d_c16_bf16_kernel<0>, wgrad3d_c16_bf16_kernel<1>, wgrad3d_c16_bf16_kernel<2>, wgrad3d_c16_bf16_kernel<3>};
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)wgrad3d_c16_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    if (e != hipSuccess) return (int)e;
+    for (int i = 0; i < 4; ++i) {
+      hipError_t e = hipFuncSetAttribute((const void*)kerns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+      if (e != hipSuccess) return (int)e;
+    }
     attr_set = true;
   }
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(wgrad3d_c16_bf16_kernel, dim3(nb), dim3(256), shmem, s, x, gpre, (float*)scratch, N, D, H, W, ptx, pty, ptz, (int)pt);
+  hipLaunchKernelGGL(kerns[io], dim3(nb), dim3(256), shmem, s, (const float*)x, (const float*)gpre, (float*)scratch, N, D, H, W, ptx, pty, ptz, (int)pt);
   int st = lf_launch_status();
   if (st) return st;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(27, 1, 4), dim3(256), 0, s, (const float*)scratch, gw, nb, 27, 1, 1, 16, 16, scale);

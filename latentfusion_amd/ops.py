@@ -70,9 +70,15 @@ KERNEL_TIMER = None
 KERNEL_TIMER_TAGS = None
 
 
+class _Tag(str):
+    """A kernel tag that compares like its name and carries a `detail` (form / batch / storage of the launch)."""
+    detail = ''
+
+
 class _timed:
-    def __init__(self, name):
-        self.name = name
+    def __init__(self, name, detail=''):
+        self.name = _Tag(name)
+        self.name.detail = detail
         self.on = False
 
     def __enter__(self):
@@ -315,10 +321,33 @@ def conv3d_c16_ring_bf16(x, wpack, bias, he, flags, round_out, addend=None):
     N, _, D, H, W = x.shape
     y = empty_cl((N, 16, D, H, W), x.device)
     norm = torch.empty(N * D * H * W, device=x.device, dtype=torch.float32) if (flags & LF_EPI_PIXELNORM) else None
-    with _timed('conv3d_c16_ring_bf16'):
+    with _timed('conv3d_c16_ring_bf16', f"{'add' if addend is not None else 'fwd'}:{N}:io0"):
         check(L.lf_conv3d_c16_ring_bf16(_ptr(x), _ptr(wpack), _ptr(bias) if bias is not None else None, _ptr(y),
                                         _ptr(norm) if norm is not None else None, N, D, H, W, he, flags, SLOPE, PN_EPS,
                                         _ptr(addend) if addend is not None else None, round_out, _stream()), 'lf_conv3d_c16_ring_bf16')
+    return y, norm
+
+
+def empty_cl16(shape, device, bf16):
+    """A channels-last (N,16,D,H,W) volume in fp32 or bf16 storage."""
+    return torch.empty(shape, device=device, dtype=torch.bfloat16 if bf16 else torch.float32, memory_format=torch.channels_last_3d)
+
+
+def conv3d_c16_ring_bf16_io(x, wpack, bias, he, flags, round_out, addend=None, out=None, out_bf16=False):
+    """lf_conv3d_c16_ring_bf16_io: the bf16 ring convolution on volumes stored as fp32 OR bf16 channels-last records (the
+    dtype of `x` / `addend` / `out` says which).  `out`: write into this (N,16,D,H,W) channels-last tensor (e.g. a slice of a
+    gradient block) instead of a new one.  Returns (y, norm)."""
+    L = _lib.lib()
+    N, _, D, H, W = x.shape
+    y = out if out is not None else empty_cl16((N, 16, D, H, W), x.device, out_bf16)
+    io = ((_lib.LF_IO_IN_BF16 if x.dtype == torch.bfloat16 else 0) | (_lib.LF_IO_OUT_BF16 if y.dtype == torch.bfloat16 else 0)
+          | (_lib.LF_IO_ADDEND_BF16 if (addend is not None and addend.dtype == torch.bfloat16) else 0))
+    norm = torch.empty(N * D * H * W, device=x.device, dtype=torch.float32) if (flags & LF_EPI_PIXELNORM) else None
+    with _timed('conv3d_c16_ring_bf16', f"{'add' if addend is not None else 'fwd'}:{N}:io{io}"):
+        check(L.lf_conv3d_c16_ring_bf16_io(_ptr(x), _ptr(wpack), _ptr(bias) if bias is not None else None, _ptr(y),
+                                           _ptr(norm) if norm is not None else None, N, D, H, W, he, flags, SLOPE, PN_EPS,
+                                           _ptr(addend) if addend is not None else None, round_out, io, _stream()),
+              'lf_conv3d_c16_ring_bf16_io')
     return y, norm
 
 
@@ -371,11 +400,11 @@ def conv3d_c16_wino_split(x, upack, bias, he, flags, prev=None, amax_in=None, am
     return y, norm
 
 
-def conv3d_c16_wino(x, upack, bias, he, flags, prev=None, amax_out=None):
-    """Launch lf_conv3d_c16_wino on a channels-last (N,16,D,H,W) tensor."""
+def conv3d_c16_wino(x, upack, bias, he, flags, prev=None, amax_out=None, out=None):
+    """Launch lf_conv3d_c16_wino on a channels-last (N,16,D,H,W) tensor (`out`: write into this tensor)."""
     L = _lib.lib()
     N, _, D, H, W = x.shape
-    y = empty_cl((N, 16, D, H, W), x.device)
+    y = out if out is not None else empty_cl((N, 16, D, H, W), x.device)
     norm = torch.empty(N * D * H * W, device=x.device, dtype=torch.float32) if (flags & LF_EPI_PIXELNORM) else None
     py, pn, pf = (prev[0], prev[1], prev[2]) if prev is not None else (None, None, 0)
     with _timed('conv3d_c16_wino'):
@@ -1019,6 +1048,174 @@ class _LstmCell(torch.autograd.Function):
         check(L.lf_lstm_cell_bwd(_ptr(cc), _ptr(c_cur), _ptr(gh) if gh is not None else None, _ptr(gcn) if gcn is not None else None,
                                  _ptr(gcc), _ptr(gc), c_cur.numel() // Ch, Ch, _stream()), 'lf_lstm_cell_bwd')
         return gcc, gc
+
+
+class _GruFuse(torch.autograd.Function):
+    """GRUFuser.forward for 16-channel volumes as ONE autograd node (recon/fusion.py:188-197 over modules/gru.py:30-43): the
+    recurrence h_i = cell(cat(z_i, coords), h_{i-1}), h_0 = z_0, forward and backward sequenced explicitly.
+
+    Compared with the per-gate autograd functions (_Conv3x3Sum16 / _GruGates / _GruBlend) this removes every ATen gradient
+    accumulation over full volumes (the data gradients of a step chain through the addend form of the convolution, the
+    gate gradients' sums over the views are kept by the stage kernels), the sigmoid outputs are recomputed instead of stored,
+    and under the bf16 autocast policy the tensors that only half-precision convolutions produce / consume (gate
+    pre-activations, h*r, candidate, gate gradients) live in bf16 storage: 37 instead of ~90 volume passes per view.
+    z: (1,V,16,D,H,W) with dense channels-last views.  Returns h_V (1,16,D,H,W)."""
+
+    @staticmethod
+    def forward(ctx, z, c16, wu, bu, wr, br, wo, bo):
+        L = _lib.lib()
+        _req(z, 'z')
+        B, V = z.shape[0], z.shape[1]
+        assert B == 1 and z.shape[2] == 16
+        zz = _dense_views(z)                                      # (V,16,D,H,W) channels-last
+        D, H, W = zz.shape[2:]
+        ac = AUTOCAST is not None
+        T16 = ac                                                  # bf16 storage of the once-per-step tensors
+        he = he_constant(wu)
+        gates = ((wu, bu), (wr, br), (wo, bo))
+
+        def packs(w):
+            def make():
+                wd = _wsrc(w).detach()
+                wc = wd.new_zeros(16, 16, 3, 3, 3)
+                wc[:, :3] = wd[:, 16:19]
+                pk = pack_conv3d_c16_ring_bf16 if ac else pack_conv3d_c16_wino
+                return tuple((pk(t), pk(t, transpose=True)) for t in (wd[:, :16].contiguous(), wc, wd[:, 19:].contiguous()))
+            return _cached(w, 'gru_fuse' + ('@ac' if ac else ''), make)
+        pk = [packs(w) for w, _ in gates]                         # [gate][z | coords | state][fwd | transposed]
+
+        def conv(x, pack, addend=None, bias=None, out=None, out16=False, rnd=0):
+            if ac:
+                return conv3d_c16_ring_bf16_io(x, pack, bias, he, 0, rnd if addend is None else 0, addend=addend, out=out,
+                                               out_bf16=out16)[0]
+            prev = None if addend is None else (addend, None, _lib.LF_EPI_ADD)
+            return conv3d_c16_wino(x, pack, bias, he, 0, prev=prev, out=out)[0]
+        n = zz[0].numel()
+        s = _stream()
+        base = [conv(c16, pk[k][1][0], bias=(b.detach() if b is not None else None)) for k, (_, b) in enumerate(gates)]
+        hs, saved = [zz[0:1]], []
+        for i in range(1, V):
+            zi, h = zz[i:i + 1], hs[-1]
+            pre = []
+            for k in (0, 1):
+                xk = conv(zi, pk[k][0][0], addend=base[k], out16=T16)
+                pre.append(conv(h, pk[k][2][0], addend=xk, out16=T16))
+                del xk
+            upre, rpre = pre
+            rh = empty_cl16(h.shape, h.device, T16)
+            check(L.lf_gru_train_stage_a(_ptr(rpre), _ptr(h), _ptr(rh), n, int(T16), s), 'lf_gru_train_stage_a')
+            xo = conv(zi, pk[2][0][0], addend=base[2], out16=T16)
+            cand = conv(rh, pk[2][2][0], addend=xo, out16=T16)
+            del xo
+            hn = empty_cl(h.shape, h.device)
+            check(L.lf_gru_train_stage_b(_ptr(h), _ptr(upre), _ptr(cand), _ptr(hn), n, int(T16), s), 'lf_gru_train_stage_b')
+            saved.append((upre, rpre, rh, cand))
+            hs.append(hn)
+        ctx.ac, ctx.T16, ctx.he, ctx.pk = ac, T16, he, pk
+        ctx.steps = saved
+        ctx.hs = hs[1:-1]                                         # h_1 .. h_{V-2}; h_0 is a view of z (saved below)
+        ctx.zshape = tuple(z.shape)
+        ctx.save_for_backward(zz, c16, wu, wr, wo)
+        ctx.has_bias = tuple(b is not None for _, b in gates)
+        return hs[-1].clone() if V == 1 else hs[-1]
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        zz, c16, wu, wr, wo = ctx.saved_tensors
+        V = zz.shape[0]
+        ac, T16, he, pk = ctx.ac, ctx.T16, ctx.he, ctx.pk
+        dev = zz.device
+        s = _stream()
+        n = zz[0].numel()
+        shape1 = (1,) + tuple(zz.shape[1:])
+        D, H, W = zz.shape[2:]
+        need_z = ctx.needs_input_grad[0]
+        need_w = any(ctx.needs_input_grad[i] for i in (2, 3, 4, 5, 6, 7))
+        g = cl(g.reshape(shape1))
+
+        def conv(x, pack, addend=None, out=None, out16=False, rnd=0):
+            if ac:
+                return conv3d_c16_ring_bf16_io(x, pack, None, he, 0, rnd if addend is None else 0, addend=addend, out=out,
+                                               out_bf16=out16)[0]
+            prev = None if addend is None else (addend, None, _lib.LF_EPI_ADD)
+            return conv3d_c16_wino(x, pack, None, he, 0, prev=prev, out=out)[0]
+        gz = empty_cl((V, 16, D, H, W), dev) if need_z else None
+        acc = [empty_cl(shape1, dev).zero_() for _ in range(3)] if need_w else [None] * 3
+        # weight-gradient blocks [step][gate][z | state][27][16][16], summed over the steps at the end (fixed order)
+        gwb = torch.zeros(max(V - 1, 1), 3, 2, 27, 16, 16, device=dev, dtype=torch.float32) if need_w else None
+        nbytes = max(L.lf_conv_bwd_weight_scratch_bytes(3, 1, D, H, W, 16, 16), L.lf_conv_bwd_weight_scratch_bytes(0, 1, D, H, W, 0, 16))
+        scratch = torch.empty(nbytes // 4 + 1, device=dev, dtype=torch.float32) if need_w else None
+        fast = _wgrad_bf16_ok(zz[0:1], 3, 16, 16)
+
+        def wgrad(x, gp, dst):
+            if ac and fast:
+                io = (1 if x.dtype == torch.bfloat16 else 0) | (2 if gp.dtype == torch.bfloat16 else 0)
+                check(L.lf_conv_bwd_weight_bf16_io(_ptr(x), _ptr(gp), _ptr(dst), _ptr(scratch), scratch.numel() * 4, 3, 1, D, H, W,
+                                                   16, 16, he, io, s), 'lf_conv_bwd_weight_bf16_io')
+            else:
+                xf = round_bf16(x.float()) if ac else x
+                gf = round_bf16(gp.float()) if ac else gp
+                check(L.lf_conv_bwd_weight(_ptr(xf), _ptr(gf), _ptr(dst), _ptr(scratch), scratch.numel() * 4, 3, 1, D, H, W, 16, 16,
+                                           he, s), 'lf_conv_bwd_weight')
+        gh1 = empty_cl(shape1, dev)
+        gh12 = empty_cl(shape1, dev)
+        gupre, gc, grh, grpre = (empty_cl16(shape1, dev, T16) for _ in range(4))
+        steps, hs = ctx.steps, ctx.hs
+        for i in range(V - 1, 0, -1):
+            if steps[i - 1] is None:
+                raise RuntimeError('the fused GRU recurrence frees its activations during backward: a second backward through '
+                                   'the same graph is not supported')
+            upre, rpre, rh, cand = steps[i - 1]
+            h = zz[0:1] if i == 1 else hs[i - 2]
+            zi = zz[i:i + 1]
+            check(L.lf_gru_train_stage_b_bwd(_ptr(g), _ptr(h), _ptr(upre), _ptr(cand), _ptr(gh1), _ptr(gupre), _ptr(gc),
+                                             _ptr(acc[0]) if need_w else None, _ptr(acc[2]) if need_w else None, n, int(T16), s),
+                  'lf_gru_train_stage_b_bwd')
+            conv(gc, pk[2][2][1], out=grh, rnd=1)
+            check(L.lf_gru_train_stage_a_bwd(_ptr(grh), _ptr(rpre), _ptr(h), _ptr(gh1), _ptr(grpre), _ptr(gh12),
+                                             _ptr(acc[1]) if need_w else None, n, int(T16), s), 'lf_gru_train_stage_a_bwd')
+            if need_z:
+                gzi = gz[i:i + 1]
+                conv(gc, pk[2][0][1], out=gzi, rnd=1)
+                conv(gupre, pk[0][0][1], addend=gzi, out=gzi)
+                conv(grpre, pk[1][0][1], addend=gzi, out=gzi)
+            gnext = empty_cl(shape1, dev)
+            conv(gupre, pk[0][2][1], addend=gh12, out=gnext)
+            conv(grpre, pk[1][2][1], addend=gnext, out=gnext)
+            if need_w:
+                for k, (xs, gp) in enumerate((((zi, h), gupre), ((zi, h), grpre), ((zi, rh), gc))):
+                    wgrad(xs[0], gp, gwb[i - 1, k, 0])
+                    wgrad(xs[1], gp, gwb[i - 1, k, 1])
+            g = gnext
+            steps[i - 1] = None                                   # the step's tensors are dead: free them as the walk goes
+            if i >= 2:
+                hs[i - 2] = None
+        if need_z:
+            gz[0:1].copy_(g)
+        outs = [gz.view(ctx.zshape) if need_z else None, None]
+        if need_w:
+            gsum = gwb.sum(dim=0)                                 # [gate][z | state][27][16][16]
+            for k, w in enumerate((wu, wr, wo)):
+                gwt = torch.empty(27, 16, w.shape[1], device=dev, dtype=torch.float32)
+                gwt[:, :, :16] = gsum[k, 0]
+                gwt[:, :, 19:] = gsum[k, 1]
+                gc_, _ = conv_bwd_weight(c16, acc[k], 3, 16, he, want_bias=False, bf16=ac)
+                gwt[:, :, 16:19] = gc_[:, :, :3]
+                gw = gwt.reshape(3, 3, 3, 16, w.shape[1]).permute(3, 4, 0, 1, 2).contiguous()
+                if ac:
+                    gw = round_bf16(gw)
+                outs.append(gw if ctx.needs_input_grad[2 + 2 * k] else None)
+                outs.append(bias_grad(acc[k], 3) if (ctx.has_bias[k] and ctx.needs_input_grad[3 + 2 * k]) else None)
+        else:
+            outs += [None] * 6
+        return tuple(outs)
+
+
+def gru_fuse(z, c16, cell):
+    """See _GruFuse.  `cell`: the ConvGRUCell (three EqualizedConv3d gates over 16 + 3 + 16 input channels)."""
+    gs = (cell.update_gate, cell.reset_gate, cell.out_gate)
+    return _GruFuse.apply(z, c16, gs[0].module.weight, gs[0].bias, gs[1].module.weight, gs[1].bias, gs[2].module.weight, gs[2].bias)
 
 
 def lstm_cell(cc, c_cur):

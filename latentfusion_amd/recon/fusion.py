@@ -200,6 +200,7 @@ class GRUFuser(_ArgsFuser):
         self.gru = ConvGRUCell(in_channels + n_coord, in_channels, kernel_size=3, bias=True, conv_module=conv_module)
         self.split_gates = True        # False: always the concatenated 35-channel convolutions (tests compare the two)
         self.hoist_coords = True       # the coordinate channels' share of the gates once per forward, not once per view
+        self.fused_recurrence = True   # the whole recurrence as one autograd node (ops.gru_fuse); False: per-gate functions
 
     def _args(self):
         return {'in_channels': self.in_channels, 'cube_size': self.cube_size}
@@ -219,6 +220,8 @@ class GRUFuser(_ArgsFuser):
             from .. import ops
             c16 = ops.empty_cl((h.shape[0], 16) + tuple(h.shape[2:]), h.device).zero_()
             c16[:, :3] = coords
+            if self.fused_recurrence and self.hoist_coords and z_obj.shape[0] == 1 and z_obj.dim() == 6:
+                return ops.gru_fuse(z_obj, c16, self.gru).unsqueeze(1), {}
             base = self.gru.coords_base(c16) if self.hoist_coords else None
             for v in views[1:]:
                 h = self.gru.forward_parts(v, c16, h, base)

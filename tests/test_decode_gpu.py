@@ -535,3 +535,102 @@ def test_skip_connections_quirk(golden):
         z, zc, zo = sc(torch.randn(2, 4, g['in_size'], g['in_size'], device=DEV), cam)
         with pytest.raises(RuntimeError, match='channels'):
             ph(z, cam, z_cam_mid=zc, z_obj_mid=zo)
+
+
+@pytest.mark.parametrize('autocast', [False, True])
+def test_gru_fuser_fused_recurrence_matches_per_gate_functions(autocast):
+    """ops.gru_fuse (round 5: the whole ConvGRU recurrence as one autograd node, explicit backward, addend-chained data
+    gradients, gate-gradient sums kept by the stage kernels, bf16 storage of the per-step tensors under autocast) against
+    the per-gate autograd functions it replaces (ops.conv3x3_sum16 / gru_gates / gru_blend): output, gradient of the
+    per-view volumes, gradients of every gate weight and bias.  fp32: the two forms run the same kernels on the same
+    numbers in another order (tolerance = accumulation order); autocast: the fused form additionally rounds the gate
+    pre-activations / gate gradients to bf16 where it stores them (tolerance = bf16 storage of O(1) tensors)."""
+    from latentfusion_amd import ops
+    from latentfusion_amd.recon import fusion
+    torch.manual_seed(6)
+    fu = fusion.GRUFuser(16).to(DEV)
+    for p in fu.parameters():
+        p.requires_grad_(True)
+    with torch.no_grad():
+        for gate in (fu.gru.update_gate, fu.gru.reset_gate, fu.gru.out_gate):
+            gate.bias.normal_(0.0, 0.3)
+    gen = torch.Generator().manual_seed(29)
+    z0 = torch.randn(1, 4, 16, 10, 24, 33, generator=gen).to(DEV)
+    gout = torch.randn(1, 1, 16, 10, 24, 33, generator=gen).to(DEV)
+    res = {}
+    for fused in (False, True, True):
+        fu.fused_recurrence = fused
+        fu.zero_grad()
+        z = z0.clone().requires_grad_(True)
+        with ops.autocast(autocast):
+            out, _ = fu(z, None, None, None)
+        (out * gout).sum().backward()
+        res.setdefault(fused, []).append((out.detach(), z.grad.clone(), {k: p.grad.clone() for k, p in fu.named_parameters()}))
+    # run-to-run identical
+    a, b = res[True]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and all(torch.equal(a[2][k], b[2][k]) for k in a[2])
+    ref = res[False][0]
+    tol = 3e-2 if autocast else 3e-5
+    close(a[0], ref[0], atol=tol, rtol=1e-2 if autocast else 1e-4)
+    scale = ref[1].abs().max().item()
+    if autocast:
+        cos = torch.nn.functional.cosine_similarity(a[1].reshape(1, -1).double(), ref[1].reshape(1, -1).double()).item()
+        assert cos > 0.999, cos
+        for k, g in ref[2].items():
+            cos = torch.nn.functional.cosine_similarity(a[2][k].reshape(1, -1).double(), g.reshape(1, -1).double()).item()
+            assert cos > 0.995, (k, cos)
+    else:
+        close(a[1], ref[1], atol=2e-5 * scale, rtol=1e-3)
+        for k, g in ref[2].items():
+            close(a[2][k], g, atol=2e-5 * max(g.abs().max().item(), 1e-3), rtol=1e-3)
+
+
+def test_ring_conv_bf16_storage_variants():
+    """lf_conv3d_c16_ring_bf16_io: every storage combination of input / output / addend gives the result of the fp32-storage
+    launch on the same (bf16-representable) numbers, rounded once where the output is stored as bf16."""
+    from latentfusion_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    N, D, H, W = 2, 6, 11, 19
+    x = ops.cl(ops.round_bf16(torch.randn(N, 16, D, H, W, generator=gen).to(DEV)))
+    add = ops.cl(ops.round_bf16(torch.randn(N, 16, D, H, W, generator=gen).to(DEV)))
+    w = torch.randn(16, 16, 3, 3, 3, generator=gen).to(DEV)
+    bias = torch.randn(16, generator=gen).to(DEV)
+    wp = ops.pack_conv3d_c16_ring_bf16(w)
+    he = 0.21
+    cl3 = torch.channels_last_3d
+    for flags, addend, b in ((0, None, None), (3, None, bias), (0, add, None)):
+        ref, nref = ops.conv3d_c16_ring_bf16_io(x, wp, b, he, flags, 0, addend=addend)
+        for in16 in (False, True):
+            for out16 in (False, True):
+                for add16 in ((False, True) if addend is not None else (False,)):
+                    xi = x.to(torch.bfloat16).contiguous(memory_format=cl3) if in16 else x
+                    ai = (addend.to(torch.bfloat16).contiguous(memory_format=cl3) if add16 else addend) if addend is not None else None
+                    y, nrm = ops.conv3d_c16_ring_bf16_io(xi, wp, b, he, flags, 0, addend=ai, out_bf16=out16)
+                    assert y.dtype == (torch.bfloat16 if out16 else torch.float32)
+                    want = ref.to(torch.bfloat16) if out16 else ref
+                    assert torch.equal(y, want), (flags, in16, out16, add16, (y.float() - want.float()).abs().max().item())
+                    if nref is not None:
+                        assert torch.equal(nrm, nref)
+
+
+def test_wgrad_bf16_storage_variants():
+    """lf_conv_bwd_weight_bf16_io: bf16-stored operands give bit-identical weight gradients to fp32-stored ones holding the
+    same (bf16-representable) values."""
+    from latentfusion_amd import _lib, ops
+    gen = torch.Generator().manual_seed(4)
+    N, D, H, W = 1, 16, 24, 32
+    x = ops.cl(ops.round_bf16(torch.randn(N, 16, D, H, W, generator=gen).to(DEV)))
+    gp = ops.cl(ops.round_bf16((torch.randn(N, 16, D, H, W, generator=gen) * 1e-2).to(DEV)))
+    L = _lib.lib()
+    nb = L.lf_conv_bwd_weight_scratch_bytes(3, N, D, H, W, 16, 16)
+    scr = torch.empty(nb // 4 + 1, device=DEV)
+    outs = {}
+    for io in range(4):
+        xi = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last_3d) if io & 1 else x
+        gi = gp.to(torch.bfloat16).contiguous(memory_format=torch.channels_last_3d) if io & 2 else gp
+        gw = torch.empty(27, 16, 16, device=DEV)
+        _lib.check(L.lf_conv_bwd_weight_bf16_io(xi.data_ptr(), gi.data_ptr(), gw.data_ptr(), scr.data_ptr(), scr.numel() * 4, 3, N, D, H, W,
+                                                16, 16, 0.3, io, torch.cuda.current_stream().cuda_stream), 'wgrad io')
+        outs[io] = gw
+    for io in (1, 2, 3):
+        assert torch.equal(outs[io], outs[0]), io
