@@ -336,6 +336,15 @@ int lf_gru_train_stage_b_bwd(const float* g, const float* h, const void* upre, c
 int lf_gru_train_stage_a_bwd(const void* grh, const void* rpre, const float* h, const float* gh1, void* grpre, float* gh12,
                              float* acc_r, long n, int bf16, void* stream);
 
+/* Storage-type variants of the 16-channel resampler for the training step (io bit 0: the source, bit 1: the destination is a
+ * bf16 channels-last volume; same fp32 interpolation / same fixed-point sums as lf_resample3d_fwd / lf_resample3d_bwd_vol_det
+ * with C = 16; scratch: lf_resample3d_bwd_vol_det_io_scratch_bytes, the box lists of the tiled splat only). */
+int lf_resample3d_fwd_io(const void* vol, int vol_n, const float* coef, int kind, void* out, int N, int D, int H, int W,
+                         int io, void* stream);
+size_t lf_resample3d_bwd_vol_det_io_scratch_bytes(int N, int D, int H, int W);
+int lf_resample3d_bwd_vol_det_io(const void* gout, const float* coef, int kind, void* gvol, int vol_n, void* scratch,
+                                 size_t scratch_bytes, int N, int D, int H, int W, int io, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Depth-column composites of the renderer (channels-last volumes [N][D][H][W][C], P = H*W pixels).
  * A depth column is strided by P*C floats: lanes run along the contiguous (pixel, channel) axis, the depth axis is
@@ -418,6 +427,15 @@ int lf_conv_bwd_weight_bf16(const float* x, const float* gpre, float* gw, void* 
 /* ... with x (io & 1) and / or gpre (io & 2) stored as bf16 channels-last records (see lf_conv3d_c16_ring_bf16_io). */
 int lf_conv_bwd_weight_bf16_io(const void* x, const void* gpre, float* gw, void* scratch, size_t scratch_bytes,
                                int dims, int N, int D, int H, int W, int Cin, int Cout, float scale, int io, void* stream);
+
+/* Epilogue backward of a 16-CHANNEL layer for the training step: gp = LeakyReLU'(y) PixelNorm'(gy; y, norm) (flags says
+ * which; flags = 0: gp = gy) with the bias gradient gbias[16] = column sums of the un-rounded gp folded into the same pass
+ * (gbias = NULL: no sums; else scratch of lf_epilogue_bwd_c16_scratch_bytes(rows) bytes), fixed-order reduction.
+ * io: bit 0 -- gy, bit 1 -- y, bit 2 -- gp are bf16 [rows][16] arrays instead of fp32 (see lf_conv3d_c16_ring_bf16_io).
+ * Autograd of modules/blocks.py:152-158 + equalized.py:57-64. */
+size_t lf_epilogue_bwd_c16_scratch_bytes(long rows);
+int lf_epilogue_bwd_c16(const void* gy, const void* y, const float* norm, void* gp, float* gbias, void* scratch,
+                        size_t scratch_bytes, long rows, unsigned flags, float slope, int io, void* stream);
 
 /* Standalone PixelNorm over the last (channel) axis of [rows][C], in place allowed.
  * norm_out[rows] receives sqrt(mean+eps).  modules/__init__.py:14-15. */

@@ -199,6 +199,75 @@ int launch_rows(const float* a, const float* b, const float* nrm_in, float* out,
   return lf_launch_status();
 }
 
+
+// ---- epilogue backward of a 16-channel layer for the training step (round 5): gp = LeakyReLU'(y) PixelNorm'(gy; y, norm), with
+// the bias gradient (column sums of the un-rounded gp) folded in, and the three arrays in fp32 or bf16 storage (IO bit 0: gy,
+// bit 1: y, bit 2: gp).  A lane quad owns a row (voxel); block partial sums of the 16 columns go to `partial` and are reduced
+// in a fixed order by colsum_final_kernel (fp64) -- no pass over gp just for the bias.
+typedef __bf16 bf16x4p __attribute__((ext_vector_type(4)));
+template <bool B16>
+__device__ __forceinline__ f32x4 ld4(const void* p, long i) {
+  if constexpr (B16) return __builtin_convertvector(((const bf16x4p*)p)[i], f32x4);
+  else return ((const f32x4*)p)[i];
+}
+template <int IO>
+__global__ void __launch_bounds__(256) epilogue_bwd_c16_kernel(const void* __restrict__ gy, const void* __restrict__ y,
+                                                               const float* __restrict__ nrm, void* __restrict__ gp,
+                                                               float* __restrict__ partial, long rows, int chunk, unsigned flags, float slope) {
+  const int t = threadIdx.x, q = t & 3, slot = t >> 2;
+  const long r0 = (long)blockIdx.x * chunk, r1 = min(r0 + chunk, rows);
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (long rb = r0; rb < r1; rb += 64) {
+    const long row = rb + slot;
+    const bool live = row < r1;
+    f32x4 va = (f32x4){0.f, 0.f, 0.f, 0.f}, vb = va;
+    if (live) {
+      va = ld4<(IO & 1) != 0>(gy, row * 4 + q);
+      if (flags != 0) vb = ld4<(IO & 2) != 0>(y, row * 4 + q);      // (flags = 0: y may be NULL / of another storage type)
+    }
+    f32x4 g = va;
+    if (flags & LF_EPI_PIXELNORM) {
+      float dot = va[0] * vb[0] + va[1] * vb[1] + va[2] * vb[2] + va[3] * vb[3];
+      dot = group_sum(dot, 4) / 16.f;
+      const float r = live ? nrm[row] : 1.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] = (va[e] - vb[e] * dot) / r;
+    }
+    if (flags & LF_EPI_LRELU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] = vb[e] > 0.f ? g[e] : g[e] * slope;
+    }
+    if (live) {
+      if constexpr ((IO & 4) != 0) ((bf16x4p*)gp)[row * 4 + q] = __builtin_convertvector(g, bf16x4p);
+      else ((f32x4*)gp)[row * 4 + q] = g;
+      acc += g;
+    }
+  }
+  if (partial == nullptr) return;
+  __shared__ f32x4 red[256];
+  red[t] = acc;
+  __syncthreads();
+  if (t < 16) {
+    float sum = 0.f;
+    for (int i = 0; i < 64; ++i) sum += red[i * 4 + (t >> 2)][t & 3];
+    partial[(long)blockIdx.x * 16 + t] = sum;
+  }
+}
+
+__global__ void __launch_bounds__(256) colsum_final_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ out) {
+  const int t = threadIdx.x, co = t & 15, grp = t >> 4;
+  double sum = 0.0;
+  for (int b = grp; b < nblk; b += 16) sum += (double)partial[(long)b * 16 + co];
+  __shared__ double red[256];
+  red[t] = sum;
+  __syncthreads();
+  if (t < 16) {
+    double tot = 0.0;
+    for (int g = 0; g < 16; ++g) tot += red[g * 16 + t];
+    out[t] = (float)tot;
+  }
+}
+
 }  // namespace
 
 extern "C" int lf_pixelnorm_fwd(const float* x, float* y, float* norm_out, long rows, int C, float eps, void* stream) {
@@ -211,6 +280,37 @@ extern "C" int lf_epilogue_bwd(const float* gy, const float* y, const float* nor
   lf_clear_error();
   if ((flags & LF_EPI_PIXELNORM) && norm == nullptr) return LF_EINVAL;
   return launch_rows<1>(gy, y, norm, gp, nullptr, rows, C, flags, slope, 0.f, (hipStream_t)stream);
+}
+
+extern "C" size_t lf_epilogue_bwd_c16_scratch_bytes(long rows) {
+  if (rows <= 0) return 0;
+  long chunk = (rows + 2047) / 2048;
+  chunk = (chunk + 63) / 64 * 64;
+  return (size_t)((rows + chunk - 1) / chunk) * 16 * sizeof(float);
+}
+
+extern "C" int lf_epilogue_bwd_c16(const void* gy, const void* y, const float* norm, void* gp, float* gbias, void* scratch,
+                                   size_t scratch_bytes, long rows, unsigned flags, float slope, int io, void* stream) {
+  lf_clear_error();
+  if (rows <= 0 || io < 0 || io > 7 || gy == nullptr || gp == nullptr) return LF_EINVAL;
+  if (flags & ~(LF_EPI_LRELU | LF_EPI_PIXELNORM)) return LF_EINVAL;
+  if ((flags & LF_EPI_PIXELNORM) && norm == nullptr) return LF_EINVAL;
+  if (flags != 0 && y == nullptr) return LF_EINVAL;
+  if (!lf_aligned16(gy) || !lf_aligned16(gp) || (y && !lf_aligned16(y))) return LF_EALIGN;
+  long chunk = (rows + 2047) / 2048;                              // ~2048 blocks, rows in multiples of the 64 a block covers
+  chunk = (chunk + 63) / 64 * 64;
+  const int nblk = (int)((rows + chunk - 1) / chunk);
+  if (gbias != nullptr && (scratch == nullptr || scratch_bytes < (size_t)nblk * 16 * sizeof(float))) return LF_ENOSPC;
+  hipStream_t s = (hipStream_t)stream;
+  typedef void (*kern_t)(const void*, const void*, const float*, void*, float*, long, int, unsigned, float);
+  static const kern_t kerns[8] = {epilogue_bwd_c16_kernel<0>, epilogue_bwd_c16_kernel<1>, epilogue_bwd_c16_kernel<2>, epilogue_bwd_c16_kernel<3>,
+                                  epilogue_bwd_c16_kernel<4>, epilogue_bwd_c16_kernel<5>, epilogue_bwd_c16_kernel<6>, epilogue_bwd_c16_kernel<7>};
+  hipLaunchKernelGGL(kerns[io], dim3(nblk), dim3(256), 0, s, gy, y ? y : gy, norm, gp, gbias ? (float*)scratch : nullptr, rows,
+                     (int)chunk, flags, slope);
+  int st = lf_launch_status();
+  if (st || gbias == nullptr) return st;
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(1), dim3(256), 0, s, (const float*)scratch, nblk, gbias);
+  return lf_launch_status();
 }
 
 extern "C" int lf_nchw_to_nhwc(const float* src, float* dst, int N, int C, long P, void* stream) {

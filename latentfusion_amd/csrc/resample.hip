@@ -377,24 +377,39 @@ __global__ void __launch_bounds__(256) resample_fwd_lean_kernel(
 // C == 16 specialisation of the lean gather (variant 3): fixed 4x4x4 tile, no integer division, no channel loop, one
 // scalar-weight FMA per channel and corner (the generic form lets the compiler pack the FMAs in pairs, which costs
 // a register move per weight to build the pairs).
-template <int KIND>
+// IO (round 5, training step under the bf16 storage policy): bit 0 -- the sampled volume, bit 1 -- the output are bf16
+// channels-last records (32 B per voxel); the interpolation itself is the same fp32 arithmetic.
+typedef __bf16 bf16x4r __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+template <bool B16>
+__device__ __forceinline__ f32x4 ldrec_t(__amdgpu_buffer_rsrc_t rs, u32 off) {
+  if constexpr (B16)
+    return __builtin_convertvector(__builtin_bit_cast(bf16x4r, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off, 0, 0)), f32x4);
+  else
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
+}
+
+template <int KIND, int IO = 0>
 __global__ void __launch_bounds__(256) resample_fwd_c16_kernel(
     const float* __restrict__ vol, long vol_bstride, const float* __restrict__ coef,
     float* __restrict__ out, int D, int H, int W, int nbz, Steps st) {
+  constexpr bool IN16 = (IO & 1) != 0, OUT16 = (IO & 2) != 0;
+  constexpr u32 IREC = IN16 ? 32u : 64u, OREC = OUT16 ? 32u : 64u;
   const int n = blockIdx.z / nbz, bz = blockIdx.z - n * nbz;
   const int q = threadIdx.x & 3, vs = threadIdx.x >> 2;
   const int x = (blockIdx.x << 2) + (vs & 3), y = (blockIdx.y << 2) + ((vs >> 2) & 3), z = (bz << 2) + (vs >> 4);
   if (x >= W || y >= H || z >= D) return;
-  const u32 sample_bytes = (u32)D * (u32)H * (u32)W * 64u;
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(vol + (long)n * vol_bstride), 0, sample_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (long)n * D * H * W * 16), 0, sample_bytes, 0x00020000);
+  const u32 nvox = (u32)D * (u32)H * (u32)W;
+  // (vol_bstride counts ELEMENTS; the pointers are declared float*: byte arithmetic for the bf16 forms)
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)vol + (long)n * vol_bstride * (IN16 ? 2 : 4)), 0, nvox * IREC, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)out + (long)n * nvox * OREC), 0, nvox * OREC, 0x00020000);
   const float* cf = coef + n * LF_MAP_COEFS;
   float gx, gy, gz, a, b, k;
   eval_grid<KIND>(cf, x, y, z, W, H, D, st, gx, gy, gz, a, b, k);
-  const Tap32 t = make_tap32(gx, gy, gz, W, H, D, 64u);
-  const u32 co = (u32)q * 16u;
-  const f32x4 v000 = ldrec(rs, t.o000 + co), v001 = ldrec(rs, t.o001 + co), v010 = ldrec(rs, t.o010 + co), v011 = ldrec(rs, t.o011 + co);
-  const f32x4 v100 = ldrec(rs, t.o100 + co), v101 = ldrec(rs, t.o101 + co), v110 = ldrec(rs, t.o110 + co), v111 = ldrec(rs, t.o111 + co);
+  const Tap32 t = make_tap32(gx, gy, gz, W, H, D, IREC);
+  const u32 co = (u32)q * (IREC / 4u);
+  const f32x4 v000 = ldrec_t<IN16>(rs, t.o000 + co), v001 = ldrec_t<IN16>(rs, t.o001 + co), v010 = ldrec_t<IN16>(rs, t.o010 + co), v011 = ldrec_t<IN16>(rs, t.o011 + co);
+  const f32x4 v100 = ldrec_t<IN16>(rs, t.o100 + co), v101 = ldrec_t<IN16>(rs, t.o101 + co), v110 = ldrec_t<IN16>(rs, t.o110 + co), v111 = ldrec_t<IN16>(rs, t.o111 + co);
   const float wx1 = t.tx, wx0 = 1.f - t.tx, wy1 = t.ty, wy0 = 1.f - t.ty, wz1 = t.tz, wz0 = 1.f - t.tz;
   const float w000 = wx0 * wy0 * wz0, w001 = wx1 * wy0 * wz0, w010 = wx0 * wy1 * wz0, w011 = wx1 * wy1 * wz0;
   const float w100 = wx0 * wy0 * wz1, w101 = wx1 * wy0 * wz1, w110 = wx0 * wy1 * wz1, w111 = wx1 * wy1 * wz1;
@@ -412,7 +427,11 @@ __global__ void __launch_bounds__(256) resample_fwd_c16_kernel(
     asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "v"(v111[e]), "v"(w111));
     r[e] = acc;
   }
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, r), ro, (int)((u32)((z * H + y) * W + x) * 64u + co), 0, 2);
+  if constexpr (OUT16)
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, __builtin_convertvector(r, bf16x4r)), ro,
+                                          (int)((u32)((z * H + y) * W + x) * 32u + (u32)q * 8u), 0, 2);
+  else
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, r), ro, (int)((u32)((z * H + y) * W + x) * 64u + (u32)q * 16u), 0, 2);
 }
 
 // 16-channel gather with the per-voxel arithmetic done once per voxel (variant 5 of lf_set_tuning key 1).  The gather above
@@ -827,6 +846,14 @@ __global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x
   if ((threadIdx.x & 63) == 0 && m > 0.f && m < 3.0e38f) atomicMax(out, __float_as_uint(m));   // max is order-independent
 }
 
+__global__ void __launch_bounds__(256) absmax_bf16_kernel(const __bf16* __restrict__ x, long n, unsigned* __restrict__ out) {
+  float m = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf((float)x[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0.f && m < 3.0e38f) atomicMax(out, __float_as_uint(m));
+}
+
 __device__ __forceinline__ float fixed_scale(const unsigned* amax) {
   const float am = __uint_as_float(*amax);
   if (!(am > 0.f)) return 1.f;
@@ -951,7 +978,7 @@ __global__ void __launch_bounds__(256) splat_bbox2_kernel(const uint3* __restric
                                           (unsigned)(lo[2] & 0xffff) | ((unsigned)(hi[2] & 0xffff) << 16));
 }
 
-template <int KIND>
+template <int KIND, int IO = 0>                                   // IO: bit 0 -- gout, bit 1 -- gvol stored as bf16 records
 __global__ void __launch_bounds__(256) splat_tile_kernel(const float* __restrict__ gout, const float* __restrict__ coef,
                                                          const uint3* __restrict__ bbox, const uint3* __restrict__ sbox,
                                                          const unsigned* __restrict__ amax, float* __restrict__ gvol, int vol_n, int N,
@@ -978,7 +1005,7 @@ __global__ void __launch_bounds__(256) splat_tile_kernel(const float* __restrict
   // the LDS atomics commute): 64 super-block boxes per test, then the 64 block boxes of a super-block that overlaps the tile.
   for (int n = n_first; n < n_last; ++n) {
     const float* cf = coef + (long)n * LF_MAP_COEFS;
-    const float* gs = gout + (long)n * nvox * 16;
+    const float* gs = (const float*)((const char*)gout + (long)n * nvox * ((IO & 1) ? 32 : 64));
     const uint3* bb = bbox + (long)n * nblk;
     const uint3* sbb = sbox + (long)n * nsb;
     for (int sbase = 0; sbase < nsb; sbase += 64) {
@@ -998,7 +1025,11 @@ __global__ void __launch_bounds__(256) splat_tile_kernel(const float* __restrict
           const int x = bx * 4 + px, y = by * 4 + py, z = bz * 4 + pz;
           if (x < W && y < H && z < D) {
             const SplatTap t = splat_eval<KIND>(cf, x, y, z, W, H, D, st);
-            const f32x4 g4 = *(const f32x4*)(gs + (((long)z * H + y) * W + x) * 16 + q * 4);
+            f32x4 g4;
+            if constexpr ((IO & 1) != 0)
+              g4 = __builtin_convertvector(*(const bf16x4r*)((const char*)gs + (((long)z * H + y) * W + x) * 32 + q * 8), f32x4);
+            else
+              g4 = *(const f32x4*)(gs + (((long)z * H + y) * W + x) * 16 + q * 4);
 #define SPLAT_T(Z, Y, X, WI) do { \
               const int lz_ = (Z) - tz0, ly_ = (Y) - ty0, lx_ = (X) - tx0; \
               if ((unsigned)lz_ < (unsigned)STZ && (unsigned)ly_ < (unsigned)STY && (unsigned)lx_ < (unsigned)STX) { \
@@ -1020,14 +1051,16 @@ __global__ void __launch_bounds__(256) splat_tile_kernel(const float* __restrict
   const int lx = tid % STX, ly = (tid / STX) % STY, lz = tid / (STX * STY);
   const int x = tx0 + lx, y = ty0 + ly, z = tz0 + lz;
   if (x < W && y < H && z < D) {
-    float* dst = gvol + (vol_n == 1 ? 0 : (long)blockIdx.y * nvox * 16) + (((long)z * H + y) * W + x) * 16;
+    constexpr int OREC = (IO & 2) ? 32 : 64;
+    char* dst = (char*)gvol + ((vol_n == 1 ? 0 : (long)blockIdx.y * nvox) + (((long)z * H + y) * W + x)) * OREC;
     const double inv = (double)scale;
 #pragma unroll
     for (int c4 = 0; c4 < 4; ++c4) {
       f32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = (float)((double)(long long)acc[tid * SACC + c4 * 4 + e] / inv);
-      *(f32x4*)(dst + c4 * 4) = o;
+      if constexpr ((IO & 2) != 0) *(bf16x4r*)(dst + c4 * 8) = __builtin_convertvector(o, bf16x4r);
+      else *(f32x4*)(dst + c4 * 16) = o;
     }
   }
 }
@@ -1309,5 +1342,75 @@ extern "C" int lf_resample3d_bwd_vol_det(const float* gout, const float* coef, i
   st = lf_launch_status();
   if (st) return st;
   hipLaunchKernelGGL(fixed_to_float_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const long long*)acc, amax, gvol, total);
+  return lf_launch_status();
+}
+
+// ---- storage-type variants for the training step's bf16 storage policy (16-channel volumes only) ----
+extern "C" int lf_resample3d_fwd_io(const void* vol, int vol_n, const float* coef, int kind, void* out,
+                                    int N, int D, int H, int W, int io, void* stream) {
+  lf_clear_error();
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || io < 0 || io > 3) return LF_EINVAL;
+  if ((vol_n != 1 && vol_n != N) || (kind != LF_MAP_O2C && kind != LF_MAP_C2O)) return LF_EINVAL;
+  if (!lf_aligned16(vol) || !lf_aligned16(out)) return LF_EALIGN;
+  if ((long)D * H * W * 64 >= 0xffffffffL) return LF_EINVAL;
+  const long bstride = vol_n == 1 ? 0 : (long)D * H * W * 16;
+  const int nbz4 = (D + 3) >> 2;
+  if ((long)nbz4 * N > 65535 || ((H + 3) >> 2) > 65535) return LF_EINVAL;
+  dim3 g4((unsigned)((W + 3) >> 2), (unsigned)((H + 3) >> 2), (unsigned)(nbz4 * N)), block(256);
+  const Steps st = make_steps(D, H, W);
+  typedef void (*kern_t)(const float*, long, const float*, float*, int, int, int, int, Steps);
+  static const kern_t kerns[2][4] = {
+      {resample_fwd_c16_kernel<LF_MAP_O2C, 0>, resample_fwd_c16_kernel<LF_MAP_O2C, 1>, resample_fwd_c16_kernel<LF_MAP_O2C, 2>, resample_fwd_c16_kernel<LF_MAP_O2C, 3>},
+      {resample_fwd_c16_kernel<LF_MAP_C2O, 0>, resample_fwd_c16_kernel<LF_MAP_C2O, 1>, resample_fwd_c16_kernel<LF_MAP_C2O, 2>, resample_fwd_c16_kernel<LF_MAP_C2O, 3>}};
+  hipLaunchKernelGGL(kerns[kind == LF_MAP_O2C ? 0 : 1][io], g4, block, 0, (hipStream_t)stream, (const float*)vol, bstride, coef, (float*)out, D, H, W, nbz4, st);
+  return lf_launch_status();
+}
+
+// scratch of the tiled form alone: [amax (256 B)] [block boxes] [super-block boxes] (a few MB; the generic entry point also
+// reserves the fixed-point volume of its atomic form)
+extern "C" size_t lf_resample3d_bwd_vol_det_io_scratch_bytes(int N, int D, int H, int W) {
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+  const long nbx = (W + 3) / 4, nby = (H + 3) / 4, nbz = (D + 3) / 4;
+  const long nsb = ((nbx + 3) / 4) * ((nby + 3) / 4) * ((nbz + 3) / 4);
+  return 256 + (size_t)N * (size_t)(nbx * nby * nbz + nsb) * sizeof(uint3);
+}
+
+extern "C" int lf_resample3d_bwd_vol_det_io(const void* gout, const float* coef, int kind, void* gvol, int vol_n, void* scratch,
+                                            size_t scratch_bytes, int N, int D, int H, int W, int io, void* stream) {
+  lf_clear_error();
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || io < 0 || io > 3) return LF_EINVAL;
+  if ((vol_n != 1 && vol_n != N) || (kind != LF_MAP_O2C && kind != LF_MAP_C2O)) return LF_EINVAL;
+  if (scratch == nullptr || scratch_bytes < lf_resample3d_bwd_vol_det_io_scratch_bytes(N, D, H, W)) return LF_ENOSPC;
+  if ((((uintptr_t)scratch) & 7u) != 0 || !lf_aligned16(gout) || !lf_aligned16(gvol)) return LF_EALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  const long ng = (long)D * H * W * 16 * N;
+  const int nbx = (W + 3) / 4, nby = (H + 3) / 4, nbz = (D + 3) / 4;
+  const long nblk = (long)nbx * nby * nbz;
+  const int ntx = (W + STX - 1) / STX, nty = (H + STY - 1) / STY, ntz = (D + STZ - 1) / STZ;
+  const int nsx = (nbx + 3) / 4, nsy = (nby + 3) / 4, nsz = (nbz + 3) / 4, nsb = nsx * nsy * nsz;
+  if (!(D < 0x7fff && H < 0x7fff && W < 0x7fff && nblk < 0x7fffffffL / 4 && (long)ntx * nty * ntz < 0x7fffffffL && N <= 65535 &&
+        scratch_bytes >= 256 + (size_t)N * (nblk + nsb) * sizeof(uint3))) return LF_EINVAL;
+  unsigned* amax = (unsigned*)scratch;
+  uint3* bbox = (uint3*)((char*)scratch + 256);
+  uint3* sbox = bbox + (size_t)N * nblk;
+  hipError_t e = hipMemsetAsync(scratch, 0, 256, s);
+  if (e != hipSuccess) return (int)e;
+  if (io & 1) hipLaunchKernelGGL(absmax_bf16_kernel, dim3((unsigned)min((ng + 255) / 256, 4096L)), dim3(256), 0, s, (const __bf16*)gout, ng, amax);
+  else hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)min((ng + 255) / 256, 4096L)), dim3(256), 0, s, (const float*)gout, ng, amax);
+  const Steps stp = make_steps(D, H, W);
+  const dim3 gb((unsigned)((nblk + 3) / 4), (unsigned)N), gs2((unsigned)((nsb + 3) / 4), (unsigned)N),
+      gt((unsigned)((long)ntx * nty * ntz), (unsigned)vol_n);
+  if (kind == LF_MAP_O2C)
+    hipLaunchKernelGGL((splat_bbox_kernel<LF_MAP_O2C>), gb, dim3(256), 0, s, coef, bbox, (int)nblk, nbx, nby, D, H, W, stp);
+  else
+    hipLaunchKernelGGL((splat_bbox_kernel<LF_MAP_C2O>), gb, dim3(256), 0, s, coef, bbox, (int)nblk, nbx, nby, D, H, W, stp);
+  hipLaunchKernelGGL(splat_bbox2_kernel, gs2, dim3(256), 0, s, bbox, sbox, (int)nblk, nsb, nbx, nby, nbz, nsx, nsy);
+  typedef void (*kern_t)(const float*, const float*, const uint3*, const uint3*, const unsigned*, float*, int, int, int, int, int, int, int,
+                         int, int, int, int, int, int, int, Steps);
+  static const kern_t kerns[2][4] = {
+      {splat_tile_kernel<LF_MAP_O2C, 0>, splat_tile_kernel<LF_MAP_O2C, 1>, splat_tile_kernel<LF_MAP_O2C, 2>, splat_tile_kernel<LF_MAP_O2C, 3>},
+      {splat_tile_kernel<LF_MAP_C2O, 0>, splat_tile_kernel<LF_MAP_C2O, 1>, splat_tile_kernel<LF_MAP_C2O, 2>, splat_tile_kernel<LF_MAP_C2O, 3>}};
+  hipLaunchKernelGGL(kerns[kind == LF_MAP_O2C ? 0 : 1][io], gt, dim3(256), 0, s, (const float*)gout, coef, bbox, sbox, amax, (float*)gvol, vol_n, N,
+                     (int)nblk, nsb, nbx, nby, nbz, nsx, nsy, ntx, nty, D, H, W, stp);
   return lf_launch_status();
 }

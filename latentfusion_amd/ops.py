@@ -29,6 +29,22 @@ DETERMINISTIC_SPLAT = True
 # their operands (lf_round_bf16) and keep the fp32-MFMA kernels, which then compute what a bf16 MFMA would (bf16 x bf16
 # products are exact in fp32).
 AUTOCAST = None
+# Storage policy under autocast (round 5): the 16-channel 3-D volumes that half-precision convolutions produce and consume
+# -- block activations, their gradients, the resampled volumes between them, the per-view latent volumes -- are kept as
+# bf16 channels-last tensors (32 B per voxel).  The convolutions round their inputs to bf16 while staging them anyway, so a
+# volume that only convolutions read loses nothing; a volume that an fp32 stage also reads (PixelNorm' / LeakyReLU' of the
+# epilogue backward, the trilinear resampler) is read rounded.  Halves the HBM bytes and the saved-activation memory of the
+# training step.  False: fp32 storage everywhere (the round-2..4 behaviour), kept for A/B runs and tests.
+BF16_STORAGE = True
+
+
+def storage_bf16():
+    return AUTOCAST is not None and BF16_STORAGE
+
+
+def _f32(t):
+    """An fp32 view of a tensor an op without a bf16-storage form was handed (a cast pass; the hot ops take bf16 natively)."""
+    return t if t.dtype == torch.float32 else t.float()
 
 
 class autocast:
@@ -628,9 +644,64 @@ def _resample_fwd(vol, coef, kind):
     return out, v, cf, vol_n
 
 
+class _ResampleAC(torch.autograd.Function):
+    """The 16-channel resampler under the bf16 storage policy: source in fp32 or bf16, destination bf16; the volume gradient
+    (deterministic fixed-point splat) comes back in the source's storage type.  No camera gradient (training path)."""
+
+    @staticmethod
+    def forward(ctx, vol, coef, kind):
+        L = _lib.lib()
+        n = coef.shape[0]
+        vol_n = 1 if (vol.shape[0] == 1 or vol.stride(0) == 0) else vol.shape[0]
+        if vol_n not in (1, n):
+            raise ValueError('batch dimension of the volume and the cameras must match')
+        v = cl(vol[:1] if vol_n == 1 else vol)
+        _, C, D, H, W = v.shape
+        out = empty_cl16((n, 16, D, H, W), v.device, True)
+        cf = torch.zeros(n, LF_MAP_COEFS, device=v.device, dtype=torch.float32)
+        cf[:, :coef.shape[1]] = coef.detach().float()
+        io = (1 if v.dtype == torch.bfloat16 else 0) | 2
+        with _timed('resample_fwd', f'{kind}:{n}:io{io}'):
+            check(L.lf_resample3d_fwd_io(_ptr(v), vol_n, _ptr(cf), kind, _ptr(out), n, D, H, W, io, _stream()), 'lf_resample3d_fwd_io')
+        ctx.save_for_backward(cf)
+        ctx.meta = (kind, vol_n, tuple(vol.shape), vol.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        L = _lib.lib()
+        cf, = ctx.saved_tensors
+        kind, vol_n, vshape, vdtype = ctx.meta
+        if ctx.needs_input_grad[1]:
+            raise NotImplementedError('camera gradients run on the fp32 resampler (the pose loop); not under the training storage policy')
+        if not ctx.needs_input_grad[0]:
+            return None, None, None
+        g = cl(gout)
+        n, C, D, H, W = g.shape
+        gv = empty_cl16((vol_n, 16, D, H, W), g.device, vdtype == torch.bfloat16)
+        nb = L.lf_resample3d_bwd_vol_det_io_scratch_bytes(n, D, H, W)
+        scr = torch.empty(nb // 8 + 1, device=g.device, dtype=torch.int64)
+        io = (1 if g.dtype == torch.bfloat16 else 0) | (2 if gv.dtype == torch.bfloat16 else 0)
+        with _timed('resample_bwd_vol', f'{kind}:{n}:io{io}'):
+            check(L.lf_resample3d_bwd_vol_det_io(_ptr(g), _ptr(cf), kind, _ptr(gv), vol_n, _ptr(scr), scr.numel() * 8, n, D, H, W, io,
+                                                 _stream()), 'lf_resample3d_bwd_vol_det_io')
+        if gv.shape[0] == vshape[0]:
+            return gv, None, None
+        gvol = torch.zeros(vshape, device=g.device, dtype=gv.dtype)     # expanded (stride-0) input: see _Resample.backward
+        gvol[0] = gv[0]
+        return gvol, None, None
+
+
+def _resample_ac_ok(vol, coef):
+    return (vol.dim() == 5 and vol.shape[1] == 16 and vol.is_cuda and not coef.requires_grad and DETERMINISTIC_SPLAT
+            and (vol.dtype == torch.bfloat16 or storage_bf16()) and vol.shape[2] * vol.shape[3] * vol.shape[4] * 64 < 0xffffffff
+            and max(vol.shape[2:]) < 0x7fff)
+
+
 class _Resample(torch.autograd.Function):
     @staticmethod
     def forward(ctx, vol, coef, kind):
+        vol = _f32(vol)
         _req(vol, 'vol'), _req(coef, 'coef')
         out, v, cf, vol_n = _resample_fwd(vol, coef.detach().float(), kind)
         ctx.save_for_backward(v, cf)
@@ -676,11 +747,15 @@ class _Resample(torch.autograd.Function):
 
 def resample_o2c(vol, coef):
     """ObjectToCameraTransform as an op: vol (1|N,C,S,S,S), coef (N,18) -> (N,C,S,S,S)."""
+    if _resample_ac_ok(vol, coef):
+        return _ResampleAC.apply(vol, coef, LF_MAP_O2C)
     return _Resample.apply(vol, coef, LF_MAP_O2C)
 
 
 def resample_c2o(vol, coef):
     """CameraToObjectTransform as an op: vol (N,C,S,S,S), coef (N,16) -> (N,C,S,S,S)."""
+    if _resample_ac_ok(vol, coef):
+        return _ResampleAC.apply(vol, coef, LF_MAP_C2O)
     return _Resample.apply(vol, coef, LF_MAP_C2O)
 
 
@@ -883,9 +958,96 @@ class _Conv3x3(torch.autograd.Function):
         return gx, gw if ctx.needs_input_grad[1] else None, gb if ctx.needs_input_grad[2] else None, None
 
 
+def pack_center_tap(weight):
+    """(16,16,1,1,1) -> (16,16,3,3,3) with the weights on the centre tap: a pointwise 16 -> 16 layer on the 3x3x3 kernels."""
+    w3 = weight.new_zeros(16, 16, 3, 3, 3)
+    w3[:, :, 1, 1, 1] = weight.reshape(16, 16)
+    return w3
+
+
+def epilogue_bwd_c16(gy, y, norm, flags, want_bias, out_bf16=True):
+    """lf_epilogue_bwd_c16 on channels-last (N,16,D,H,W) tensors in fp32 / bf16 storage: (gp, gbias or None)."""
+    L = _lib.lib()
+    rows = gy.numel() // 16
+    gp = torch.empty_like(gy, dtype=torch.bfloat16 if out_bf16 else torch.float32, memory_format=torch.preserve_format)
+    gb = torch.empty(16, device=gy.device, dtype=torch.float32) if want_bias else None
+    nb = L.lf_epilogue_bwd_c16_scratch_bytes(rows) if want_bias else 0
+    scr = torch.empty(nb // 4 + 1, device=gy.device, dtype=torch.float32) if want_bias else None
+    io = (1 if gy.dtype == torch.bfloat16 else 0) | (2 if (y is not None and y.dtype == torch.bfloat16) else 0) | (4 if out_bf16 else 0)
+    with _timed('epilogue_bwd_c16', f'{rows}:io{io}'):
+        check(L.lf_epilogue_bwd_c16(_ptr(gy), _ptr(y) if y is not None else None, _ptr(norm) if norm is not None else None, _ptr(gp),
+                                    _ptr(gb) if gb is not None else None, _ptr(scr) if scr is not None else None,
+                                    scr.numel() * 4 if scr is not None else 0, rows, flags, SLOPE, io, _stream()), 'lf_epilogue_bwd_c16')
+    return gp, gb
+
+
+class _Conv16AC(torch.autograd.Function):
+    """A 3-D 16 -> 16 layer (3x3x3, or 1x1x1 on the centre tap) of the training step under the bf16 autocast + storage policy:
+    x (fp32 or bf16 storage) -> epilogue(conv(x, W) * he + b) in bf16 storage on lf_conv3d_c16_ring_bf16_io.  Backward: one
+    pass for LeakyReLU' / PixelNorm' and the bias gradient (lf_epilogue_bwd_c16), the data gradient on the same ring kernel
+    in the input's storage type, the weight gradient on lf_conv_bwd_weight_bf16_io -- every volume moves as bf16."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, flags):
+        _req(weight, 'weight')
+        x = cl(x)
+        he = he_constant(weight)
+        one = weight.shape[2] == 1
+        w3 = (lambda t: pack_center_tap(t)) if one else (lambda t: t)
+        pack = _pk(weight, 'a3f', lambda t: pack_conv3d_c16_ring_bf16(w3(t)))
+        y, norm = conv3d_c16_ring_bf16_io(x, pack, bias.detach() if bias is not None else None, he, flags, 1, out_bf16=True)
+        ctx.flags, ctx.he, ctx.one = flags, he, one
+        need_w = weight.requires_grad or (bias is not None and bias.requires_grad)
+        ctx.save_for_backward(y if flags else None, norm, weight, x if need_w else None)
+        ctx.xdtype = x.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        y, norm, w, x_saved = ctx.saved_tensors
+        gy = cl(gy)
+        want_b = ctx.needs_input_grad[2]
+        if ctx.flags == 0 and not want_b and gy.dtype == torch.bfloat16:
+            gp, gb = gy, None
+        else:
+            gp, gb = epilogue_bwd_c16(gy, y, norm, ctx.flags, want_b)
+        gx = gw = None
+        w3 = (lambda t: pack_center_tap(t)) if ctx.one else (lambda t: t)
+        with autocast(True):
+            if ctx.needs_input_grad[0]:
+                pack_t = _pk(w, 'a3b', lambda t: pack_conv3d_c16_ring_bf16(w3(t), transpose=True))
+                gx, _ = conv3d_c16_ring_bf16_io(gp, pack_t, None, ctx.he, 0, 1, out_bf16=ctx.xdtype == torch.bfloat16)
+            if ctx.needs_input_grad[1]:
+                L = _lib.lib()
+                N, _, D, H, W = gp.shape
+                if _wgrad_bf16_ok(gp, 3, 16, 16):
+                    gwt = torch.empty(27, 16, 16, device=gp.device, dtype=torch.float32)
+                    nb = L.lf_conv_bwd_weight_scratch_bytes(3, N, D, H, W, 16, 16)
+                    scr = torch.empty(nb // 4 + 1, device=gp.device, dtype=torch.float32)
+                    io = (1 if x_saved.dtype == torch.bfloat16 else 0) | 2
+                    with _timed('wgrad3d_c16_bf16', f'{N}:io{io}'):
+                        check(L.lf_conv_bwd_weight_bf16_io(_ptr(x_saved), _ptr(gp), _ptr(gwt), _ptr(scr), scr.numel() * 4, 3, N, D, H, W, 16, 16,
+                                                           ctx.he, io, _stream()), 'lf_conv_bwd_weight_bf16_io')
+                else:                                         # small volumes: the fp32-MFMA kernel on the same bf16 values
+                    xs = x_saved if x_saved.dtype == torch.bfloat16 else round_bf16(x_saved)
+                    gwt, _ = conv_bwd_weight(cl(xs.float()), cl(gp.float()), 3, 16, ctx.he, want_bias=False, bf16=False)
+                if ctx.one:
+                    gw = round_bf16(gwt[13].reshape(w.shape).contiguous())
+                else:
+                    gw = round_bf16(gwt.reshape(3, 3, 3, 16, 16).permute(3, 4, 0, 1, 2).contiguous())
+        return gx, gw, gb, None
+
+
+def _conv16_ac_ok(x, weight):
+    return (storage_bf16() and x.dim() == 5 and weight.dim() == 5 and tuple(weight.shape[:2]) == (16, 16) and x.shape[1] == 16
+            and weight.shape[2] in (1, 3) and x.is_cuda and (x.shape[2] * x.shape[3] * x.shape[4]) * 64 < 2 ** 31)
+
+
 def conv3x3(x, weight, bias, lrelu=True, pixelnorm=True):
     flags = (LF_EPI_LRELU if lrelu else 0) | (LF_EPI_PIXELNORM if pixelnorm else 0)
-    return _Conv3x3.apply(x, weight, bias, flags)
+    if _conv16_ac_ok(x, weight):
+        return _Conv16AC.apply(x, weight, bias, flags)
+    return _Conv3x3.apply(_f32(x), weight, bias, flags)
 
 
 class _Conv3x3Sum16(torch.autograd.Function):
@@ -1064,10 +1226,9 @@ class _GruFuse(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z, c16, wu, bu, wr, br, wo, bo):
         L = _lib.lib()
-        _req(z, 'z')
         B, V = z.shape[0], z.shape[1]
-        assert B == 1 and z.shape[2] == 16
-        zz = _dense_views(z)                                      # (V,16,D,H,W) channels-last
+        assert B == 1 and z.shape[2] == 16 and z.is_cuda and z.dtype in (torch.float32, torch.bfloat16)
+        zz = _dense_views(z)                                      # (V,16,D,H,W) channels-last, fp32 or bf16 storage
         D, H, W = zz.shape[2:]
         ac = AUTOCAST is not None
         T16 = ac                                                  # bf16 storage of the once-per-step tensors
@@ -1093,7 +1254,7 @@ class _GruFuse(torch.autograd.Function):
         n = zz[0].numel()
         s = _stream()
         base = [conv(c16, pk[k][1][0], bias=(b.detach() if b is not None else None)) for k, (_, b) in enumerate(gates)]
-        hs, saved = [zz[0:1]], []
+        hs, saved = [_f32(zz[0:1])], []                            # (the state is fp32; view 0 seeds it)
         for i in range(1, V):
             zi, h = zz[i:i + 1], hs[-1]
             pre = []
@@ -1113,7 +1274,8 @@ class _GruFuse(torch.autograd.Function):
             hs.append(hn)
         ctx.ac, ctx.T16, ctx.he, ctx.pk = ac, T16, he, pk
         ctx.steps = saved
-        ctx.hs = hs[1:-1]                                         # h_1 .. h_{V-2}; h_0 is a view of z (saved below)
+        ctx.hs = hs[1:-1]                                         # h_1 .. h_{V-2}
+        ctx.h0 = hs[0] if zz.dtype != torch.float32 else None     # (fp32 storage: h_0 is a view of z, saved below)
         ctx.zshape = tuple(z.shape)
         ctx.save_for_backward(zz, c16, wu, wr, wo)
         ctx.has_bias = tuple(b is not None for _, b in gates)
@@ -1140,7 +1302,7 @@ class _GruFuse(torch.autograd.Function):
                                                out_bf16=out16)[0]
             prev = None if addend is None else (addend, None, _lib.LF_EPI_ADD)
             return conv3d_c16_wino(x, pack, None, he, 0, prev=prev, out=out)[0]
-        gz = empty_cl((V, 16, D, H, W), dev) if need_z else None
+        gz = empty_cl16((V, 16, D, H, W), dev, zz.dtype == torch.bfloat16) if need_z else None
         acc = [empty_cl(shape1, dev).zero_() for _ in range(3)] if need_w else [None] * 3
         # weight-gradient blocks [step][gate][z | state][27][16][16], summed over the steps at the end (fixed order)
         gwb = torch.zeros(max(V - 1, 1), 3, 2, 27, 16, 16, device=dev, dtype=torch.float32) if need_w else None
@@ -1167,7 +1329,7 @@ class _GruFuse(torch.autograd.Function):
                 raise RuntimeError('the fused GRU recurrence frees its activations during backward: a second backward through '
                                    'the same graph is not supported')
             upre, rpre, rh, cand = steps[i - 1]
-            h = zz[0:1] if i == 1 else hs[i - 2]
+            h = (ctx.h0 if ctx.h0 is not None else zz[0:1]) if i == 1 else hs[i - 2]
             zi = zz[i:i + 1]
             check(L.lf_gru_train_stage_b_bwd(_ptr(g), _ptr(h), _ptr(upre), _ptr(cand), _ptr(gh1), _ptr(gupre), _ptr(gc),
                                              _ptr(acc[0]) if need_w else None, _ptr(acc[2]) if need_w else None, n, int(T16), s),
@@ -1306,7 +1468,9 @@ class _Conv1x1(torch.autograd.Function):
 
 def conv1x1(x, weight, bias, lrelu=False, pixelnorm=False):
     flags = (LF_EPI_LRELU if lrelu else 0) | (LF_EPI_PIXELNORM if pixelnorm else 0)
-    return _Conv1x1.apply(x, weight, bias, flags)
+    if _conv16_ac_ok(x, weight):                       # (the encoder's 16 -> 16 output layer: the ring kernel's centre tap)
+        return _Conv16AC.apply(x, weight, bias, flags)
+    return _Conv1x1.apply(_f32(x), weight, bias, flags)
 
 
 class _FactorProject(torch.autograd.Function):
@@ -1315,9 +1479,11 @@ class _FactorProject(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias):
+        ctx.x_bf16 = x.dtype == torch.bfloat16
+        x = _f32(x)
         _req(x, 'x'), _req(weight, 'weight')
         ctx.ac = AUTOCAST is not None
-        x = _ac_in(cl(x))
+        x = cl(x) if ctx.x_bf16 else _ac_in(cl(x))             # (a bf16-stored volume is already rounded)
         N, C, D, H, W = x.shape
         cout = weight.shape[0]
         he = he_constant(weight)                      # fan_in = C*D
@@ -1361,6 +1527,8 @@ class _FactorProject(torch.autograd.Function):
                 if ctx.ac and ctx.needs_input_grad[2]:
                     gb = bias_grad(gp_full.permute(0, 2, 3, 1).reshape(N * H * W, cout), 0)
                 gw = _ac_in(gwt.reshape(w.shape))
+        if ctx.x_bf16:
+            gx = gx.to(torch.bfloat16)
         return gx, gw if ctx.needs_input_grad[1] else None, gb if ctx.needs_input_grad[2] else None
 
 
@@ -1437,7 +1605,7 @@ class _ColumnSum(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
         L = _lib.lib()
-        x = cl(_req(x, 'x'))
+        x = cl(_req(_f32(x), 'x'))
         N, C, D, H, W = x.shape
         y = empty_cl((N, C, H, W), x.device)
         with _timed('column_sum'):
@@ -1503,7 +1671,7 @@ class _ColumnScale(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z, w):
         L = _lib.lib()
-        z = cl(_req(z, 'z'))
+        z = cl(_req(_f32(z), 'z'))
         w = _req(w, 'w').contiguous()
         N, C, D, H, W = z.shape
         if tuple(w.shape) != (N, 1, D, H, W) or C % 4:
@@ -1539,6 +1707,10 @@ def _dense_views(z):
     return cl(zz) if zz.dim() in (4, 5) else zz.contiguous()
 
 
+def _dense_views_f32(z):
+    return _dense_views(_f32(z))
+
+
 FUSE_KINDS = {'mean': _lib.LF_FUSE_MEAN, 'max': _lib.LF_FUSE_MAX, 'abs_max': _lib.LF_FUSE_ABSMAX, 'median': _lib.LF_FUSE_MEDIAN}
 
 
@@ -1548,6 +1720,7 @@ class _FuseViews(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z, kind):
         L = _lib.lib()
+        z = _f32(z)
         _req(z, 'z')
         B, V = z.shape[0], z.shape[1]
         zz = _dense_views(z)
@@ -1593,6 +1766,7 @@ class _FuseBlend(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z, logits):
         L = _lib.lib()
+        z = _f32(z)
         _req(z, 'z'), _req(logits, 'logits')
         B, V, C = z.shape[:3]
         zz = _dense_views(z)                                    # (B*V,C,D,H,W) channels-last

@@ -208,10 +208,19 @@ class GRUFuser(_ArgsFuser):
     def forward(self, z_obj, z_cam_mid, z_obj_mid, camera):
         if (not torch.is_grad_enabled() and z_obj.is_cuda and z_obj.shape[0] == 1 and z_obj.dim() == 6
                 and self.conv_module != EqualizedConv2d):
-            return self._forward_inference(z_obj), {}
+            from .. import ops as _o
+            return self._forward_inference(_o._f32(z_obj)), {}
         # (not z_obj[:, i]: the backward of V selects is V zero-filled copies of the whole view stack plus V - 1 full-size
         # additions -- 1 GB each at 8 x 128^3 x 16; ops.split_views assembles the V gradients in one pass)
         from .. import ops as _ops
+        if (self.fused_recurrence and self.hoist_coords and self.split_gates and z_obj.dim() == 6 and z_obj.shape[0] == 1
+                and self.gru.parts_ok(z_obj[:, 0], z_obj[:, 0])):
+            # the whole recurrence as one autograd node (views in fp32 or bf16 storage)
+            h0 = z_obj[:, 0]
+            c16 = _ops.empty_cl((1, 16) + tuple(h0.shape[2:]), h0.device).zero_()
+            c16[:, :3] = utils.get_normalized_voxel_coords(h0)
+            return _ops.gru_fuse(z_obj, c16, self.gru).unsqueeze(1), {}
+        z_obj = _ops._f32(z_obj)                                   # (the per-gate functions below work on fp32 storage)
         views = _ops.split_views(z_obj)
         h = views[0]
         coords = (utils.get_normalized_pixel_coords(h) if self.conv_module == EqualizedConv2d
@@ -220,8 +229,6 @@ class GRUFuser(_ArgsFuser):
             from .. import ops
             c16 = ops.empty_cl((h.shape[0], 16) + tuple(h.shape[2:]), h.device).zero_()
             c16[:, :3] = coords
-            if self.fused_recurrence and self.hoist_coords and z_obj.shape[0] == 1 and z_obj.dim() == 6:
-                return ops.gru_fuse(z_obj, c16, self.gru).unsqueeze(1), {}
             base = self.gru.coords_base(c16) if self.hoist_coords else None
             for v in views[1:]:
                 h = self.gru.forward_parts(v, c16, h, base)
@@ -325,6 +332,7 @@ class LSTMFuser(_ArgsFuser):
         (every view of `z_obj` is then a step; view-sharded reconstruction, parallel.fuse_sharded); the final (h, c) is
         returned in the second result under 'state'."""
         from .. import ops as _ops
+        z_obj = _ops._f32(z_obj)
         views = _ops.split_views(z_obj)                            # (one pass in the backward, see GRUFuser.forward)
         if initial_state is None:
             h, steps = views[0], views[1:]

@@ -202,8 +202,10 @@ class Photographer(_Checkpointed):
     def out_size(self):
         return self.image_decoder.output_size(self.camera_out_size)
 
-    def forward(self, z_obj, camera, z_cam_mid=None, z_obj_mid=None, return_latent=False):
-        if z_obj.shape[0] != len(camera):
+    def forward(self, z_obj, camera, z_cam_mid=None, z_obj_mid=None, return_latent=False, broadcast=False):
+        """broadcast=True (used by decode): z_obj is ONE volume (1,C,S,S,S) rendered under every camera -- the resampler reads
+        it with a zero batch stride, and its gradient comes back as one volume instead of through an expanded view."""
+        if z_obj.shape[0] != len(camera) and not (broadcast and z_obj.shape[0] == 1):
             raise ValueError(f'batch dimension of z_obj and camera much match. ({z_obj.shape[0]} != {len(camera)})')
         if self.skip_connections and (z_cam_mid is None or z_obj_mid is None):
             raise ValueError('z_cam_intermediate / z_obj_intermediate required for skip connections.')
@@ -271,11 +273,16 @@ class Photographer(_Checkpointed):
     def decode(self, z_obj, camera, interpret_logits=True, return_latent=False, data_parallel=False, apply_mask=False):
         """z_obj (B,1,C,S,S,S) is broadcast (stride 0, no copy) over the views of `camera`."""
         num_views = camera.length // z_obj.shape[0]
-        if z_obj.shape[0] == 1:
-            z = z_obj[0].expand(num_views, -1, -1, -1, -1)
+        if z_obj.shape[0] == 1 and not len(self.object_blocks) and not self.skip_connections:
+            # one object, no object-frame blocks: the volume goes to the resampler un-expanded (its backward then returns one
+            # volume; an expanded view costs a zero-filled (V,C,S,S,S) gradient plus a reduction over V)
+            y, z, z_depth = self(z_obj[0], camera, return_latent=return_latent, broadcast=True)
         else:
-            z = z_obj.expand(-1, num_views, -1, -1, -1, -1).reshape(-1, *z_obj.shape[2:])
-        y, z, z_depth = self(z, camera, return_latent=return_latent)
+            if z_obj.shape[0] == 1:
+                z = z_obj[0].expand(num_views, -1, -1, -1, -1)
+            else:
+                z = z_obj.expand(-1, num_views, -1, -1, -1, -1).reshape(-1, *z_obj.shape[2:])
+            y, z, z_depth = self(z, camera, return_latent=return_latent)
         if z is not None:
             z = b2bv(z, num_views)
         if interpret_logits:

@@ -194,7 +194,10 @@ def test_generator_step_under_bf16_autocast():
             continue
         cos_hip = F.cosine_similarity(p.grad.reshape(1, -1).cpu().double(), ref).item()
         cos_orc = F.cosine_similarity(gw.reshape(1, -1).double(), ref).item()
-        assert cos_hip > min(0.99, cos_orc - 0.15) and cos_hip > 0.5, (k, n, cos_hip, cos_orc)
+        # (round 5: slack 0.15 -> 0.2.  With the 16-channel volumes STORED in bf16 the per-parameter statistic of this seed moved by
+        # up to -0.13 on the first 2-D encoder layers (0.83 -> 0.69 on one bias) while seeds 1-3 moved by +0.00..+0.06 and the
+        # whole-vector cosine below stayed within the oracle's own bf16 noise: tools/ac_noise_probe.py, profiles/r05_ac_noise.txt)
+        assert cos_hip > min(0.99, cos_orc - 0.2) and cos_hip > 0.5, (k, n, cos_hip, cos_orc)
     hip_all, orc_all, ref_all = torch.cat(hip_all), torch.cat(orc_all), torch.cat(ref_all)
     cos_hip = F.cosine_similarity(hip_all, ref_all, dim=0).item()
     cos_orc = F.cosine_similarity(orc_all, ref_all, dim=0).item()
@@ -202,3 +205,107 @@ def test_generator_step_under_bf16_autocast():
     assert cos_hip > cos_orc - 0.03, (cos_hip, cos_orc)
     losses = [float(step.run_iteration(batch)['total']) for _ in range(6)]
     assert losses[-1] < losses[0]
+
+
+# ---- round 5: bf16 STORAGE of the 16-channel volumes under the autocast policy ------------------------------------------
+def _b16(t):
+    return t.to(torch.bfloat16).contiguous(memory_format=torch.channels_last_3d)
+
+
+def test_resampler_bf16_storage_variants():
+    """lf_resample3d_fwd_io / lf_resample3d_bwd_vol_det_io: a bf16-stored source holding the same (bf16-representable) values
+    gives the fp32 kernel's result bit for bit; a bf16-stored destination is that result rounded once (RNE)."""
+    from latentfusion_amd import _lib, ops, synth
+    from latentfusion_amd.modules.geometry import Camera, c2o_coefficients, o2c_coefficients
+    from latentfusion_amd.pose import utils as pu
+    L = _lib.lib()
+    S, N = 24, 3
+    gen = torch.Generator().manual_seed(11)
+    td = synth.make_observation_data(1, seed=2)
+    torch.manual_seed(3)
+    cams = pu.sample_cameras_with_estimate(N, Camera(td['intrinsic'], td['extrinsic'])).zoom(None, S, 2.85).to(DEV)
+    s = torch.cuda.current_stream().cuda_stream
+    for kind, coef in ((_lib.LF_MAP_O2C, o2c_coefficients(cams, 1.0)), (_lib.LF_MAP_C2O, c2o_coefficients(cams, 1.0))):
+        cf = torch.zeros(N, _lib.LF_MAP_COEFS, device=DEV)
+        cf[:, :coef.shape[1]] = coef
+        vol = ops.cl(ops.round_bf16(torch.randn(N, 16, S, S, S, generator=gen).to(DEV)))
+        g = ops.cl(ops.round_bf16((torch.randn(N, 16, S, S, S, generator=gen) * 1e-2).to(DEV)))
+        ref = ops.empty_cl((N, 16, S, S, S), DEV)
+        _lib.check(L.lf_resample3d_fwd(vol.data_ptr(), N, cf.data_ptr(), kind, ref.data_ptr(), N, S, S, S, 16, s), 'fwd')
+        nb = L.lf_resample3d_bwd_vol_det_scratch_bytes(N, S, S, S, 16)
+        assert L.lf_resample3d_bwd_vol_det_io_scratch_bytes(N, S, S, S) <= nb
+        scr = torch.empty(nb // 8 + 1, device=DEV, dtype=torch.int64)
+        gref = ops.empty_cl((N, 16, S, S, S), DEV)
+        _lib.check(L.lf_resample3d_bwd_vol_det(g.data_ptr(), cf.data_ptr(), kind, gref.data_ptr(), N, scr.data_ptr(), scr.numel() * 8,
+                                               N, S, S, S, 16, s), 'bwd')
+        for io in range(4):
+            vi = _b16(vol) if io & 1 else vol
+            out = ops.empty_cl16((N, 16, S, S, S), DEV, bool(io & 2))
+            _lib.check(L.lf_resample3d_fwd_io(vi.data_ptr(), N, cf.data_ptr(), kind, out.data_ptr(), N, S, S, S, io, s), 'fwd io')
+            assert torch.equal(out, ref.to(torch.bfloat16) if io & 2 else ref), (kind, io)
+            gi = _b16(g) if io & 1 else g
+            gv = ops.empty_cl16((N, 16, S, S, S), DEV, bool(io & 2))
+            _lib.check(L.lf_resample3d_bwd_vol_det_io(gi.data_ptr(), cf.data_ptr(), kind, gv.data_ptr(), N, scr.data_ptr(), scr.numel() * 8,
+                                                      N, S, S, S, io, s), 'bwd io')
+            assert torch.equal(gv, gref.to(torch.bfloat16) if io & 2 else gref), (kind, io)
+
+
+@pytest.mark.parametrize('flags', [0, 1, 3])
+def test_epilogue_bwd_c16_with_bias_sums(flags):
+    """lf_epilogue_bwd_c16 = lf_epilogue_bwd on 16 channels + the bias gradient (column sums) in the same pass, in every
+    storage combination."""
+    from latentfusion_amd import ops
+    gen = torch.Generator().manual_seed(flags)
+    shape = (2, 16, 7, 13, 21)
+    gy = ops.cl(ops.round_bf16(torch.randn(shape, generator=gen).to(DEV)))
+    y = ops.cl(ops.round_bf16(torch.randn(shape, generator=gen).to(DEV)))
+    norm = (torch.rand(shape[0] * shape[2] * shape[3] * shape[4], generator=gen) + 0.5).to(DEV)
+    want = ops._epilogue_bwd(gy, y, norm, flags)
+    wb = want.double().sum(dim=(0, 2, 3, 4))
+    for io in range(8):
+        gp, gb = ops.epilogue_bwd_c16(_b16(gy) if io & 1 else gy, _b16(y) if io & 2 else y, norm, flags, True, out_bf16=bool(io & 4))
+        assert torch.equal(gp, want.to(torch.bfloat16) if io & 4 else want), io
+        assert (gb.double() - wb).abs().max().item() < 1e-5 * max(wb.abs().max().item(), 1.0)
+
+
+def test_conv16_layers_under_the_storage_policy():
+    """A camera block + the pointwise output layer under autocast: bf16 storage (ops.BF16_STORAGE, default) against fp32 storage
+    of the same policy -- activations equal up to one bf16 rounding of the stored values, gradients of input / weights /
+    biases agree (cosine > 0.999), the output is a bf16 channels-last tensor and two runs agree bit for bit."""
+    from latentfusion_amd import ops
+    from latentfusion_amd.modules import EqualizedConv3d
+    from latentfusion_amd.modules.blocks import Block
+    torch.manual_seed(2)
+    blk = Block(16, 16, conv_module=EqualizedConv3d).to(DEV)
+    out1 = EqualizedConv3d(16, 16, 1).to(DEV)
+    with torch.no_grad():
+        for c in (blk.conv1, blk.conv2, out1):
+            c.bias.normal_(0, 0.2)
+    gen = torch.Generator().manual_seed(5)
+    x0 = torch.randn(2, 16, 16, 24, 40, generator=gen).to(DEV)
+    gout = torch.randn(2, 16, 16, 24, 40, generator=gen).to(DEV)
+    res = {}
+    params = list(blk.parameters()) + list(out1.parameters())
+    for storage in (False, True, True):
+        ops.BF16_STORAGE = storage
+        try:
+            for p in params:
+                p.grad = None
+            x = x0.clone().requires_grad_(True)
+            with ops.autocast():
+                y = out1(blk(x))
+            (y.float() * gout).sum().backward()
+        finally:
+            ops.BF16_STORAGE = True
+        res.setdefault(storage, []).append((y.detach(), x.grad.clone(), [p.grad.clone() for p in params]))
+    a, b = res[True]
+    assert a[0].dtype == torch.bfloat16 and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert all(torch.equal(p, q) for p, q in zip(a[2], b[2]))
+    ref = res[False][0]
+    assert ref[0].dtype == torch.float32
+    err = (a[0].float() - ref[0]).abs()
+    assert float(err.max()) <= 2 ** -6 * float(ref[0].abs().max())
+    cos = lambda u, v: F.cosine_similarity(u.reshape(1, -1).double(), v.reshape(1, -1).double()).item()   # noqa: E731
+    assert cos(a[1], ref[1]) > 0.999
+    for p, q in zip(a[2], ref[2]):
+        assert cos(p, q) > 0.999, (p.shape, cos(p, q))
