@@ -523,6 +523,18 @@ int lf_lift_unfold(const float* src, const float* norm_or_null, float* dst,
  * FactorProjection3d2d's reshape, geometry.py:745): fold = 0: src [N][P][C0*S] -> dst [N][S][P][C0];
  * fold = 1: src [N][S][P][C0] -> dst [N][P][C0*S].  4 * C0 * (S + 1) * 4 bytes of LDS must fit 64 KB (LF_EINVAL). */
 int lf_lift_permute(const float* src, float* dst, int N, long P, int C0, int S, int fold, void* stream);
+/* FactorProjection2d3d of the TRAINING step in two passes instead of four (modules/geometry.py:711-728 and its autograd):
+ * lf_lift_norm_unfold: src [N][P][C0*S] = LeakyReLU(conv * he + b) rows (channel = c*S + d) -> PixelNorm over the C0*S channels
+ *   of every pixel, written as the (N,C0,S,H,W) channels-last volume dst [N][S][P][C0] (fp32, or bf16 with out_bf16) and
+ *   norm_out [N*P] = sqrt(mean + eps);
+ * lf_lift_bwd: gradient volume + saved volume (io bit 0 / bit 1: stored as bf16) + norm -> gp [N][P][C0*S], the gradient
+ *   w.r.t. the convolution's pre-activation (PixelNorm' then LeakyReLU'), as rows for the weight / data gradient products;
+ *   round_bf16: written as bf16 values in the fp32 container (the autocast policy's operand rounding).
+ * C0 % 4 == 0, S % 4 == 0, 2 * 4 * C0 * (S + 1) floats of LDS (<= 150 KB). */
+int lf_lift_norm_unfold(const float* src, void* dst, float* norm_out, int N, long P, int C0, int S, float eps, int out_bf16,
+                        void* stream);
+int lf_lift_bwd(const void* gvol, const void* yvol, const float* norm, float* gp, int N, long P, int C0, int S, float slope,
+                int round_bf16, int io, void* stream);
 
 #ifdef __cplusplus
 }

@@ -118,6 +118,8 @@ SIGNATURES = {
     'lf_nhwc_to_nchw': (c_int, [P, P, c_int, c_int, c_long, P]),
     'lf_lift_unfold': (c_int, [P, P, P, c_int, c_long, c_int, c_int, P]),
     'lf_lift_permute': (c_int, [P, P, c_int, c_long, c_int, c_int, c_int, P]),
+    'lf_lift_norm_unfold': (c_int, [P, P, P, c_int, c_long, c_int, c_int, c_float, c_int, P]),
+    'lf_lift_bwd': (c_int, [P, P, P, P, c_int, c_long, c_int, c_int, c_float, c_int, c_int, P]),
 }
 
 _lib = None

@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(256) lift_permute_kernel(const float* __restri
 }
 
 bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
-
+// (the fused lift kernels below use ld4 / bf16x4p, declared with the 16-channel epilogue kernel further down)
 template <int MODE>
 int launch_rows(const float* a, const float* b, const float* nrm_in, float* out, float* nrm_out,
                 long rows, int C, unsigned flags, float slope, float eps, hipStream_t s) {
@@ -268,6 +268,124 @@ __global__ void __launch_bounds__(256) colsum_final_kernel(const float* __restri
   }
 }
 
+// ---- FactorProjection2d3d for the training step, fused (round 5): the pointwise convolution leaves u = LeakyReLU(conv * he + b)
+// as [N][P][C0*S] rows (channel = c*S + d); ONE pass then forms the PixelNorm over all C0*S channels of a pixel and writes the
+// normalised values straight into the (N,C0,S,H,W) channels-last volume (fp32 or bf16 storage) + one norm per pixel -- instead
+// of a normalisation pass and a permutation pass over 4 GB each.  The backward pass reads the volume-layout gradient and the
+// saved volume, forms PixelNorm' / LeakyReLU' per pixel and writes the pre-activation gradient as rows for the weight / data
+// gradient GEMMs (optionally already rounded to bf16 values: the autocast policy's operand rounding).
+// Same tile as lift_permute_kernel: FT pixels per workgroup, [pixel][c][d (+1 pad)] floats in LDS; global accesses are 16-byte
+// vectors on the row side (4 consecutive d) and 4-channel groups on the volume side.
+template <bool OUT16>
+__global__ void __launch_bounds__(256) lift_norm_unfold_kernel(const float* __restrict__ src, void* __restrict__ dst,
+                                                               float* __restrict__ norm_out, long P, int C0, int S, float eps) {
+  extern __shared__ float tile[];                           // [FT][C0][S + 1], then FT * 4 partial sums
+  const int n = blockIdx.y, CS = C0 * S, SP = S + 1, tid = threadIdx.x;
+  const long p0 = (long)blockIdx.x * FT;
+  const int npx = (int)min((long)FT, P - p0);
+  const f32x4* flat = (const f32x4*)(src + ((long)n * P + p0) * CS);
+  float* part = tile + FT * C0 * SP;                        // [FT][4 waves]
+  float ss[FT];
+#pragma unroll
+  for (int k = 0; k < FT; ++k) ss[k] = 0.f;
+  const int nq = npx * CS / 4;
+  for (int i = tid; i < nq; i += 256) {
+    const f32x4 v = flat[i];
+    const int e = i * 4, px = e / CS, j = e - px * CS, c = j / S, d = j - c * S;
+    float* t = tile + (px * C0 + c) * SP + d;
+    t[0] = v[0]; t[1] = v[1]; t[2] = v[2]; t[3] = v[3];
+    const float q = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+#pragma unroll
+    for (int k = 0; k < FT; ++k) ss[k] += (px == k) ? q : 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < FT; ++k) {
+    float v = ss[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((tid & 63) == 0) part[k * 4 + (tid >> 6)] = v;
+  }
+  __syncthreads();
+  float rn[FT];
+#pragma unroll
+  for (int k = 0; k < FT; ++k) rn[k] = sqrtf(((part[k * 4] + part[k * 4 + 1]) + (part[k * 4 + 2] + part[k * 4 + 3])) / (float)CS + eps);
+  if (tid < npx) norm_out[(long)n * P + p0 + tid] = rn[tid];
+  const int C4 = C0 / 4;
+  char* vol = (char*)dst + ((long)n * S * P * C0 + p0 * C0) * (OUT16 ? 2 : 4);
+  for (int i = tid; i < S * npx * C4; i += 256) {
+    const int c4 = i % C4, px = (i / C4) % npx, d = i / (C4 * npx);
+    const float* t = tile + (px * C0 + c4 * 4) * SP + d;
+    float r = rn[0];
+#pragma unroll
+    for (int k = 1; k < FT; ++k) r = (px == k) ? rn[k] : r;
+    const f32x4 o = (f32x4){t[0] / r, t[SP] / r, t[2 * SP] / r, t[3 * SP] / r};
+    const long off = ((long)d * P + px) * C0 + c4 * 4;
+    if constexpr (OUT16) *(bf16x4p*)(vol + off * 2) = __builtin_convertvector(o, bf16x4p);
+    else *(f32x4*)(vol + off * 4) = o;
+  }
+}
+
+// IO bit 0: the gradient volume, bit 1: the saved volume are bf16.  round_bf16 != 0: gp is written as bf16 VALUES (fp32 container).
+template <int IO>
+__global__ void __launch_bounds__(256) lift_bwd_fused_kernel(const void* __restrict__ gvol, const void* __restrict__ yvol,
+                                                             const float* __restrict__ nrm, float* __restrict__ gp, long P, int C0,
+                                                             int S, float slope, int round_bf16) {
+  extern __shared__ float tile[];                           // g: [FT][C0][S + 1]; y: the same; then FT * 4 partial sums
+  const int n = blockIdx.y, CS = C0 * S, SP = S + 1, tid = threadIdx.x, C4 = C0 / 4;
+  const long p0 = (long)blockIdx.x * FT;
+  const int npx = (int)min((long)FT, P - p0);
+  float* tg = tile;
+  float* ty = tile + FT * C0 * SP;
+  float* part = ty + FT * C0 * SP;
+  const long vbase = (long)n * S * P * C0 + p0 * C0;
+  float dot[FT];
+#pragma unroll
+  for (int k = 0; k < FT; ++k) dot[k] = 0.f;
+  for (int i = tid; i < S * npx * C4; i += 256) {
+    const int c4 = i % C4, px = (i / C4) % npx, d = i / (C4 * npx);
+    const long off = vbase + ((long)d * P + px) * C0 + c4 * 4;
+    const f32x4 g = ld4<(IO & 1) != 0>(gvol, off >> 2), y = ld4<(IO & 2) != 0>(yvol, off >> 2);
+    const int t = (px * C0 + c4 * 4) * SP + d;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { tg[t + e * SP] = g[e]; ty[t + e * SP] = y[e]; }
+    const float q = g[0] * y[0] + g[1] * y[1] + g[2] * y[2] + g[3] * y[3];
+#pragma unroll
+    for (int k = 0; k < FT; ++k) dot[k] += (px == k) ? q : 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < FT; ++k) {
+    float v = dot[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((tid & 63) == 0) part[k * 4 + (tid >> 6)] = v;
+  }
+  __syncthreads();
+  float dt[FT], rn[FT];
+#pragma unroll
+  for (int k = 0; k < FT; ++k) {
+    dt[k] = ((part[k * 4] + part[k * 4 + 1]) + (part[k * 4 + 2] + part[k * 4 + 3])) / (float)CS;
+    rn[k] = k < npx ? nrm[(long)n * P + p0 + k] : 1.f;
+  }
+  f32x4* flat = (f32x4*)(gp + ((long)n * P + p0) * CS);
+  const int nq = npx * CS / 4;
+  for (int i = tid; i < nq; i += 256) {
+    const int e0 = i * 4, px = e0 / CS, j = e0 - px * CS, c = j / S, d = j - c * S;
+    const int t = (px * C0 + c) * SP + d;
+    float dk = dt[0], rk = rn[0];
+#pragma unroll
+    for (int k = 1; k < FT; ++k) { dk = (px == k) ? dt[k] : dk; rk = (px == k) ? rn[k] : rk; }
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float yv = ty[t + e];
+      float v = (tg[t + e] - yv * dk) / rk;
+      v = yv > 0.f ? v : v * slope;
+      o[e] = round_bf16 ? (float)(__bf16)v : v;
+    }
+    flat[i] = o;
+  }
+}
+
 }  // namespace
 
 extern "C" int lf_pixelnorm_fwd(const float* x, float* y, float* norm_out, long rows, int C, float eps, void* stream) {
@@ -352,6 +470,50 @@ extern "C" int lf_lift_permute(const float* src, float* dst, int N, long P, int 
     hipLaunchKernelGGL((lift_permute_kernel<true>), grid, dim3(256), shmem, (hipStream_t)stream, src, dst, P, C0, S);
   else
     hipLaunchKernelGGL((lift_permute_kernel<false>), grid, dim3(256), shmem, (hipStream_t)stream, src, dst, P, C0, S);
+  return lf_launch_status();
+}
+
+static bool lift_fused_ok(int N, long P, int C0, int S) {
+  return N > 0 && P > 0 && C0 > 0 && S > 0 && C0 % 4 == 0 && S % 4 == 0 && N <= 65535 && (P + FT - 1) / FT <= 0x7fffffffL &&
+         (size_t)(2 * FT * C0 * (S + 1) + 4 * FT) * sizeof(float) <= 150 * 1024;
+}
+
+extern "C" int lf_lift_norm_unfold(const float* src, void* dst, float* norm_out, int N, long P, int C0, int S, float eps,
+                                   int out_bf16, void* stream) {
+  lf_clear_error();
+  if (!lift_fused_ok(N, P, C0, S) || src == nullptr || dst == nullptr || norm_out == nullptr) return LF_EINVAL;
+  if (!lf_aligned16(src) || !lf_aligned16(dst)) return LF_EALIGN;
+  const size_t shmem = (size_t)(FT * C0 * (S + 1) + 4 * FT) * sizeof(float);
+  const dim3 grid((unsigned)((P + FT - 1) / FT), (unsigned)N);
+  typedef void (*kern_t)(const float*, void*, float*, long, int, int, float);
+  const kern_t k = out_bf16 ? (kern_t)lift_norm_unfold_kernel<true> : (kern_t)lift_norm_unfold_kernel<false>;
+  static bool attr[2] = {false, false};
+  if (!attr[out_bf16 ? 1 : 0] && shmem > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr[out_bf16 ? 1 : 0] = true;
+  }
+  hipLaunchKernelGGL(k, grid, dim3(256), shmem, (hipStream_t)stream, src, dst, norm_out, P, C0, S, eps);
+  return lf_launch_status();
+}
+
+extern "C" int lf_lift_bwd(const void* gvol, const void* yvol, const float* norm, float* gp, int N, long P, int C0, int S,
+                           float slope, int round_bf16, int io, void* stream) {
+  lf_clear_error();
+  if (!lift_fused_ok(N, P, C0, S) || gvol == nullptr || yvol == nullptr || norm == nullptr || gp == nullptr || io < 0 || io > 3)
+    return LF_EINVAL;
+  if (!lf_aligned16(gvol) || !lf_aligned16(yvol) || !lf_aligned16(gp)) return LF_EALIGN;
+  const size_t shmem = (size_t)(2 * FT * C0 * (S + 1) + 4 * FT) * sizeof(float);
+  const dim3 grid((unsigned)((P + FT - 1) / FT), (unsigned)N);
+  typedef void (*kern_t)(const void*, const void*, const float*, float*, long, int, int, float, int);
+  static const kern_t kerns[4] = {lift_bwd_fused_kernel<0>, lift_bwd_fused_kernel<1>, lift_bwd_fused_kernel<2>, lift_bwd_fused_kernel<3>};
+  static bool attr[4] = {false, false, false, false};
+  if (!attr[io] && shmem > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kerns[io], hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr[io] = true;
+  }
+  hipLaunchKernelGGL(kerns[io], grid, dim3(256), shmem, (hipStream_t)stream, gvol, yvol, norm, gp, P, C0, S, slope, round_bf16);
   return lf_launch_status();
 }
 

@@ -1536,6 +1536,9 @@ def factor_project(x, weight, bias):
     return _FactorProject.apply(x, weight, bias)
 
 
+LIFT_FUSED = True          # A/B switch of the fused training-path lift (_LiftFused); False: conv1x1 + PixelNorm + permutation
+
+
 def _lift_permute(src, V, P, c0, S, fold, out):
     check(_lib.lib().lf_lift_permute(_ptr(src), _ptr(out), V, P, c0, S, 1 if fold else 0, _stream()), 'lf_lift_permute')
     return out
@@ -1563,6 +1566,67 @@ def _lift_ok(c0, S):
     return 4 * c0 * (S + 1) * 4 <= 64 * 1024
 
 
+def _lift_fused_ok(c0, S):
+    return c0 % 4 == 0 and S % 4 == 0 and (2 * 4 * c0 * (S + 1) + 16) * 4 <= 150 * 1024
+
+
+class _LiftFused(torch.autograd.Function):
+    """FactorProjection2d3d with a gradient (training step), two passes each way: pointwise conv + LeakyReLU as rows, then
+    lf_lift_norm_unfold (PixelNorm over all C0*S channels + the layout change into the channels-last volume, bf16 storage under
+    the autocast storage policy); backward lf_lift_bwd (PixelNorm' / LeakyReLU' from the volume-layout gradient and the saved
+    volume, written as rows) feeding the weight / data gradient products.  Replaces conv1x1 + PixelNorm pass + lift_permute
+    (and their three backward passes): the (V, C0*S, H, W) activation is never stored."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, S):
+        L = _lib.lib()
+        _req(x, 'x'), _req(weight, 'weight')
+        ctx.ac = AUTOCAST is not None
+        x = _ac_in(cl(x))
+        V, cin, H, W = x.shape
+        cs = weight.shape[0]
+        c0 = cs // S
+        P = H * W
+        he = he_constant(weight)
+        wpack = _pk(weight, 'c1f', lambda w: pack_conv1x1(w.reshape(cs, cin)))
+        tmp = torch.empty(V * P, cs, device=x.device, dtype=torch.float32)
+        _conv1x1_raw(x, wpack, bias.detach() if bias is not None else None, V, P, cin, 1, P * cin, 0, cs, tmp, he, LF_EPI_LRELU)
+        out16 = storage_bf16() and c0 == 16
+        vol = empty_cl16((V, c0, S, H, W), x.device, out16)
+        norm = torch.empty(V * P, device=x.device, dtype=torch.float32)
+        with _timed('lift_norm_unfold'):
+            check(L.lf_lift_norm_unfold(_ptr(tmp), _ptr(vol), _ptr(norm), V, P, c0, S, PN_EPS, int(out16), _stream()), 'lf_lift_norm_unfold')
+        del tmp
+        ctx.dims, ctx.he = (V, cin, H, W, c0, S), he
+        ctx.save_for_backward(vol, norm, weight, x)
+        return vol
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        vol, norm, w, x = ctx.saved_tensors
+        V, cin, H, W, c0, S = ctx.dims
+        cs, P = c0 * S, H * W
+        g = cl(g)
+        gp = torch.empty(V * P, cs, device=g.device, dtype=torch.float32)
+        io = (1 if g.dtype == torch.bfloat16 else 0) | (2 if vol.dtype == torch.bfloat16 else 0)
+        with _timed('lift_bwd'):
+            check(L.lf_lift_bwd(_ptr(g), _ptr(vol), _ptr(norm), _ptr(gp), V, P, c0, S, SLOPE, int(ctx.ac), io, _stream()), 'lf_lift_bwd')
+        gx = gw = gb = None
+        with autocast(ctx.ac):
+            if ctx.needs_input_grad[0]:
+                wpack_t = _pk(w, 'c1b', lambda t: pack_conv1x1(t.reshape(cs, cin).t()))
+                gx = empty_cl((V, cin, H, W), g.device)
+                _conv1x1_raw(gp, wpack_t, None, V, P, cs, 1, P * cs, 0, cin, gx, ctx.he, 0)
+                gx = _ac_in(gx)
+            if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+                gwt, gb = conv_bwd_weight(x.permute(0, 2, 3, 1).reshape(V * P, cin), gp, 0, cin, ctx.he, want_bias=not ctx.ac)
+                if ctx.ac and ctx.needs_input_grad[2]:
+                    gb = bias_grad(gp, 0)              # (of the rounded rows: 5e5 roundings of 2^-9 average out far below fp32's own noise)
+                gw = _ac_in(gwt.reshape(w.shape))
+        return gx, gw if ctx.needs_input_grad[1] else None, gb if ctx.needs_input_grad[2] else None, None
+
+
 def lift(x, weight, bias, out_size):
     """FactorProjection2d3d (modules/geometry.py:711-728): 1x1 conv to C0*S channels, LeakyReLU,
     PixelNorm over ALL C0*S channels, viewed as (V,C0,S,H,W).  The fused unfold below is the inference path;
@@ -1575,6 +1639,8 @@ def lift(x, weight, bias, out_size):
     cs = weight.shape[0]
     c0 = cs // out_size
     if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)):
+        if LIFT_FUSED and _lift_fused_ok(c0, out_size) and c0 * out_size == cs:
+            return _LiftFused.apply(x, weight, bias, out_size)
         y = conv1x1(x, weight, bias, lrelu=True, pixelnorm=True)            # (V, c0*S, H, W), channel = c*S + d
         if _lift_ok(c0, out_size):
             return _LiftView.apply(y, c0, out_size)
