@@ -38,6 +38,21 @@ AUTOCAST = None
 BF16_STORAGE = True
 
 
+# Weight-gradient launches of the training step on a second HIP stream (round 5).  The 16 -> 16 kernels of the step are bound by
+# latency at two resident workgroups per CU, not by HBM or the matrix pipe, and a CU has room for two weight-gradient
+# workgroups (62 KB of LDS each) plus one ring-convolution workgroup (35 KB): the weight gradient of a layer -- nothing in the
+# backward chain waits for it -- runs beside the data-gradient convolution of the same layer instead of in front of it.
+WGRAD_STREAM = True
+_SIDE = {}
+
+
+def side_stream(device):
+    st = _SIDE.get(device)
+    if st is None:
+        st = _SIDE[device] = torch.cuda.Stream(device=device)
+    return st
+
+
 def storage_bf16():
     return AUTOCAST is not None and BF16_STORAGE
 
@@ -1011,24 +1026,38 @@ class _Conv16AC(torch.autograd.Function):
             gp, gb = gy, None
         else:
             gp, gb = epilogue_bwd_c16(gy, y, norm, ctx.flags, want_b)
-        gx = gw = None
+        gx = gw = gwt = None
         w3 = (lambda t: pack_center_tap(t)) if ctx.one else (lambda t: t)
         with autocast(True):
+            fast = ctx.needs_input_grad[1] and _wgrad_bf16_ok(gp, 3, 16, 16)
+            side = done = None
+            if fast:
+                # the weight gradient first, on the side stream (WGRAD_STREAM): it then runs beside the data gradient below
+                L = _lib.lib()
+                N, _, D, H, W = gp.shape
+                gwt = torch.empty(27, 16, 16, device=gp.device, dtype=torch.float32)
+                nb = L.lf_conv_bwd_weight_scratch_bytes(3, N, D, H, W, 16, 16)
+                scr = torch.empty(nb // 4 + 1, device=gp.device, dtype=torch.float32)
+                io = (1 if x_saved.dtype == torch.bfloat16 else 0) | 2
+                main = torch.cuda.current_stream()
+                if WGRAD_STREAM and KERNEL_TIMER is None:
+                    side = side_stream(gp.device)
+                    side.wait_stream(main)                    # gp (and the allocations above) are ready
+                with torch.cuda.stream(side) if side is not None else _timed('wgrad3d_c16_bf16', f'{N}:io{io}'):
+                    check(L.lf_conv_bwd_weight_bf16_io(_ptr(x_saved), _ptr(gp), _ptr(gwt), _ptr(scr), scr.numel() * 4, 3, N, D, H, W, 16, 16,
+                                                       ctx.he, io, _stream()), 'lf_conv_bwd_weight_bf16_io')
+                    if side is not None:
+                        done = torch.cuda.Event()
+                        done.record(side)
+                        for t in (x_saved, gp, gwt, scr):
+                            t.record_stream(side)
             if ctx.needs_input_grad[0]:
                 pack_t = _pk(w, 'a3b', lambda t: pack_conv3d_c16_ring_bf16(w3(t), transpose=True))
                 gx, _ = conv3d_c16_ring_bf16_io(gp, pack_t, None, ctx.he, 0, 1, out_bf16=ctx.xdtype == torch.bfloat16)
             if ctx.needs_input_grad[1]:
-                L = _lib.lib()
-                N, _, D, H, W = gp.shape
-                if _wgrad_bf16_ok(gp, 3, 16, 16):
-                    gwt = torch.empty(27, 16, 16, device=gp.device, dtype=torch.float32)
-                    nb = L.lf_conv_bwd_weight_scratch_bytes(3, N, D, H, W, 16, 16)
-                    scr = torch.empty(nb // 4 + 1, device=gp.device, dtype=torch.float32)
-                    io = (1 if x_saved.dtype == torch.bfloat16 else 0) | 2
-                    with _timed('wgrad3d_c16_bf16', f'{N}:io{io}'):
-                        check(L.lf_conv_bwd_weight_bf16_io(_ptr(x_saved), _ptr(gp), _ptr(gwt), _ptr(scr), scr.numel() * 4, 3, N, D, H, W, 16, 16,
-                                                           ctx.he, io, _stream()), 'lf_conv_bwd_weight_bf16_io')
-                else:                                         # small volumes: the fp32-MFMA kernel on the same bf16 values
+                if done is not None:
+                    torch.cuda.current_stream().wait_event(done)
+                if not fast:                                  # small volumes: the fp32-MFMA kernel on the same bf16 values
                     xs = x_saved if x_saved.dtype == torch.bfloat16 else round_bf16(x_saved)
                     gwt, _ = conv_bwd_weight(cl(xs.float()), cl(gp.float()), 3, 16, ctx.he, want_bias=False, bf16=False)
                 if ctx.one:
@@ -1314,17 +1343,30 @@ class _GruFuse(torch.autograd.Function):
             if ac and fast:
                 io = (1 if x.dtype == torch.bfloat16 else 0) | (2 if gp.dtype == torch.bfloat16 else 0)
                 check(L.lf_conv_bwd_weight_bf16_io(_ptr(x), _ptr(gp), _ptr(dst), _ptr(scratch), scratch.numel() * 4, 3, 1, D, H, W,
-                                                   16, 16, he, io, s), 'lf_conv_bwd_weight_bf16_io')
+                                                   16, 16, he, io, _stream()), 'lf_conv_bwd_weight_bf16_io')
             else:
                 xf = round_bf16(x.float()) if ac else x
                 gf = round_bf16(gp.float()) if ac else gp
                 check(L.lf_conv_bwd_weight(_ptr(xf), _ptr(gf), _ptr(dst), _ptr(scratch), scratch.numel() * 4, 3, 1, D, H, W, 16, 16,
-                                           he, s), 'lf_conv_bwd_weight')
+                                           he, _stream()), 'lf_conv_bwd_weight')
         gh1 = empty_cl(shape1, dev)
         gh12 = empty_cl(shape1, dev)
-        gupre, gc, grh, grpre = (empty_cl16(shape1, dev, T16) for _ in range(4))
+        grh = empty_cl16(shape1, dev, T16)
+        # the six weight gradients of a step run on the side stream (WGRAD_STREAM) beside the data-gradient chain; the gate
+        # gradients they read are double-buffered, a buffer is rewritten only after the launches that read it have finished
+        main = torch.cuda.current_stream()
+        side = side_stream(dev) if (WGRAD_STREAM and need_w and KERNEL_TIMER is None) else None
+        gbuf = [tuple(empty_cl16(shape1, dev, T16) for _ in range(3)) for _ in range(2 if side is not None else 1)]
+        gdone = [None, None]
+        if side is not None:
+            side.wait_stream(main)
+            for t in (gwb, scratch, zz) + tuple(b for bb in gbuf for b in bb):
+                t.record_stream(side)
         steps, hs = ctx.steps, ctx.hs
         for i in range(V - 1, 0, -1):
+            gupre, gc, grpre = gbuf[i & 1 if side is not None else 0]
+            if gdone[i & 1] is not None:
+                main.wait_event(gdone[i & 1])
             if steps[i - 1] is None:
                 raise RuntimeError('the fused GRU recurrence frees its activations during backward: a second backward through '
                                    'the same graph is not supported')
@@ -1337,6 +1379,18 @@ class _GruFuse(torch.autograd.Function):
             conv(gc, pk[2][2][1], out=grh, rnd=1)
             check(L.lf_gru_train_stage_a_bwd(_ptr(grh), _ptr(rpre), _ptr(h), _ptr(gh1), _ptr(grpre), _ptr(gh12),
                                              _ptr(acc[1]) if need_w else None, n, int(T16), s), 'lf_gru_train_stage_a_bwd')
+            if side is not None:
+                ready = torch.cuda.Event()
+                ready.record(main)                                # the three gate gradients of this step are complete
+                side.wait_event(ready)
+                h.record_stream(side)
+                rh.record_stream(side)
+                with torch.cuda.stream(side):
+                    for k, (xs, gp) in enumerate((((zi, h), gupre), ((zi, h), grpre), ((zi, rh), gc))):
+                        wgrad(xs[0], gp, gwb[i - 1, k, 0])
+                        wgrad(xs[1], gp, gwb[i - 1, k, 1])
+                    gdone[i & 1] = torch.cuda.Event()
+                    gdone[i & 1].record(side)
             if need_z:
                 gzi = gz[i:i + 1]
                 conv(gc, pk[2][0][1], out=gzi, rnd=1)
@@ -1345,7 +1399,7 @@ class _GruFuse(torch.autograd.Function):
             gnext = empty_cl(shape1, dev)
             conv(gupre, pk[0][2][1], addend=gh12, out=gnext)
             conv(grpre, pk[1][2][1], addend=gnext, out=gnext)
-            if need_w:
+            if need_w and side is None:
                 for k, (xs, gp) in enumerate((((zi, h), gupre), ((zi, h), grpre), ((zi, rh), gc))):
                     wgrad(xs[0], gp, gwb[i - 1, k, 0])
                     wgrad(xs[1], gp, gwb[i - 1, k, 1])
@@ -1353,6 +1407,8 @@ class _GruFuse(torch.autograd.Function):
             steps[i - 1] = None                                   # the step's tensors are dead: free them as the walk goes
             if i >= 2:
                 hs[i - 2] = None
+        if side is not None:
+            main.wait_stream(side)
         if need_z:
             gz[0:1].copy_(g)
         outs = [gz.view(ctx.zshape) if need_z else None, None]
