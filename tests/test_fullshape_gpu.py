@@ -244,3 +244,38 @@ def test_cfg5_training_step_at_full_shape_bf16():
     losses = [float(step.run_iteration(batch)['total']) for _ in range(4)]
     assert all(l == l for l in losses) and losses[-1] < losses[0], losses
     assert torch.cuda.max_memory_allocated() < 200 * 2 ** 30
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# cfg 2 against the REFERENCE ITSELF at the headline shape, over the preset's real length (golden g26)
+# ----------------------------------------------------------------------------------------------------------------------
+def test_cfg2_headline_loop_vs_reference_fixture():
+    """tests/golden/g26_headline_trace.pt holds what the imported REFERENCE produced for BASELINE cfg 2 exactly as bench.py runs
+    it (oracle/make_golden_headline.py: SYN(128,16), GRU, 16 views, N = 8, all 100 iterations of adam_quick; 49 min on 8 cores).
+    HIP end to end against it (tools/headline_trace_probe.py; measured numbers: profiles/r05_headline_trace_vs_reference.json):
+      * the reconstructed volume (sub-sampled) and the iteration-0 renders: 1e-3 relative (measured 3e-6 / 2e-6 rel-L2);
+      * the loop: fp32 rounding differences are amplified by Adam's first steps (1e-7 -> 4e-3 over iterations 0-8) and then
+        stay BOUNDED (<= 5e-3 relative over all 100 iterations, asserted <= 2e-2); the argmin pose index is identical for the
+        first 10 iterations (measured: 14) and at EVERY iteration where the reference separates its best two hypotheses by
+        more than twice that iteration's loss deviation; the final best loss agrees to 1e-3 (measured 1e-4).
+    The reference's own top-2 gap falls below 1e-3 relative in 66 of the 100 iterations (down to 4e-7): there the index of
+    the best hypothesis is decided by rounding in either implementation -- 'identical argmin' is not a property the
+    reference has against itself on another BLAS."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('headline_trace_probe', os.path.join(root, 'tools', 'headline_trace_probe.py'))
+    probe = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(probe)
+    res = probe.compare(DEV)
+    assert res['fixture']['T'] >= 20 and res['fixture']['S'] == 128 and res['fixture']['V'] == 16
+    assert res['volume']['max_abs_diff_over_absmax'] <= 1e-4 and res['volume']['rel_l2'] <= 1e-4, res['volume']
+    for k, r in res['iteration0_renders'].items():
+        assert r['max_abs_diff'] <= 1e-3 * max(1.0, r['max_abs_ref']) and r['rel_l2'] <= 1e-4, (k, r)
+    t = res['trace']
+    rows = t['per_iteration']
+    assert t['iterations'] == res['fixture']['T']
+    assert t['max_rel_diff_first_5'] <= 1e-3 and t['max_rel_diff_all'] <= 2e-2, (t['max_rel_diff_first_5'], t['max_rel_diff_all'])
+    assert all(r['argmin_equal'] for r in rows[:10]), t['first_iteration_argmin_differs']
+    decided = [r for r in rows if r['reference_top2_rel_gap'] > 2.0 * r['rank_loss_max_rel_diff']]
+    assert len(decided) >= 10 and all(r['argmin_equal'] for r in decided), [r['iteration'] for r in decided if not r['argmin_equal']]
+    assert abs(t['final_best_loss_hip'] - t['final_best_loss_reference']) <= 1e-3 * abs(t['final_best_loss_reference'])
