@@ -414,7 +414,8 @@ def cfg5_report(a, dev):
                 fresh_ = all(hashlib.sha256(open(os.path.join(ROOT, 'latentfusion_amd', 'csrc', f), 'rb').read()).hexdigest() == h
                              for f, h in tj['source_sha256'].items())
                 kk = 'conv3d_c16_ring_bf16_addend' if key.startswith('add') else 'conv3d_c16_ring_bf16'
-                if fresh_ and kk in tj['kernels']:
+                # (the PMC probe measures the bf16-storage forms: plain io = 3, addend io = 7)
+                if fresh_ and kk in tj['kernels'] and (':io=7:' in key if key.startswith('add') else ':io=3:' in key):
                     # the PMC probe launches the kernel on 8 volumes: per-volume bytes x the volumes of this launch
                     tr = tj['kernels'][kk]['bytes_per_launch'] / 8.0 * int(key.split('N=')[1])
                     trs = os.path.basename(tpath)
@@ -838,6 +839,24 @@ def main():
         except Exception as e:                                       # noqa: BLE001  (auxiliary: never loses the headline)
             cfg3 = {'error': f'{type(e).__name__}: {e}'[:300]}
 
+    # the same workload against what the REFERENCE ITSELF produced for it (tests/golden/g26_headline_trace.pt, generated in the
+    # build container by oracle/make_golden_headline.py from the imported reference): volume, iteration-0 renders and the whole
+    # 100-iteration adam_quick trace (GPU only, ~1 s; the fixture is data, the reference never runs here)
+    ref_trace = None
+    if world == 1 and (S, C, V, N, a.fuser) == (128, 16, 16, 8, 'gru'):
+        try:
+            import importlib.util
+            spec = importlib.util.spec_from_file_location('headline_trace_probe', os.path.join(ROOT, 'tools', 'headline_trace_probe.py'))
+            probe = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(probe)
+            r_ = probe.compare(dev)
+            ref_trace = {'fixture': r_['fixture'], 'volume': r_['volume'], 'iteration0_renders': r_['iteration0_renders'],
+                         'trace': {k_: v_ for k_, v_ in r_['trace'].items() if k_ != 'per_iteration'},
+                         'what': 'HIP end to end vs the fixture the imported reference wrote for this exact workload (g26): first '
+                                 'iteration whose argmin / ranking differs, loss deviation over all iterations, final top-1'}
+        except Exception as e:                                       # noqa: BLE001  (auxiliary: never loses the headline)
+            ref_trace = {'error': f'{type(e).__name__}: {e}'[:300]}
+
     cfg5 = None
     if world == 1 and not a.no_cfg5 and C == 16:
         try:
@@ -972,6 +991,8 @@ def main():
         out['cfg3'] = cfg3
     if cfg5 is not None:
         out['cfg5'] = cfg5
+    if ref_trace is not None:
+        out['reference_trace_parity'] = ref_trace
     if pipelined is not None:
         out['pipelined_gru_build'] = pipelined
     if hyp is not None:

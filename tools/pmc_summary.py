@@ -37,22 +37,27 @@ KERNELS = collections.OrderedDict([
 # --train: the kernels of tools/train_kernels_probe.py (training step, 8 x 128^3 x 16)
 V = 8 * 16 * 128 ** 3 * 4
 TRAIN_KERNELS = collections.OrderedDict([
-    ('conv3d_c16_ring_bf16', (('conv3d_c16_f16x3_kernel<false, 1>', 'conv3d_c16_f16x3_kernelILb0ELi1E'), 2 * V + V // 16)),
-    ('conv3d_c16_ring_bf16_addend', (('conv3d_c16_f16x3_kernel<true, 1>', 'conv3d_c16_f16x3_kernelILb1ELi1E'), 3 * V)),
-    ('wgrad3d_c16_bf16_kernel', ('wgrad3d_c16_bf16_kernel', 2 * V)),
-    ('wgrad3d_c16_kernel', ('wgrad3d_c16_kernel', 2 * V)),
-    ('splat_tile_kernel', ('splat_tile_kernel', 2 * V)),
+    # round 5: bf16 STORAGE (32 B per voxel record): Vh = one 8 x 128^3 x 16 volume in bf16
+    ('conv3d_c16_ring_bf16', (('conv3d_c16_f16x3_kernel<false, 1, 3>', 'conv3d_c16_f16x3_kernelILb0ELi1ELi3E'), V + V // 16)),
+    ('conv3d_c16_ring_bf16_addend', (('conv3d_c16_f16x3_kernel<true, 1, 7>', 'conv3d_c16_f16x3_kernelILb1ELi1ELi7E'), 3 * V // 2)),
+    ('wgrad3d_c16_bf16_kernel', (('wgrad3d_c16_bf16_kernel<3>', 'wgrad3d_c16_bf16_kernelILi3E'), V)),
+    ('epilogue_bwd_c16_kernel', (('epilogue_bwd_c16_kernel<7>', 'epilogue_bwd_c16_kernelILi7E'), 3 * V // 2 + V // 16)),
+    ('resample_fwd_c16_kernel', (('resample_fwd_c16_kernel<1, 3>', 'resample_fwd_c16_kernelILi1ELi3E'), V)),
+    ('splat_tile_kernel', (('splat_tile_kernel<1, 3>', 'splat_tile_kernelILi1ELi3E'), V)),
+    ('lift_norm_unfold_kernel', ('lift_norm_unfold_kernel', V + V // 2)),
+    ('lift_bwd_fused_kernel', ('lift_bwd_fused_kernel', 2 * V)),
 ])
 # hbm_probe.py launches the Winograd kernel REP times in its forward form, then REP times as a data gradient with the
 # producer's epilogue backward fused (reads the saved activation and norm as well): reported separately
 SPLIT = {'conv3d_c16_wino_kernel': (('forward form', 2 * 8 * 16 * 128 ** 3 * 4 + 8 * 128 ** 3 * 4),
                                     ('data-gradient form + fused previous-layer backward', 3 * 8 * 16 * 128 ** 3 * 4 + 8 * 128 ** 3 * 4))}
 SOURCES = ['conv_wino.hip', 'conv.hip', 'conv_split.hip', 'resample.hip', 'pointwise.hip', 'reduce.hip']
+TRAIN_SOURCES = ['conv_split.hip', 'wgrad.hip', 'resample.hip', 'pointwise.hip', 'gru.hip']
 
 
-def source_hashes():
+def source_hashes(sources=None):
     out = {}
-    for f in SOURCES:
+    for f in (sources or SOURCES):
         p = os.path.join(ROOT, 'latentfusion_amd', 'csrc', f)
         if os.path.exists(p):
             out[f] = hashlib.sha256(open(p, 'rb').read()).hexdigest()
@@ -83,20 +88,23 @@ def find(data, sub, floor_counter=None, floor=0.0):
     return max(hits, key=lambda k: mean(data[k].get('SQ_WAVE_CYCLES', data[k].get('FETCH_SIZE', [0]))) or 0)
 
 
-def main(dirname, prefix, kernels=None, probe='tools/hbm_probe.py'):
+def main(dirname, prefix, kernels=None, probe='tools/hbm_probe.py', sources=None):
     kernels = kernels or KERNELS
     data = load(dirname)
     GiB = 1024.0 ** 3
     cal = find(data, 'copyBuffer') or find(data, 'direct_copy_kernel')
     calf = [v for v in data.get(cal, {}).get('FETCH_SIZE', []) if v > 1e5] if cal else []
     calw = [v for v in data.get(cal, {}).get('WRITE_SIZE', []) if v > 1e5] if cal else []
+    # the calibration copies are the LARGEST dispatches of the copy kernel (the probes also clone smaller tensors with it)
+    calf = [v for v in calf if v > 0.9 * max(calf)] if calf else calf
+    calw = [v for v in calw if v > 0.9 * max(calw)] if calw else calw
     corr = (GiB / 1024.0) / mean(calf) if calf else 2.0
     wcorr = (GiB / 1024.0) / mean(calw) if calw else 1.0
     lines = [f'# PMC counters per launch (means over the dispatches of {probe}), from {dirname}',
              '# bench shape SYN(128,16), N = 8: 8 x 128^3 voxels x 16 channels fp32 per volume',
              f'# FETCH_SIZE correction (1 GiB copy in the same run): x{corr:.4f};  WRITE_SIZE: x{wcorr:.4f}', '']
-    hbm = {'shape': 'N=8, C=16, S=128 (SYN(128,16) bench shape), fp32', 'collected': 'tools/pmc_collect.sh (separate --pmc passes)',
-           'fetch_correction': corr, 'write_correction': wcorr, 'source_sha256': source_hashes(), 'kernels': {}}
+    hbm = {'shape': 'N=8, C=16, S=128 (SYN(128,16) bench shape), ' + ('bf16 storage (32 B per voxel record)' if sources else 'fp32'), 'collected': 'tools/pmc_collect.sh (separate --pmc passes)',
+           'fetch_correction': corr, 'write_correction': wcorr, 'source_sha256': source_hashes(sources), 'kernels': {}}
     for key, (sub, alg) in kernels.items():
         k = find(data, sub)
         if k is None:
@@ -140,6 +148,6 @@ def summarise(lines, hbm, key, vkey, k, alg, c, corr, wcorr):
 
 if __name__ == '__main__':
     if sys.argv[1] == '--train':
-        main(sys.argv[2], sys.argv[3], TRAIN_KERNELS, 'tools/train_kernels_probe.py')
+        main(sys.argv[2], sys.argv[3], TRAIN_KERNELS, 'tools/train_kernels_probe.py', TRAIN_SOURCES)
     else:
         main(sys.argv[1], sys.argv[2])

@@ -1,49 +1,67 @@
 #!/usr/bin/env python
 """Workload for the PMC passes over the training-step kernels (tools/pmc_collect_train.sh): a calibration copy of known
-size (1 GiB read + 1 GiB written), then at 8 x 128^3 x 16: the bf16 ring convolution (forward and addend form), the bf16
-and the fp32 weight gradient, and the deterministic volume splat (object->camera map, per-sample volumes)."""
+size (1 GiB read + 1 GiB written), then at 8 x 128^3 x 16 in the bf16 STORAGE the autocast step uses (round 5): the bf16
+ring convolution (forward with epilogue, and the addend form), the bf16 weight gradient, the 16-channel epilogue backward,
+the camera->object gather and its deterministic splat, the fused lift passes and the ConvGRU backward stage."""
 import os
 import sys
 
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from latentfusion_amd import ops, synth  # noqa: E402
+from latentfusion_amd import _lib, ops, synth  # noqa: E402
 from latentfusion_amd._lib import LF_EPI_LRELU, LF_EPI_PIXELNORM  # noqa: E402
-from latentfusion_amd.modules.geometry import Camera, o2c_coefficients  # noqa: E402
+from latentfusion_amd.modules.geometry import Camera, c2o_coefficients  # noqa: E402
 from latentfusion_amd.pose import utils as pu  # noqa: E402
 
 REP = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 N, C, S = 8, 16, 128
+L = _lib.lib()
+s = torch.cuda.current_stream().cuda_stream
 g = torch.Generator().manual_seed(0)
-x = ops.cl(torch.randn(N, C, S, S, S, generator=g).cuda())
-gp = ops.cl((torch.randn(N, C, S, S, S, generator=g) * 1e-3).cuda())
+cl3 = torch.channels_last_3d
+x32 = ops.cl(torch.randn(N, C, S, S, S, generator=g).cuda())
+x = x32.to(torch.bfloat16).contiguous(memory_format=cl3)
+gp = ops.cl((torch.randn(N, C, S, S, S, generator=g) * 1e-3).cuda()).to(torch.bfloat16).contiguous(memory_format=cl3)
 w = torch.randn(16, 16, 3, 3, 3, generator=g).cuda()
 b = torch.zeros(16).cuda()
 he = ops.he_constant(w)
 for _ in range(REP):
-    y = x.clone()            # calibration: 1 GiB in, 1 GiB out
+    y = x32.clone()            # calibration: 1 GiB in, 1 GiB out
 torch.cuda.synchronize()
 wp = ops.pack_conv3d_c16_ring_bf16(w)
 for _ in range(REP):
-    y, nrm = ops.conv3d_c16_ring_bf16(x, wp, b, he, LF_EPI_LRELU | LF_EPI_PIXELNORM, 1)
+    y, nrm = ops.conv3d_c16_ring_bf16_io(x, wp, b, he, LF_EPI_LRELU | LF_EPI_PIXELNORM, 1, out_bf16=True)      # <false,1,3>
 torch.cuda.synchronize()
 for _ in range(REP):
-    ya, _ = ops.conv3d_c16_ring_bf16(x, wp, None, he, 0, 0, addend=gp)
+    ya, _ = ops.conv3d_c16_ring_bf16_io(x, wp, None, he, 0, 0, addend=gp, out_bf16=True)                       # <true,1,7>
+torch.cuda.synchronize()
+nb = L.lf_conv_bwd_weight_scratch_bytes(3, N, S, S, S, 16, 16)
+scr = torch.empty(nb // 4 + 1, device='cuda')
+gw = torch.empty(27, 16, 16, device='cuda')
+for _ in range(REP):
+    _lib.check(L.lf_conv_bwd_weight_bf16_io(x.data_ptr(), gp.data_ptr(), gw.data_ptr(), scr.data_ptr(), scr.numel() * 4, 3, N, S, S, S, 16, 16,
+                                            he, 3, s), 'wgrad')                                                 # <3>
 torch.cuda.synchronize()
 for _ in range(REP):
-    with ops.autocast():
-        gw, _ = ops.conv_bwd_weight(x, gp, 3, 16, he, want_bias=False)
-torch.cuda.synchronize()
-for _ in range(REP):
-    gw32, _ = ops.conv_bwd_weight(x, gp, 3, 16, he, want_bias=False)
+    ops.epilogue_bwd_c16(gp, y, nrm, LF_EPI_LRELU | LF_EPI_PIXELNORM, True)                                    # <7>
 torch.cuda.synchronize()
 td = synth.make_observation_data(1, seed=2)
 torch.manual_seed(3)
 cams = pu.sample_cameras_with_estimate(N, Camera(td['intrinsic'], td['extrinsic'])).zoom(None, S, 2.85).to('cuda')
-coef = o2c_coefficients(cams, 1.0).cuda()
+coef = c2o_coefficients(cams, 1.0).cuda()
+with ops.autocast():
+    for _ in range(REP):
+        v = x.clone().requires_grad_(True)
+        ops.resample_c2o(v, coef).backward(gp)                                                                 # gather <1,3>, splat <1,3>
+torch.cuda.synchronize()
+# fused lift passes at 8 views (rows [8 * 128^2][2048])
+rows = torch.randn(N * S * S, C * S, generator=g).cuda()
+vol = ops.empty_cl16((N, C, S, S, S), 'cuda', True)
+norm = torch.empty(N * S * S, device='cuda')
+gpr = torch.empty(N * S * S, C * S, device='cuda')
 for _ in range(REP):
-    v = x.clone().requires_grad_(True)
-    ops.resample_o2c(v, coef).backward(gp)
+    _lib.check(L.lf_lift_norm_unfold(rows.data_ptr(), vol.data_ptr(), norm.data_ptr(), N, S * S, C, S, 1e-8, 1, s), 'lift fwd')
+    _lib.check(L.lf_lift_bwd(gp.data_ptr(), vol.data_ptr(), norm.data_ptr(), gpr.data_ptr(), N, S * S, C, S, 0.2, 1, 3, s), 'lift bwd')
 torch.cuda.synchronize()
 print('ok')
