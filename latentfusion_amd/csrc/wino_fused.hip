@@ -179,6 +179,21 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) wino_fus
 #pragma unroll
       for (int t = 0; t < BB; ++t) fb[j][t] = *(const f32x4*)(base + rdB[t][j]);
     }
+#if defined(WF_ABL_XFORM) && WF_ABL_XFORM
+    // ABLATION (tools/wino_fused_ab.py; never in the shipped library): the instruction stream of forming every B fragment
+    // from the 8 raw halo records of its Winograd frequency INSIDE this kernel -- 7 more ds_read_b128
+    // and 7 packed add/sub pairs per fragment -- on top of the unchanged DMA of a same-sized chunk: an upper bound on what
+    // an in-kernel input transform could reach (its halo staging would cost extra on top).  Results are garbage.
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int t = 0; t < BB; ++t)
+#pragma unroll
+        for (int r = 1; r < 8; ++r) {
+          const f32x4 e = *(const f32x4*)(base + A_BYTES + ((rdB[t][j] - A_BYTES + r * 1040) & (MTc * 128 - 16)));
+          fb[j][t] = (r & 1) ? fb[j][t] + e : fb[j][t] - e;
+        }
+#endif
     // the DMA pieces of stage s+3 are issued BETWEEN groups of MFMAs: an LDS-DMA instruction holds the issuing
     // (in-order) wave for ~60-180 cycles, which the matrix work already queued ahead of it covers
 #pragma unroll

@@ -167,7 +167,7 @@ class PoseEstimator:
                 z_camera = cameras.zoom(None, self.model.input_size, self.model.camera_dist).to(self.device)
                 losses, _ = eng.forward_backward(z_camera, need_grad=False, z_target_latent=z_target_latent, masked_depth=True)
                 return losses[:, 4].clone()
-            zd, zl, z_lat, z_camera = self._render_observation(z_obj, cameras)
+            zd, zl, z_lat, z_camera = self._render_observation(z_obj, cameras.to(self.device))
             ld = self.loss_func(target_obs, zd, zl, z_camera, z_pred_latent=z_lat, z_target_latent=z_target_latent)
             return sum(weigh_losses(ld, self.loss_weights).values())
 
@@ -284,7 +284,7 @@ class CrossEntropyPoseEstimator(PoseEstimator):
         z_target_latent = None
         if self.loss_weights.get('latent', 0.0) > 0.0:
             with torch.no_grad():
-                z_target_latent = self.model.compute_latent_code(target_obs, cameras[0])
+                z_target_latent = self.model.compute_latent_code(target_obs, cameras[0].to(self.device))
         rank, size = self._sharding()
         local = cameras
         if size > 1:                                               # this rank's contiguous slice of the hypotheses
@@ -303,14 +303,21 @@ class CrossEntropyPoseEstimator(PoseEstimator):
     def _refine_pose(self, z_obj, target_obs, prev_gmm, gmm, num_elites, camera_init):
         sample_gmm = self._combined_gmm(prev_gmm, gmm, self.learning_rate) if prev_gmm is not None else gmm
         n = self.num_samples // 4 if self.sample_flipped else self.num_samples
-        cameras = self._params_to_camera(self._sample_poses(sample_gmm, n), camera_init, device=self.device)
+        # Single rank: the sampled cameras stay HOST tensors through the jitter, the three flips and the zoom (a few hundred
+        # scalars; on the device this was ~100 one-microsecond launches per iteration: quaternion products, sin / cos, norms,
+        # concatenations) -- the zoomed cameras reach the device in one hop inside _score_samples (round 5; the GMM is fitted
+        # and sampled on the host anyway, as in the reference :449-473)
+        host = self._sharding()[1] == 1
+        cameras = self._params_to_camera(self._sample_poses(sample_gmm, n, 'cpu' if host else self.device), camera_init,
+                                         device='cpu' if host else self.device)
         cameras, loss = self.evaluate_samples(z_obj, target_obs, cameras)
         elite = torch.argsort(loss)[:num_elites]
-        return cameras[elite], loss[elite]
+        return cameras[elite.to(cameras.device)], loss[elite]
 
-    def _sample_poses(self, gmm, n):
+    def _sample_poses(self, gmm, n, device=None):
+        device = self.device if device is None else device
         params, _ = gmm.sample(n)
-        params = torch.tensor(params, dtype=torch.float32, device=self.device)
+        params = torch.tensor(params, dtype=torch.float32, device=device)
         params[:, :3] += torch.randn_like(params[:, :3]) * self.translation_std
         params[:, 3:] += torch.randn_like(params[:, 3:]) * self.quaternion_std
         if self._sharding()[1] > 1:                                # numpy / torch host RNGs differ per rank
