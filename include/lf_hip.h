@@ -503,6 +503,18 @@ int lf_pose_loss_bwd(const float* logits, const float* coefs, const float* targe
 int lf_pose_loss_fwd_masked(const float* logits, const float* coefs, const float* target_depth,
                             const float* target_mask, const float* weights, float* sums, float* losses,
                             void* scratch, size_t scratch_bytes, int N, int h, int w, int H, int W, void* stream);
+/* The loss as the MODULE path evaluates it (default_pose_loss handed the predicted metric depth crop and the mask-logit
+ * crop, pose/estimation.py:70-118 called from :703-713 with the caller's own de-normalisation): channel 0 of
+ * depth_and_logits [N][h*w][2] is the depth itself (no tanh / apply_mask / denormalize_depth inside), channel 1 the mask
+ * logit; coefs entries 18..21 (the uncrop map) are used.  lf_pose_loss_bwd_depth writes d/d(depth crop, logit crop) and
+ * gcoefs entries 18..21 (22, 23 = 0).  Same sums / losses / gsums / scratch as lf_pose_loss_fwd / _bwd. */
+int lf_pose_loss_fwd_depth(const float* depth_and_logits, const float* coefs, const float* target_depth,
+                           const float* target_mask, const float* weights, float* sums, float* losses,
+                           float* gsums, void* scratch, size_t scratch_bytes,
+                           int N, int h, int w, int H, int W, void* stream);
+int lf_pose_loss_bwd_depth(const float* depth_and_logits, const float* coefs, const float* target_depth,
+                           const float* target_mask, const float* gsums, float* gcrop, float* gcoefs,
+                           void* scratch, size_t scratch_bytes, int N, int h, int w, int H, int W, void* stream);
 
 /* Batched Adam / AdamW step over N independent rows of P parameters (pose/estimation.py:579-594,
  * 664-666).  step_size[n] = lr[n] / (1 - beta1^t) and bias_correction2_sqrt = sqrt(1 - beta2^t)

@@ -112,6 +112,8 @@ SIGNATURES = {
     'lf_pose_loss_scratch_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     'lf_pose_loss_fwd': (c_int, [P, P, P, P, P, P, P, P, P, c_size_t, c_int, c_int, c_int, c_int, c_int, P]),
     'lf_pose_loss_bwd': (c_int, [P, P, P, P, P, P, P, P, c_size_t, c_int, c_int, c_int, c_int, c_int, P]),
+    'lf_pose_loss_fwd_depth': (c_int, [P, P, P, P, P, P, P, P, P, c_size_t, c_int, c_int, c_int, c_int, c_int, P]),
+    'lf_pose_loss_bwd_depth': (c_int, [P, P, P, P, P, P, P, P, c_size_t, c_int, c_int, c_int, c_int, c_int, P]),
     'lf_pose_loss_fwd_masked': (c_int, [P, P, P, P, P, P, P, P, c_size_t, c_int, c_int, c_int, c_int, c_int, P]),
     'lf_adam_step': (c_int, [P, P, P, P, P, P, c_float, c_float, c_float, c_float, c_float, c_int, c_int, P]),
     'lf_nchw_to_nhwc': (c_int, [P, P, c_int, c_int, c_long, P]),

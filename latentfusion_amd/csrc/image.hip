@@ -159,7 +159,10 @@ __device__ __forceinline__ void clip_pos(float p, int size, float& pos, float& m
 // MASKED: the form the cross-entropy / Metropolis estimators feed the loss (reference pose/estimation.py:207-216): the
 // de-normalised crop depth is multiplied by the crop's own sigmoid mask BEFORE it is uncropped (the gradient estimator
 // passes the depth without that factor, :703-713)
-template <bool MASKED = false>
+// MODE 0: head logits as above.  MODE 1 = MASKED.  MODE 2 (round 5; the MODULE path's default_pose_loss, which is handed the
+// metric depth crop itself -- already de-normalised / gated by the caller, reference pose/estimation.py:703-713): channel 0
+// of `lg` IS the predicted depth; tanh, apply_mask and denormalize_depth are skipped and have no gradient here.
+template <int MODE = 0>
 __device__ __forceinline__ PixelFwd pixel_forward(const float* __restrict__ lg, const float* __restrict__ cf,
                                                   int h, int w, int x, int y, float td_raw, float mt) {
   PixelFwd r;
@@ -175,10 +178,16 @@ __device__ __forceinline__ PixelFwd pixel_forward(const float* __restrict__ lg, 
   r.logit = m00 * (r.wx0 * r.wy0) + m01 * (r.wx1 * r.wy0) + m10 * (r.wx0 * r.wy1) + m11 * (r.wx1 * r.wy1);
   r.sig = sigmoidf_(r.logit);
   const float dl = lg[(r.yn * w + r.xn) * 2 + 0], ml = lg[(r.yn * w + r.xn) * 2 + 1];
-  r.mask_on = sigmoidf_(ml) > 0.5f;
-  r.dn = r.mask_on ? tanhf(dl) : -1.f;                               // (tanh+1)*(mask>0.5)-1
-  r.dhat = r.dn * cf[4] + cf[5];
-  if constexpr (MASKED) r.dhat *= sigmoidf_(ml);
+  if constexpr (MODE == 2) {
+    r.mask_on = true;
+    r.dn = dl;
+    r.dhat = dl;
+  } else {
+    r.mask_on = sigmoidf_(ml) > 0.5f;
+    r.dn = r.mask_on ? tanhf(dl) : -1.f;                             // (tanh+1)*(mask>0.5)-1
+    r.dhat = r.dn * cf[4] + cf[5];
+    if constexpr (MODE == 1) r.dhat *= sigmoidf_(ml);
+  }
   r.pd = r.dhat * r.sig;
   r.mt = mt;
   r.valid = (td_raw == 0.f && mt > 0.1f) ? 0.f : 1.f;
@@ -203,7 +212,7 @@ __device__ __forceinline__ void block_reduce_store(float (&acc)[NSUM], float* __
   }
 }
 
-template <bool MASKED>
+template <int MODE>
 __global__ void __launch_bounds__(LOSS_BLOCK) pose_loss_fwd_kernel(
     const float* __restrict__ logits, const float* __restrict__ coef, const float* __restrict__ tdepth,
     const float* __restrict__ tmask, float* __restrict__ partial, int nblk, int h, int w, int H, int W) {
@@ -215,7 +224,7 @@ __global__ void __launch_bounds__(LOSS_BLOCK) pose_loss_fwd_kernel(
   for (int i = 0; i < NSUM; ++i) acc[i] = 0.f;
   for (int p = blockIdx.x * LOSS_BLOCK + threadIdx.x; p < H * W; p += nblk * LOSS_BLOCK) {
     const int y = p / W, x = p - y * W;
-    const PixelFwd f = pixel_forward<MASKED>(lg, cf, h, w, x, y, tdepth[p], tmask[p]);
+    const PixelFwd f = pixel_forward<MODE>(lg, cf, h, w, x, y, tdepth[p], tmask[p]);
     acc[0] += f.l1;
     acc[1] += f.l1 * (f.sig * f.mt);
     acc[2] += f.sig * f.mt;
@@ -277,6 +286,7 @@ __global__ void pose_loss_finish_kernel(const float* __restrict__ partial, int n
 }
 
 // backward stage A: per frame pixel, d/d(sampled depth) and d/d(sampled logit) + coefficient grads
+template <int MODE>
 __global__ void __launch_bounds__(LOSS_BLOCK) pose_loss_bwd_pixels_kernel(
     const float* __restrict__ logits, const float* __restrict__ coef, const float* __restrict__ tdepth,
     const float* __restrict__ tmask, const float* __restrict__ gsums, float* __restrict__ gd_frame,
@@ -291,7 +301,7 @@ __global__ void __launch_bounds__(LOSS_BLOCK) pose_loss_bwd_pixels_kernel(
   for (int i = 0; i < NSUM; ++i) acc[i] = 0.f;
   for (int p = blockIdx.x * LOSS_BLOCK + threadIdx.x; p < H * W; p += nblk * LOSS_BLOCK) {
     const int y = p / W, x = p - y * W;
-    const PixelFwd f = pixel_forward(lg, cf, h, w, x, y, tdepth[p], tmask[p]);
+    const PixelFwd f = pixel_forward<MODE>(lg, cf, h, w, x, y, tdepth[p], tmask[p]);
     const float dl1 = g0 + g1 * (f.sig * f.mt);
     const float diff = f.pd - f.td;
     const float dpd = dl1 * f.valid * (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f));
@@ -307,7 +317,7 @@ __global__ void __launch_bounds__(LOSS_BLOCK) pose_loss_bwd_pixels_kernel(
     const float diy = ((m10 - m00) * f.wx0 + (m11 - m01) * f.wx1) * f.my * dlogit;
     acc[0] += dix * (float)x; acc[1] += dix;
     acc[2] += diy * (float)y; acc[3] += diy;
-    acc[4] += ddhat * f.dn;   acc[5] += ddhat;
+    if constexpr (MODE != 2) { acc[4] += ddhat * f.dn;   acc[5] += ddhat; }
   }
   block_reduce_store(acc, partial + ((long)n * nblk + blockIdx.x) * NSUM);
 }
@@ -348,7 +358,8 @@ __global__ void __launch_bounds__(256) pose_loss_bwd_rows_kernel(
 }
 
 // backward stage C (columns): finish along y, apply the tanh / sigmoid / apply_mask chain, write
-// d(loss)/d(head logits) [N][h*w][2]
+// d(loss)/d(head logits) [N][h*w][2]  (MODE 2: channel 0 is d(loss)/d(depth crop) itself)
+template <int MODE>
 __global__ void __launch_bounds__(256) pose_loss_bwd_cols_kernel(
     const float* __restrict__ logits, const float* __restrict__ coef, const float* __restrict__ Td,
     const float* __restrict__ Tm, float* __restrict__ glogits, int h, int w, int H) {
@@ -375,10 +386,14 @@ __global__ void __launch_bounds__(256) pose_loss_bwd_cols_kernel(
     if ((int)nearbyintf(py) == cy) sd += Td[((long)n * H + y) * w + cx];
   }
   const long o = ((long)n * h * w + (long)cy * w + cx) * 2;
-  const float dl = logits[o], ml = logits[o + 1];
-  const float th = tanhf(dl);
-  const bool on = sigmoidf_(ml) > 0.5f;
-  glogits[o] = on ? sd * a_depth * (1.f - th * th) : 0.f;       // d dhat/d dn = a_depth; (mask>0.5) gate has no gradient
+  if constexpr (MODE == 2) {
+    glogits[o] = sd;
+  } else {
+    const float dl = logits[o], ml = logits[o + 1];
+    const float th = tanhf(dl);
+    const bool on = sigmoidf_(ml) > 0.5f;
+    glogits[o] = on ? sd * a_depth * (1.f - th * th) : 0.f;     // d dhat/d dn = a_depth; (mask>0.5) gate has no gradient
+  }
   glogits[o + 1] = sm;
 }
 
@@ -421,7 +436,7 @@ extern "C" size_t lf_pose_loss_scratch_bytes(int N, int h, int w, int H, int W) 
   return ((size_t)N * LOSS_NBLK * NSUM + 2 * (size_t)N * H * W + 2 * (size_t)N * H * w) * sizeof(float);
 }
 
-static int pose_loss_fwd_launch(bool masked, const float* logits, const float* coefs, const float* target_depth,
+static int pose_loss_fwd_launch(int mode, const float* logits, const float* coefs, const float* target_depth,
                                 const float* target_mask, const float* weights, float* sums, float* losses,
                                 float* gsums, void* scratch, size_t scratch_bytes,
                                 int N, int h, int w, int H, int W, void* stream) {
@@ -430,11 +445,14 @@ static int pose_loss_fwd_launch(bool masked, const float* logits, const float* c
   if (scratch_bytes < lf_pose_loss_scratch_bytes(N, h, w, H, W)) return LF_ENOSPC;
   hipStream_t s = (hipStream_t)stream;
   float* partial = (float*)scratch;
-  if (masked)
-    hipLaunchKernelGGL(pose_loss_fwd_kernel<true>, dim3(LOSS_NBLK, N), dim3(LOSS_BLOCK), 0, s, logits, coefs, target_depth,
+  if (mode == 1)
+    hipLaunchKernelGGL(pose_loss_fwd_kernel<1>, dim3(LOSS_NBLK, N), dim3(LOSS_BLOCK), 0, s, logits, coefs, target_depth,
+                       target_mask, partial, LOSS_NBLK, h, w, H, W);
+  else if (mode == 2)
+    hipLaunchKernelGGL(pose_loss_fwd_kernel<2>, dim3(LOSS_NBLK, N), dim3(LOSS_BLOCK), 0, s, logits, coefs, target_depth,
                        target_mask, partial, LOSS_NBLK, h, w, H, W);
   else
-    hipLaunchKernelGGL(pose_loss_fwd_kernel<false>, dim3(LOSS_NBLK, N), dim3(LOSS_BLOCK), 0, s, logits, coefs, target_depth,
+    hipLaunchKernelGGL(pose_loss_fwd_kernel<0>, dim3(LOSS_NBLK, N), dim3(LOSS_BLOCK), 0, s, logits, coefs, target_depth,
                        target_mask, partial, LOSS_NBLK, h, w, H, W);
   int st = lf_launch_status();
   if (st) return st;
@@ -447,7 +465,15 @@ extern "C" int lf_pose_loss_fwd(const float* logits, const float* coefs, const f
                                 const float* target_mask, const float* weights, float* sums, float* losses,
                                 float* gsums, void* scratch, size_t scratch_bytes,
                                 int N, int h, int w, int H, int W, void* stream) {
-  return pose_loss_fwd_launch(false, logits, coefs, target_depth, target_mask, weights, sums, losses, gsums, scratch,
+  return pose_loss_fwd_launch(0, logits, coefs, target_depth, target_mask, weights, sums, losses, gsums, scratch,
+                              scratch_bytes, N, h, w, H, W, stream);
+}
+
+extern "C" int lf_pose_loss_fwd_depth(const float* depth_and_logits, const float* coefs, const float* target_depth,
+                                      const float* target_mask, const float* weights, float* sums, float* losses,
+                                      float* gsums, void* scratch, size_t scratch_bytes,
+                                      int N, int h, int w, int H, int W, void* stream) {
+  return pose_loss_fwd_launch(2, depth_and_logits, coefs, target_depth, target_mask, weights, sums, losses, gsums, scratch,
                               scratch_bytes, N, h, w, H, W, stream);
 }
 
@@ -457,11 +483,29 @@ extern "C" int lf_pose_loss_fwd_masked(const float* logits, const float* coefs, 
                                        int N, int h, int w, int H, int W, void* stream) {
   // forward only (the estimators that use this form do not differentiate): gsums lands in the scratch tail
   float* gs = (float*)scratch + (size_t)N * LOSS_NBLK * NSUM;
-  return pose_loss_fwd_launch(true, logits, coefs, target_depth, target_mask, weights, sums, losses, gs, scratch,
+  return pose_loss_fwd_launch(1, logits, coefs, target_depth, target_mask, weights, sums, losses, gs, scratch,
                               scratch_bytes, N, h, w, H, W, stream);
 }
 
+static int pose_loss_bwd_launch(int mode, const float* logits, const float* coefs, const float* target_depth,
+                                const float* target_mask, const float* gsums, float* glogits, float* gcoefs,
+                                void* scratch, size_t scratch_bytes, int N, int h, int w, int H, int W, void* stream);
+
 extern "C" int lf_pose_loss_bwd(const float* logits, const float* coefs, const float* target_depth,
+                                const float* target_mask, const float* gsums, float* glogits, float* gcoefs,
+                                void* scratch, size_t scratch_bytes, int N, int h, int w, int H, int W, void* stream) {
+  return pose_loss_bwd_launch(0, logits, coefs, target_depth, target_mask, gsums, glogits, gcoefs, scratch, scratch_bytes, N, h, w, H, W,
+                              stream);
+}
+
+extern "C" int lf_pose_loss_bwd_depth(const float* depth_and_logits, const float* coefs, const float* target_depth,
+                                      const float* target_mask, const float* gsums, float* gcrop, float* gcoefs,
+                                      void* scratch, size_t scratch_bytes, int N, int h, int w, int H, int W, void* stream) {
+  return pose_loss_bwd_launch(2, depth_and_logits, coefs, target_depth, target_mask, gsums, gcrop, gcoefs, scratch, scratch_bytes, N, h, w,
+                              H, W, stream);
+}
+
+static int pose_loss_bwd_launch(int mode, const float* logits, const float* coefs, const float* target_depth,
                                 const float* target_mask, const float* gsums, float* glogits, float* gcoefs,
                                 void* scratch, size_t scratch_bytes, int N, int h, int w, int H, int W, void* stream) {
   lf_clear_error();
@@ -473,14 +517,22 @@ extern "C" int lf_pose_loss_bwd(const float* logits, const float* coefs, const f
   float* gm = gd + (size_t)N * H * W;
   float* Td = gm + (size_t)N * H * W;
   float* Tm = Td + (size_t)N * H * w;
-  hipLaunchKernelGGL(pose_loss_bwd_pixels_kernel, dim3(LOSS_NBLK, N), dim3(LOSS_BLOCK), 0, s, logits, coefs, target_depth,
-                     target_mask, gsums, gd, gm, partial, LOSS_NBLK, h, w, H, W);
+  if (mode == 2)
+    hipLaunchKernelGGL(pose_loss_bwd_pixels_kernel<2>, dim3(LOSS_NBLK, N), dim3(LOSS_BLOCK), 0, s, logits, coefs, target_depth,
+                       target_mask, gsums, gd, gm, partial, LOSS_NBLK, h, w, H, W);
+  else
+    hipLaunchKernelGGL(pose_loss_bwd_pixels_kernel<0>, dim3(LOSS_NBLK, N), dim3(LOSS_BLOCK), 0, s, logits, coefs, target_depth,
+                       target_mask, gsums, gd, gm, partial, LOSS_NBLK, h, w, H, W);
   int st = lf_launch_status();
   if (st) return st;
   // gcoefs[n][18..23] <- reduced (ax, bx, ay, by, a_depth, b_depth) gradients; [0..17] are left to the resampler
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(N), dim3(64), 0, s, partial, LOSS_NBLK, gcoefs, 6, NOUT, 18);
   hipLaunchKernelGGL(pose_loss_bwd_rows_kernel, dim3((w + 255) / 256, H, N), dim3(256), 0, s, coefs, gd, gm, Td, Tm, w, H, W);
-  hipLaunchKernelGGL(pose_loss_bwd_cols_kernel, dim3((w + 255) / 256, h, N), dim3(256), 0, s, logits, coefs, Td, Tm, glogits,
-                     h, w, H);
+  if (mode == 2)
+    hipLaunchKernelGGL(pose_loss_bwd_cols_kernel<2>, dim3((w + 255) / 256, h, N), dim3(256), 0, s, logits, coefs, Td, Tm, glogits,
+                       h, w, H);
+  else
+    hipLaunchKernelGGL(pose_loss_bwd_cols_kernel<0>, dim3((w + 255) / 256, h, N), dim3(256), 0, s, logits, coefs, Td, Tm, glogits,
+                       h, w, H);
   return lf_launch_status();
 }

@@ -443,7 +443,7 @@ class RenderLoopEngine:
                     occ = self.ph.occlusion_module(torch.cat((zt_, get_normalized_voxel_depth(zt_)), dim=1))
                     wocc = ops.column_softmax(occ)[0]
                     if tuple(occ.shape[-3:]) != tuple(zt_.shape[-3:]):
-                        wocc = ops.column_softmax(torch.nn.functional.interpolate(occ, zt_.size(-1)))[0]
+                        wocc = ops.column_softmax(ops.resize_nearest_to(occ, zt_.size(-1)))[0]
                     zt_ = ops.column_scale(zt_, wocc)
                 zp_leaf = ops.column_sum(zt_) if self.ph.projection_type == 'sum' else self.ph.projection_block(zt_)
             zp = zp_leaf

@@ -2028,3 +2028,20 @@ def interpolate(x, scale_factor, mode):
     if scale_factor not in (2.0, 0.5) or mode not in ('nearest', 'bilinear', 'trilinear'):
         raise NotImplementedError(f'rescale {scale_factor} / {mode} is not produced by the block grammar')
     return _Resize.apply(x, 0 if mode == 'nearest' else 1, 1 if scale_factor == 2.0 else 0)
+
+
+def resize_nearest_to(x, size):
+    """F.interpolate(x, size) (nearest) for cubic / square maps whose size ratio is a power of two -- what the occlusion
+    U-Net's logits need when its resolution differs from the volume's (reference recon/models.py:385) -- on lf_resize_*."""
+    cur = x.shape[-1]
+    if any(d != cur for d in x.shape[2:]):
+        raise NotImplementedError('resize_nearest_to expects equal spatial extents')
+    while cur < size:
+        x, cur = interpolate(x, 2.0, 'nearest'), cur * 2
+    while cur > size:
+        if cur % 2:
+            break
+        x, cur = interpolate(x, 0.5, 'nearest'), cur // 2
+    if cur != size:
+        raise NotImplementedError(f'resize from {x.shape[-1]} to {size} is not a power-of-two ratio')
+    return x

@@ -228,7 +228,7 @@ class Photographer(_Checkpointed):
             w, z_depth = ops.column_softmax(logits)
             if tuple(logits.shape[-3:]) != tuple(z.shape[-3:]):
                 # occlusion U-Net at another resolution: nearest resize of the logits first (reference :385)
-                w = ops.column_softmax(nn.functional.interpolate(logits, z.size(-1)))[0]
+                w = ops.column_softmax(ops.resize_nearest_to(logits, z.size(-1)))[0]
             z = ops.column_scale(z, w)
         if self.projection_type == 'sum':
             z = ops.column_sum(z)

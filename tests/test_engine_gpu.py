@@ -59,7 +59,9 @@ def test_fused_pose_loss_matches_module_loss(golden, crop):
     """Fused loss (head logits -> losses, grads) == interpret_logits + denormalize + uncrop +
     default_pose_loss of the module path (itself pinned to the reference by G6 on the CPU)."""
     from latentfusion_amd.engine import camera_coefs, pose_loss
-    from latentfusion_amd.pose.loss import default_pose_loss
+    # (the yardstick is the reference's EXPRESSIONS -- since round 5 default_pose_loss itself takes fused kernels on device
+    # tensors; test_module_path_pose_loss_on_fused_kernels below pins that form against the same expressions)
+    from latentfusion_amd.pose.loss import _pose_loss_expressions as default_pose_loss
     g6 = golden('g6_loss')
     target = _target(g6)
     target.depth[:, :, 100:140, 200:260] = 0.0            # invalid pixels inside the mask
@@ -776,3 +778,65 @@ def test_engine_graph_replay_equals_eager(golden):
         best, hist = est.estimate(z_obj, target, camera=prod_camera(g['init']))
         runs.append((torch.cat((best.log_quaternion, best.translation), dim=1).cpu(), torch.stack([h[0] for h in hist])))
     assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+
+
+@pytest.mark.parametrize('crop', [16, 33])
+def test_module_path_pose_loss_on_fused_kernels(golden, crop):
+    """default_pose_loss on device tensors (the module path: GradientPoseEstimator(use_engine=False), custom estimators) runs
+    lf_pose_loss_fwd_depth / _bwd_depth (pose/loss.py:_PoseLossTerms) -- no ATen reduction over the frame -- and equals the
+    reference's expressions (pinned by G6 on the CPU): the four terms, and the gradients of an arbitrary weighting w.r.t. the
+    depth crop, the mask-logit crop and the camera's viewport."""
+    from latentfusion_amd import ops
+    from latentfusion_amd.pose.loss import _pose_loss_expressions, default_pose_loss
+    g6 = golden('g6_loss')
+    target = _target(g6)
+    target.depth[:, :, 100:140, 200:260] = 0.0
+    gen = torch.Generator().manual_seed(crop + 1)
+    depth0 = (torch.rand(3, 1, crop, crop, generator=gen) * 0.6 + 0.7).to(DEV)
+    logit0 = (torch.randn(3, 1, crop, crop, generator=gen) * 2).to(DEV)
+    weights = {'depth': 1.0, 'ov_depth': 0.3, 'iou': 0.7, 'mask': 0.5}
+    res = []
+    for fn in (_pose_loss_expressions, default_pose_loss):
+        cam = prod_camera(g6['cam'])
+        cam.viewport = cam.viewport.clone().requires_grad_(True)
+        d, l = depth0.clone().requires_grad_(True), logit0.clone().requires_grad_(True)
+        ops.KERNEL_TIMER = []
+        try:
+            ld = fn(target, d, l, cam)
+            tags = {str(n) for n, _, _ in ops.KERNEL_TIMER}
+        finally:
+            ops.KERNEL_TIMER = None
+        (sum(weights[k] * v for k, v in ld.items()) * torch.tensor([1.0, 0.5, 2.0], device=DEV)).sum().backward()
+        res.append((ld, d.grad.clone(), l.grad.clone(), cam.viewport.grad.clone(), tags))
+    assert 'pose_loss_terms' in res[1][4] and 'pose_loss_terms' not in res[0][4]
+    for k in ('depth', 'ov_depth', 'iou', 'mask'):
+        close(res[1][0][k], res[0][0][k], atol=2e-6, rtol=2e-5)
+    close(res[1][1], res[0][1], atol=1e-8, rtol=2e-3)
+    close(res[1][2], res[0][2], atol=1e-8, rtol=2e-3)
+    close(res[1][3], res[0][3], atol=1e-6, rtol=5e-3)
+
+
+def test_gradient_estimator_module_path_uses_the_fused_loss(golden):
+    """GradientPoseEstimator(use_engine=False): the loss of every iteration comes from the fused kernels (tag 'pose_loss_terms'),
+    and the 10-iteration reference trace (g7) still holds on that path."""
+    from latentfusion_amd import ops
+    from latentfusion_amd.pose import estimation
+    import copy
+    from latentfusion_amd.recon import fusion
+    from latentfusion_amd.recon.inference import LatentFusionModel
+    from latentfusion_amd.recon.models import Photographer, Sculptor
+    g = golden('g7_adam_trace')
+    model = LatentFusionModel(Sculptor.from_checkpoint(g['sculptor']), fusion.from_checkpoint(g['fuser']),
+                              Photographer.from_checkpoint(g['photographer']), g['camera_dist'], DEV)
+    target = _target(g, 'cpu')
+    z_obj = g['z_obj'].to(DEV)
+    est = estimation.load_from_config(copy.deepcopy(g['cfg']), model, track_stats=True, use_engine=False)
+    ops.KERNEL_TIMER, ops.KERNEL_TIMER_TAGS = [], {'pose_loss_terms'}
+    try:
+        _, stats = est.estimate(z_obj, target, camera=prod_camera(g['init'], 'cpu'))
+        n_loss = len(ops.KERNEL_TIMER)
+    finally:
+        ops.KERNEL_TIMER, ops.KERNEL_TIMER_TAGS = None, None
+    assert n_loss == g['rank_loss'].shape[0], n_loss
+    close(stats['rank_loss'][:3], g['rank_loss'][:3], atol=1e-5, rtol=1e-4)
+    assert torch.equal(torch.argmin(stats['rank_loss'], dim=1), g['argmin'])
