@@ -60,9 +60,7 @@ def parse(argv=None):
                     help='timed oracle iterations of the CPU baseline (after 1 warm-up); their per-iteration trace is compared with '
                          'the HIP loop from the same start (trace_parity_at_full_size)')
     ap.add_argument('--no-alt', action='store_true', help='skip the secondary f16x3 measurement')
-    ap.add_argument('--no-graph', action='store_true', help='skip the secondary hipGraph-replay measurement')
-    ap.add_argument('--engine-streams', type=int, default=1,
-                    help='hypothesis groups of the render-loop engine evaluated concurrently on separate HIP streams')
+    ap.add_argument('--no-graph', action='store_true', help='(accepted, no effect: the hipGraph block moved to tools/engine_ab.py)')
     ap.add_argument('--repeats', type=int, default=25,
                     help='the timed region (exactly --steps iterations between barriers) is run this many times back to back; '
                          '`value` is steps / MEDIAN block time, every block time is reported (box-to-box and run-to-run '
@@ -75,9 +73,9 @@ def parse(argv=None):
                          'RCCL all-reduce of the latent volume (parallel.build_latent_object_sharded); reported as '
                          '`sharded_build`.  ON by default when N > 1 (the north-star collective); this flag forces it at N = 1')
     ap.add_argument('--no-sharded-build', action='store_true', help='skip the view-sharded build at N > 1')
-    ap.add_argument('--fuse-projection', default='default', choices=['default', 'none', 'fwd', 'bwd', 'both'],
+    ap.add_argument('--fuse-projection', default='default', choices=['default', 'none', 'fwd'],
                     help="factor projection fused into the last camera block's Winograd kernels (engine.py): 'default' = forward form")
-    ap.add_argument('--conv-mode', default='winograd', choices=['fp32', 'winograd', 'f16x3', 'winograd_f16x3'],
+    ap.add_argument('--conv-mode', default='winograd', choices=['fp32', 'winograd', 'f16x3'],
                     help="conv3d kernels of the engine: 'winograd' (default; F(2^3,3^3) minimal filtering, all-fp32 "
                          "arithmetic), 'fp32' (direct implicit GEMM on the fp32 MFMA) or 'f16x3' (split precision)")
     ap.add_argument('--no-cfg3', action='store_true',
@@ -609,9 +607,8 @@ def main():
     cfg = estimation._load_toml(os.path.join(ROOT, 'configs', 'adam_quick.toml'))
     cfg['args']['num_samples'] = N
     cfg['args']['ranking_size'] = N
-    fuse_sel = {'default': None, 'none': False, 'fwd': ('fwd',), 'bwd': ('bwd',), 'both': True}[a.fuse_projection]
-    est = estimation.load_from_config(cfg, model, converge_patience=10 ** 6, conv_mode=a.conv_mode, engine_streams=a.engine_streams,
-                                      fuse_projection=fuse_sel)
+    fuse_sel = {'default': None, 'none': False, 'fwd': ('fwd',)}[a.fuse_projection]
+    est = estimation.load_from_config(cfg, model, converge_patience=10 ** 6, conv_mode=a.conv_mode, fuse_projection=fuse_sel)
     torch.manual_seed(300 + rank)
     init = pu.sample_cameras_with_estimate(N, target.camera.to('cpu'))
     init_rec = {'K': init.intrinsic.clone(), 'log_q': init.log_quaternion.clone(), 't': init.translation.clone()}
@@ -675,7 +672,7 @@ def main():
         # secondary line (never `value`): the same loop with the split-precision conv3d kernels
         st = est = None
         torch.cuda.empty_cache()
-        est2 = estimation.load_from_config(cfg, model, converge_patience=10 ** 6, conv_mode='f16x3', engine_streams=a.engine_streams)
+        est2 = estimation.load_from_config(cfg, model, converge_patience=10 ** 6, conv_mode='f16x3')
         st2 = est2.start(z_obj, target, init.zoom(None, model.input_size, model.camera_dist).to(dev))
         with torch.no_grad():
             l2, g2 = st2['engine'].forward_backward(st2['cam'], need_grad=True)
@@ -696,33 +693,8 @@ def main():
                                'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ab2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                'f16_mfma_frac': fl2 / (ms2 * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS, 'launches_timed': len(d2)}
 
-    # secondary line (never `value`): the same all-fp32 loop with the engine's evaluation replayed from a captured hipGraph
-    # (RenderLoopEngine.forward_backward_graph) -- no HIP events can live inside a captured graph, so the headline above, which
-    # must time its dominant kernel inside the timed region, runs eagerly; this is what a user of the library gets
-    graph = None
-    # (single-rank runs only: a capture in 'global' error mode next to a live RCCL communicator's watchdog thread is not worth
-    # risking the multi-rank sections for a number that does not depend on the rank count)
-    if not a.no_graph and world == 1 and a.conv_mode in ('fp32', 'winograd'):
-        try:
-            st = est = st2 = est2 = None
-            torch.cuda.empty_cache()
-            est4 = estimation.load_from_config(cfg, model, converge_patience=10 ** 6, conv_mode=a.conv_mode, fuse_projection=fuse_sel,
-                                               engine_graph=True)
-            st4 = est4.start(z_obj, target, init.zoom(None, model.input_size, model.camera_dist).to(dev))
-            el4, blocks4, _ = timed_loop(est4, st4, events=False)
-            captured = st4['engine']._graph is not None
-            # the same estimator class without the graph and without events: what the capture itself is worth
-            est5 = estimation.load_from_config(cfg, model, converge_patience=10 ** 6, conv_mode=a.conv_mode, fuse_projection=fuse_sel)
-            st5 = est5.start(z_obj, target, init.zoom(None, model.input_size, model.camera_dist).to(dev))
-            el5, blocks5, _ = timed_loop(est5, st5, events=False)
-            graph = {'what': 'adam_quick loop, all-fp32, engine evaluation replayed from a captured hipGraph (no HIP events in the '
-                             'timed region); `eager_no_events` = the same loop launched eagerly, also without events',
-                     'value': world * a.steps / el4, 'unit': 'iters/s', 'ms_per_step': el4 / a.steps * 1e3,
-                     'ms_per_step_blocks': [b / a.steps * 1e3 for b in blocks4], 'graph_captured': bool(captured),
-                     'eager_no_events': {'value': world * a.steps / el5, 'ms_per_step': el5 / a.steps * 1e3}}
-            st4 = est4 = st5 = est5 = None
-        except Exception as e:                                       # noqa: BLE001  (auxiliary: never loses the headline)
-            graph = {'error': f'{type(e).__name__}: {e}'[:300]}
+    graph = None     # (round 4 measured hipGraph replay of the evaluation: 186.8 vs 187.0 it/s eager -- profiles/r04_hipgraph_ab.json;
+                     #  the variant lives in latentfusion_amd/experimental.py, its A/B in tools/engine_ab.py)
 
     # ---- roofline of the dominant kernel (fused conv3d 16->16 block step; 2 forward + 2 data-gradient launches per
     # iteration), from HIP events recorded on the launch stream inside the timed region -------------------------------
@@ -905,7 +877,7 @@ def main():
         'dtype': 'f32' if a.conv_mode in ('fp32', 'winograd') else 'f32 (conv3d products split into 3 f16 MFMAs, fp32 accumulate)', 'data': 'synthetic (SYN(S,C) random-init weights, synthetic observations)',
         'config': {'workload': f'SYN({S},{C}) latent volume, {V} reference views, adam_quick pose loop, '
                                f'{N} pose samples per iteration, one object per GPU',
-                   'engine_streams': a.engine_streams, 'fuser': a.fuser, 'pose_samples': N, 'ref_views': V, 'volume': S, 'channels': C,
+                   'fuser': a.fuser, 'pose_samples': N, 'ref_views': V, 'volume': S, 'channels': C,
                    'parallelism': f'objects x{world} (no data-path collective in the loop)'},
         't_build_s': t_build, 't_build_warm_s': t_build_warm,
         'e2e_100_iters_per_s': 100.0 / (t_build_warm + 100.0 * elapsed / a.steps),

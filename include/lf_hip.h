@@ -47,21 +47,6 @@ int lf_abi_version(void);
 /* Name of the device the library is running on (for logs); returns 0 / hip error. */
 int lf_device_name(char* buf, int buflen);
 
-/* Kernel-variant switch for in-process A/B measurements (tools/, profiles/); results are equivalent within the test
- * tolerances for every value.  key 1: 3-D resampler kernels, 1 = generic (64-bit addressing, any C), 2 = lean
- * (32-bit buffer addressing, C % 4 == 0, volumes < 4 GB per sample; other shapes take the generic ones),
- * 3 = lean + the 16-channel specialisation of the gather (default), 4 = LDS-staged source footprint (16 channels; measured
- * slower, profiles/r03_resample_staged_ab.txt), 5 = gather with the map evaluated once per voxel (bit-identical to 3, 6 % slower).  key 2: lean coefficient-gradient kernel, sub-tiles in
- * flight per workgroup iteration: 1 = one, 2 = two (round-2 default), 3-5 = register-capped forms of 2 / 1, 6-11 = forms that do the
- * per-voxel arithmetic once per voxel instead of once per lane (10 = default: two gather passes in flight, gradient records
- * requested one sub-tile ahead).  key 3: workgroup
- * shape of lf_wino_fused_gemm (output channels x Winograd tiles): 0 = 64 x 64, 1 = 128 x 64, 2 = 64 x 128, 3 = 128 x 128,
- * 4 = 64 x 256 (3, 4: 2-D only), -1 = chosen from the problem shape (default).  key 4: lf_resample3d_bwd_vol_det, 1 = global
- * 64-bit atomics, 2 = source tiles accumulated in LDS (default; C == 16; bit-identical results).  key 5: resident workgroups
- * per CU of lf_conv3d_c16_ring_bf16, 2 (default) or 3.
- * Returns the previous value or LF_EINVAL. */
-int lf_set_tuning(int key, int value);
-
 /* ------------------------------------------------------------------------------------------
  * 3-D resampling: out[n,z,y,x,:] = trilinear(vol[n or 0], g(n; x,y,z)), padding=border,
  * align_corners=False, i.e. F.grid_sample as used by
@@ -90,8 +75,6 @@ int lf_resample3d_bwd_coef(const float* gout, const float* vol, int vol_n, const
 /* d(loss)/d(vol) (trilinear splat, fp32 atomics; training / encoder backward only).
  * gvol must be zero-initialised by the caller; with vol_n == 1 all samples accumulate into one
  * volume. */
-int lf_resample3d_bwd_vol(const float* gout, const float* coef, int kind, float* gvol, int vol_n,
-                          int N, int D, int H, int W, int C, void* stream);
 
 /* The same gradient, DETERMINISTIC: contributions are accumulated as round(value * 2^K) with 64-bit integer atomics
  * (integer addition is associative, so the result does not depend on the order the hardware retires them) and
@@ -202,52 +185,24 @@ int lf_conv3d_c16_wino(const float* x, const float* upack, const float* bias, fl
  * in ONE launch: same operands, same accumulation order, bit-identical zp; y / norm_out are still written (the backward
  * pass needs them).  proj_wA: lf_conv3d_c16_wino_proj_pack_floats(D) floats, [D][64 lanes l][4 i]
  *   = Wp[cout = l & 15][k = d*16 + (l >> 4)*4 + i]   (Wp = the (16, D*16) matrix lf_conv1x1_fwd takes, depth-major K).
- *
- * lf_conv3d_c16_wino_projbwd = lf_conv1x1_bwd_data(gp (N, H*W, 16), ..., prev = (act, act_norm, act_flags)) followed by
- *   lf_conv3d_c16_wino(data-gradient form on that volume, prev = (prev_y, prev_norm, prev_flags))
- * in ONE launch: the (N, 16, D, H, W) gradient volume between the two never exists; its halo planes are formed on chip
- * from `act` (the last camera block's saved output), `act_norm`, gp and the depth slices of the transposed projection.
- * proj_wtA: [D][64 lanes l][4 i] = Wp[cout = (l >> 4)*4 + i][k = d*16 + (l & 15)].  upack = the TRANSPOSED Winograd pack of
- * the block's convolution.  Differs from the two-launch form only by the reciprocal used for 1 / act_norm (<= 1 ulp). */
+ */
 size_t lf_conv3d_c16_wino_proj_pack_floats(int D);
 int lf_conv3d_c16_wino_projfwd(const float* x, const float* upack, const float* bias, float* y, float* norm_out,
                                int N, int D, int H, int W, float he, unsigned flags, float slope, float eps,
                                const float* proj_wA, const float* proj_bias, float* zp, float* pnorm,
                                float proj_he, unsigned proj_flags, void* stream);
-int lf_conv3d_c16_wino_projbwd(const float* gp, const float* proj_wtA, float proj_he, const float* act,
-                               const float* act_norm, unsigned act_flags, const float* upack, float* y,
-                               int N, int D, int H, int W, float he, float slope, const float* prev_y,
-                               const float* prev_norm, unsigned prev_flags, void* stream);
 
-/* Winograd F(2x2x2,3x3x3) with split-precision products: transforms in fp32, every Winograd-domain product
- * from three v_mfma_f32_16x16x16_f16 (U_hi.V_hi + U_hi.V_lo + U_lo.V_hi, fp32 accumulate).  Same semantics
- * as lf_conv3d_c16_wino; amax_in / amax_out as in lf_conv3d_c16_split.
- * upack: lf_conv3d_c16_wino_split_upack_halfs() f16 values, [4 a][16 b*4+c][hi, lo][64 lanes l][4 j]
- *        = split of U[a][b][c][cout = l & 15][cin = (l >> 4) * 4 + j]. */
-size_t lf_conv3d_c16_wino_split_upack_halfs(void);
-int lf_conv3d_c16_wino_split(const float* x, const void* upack, const float* bias, float* y, float* norm_out,
-                             int N, int D, int H, int W, float he, unsigned flags, float slope, float eps,
-                             const float* prev_y, const float* prev_norm, unsigned prev_flags,
-                             const float* amax_in, float* amax_out, void* stream);
-
-/* bf16-autocast form of the fused 16 -> 16 conv3d block step, for the training step (BASELINE cfg 5; the reference wraps
- * Sculptor / Photographer.forward in `autocast(enabled=self.training)`, recon/models.py:199,405):
- * operands rounded to bf16 (RNE) while the halo is staged, products on v_mfma_f32_16x16x16_bf16 with fp32 accumulation,
- * DIRECT convolution (a Winograd transform of bf16 data is not bf16-exact).  round_out: 0 = fp32 epilogue on the fp32
- * accumulator; 1 = autocast forward, y = epilogue(bf16(bf16(acc) * he) + bias) -- the convolution returns a half tensor and
- * `* he` stays in half, the fp32 bias promotes the rest (modules/equalized.py:57-64); 2 = autocast data gradient
- * (transposed / flipped pack, flags = 0, bias = NULL): the result is additionally rounded to bf16.
- * wpack: lf_conv3d_c16_bf16_wpack_elems() bf16 values, [27 taps][64 lanes l][4]: W[cout = l & 15][cin = (l >> 4)*4 + i][tap].
- * lf_round_bf16: y = bf16(x) kept in fp32 containers (the autocast cast of an operand of the other, fp32-MFMA kernels:
- * bf16 x bf16 products are exact in fp32, so those kernels then compute what a bf16 MFMA would). */
+/* bf16 autocast policy of the training step (BASELINE cfg 5; the reference wraps Sculptor / Photographer.forward in
+ * `autocast(enabled=self.training)`, recon/models.py:199,405).
+ * lf_round_bf16: y = bf16(x) kept in fp32 containers (the autocast cast of an operand of the fp32-MFMA kernels: bf16 x bf16
+ * products are exact in fp32, so those kernels then compute what a bf16 MFMA would). */
 int lf_round_bf16(const float* x, float* y, long n, void* stream);
-size_t lf_conv3d_c16_bf16_wpack_elems(void);
-int lf_conv3d_c16_bf16(const float* x, const void* wpack, const float* bias, float* y, float* norm_out, int N, int D, int H,
-                       int W, float he, unsigned flags, float slope, float eps, int round_out, void* stream);
-/* The same arithmetic on the ring organisation of lf_conv3d_c16_split (column walk over 2 x 8 x 16 tiles, six z-plane slots
- * of bf16 halo in LDS, tap pairs on v_mfma_f32_16x16x32_bf16, the epilogue under the next tile's MFMAs): the form the
- * autocast training step uses.  round_out: 0 = fp32 epilogue on the accumulator, 1 = bf16(bf16(acc) * he) before the bias
- * (autocast forward; with flags = 0 and bias = NULL also its data gradient).  addend != NULL (bias = NULL, flags = 0,
+/* The fused 16 -> 16 conv3d block step under that policy: operands rounded to bf16 (RNE) while the halo is staged, products on
+ * v_mfma_f32_16x16x32_bf16 with fp32 accumulation, DIRECT convolution (a Winograd transform of bf16 data is not bf16-exact),
+ * on the ring organisation of lf_conv3d_c16_split (column walk over 2 x 8 x 16 tiles, six z-plane slots
+ * of bf16 halo in LDS, tap pairs per MFMA, the epilogue under the next tile's MFMAs).  round_out: 0 = fp32 epilogue on the
+ * accumulator, 1 = y = epilogue(bf16(bf16(acc) * he) + bias) -- autocast's convolution returns a half tensor and `* he` stays in
+ * half, the fp32 bias promotes the rest (modules/equalized.py:57-64); with flags = 0 and bias = NULL also its data gradient.  addend != NULL (bias = NULL, flags = 0,
  * round_out = 0): y = conv(x) * he + addend, the running sum of the ConvGRU gates evaluated without the channel
  * concatenation (modules/gru.py:31-40).
  * wpack: lf_conv3d_c16_ring_bf16_wpack_elems() bf16 values, [14 pairs][16 cout][32 = 2 taps x 16 cin], the tap pairs of
@@ -268,15 +223,11 @@ int lf_conv3d_c16_ring_bf16_io(const void* x, const void* wpack, const float* bi
                                int N, int D, int H, int W, float he, unsigned flags, float slope, float eps,
                                const void* addend, int round_out, int io, void* stream);
 
-/* Winograd F(2x2x2,3x3x3) for wide 3-D convolutions in three stages (input transform, 64 library GEMMs
- * M[f] = V[f] @ U[f] on the host side, output transform with the fused epilogue).  x, y channels-last;
- * V [64][T][Cin], M [64][T][Cout], T = lf_wino3d_tiles(N, D, H, W), frequency f = (a*4 + b)*4 + c (z, y, x);
- * U[f][cin][cout] = ((G (x) G (x) G) w)[cout][cin][a][b][c].  Cin, Cout multiples of 4.  PixelNorm is fused for
- * Cout <= 256; for wider outputs the rows are stored un-normalised (then run lf_pixelnorm_fwd). */
+/* Winograd F(2x2x2,3x3x3) for wide (>= 64-channel) 3-D convolutions, stage 1: the input transform.  x channels-last;
+ * V [64][T][Cin], T = lf_wino3d_tiles(N, D, H, W), frequency f = (a*4 + b)*4 + c (z, y, x).  Cin a multiple of 4.
+ * Stages 2 + 3: lf_wino_fused_gemm below. */
 long lf_wino3d_tiles(int N, int D, int H, int W);
 int lf_wino3d_input_transform(const float* x, float* V, int N, int D, int H, int W, int C, void* stream);
-int lf_wino3d_output_transform(const float* M, const float* bias, float* y, float* norm_out, int N, int D, int H, int W,
-                               int C, float he, unsigned flags, float slope, float eps, void* stream);
 
 /* Stages 2 + 3 of the wide Winograd convolution in ONE launch, on this library's own fp32-MFMA GEMM (no library GEMM on
  * the hot path): for every frequency f the product V[f] (T x Cin) . U2[f]^T is accumulated on v_mfma_f32_16x16x4_f32 and
@@ -297,11 +248,9 @@ int lf_wino_fused_gemm(const float* V, const float* U2, const float* bias, float
                        int dims, int N, int D, int H, int W, int Cin, int Cout, float he, unsigned flags, float slope,
                        void* stream);
 
-/* 2-D counterpart, F(2x2,3x3): V [16][T][Cin], M [16][T][Cout], T = lf_wino2d_tiles(N, H, W), f = b*4 + c (y, x). */
+/* 2-D counterpart, F(2x2,3x3): V [16][T][Cin], T = lf_wino2d_tiles(N, H, W), f = b*4 + c (y, x). */
 long lf_wino2d_tiles(int N, int H, int W);
 int lf_wino2d_input_transform(const float* x, float* V, int N, int H, int W, int C, void* stream);
-int lf_wino2d_output_transform(const float* M, const float* bias, float* y, float* norm_out, int N, int H, int W,
-                               int C, float he, unsigned flags, float slope, float eps, void* stream);
 
 /* Gate arithmetic of the convolutional GRU fuser, inference path (modules/gru.py:30-43; no tanh on the
  * candidate).  `rec` is the channels-last record [x | state] (rec_stride floats per voxel, state at

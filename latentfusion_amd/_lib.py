@@ -21,15 +21,13 @@ LF_FUSE_MEAN, LF_FUSE_MAX, LF_FUSE_ABSMAX, LF_FUSE_MEDIAN = 0, 1, 2, 3
 LF_AMAX_FLOATS = 2048          # floats of a max-abs side-channel buffer (include/lf_hip.h)
 
 P = c_void_p
-# name -> (restype, argtypes); mirrors include/lf_hip.h one to one
+# name -> (restype, argtypes); mirrors include/lf_hip.h one to one (the product ABI)
 SIGNATURES = {
     'lf_abi_version': (c_int, []),
     'lf_device_name': (c_int, [c_char_p, c_int]),
-    'lf_set_tuning': (c_int, [c_int, c_int]),
     'lf_resample3d_fwd': (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
     'lf_resample3d_bwd_coef_scratch_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
     'lf_resample3d_bwd_coef': (c_int, [P, P, c_int, P, P, P, c_size_t, c_int, c_int, c_int, c_int, c_int, P]),
-    'lf_resample3d_bwd_vol': (c_int, [P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     'lf_resample3d_bwd_vol_det_scratch_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     'lf_resample3d_bwd_vol_det': (c_int, [P, P, c_int, P, c_int, P, c_size_t, c_int, c_int, c_int, c_int, c_int, P]),
     'lf_conv3x3_cout_padded': (c_int, [c_int]),
@@ -52,26 +50,17 @@ SIGNATURES = {
     'lf_conv3d_c16_wino_proj_pack_floats': (c_size_t, [c_int]),
     'lf_conv3d_c16_wino_projfwd': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint, c_float, c_float,
                                            P, P, P, P, c_float, c_uint, P]),
-    'lf_conv3d_c16_wino_projbwd': (c_int, [P, P, c_float, P, P, c_uint, P, P, c_int, c_int, c_int, c_int, c_float, c_float,
-                                           P, P, c_uint, P]),
-    'lf_conv3d_c16_wino_split_upack_halfs': (c_size_t, []),
-    'lf_conv3d_c16_wino_split': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint, c_float, c_float, P, P,
-                                         c_uint, P, P, P]),
     'lf_round_bf16': (c_int, [P, P, c_long, P]),
-    'lf_conv3d_c16_bf16_wpack_elems': (c_size_t, []),
-    'lf_conv3d_c16_bf16': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint, c_float, c_float, c_int, P]),
     'lf_conv3d_c16_ring_bf16_wpack_elems': (c_size_t, []),
     'lf_conv3d_c16_ring_bf16': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint, c_float, c_float, P, c_int, P]),
     'lf_conv3d_c16_ring_bf16_io': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint, c_float, c_float, P, c_int, c_int, P]),
     'lf_wino3d_tiles': (c_long, [c_int, c_int, c_int, c_int]),
     'lf_wino3d_input_transform': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
-    'lf_wino3d_output_transform': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_uint, c_float, c_float, P]),
     'lf_wino_fused_cout_padded': (c_int, [c_int]),
     'lf_wino_fused_scratch_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     'lf_wino_fused_gemm': (c_int, [P, P, P, P, P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_uint, c_float, P]),
     'lf_wino2d_tiles': (c_long, [c_int, c_int, c_int]),
     'lf_wino2d_input_transform': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
-    'lf_wino2d_output_transform': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint, c_float, c_float, P]),
     'lf_gru_stage_a': (c_int, [P, P, c_int, P, P, P, c_long, c_int, c_int, c_int, P]),
     'lf_gru_stage_b': (c_int, [P, P, P, P, P, c_long, c_int, c_int, c_int, P]),
     'lf_lstm_cell_fwd': (c_int, [P, P, P, P, c_long, c_int, P]),
@@ -124,6 +113,22 @@ SIGNATURES = {
     'lf_lift_bwd': (c_int, [P, P, P, P, c_int, c_long, c_int, c_int, c_float, c_int, c_int, P]),
 }
 
+# entry points of include/lf_hip_experimental.h (A/B switches, superseded kernels): same shared object, bound for
+# latentfusion_amd/experimental.py, tools/ and the tests that pin them
+EXPERIMENTAL_SIGNATURES = {
+    'lf_set_tuning': (c_int, [c_int, c_int]),
+    'lf_resample3d_bwd_vol': (c_int, [P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    'lf_conv3d_c16_wino_projbwd': (c_int, [P, P, c_float, P, P, c_uint, P, P, c_int, c_int, c_int, c_int, c_float, c_float,
+                                           P, P, c_uint, P]),
+    'lf_conv3d_c16_wino_split_upack_halfs': (c_size_t, []),
+    'lf_conv3d_c16_wino_split': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint, c_float, c_float, P, P,
+                                         c_uint, P, P, P]),
+    'lf_conv3d_c16_bf16_wpack_elems': (c_size_t, []),
+    'lf_conv3d_c16_bf16': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint, c_float, c_float, c_int, P]),
+    'lf_wino3d_output_transform': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_uint, c_float, c_float, P]),
+    'lf_wino2d_output_transform': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint, c_float, c_float, P]),
+}
+
 _lib = None
 
 
@@ -151,7 +156,7 @@ def lib():
         handle = ctypes.CDLL(LIB_PATH)
     except OSError as e:
         raise LFHipError(f'cannot load {LIB_PATH}: {e}') from e
-    for name, (res, args) in SIGNATURES.items():
+    for name, (res, args) in list(SIGNATURES.items()) + list(EXPERIMENTAL_SIGNATURES.items()):
         try:
             fn = getattr(handle, name)
         except AttributeError as e:

@@ -25,7 +25,7 @@ def needs_build():
     t = os.path.getmtime(LIB)
     deps = [os.path.join(HERE, s) for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
     deps += [os.path.join(HERE, 'lf_common.h'), os.path.join(HERE, 'resample_staged.inc'),
-             os.path.join(HERE, '..', '..', 'include', 'lf_hip.h')]
+             os.path.join(HERE, '..', '..', 'include', 'lf_hip.h'), os.path.join(HERE, '..', '..', 'include', 'lf_hip_experimental.h')]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

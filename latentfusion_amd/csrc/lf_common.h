@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/lf_hip.h"
+#include "../../include/lf_hip_experimental.h"
 
 #define LF_WAVE 64
 

@@ -129,15 +129,21 @@ class RenderLoopEngine:
                 and photographer.predict_depth and photographer.predict_mask and not photographer.predict_color
                 and photographer.camera_config[-1] % 4 == 0)
 
+    CONV_MODES = ('auto', 'fp32', 'winograd', 'f16x3')
+    FUSE_FORMS = ('fwd',)
+
     def __init__(self, photographer, z_obj, target_obs, loss_weights, conv_mode='auto', fuse_projection=None):
         """conv_mode selects the kernels of the 16->16 camera-block convolutions:
         'fp32'     direct implicit-GEMM on the fp32 MFMA (works for every channel count);
         'winograd' F(2x2x2,3x3x3) minimal filtering, all-fp32 arithmetic (fp32 MFMA + fp32 transforms);
-        'f16x3'    direct, each fp32 product from three f16 MFMAs with fp32 accumulation;
-        'winograd_f16x3'  Winograd with fp32 transforms and three-term f16 products (fastest; opt-in);
-        'auto'     (default) 'winograd' when the blocks are 16->16, else 'fp32'.
-        All three stay within the fp32 kernel's distance of an fp64 reference (tests/test_engine_gpu.py)."""
-        if conv_mode not in ('auto', 'fp32', 'winograd', 'f16x3', 'winograd_f16x3'):
+        'f16x3'    direct, each fp32 product from three f16 MFMAs with fp32 accumulation (documented preset: bench `alt`);
+        'auto'     (default) 'winograd' when the blocks are 16->16 or >= 64 channels wide, else 'fp32'.
+        All stay within the fp32 kernel's distance of an fp64 reference (tests/test_engine_gpu.py).
+        fuse_projection: None = the default (factor projection forward fused into the last block's Winograd launch where the
+        shapes allow), False = two launches, ('fwd',) = required.
+        (Measured-and-rejected variants -- three-term Winograd products, the fused projection backward, hypothesis groups on
+        several streams, hipGraph replay -- live in experimental.RenderLoopEngineX.)"""
+        if conv_mode not in self.CONV_MODES:
             raise ValueError(conv_mode)
         self.ph = photographer
         self.cube = photographer.cube_size
@@ -180,11 +186,6 @@ class RenderLoopEngine:
             self.wgemm = [w for w, *_ in self.convs]            # packs are cached on the parameters (ops.wide_conv)
         if conv_mode == 'f16x3':
             self.split = [(ops.pack_conv3d_c16_split(w), ops.pack_conv3d_c16_split(w, transpose=True)) for w, *_ in self.convs]
-        elif conv_mode == 'winograd_f16x3':
-            self.split = [(ops.pack_conv3d_c16_wino_split(w), ops.pack_conv3d_c16_wino_split(w, transpose=True))
-                          for w, *_ in self.convs]
-            # trilinear resampling is a convex combination: max|x0| <= max|z_obj|
-            self.z_amax = ops.amax_buffer(self.z.abs().max(), dev)
         elif conv_mode == 'winograd' and c16:
             self.wino = [(ops.pack_conv3d_c16_wino(w), ops.pack_conv3d_c16_wino(w, transpose=True)) for w, *_ in self.convs]
         # 'sum' projection / occlusion module: the tail between the camera blocks and the 2-D decoder runs through the
@@ -201,18 +202,17 @@ class RenderLoopEngine:
             self.proj = (pw, photographer.projection_block.conv.bias, ops.he_constant(pw),
                          ops.pack_conv1x1(pw.reshape(cout, C, D).permute(0, 2, 1).reshape(cout, D * C)),
                          ops.pack_conv1x1(pw.reshape(cout, C, D).permute(2, 1, 0).reshape(D * C, cout)))
-        # factor projection fused into the Winograd kernel of the last camera block (lf_conv3d_c16_wino_projfwd / _projbwd;
-        # round 4): forward bit-identical to the two-launch form, backward to the reciprocal of the saved norm.
-        # fuse_projection: None = the default ('fwd' where the shapes allow: measured -0.07 ms per iteration; the backward
-        # form is correct but trades its 2.1 GB of HBM traffic for +19 % MFMAs on the pipe-bound kernel and comes out even
-        # or behind -- profiles/r04_proj_fuse_ab.txt), True = both, or a subset of {'fwd', 'bwd'} / False for A/B runs
+        # factor projection fused into the Winograd kernel of the last camera block (lf_conv3d_c16_wino_projfwd; round 4):
+        # bit-identical to the two-launch form, measured -0.07 ms per iteration
         can_fuse = self.wino is not None and cout == 16 and C == 16 and not self.generic_tail
         if fuse_projection is None:
             fuse_projection = ('fwd',) if can_fuse else ()
         elif fuse_projection is False:
             fuse_projection = ()
         elif fuse_projection is True:
-            fuse_projection = ('fwd', 'bwd')
+            fuse_projection = self.FUSE_FORMS
+        if any(f not in self.FUSE_FORMS for f in fuse_projection):
+            raise ValueError(f'fuse_projection {fuse_projection!r}: this engine fuses {self.FUSE_FORMS}')
         if fuse_projection and not can_fuse:
             raise NotImplementedError("fuse_projection needs conv_mode 'winograd' on 16-channel blocks and a 16-channel projection")
         self.fuse_projection = tuple(fuse_projection)
@@ -221,9 +221,6 @@ class RenderLoopEngine:
             wdm = pw.reshape(cout, C, D).permute(0, 2, 1).reshape(cout, D * C)        # depth-major K, as ppack
             self.proj_fused = (ops.pack_wino_proj(wdm), ops.pack_wino_proj(wdm, transpose=True))
         self.dev = dev
-        self.streams, self._side_streams = 1, []
-        self._packs_built = False
-        self._graph = None
         self._params = list(photographer.parameters())
         self._intr = None                                            # (K, version, gathered): the intrinsics do not change during a loop
         # the output heads (1x1 convolutions without activation, reference blocks.py:108-119) as ONE pointwise convolution
@@ -268,13 +265,7 @@ class RenderLoopEngine:
         renderer's projected latent joins the loss (reference pose/estimation.py:112-116), column 5 of `losses`.
 
         masked_depth (forward only): the loss as the cross-entropy / Metropolis estimators evaluate it -- the crop depth
-        times the crop's sigmoid mask before the uncrop (reference pose/estimation.py:207-216; lf_pose_loss_fwd_masked).
-
-        With `streams` = k > 1 (set_streams) the N hypotheses are evaluated as k independent groups on k HIP streams:
-        hypotheses do not interact (the reference optimises N separate cameras, estimation.py:580-594), so while one
-        group is in its latency-bound stretch (2-D decoder, loss, camera algebra: ~40 small launches that leave most of the
-        chip idle) another group's volume kernels run.  Same kernels, same per-hypothesis arithmetic: the results are
-        bit-identical to the single-stream evaluation (tests/test_engine_gpu.py)."""
+        times the crop's sigmoid mask before the uncrop (reference pose/estimation.py:207-216; lf_pose_loss_fwd_masked)."""
         # `params`: the (N,10) block [log_quaternion | translation | viewport] when the caller already holds it (the estimators'
         # cameras are views of one such tensor), else it is gathered from the camera; the intrinsics are gathered once
         # the engine differentiates w.r.t. the cameras only: with trainable parameters (the default of a model that was not
@@ -301,93 +292,45 @@ class RenderLoopEngine:
             self._intr = (K, K._version, camera_intrinsics(camera))
         intr = self._intr[2]
         n = params.shape[0]
-        k = min(self.streams, n)
         zt = z_target_latent if (z_target_latent is not None and self.w_latent != 0.0) else None
         if zt is not None and zt.shape[0] == 1 and n > 1:
             zt = zt.expand(n, *zt.shape[1:])
-        if k > 1 and not self._packs_built:
-            # weight packs are memoised on the parameters when the HOST enqueues the packing kernels (ops._cached), with no
-            # stream attached: built inside one group's side stream they could be read by another group's stream before they
-            # are written.  The first evaluation therefore runs on the current stream alone
-            k = 1
-        self._packs_built = True
-        if k <= 1:
-            return self._forward_backward_group(params, intr, float(camera.z_span), need_grad, 1.0, zt, masked_depth)
-        main = torch.cuda.current_stream()
-        ready = torch.cuda.Event()
-        ready.record(main)
-        bounds = [(n * i) // k for i in range(k + 1)]
-        outs = []
-        for i in range(k):
-            b, e = bounds[i], bounds[i + 1]
-            st = self._side_streams[i]
-            st.wait_event(ready)
-            params.record_stream(st)                               # (made on the main stream, read on the side streams)
-            intr.record_stream(st)
-            if zt is not None:
-                zt.record_stream(st)
-            with torch.cuda.stream(st):
-                # d(mean over all N) = (group size / N) x d(mean over the group): an exact power-of-two factor for the
-                # usual sizes, applied to the 10 numbers per hypothesis at the end
-                lo, gp = self._forward_backward_group(params[b:e], intr[b:e], float(camera.z_span), need_grad, (e - b) / n,
-                                                      zt[b:e] if zt is not None else None, masked_depth)
-                done = torch.cuda.Event()
-                done.record(st)
-            outs.append((lo, gp, done))
-        for lo, gp, done in outs:
-            main.wait_event(done)
-            lo.record_stream(main)
-            if gp is not None:
-                gp.record_stream(main)
-        losses = torch.cat([o[0] for o in outs], dim=0)
-        gparams = torch.cat([o[1] for o in outs], dim=0) if need_grad else None
-        return losses, gparams
+        return self._run(params, intr, float(camera.z_span), need_grad, zt, masked_depth)
 
-    # -----------------------------------------------------------------------------------------
-    def forward_backward_graph(self, camera, params):
-        """forward_backward(need_grad=True) replayed from a hipGraph: the ~30 launches of one evaluation are captured once
-        (stream capture through torch.cuda.graph: the C-ABI launches go to the capturing stream like any other) and replayed
-        with one call, which removes the dispatch gaps between dependent launches (~0.08 ms of a 5.4 ms iteration).
-        Conditions: `params` is the SAME (N,10) device tensor on every call (the estimators update it in place), the loss
-        weights have not been re-set, no latent term, one stream, and no kernel timer (HIP timing events cannot be
-        captured -- bench.py's headline therefore runs eagerly).  Returns the graph's static output tensors: they are
-        overwritten by the next replay (in stream order)."""
-        if ops.KERNEL_TIMER is not None or self.streams > 1 or self.w_latent != 0.0:
-            return self.forward_backward(camera, need_grad=True, params=params)
-        if any(p.requires_grad for p in self._params):
-            raise ValueError('forward_backward_graph needs frozen parameters (LatentFusionModel.freeze())')
-        pc = params.detach()
-        if not pc.is_contiguous():
-            raise ValueError('forward_backward_graph needs a contiguous (N,10) parameter block')
-        K = camera.intrinsic
-        if self._intr is None or self._intr[0] is not K or self._intr[1] != K._version:
-            self._intr = (K, K._version, camera_intrinsics(camera))
-        intr = self._intr[2]
-        # (the captured kernels hold raw pointers: the graph is valid for exactly these tensors -- compared by identity, and kept
-        # alive in the tuple below, so a freed buffer's address cannot come back as a false match)
-        key = (pc.data_ptr(), tuple(pc.shape), intr.data_ptr(), float(camera.z_span))
-        if self._graph is None or self._graph[0] != key or self._graph[6] is not self.weights or self._graph[7] is not params:
-            cur = torch.cuda.current_stream()
-            side = torch.cuda.Stream(device=self.dev)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side), torch.no_grad():            # warm-up: weight packs, allocator pools, code objects
-                for _ in range(2):
-                    self._forward_backward_group(pc, intr, float(camera.z_span), True, 1.0)
-            cur.wait_stream(side)
-            self._packs_built = True
-            g = torch.cuda.CUDAGraph()
-            with torch.no_grad(), torch.cuda.graph(g):
-                lo, gp = self._forward_backward_group(pc, intr, float(camera.z_span), True, 1.0)
-            self._graph = (key, g, lo, gp, pc, intr, self.weights, params)        # (keeps the captured inputs alive)
-        self._graph[1].replay()
-        return self._graph[2], self._graph[3]
+    def _run(self, params, intr, z_span, need_grad, zt, masked_depth):
+        """All hypotheses as one group on the current stream (experimental.RenderLoopEngineX splits them over streams)."""
+        return self._forward_backward_group(params, intr, z_span, need_grad, 1.0, zt, masked_depth)
 
-    def set_streams(self, k):
-        """Number of hypothesis groups evaluated concurrently on separate HIP streams (1 = everything on the current stream)."""
-        self.streams = max(1, int(k))
-        while len(self._side_streams) < self.streams:
-            self._side_streams.append(torch.cuda.Stream(device=self.dev))
-        return self
+    # ---- per-layer launches of the camera blocks (the experimental subclass adds kernel variants here) ----
+    def _conv_fwd(self, li, x, flags):
+        """Forward of camera-block convolution `li`: (y, norm, (zp, pnorm) when the factor projection rode along, else None)."""
+        w, b, he, wp, _wt = self.convs[li]
+        if self.split is not None:
+            return ops.conv3d_c16_split(x, self.split[li][0], b, he, flags) + (None,)
+        if self.wino is not None and li == len(self.convs) - 1 and 'fwd' in self.fuse_projection:
+            _pw, pb, phe, _ppack, _ppack_t = self.proj
+            y, nrm, zp, pnorm = ops.conv3d_c16_wino_projfwd(x, self.wino[li][0], b, he, flags, self.proj_fused[0], pb, phe, flags)
+            return y, nrm, (zp, pnorm)
+        if self.wino is not None:
+            return ops.conv3d_c16_wino(x, self.wino[li][0], b, he, flags) + (None,)
+        if self.wgemm is not None:
+            return ops.wide_conv(x, self.wgemm[li], b, he, flags) + (None,)
+        return ops._conv3x3_raw(x, wp, b, w.shape[0], he, flags, True) + (None,)
+
+    def _conv_bwd(self, i, g, prev, amax):
+        """Data gradient of camera-block convolution `i` with the LeakyReLU' / PixelNorm' of the layer feeding it (`prev`) folded
+        into the store (16-channel blocks)."""
+        w, _b, he, _wp, wt = self.convs[i]
+        if self.split is not None:
+            return ops.conv3d_c16_split(g, self.split[i][1], None, he, 0, prev=prev, amax_in=amax[i + 1], amax_out=amax[i])[0]
+        if self.wino is not None:
+            return ops.conv3d_c16_wino(g, self.wino[i][1], None, he, 0, prev=prev)[0]
+        return ops.conv3x3_bwd_data(g, wt, w.shape[1], he, prev)
+
+    def _proj_bwd_fused(self, gp, acts, norms, flags):
+        """Hook: (gradient after the LAST block's data-gradient convolution, index of the next layer to walk) when the projection
+        backward is fused into that launch; None here (experimental.RenderLoopEngineX: lf_conv3d_c16_wino_projbwd)."""
+        return None
 
     def _forward_backward_group(self, params, intr, z_span, need_grad, grad_scale, zt=None, masked_depth=False):
         L = _lib.lib()
@@ -411,22 +354,10 @@ class RenderLoopEngine:
                   'lf_resample3d_fwd')
         acts, norms = [x0], []
         flags = LF_EPI_LRELU | LF_EPI_PIXELNORM
-        for li_, (w, b, he, wp, _wt) in enumerate(self.convs):
-            if self.conv_mode == 'winograd_f16x3':
-                y, nrm = ops.conv3d_c16_wino_split(acts[-1], self.split[li_][0], b, he, flags,
-                                                   amax_in=self.z_amax if li_ == 0 else None)
-            elif self.split is not None:
-                y, nrm = ops.conv3d_c16_split(acts[-1], self.split[li_][0], b, he, flags)
-            elif self.wino is not None and li_ == len(self.convs) - 1 and 'fwd' in self.fuse_projection:
-                pw, pb, phe, _ppack, _ppack_t = self.proj
-                y, nrm, zp, pnorm = ops.conv3d_c16_wino_projfwd(acts[-1], self.wino[li_][0], b, he, flags, self.proj_fused[0],
-                                                                  pb, phe, flags)
-            elif self.wino is not None:
-                y, nrm = ops.conv3d_c16_wino(acts[-1], self.wino[li_][0], b, he, flags)
-            elif self.wgemm is not None:
-                y, nrm = ops.wide_conv(acts[-1], self.wgemm[li_], b, he, flags)
-            else:
-                y, nrm = ops._conv3x3_raw(acts[-1], wp, b, w.shape[0], he, flags, True)
+        for li_ in range(len(self.convs)):
+            y, nrm, rode = self._conv_fwd(li_, acts[-1], flags)
+            if rode is not None:
+                zp, pnorm = rode
             acts.append(y)
             norms.append(nrm)
         Cl = acts[-1].shape[1]
@@ -562,12 +493,9 @@ class RenderLoopEngine:
                 for i in range(nconv - 1, -1, -1):
                     w, b, he, _wp, wt = self.convs[i]
                     prev = (acts[i], norms[i - 1], flags) if i > 0 else None
-                    if self.wino is not None:
-                        g, _ = ops.conv3d_c16_wino(g, self.wino[i][1], None, he, 0, prev=prev)
-                    elif self.split is not None:
+                    if self.split is not None:
                         raise NotImplementedError('split-precision kernels drive the factor renderer only')
-                    else:
-                        g = ops.conv3x3_bwd_data(g, wt, w.shape[1], he, prev)
+                    g = self._conv_bwd(i, g, prev, None)
             else:
                 for i in range(nconv - 1, -1, -1):
                     w, b, he, _wp, wt = self.convs[i]
@@ -578,17 +506,12 @@ class RenderLoopEngine:
                         g, _ = ops._conv3x3_raw(gpre, wt, None, w.shape[1], he, 0, False)
             return self._finish_backward(g, g_cf, cf20, jac, n, grad_scale, losses)
         gp = gp_explicit if (explicit and gp_explicit is not None) else ops._epilogue_bwd(ops.cl(g_zp), zp, pnorm, flags)
-        fuse_pb = fuse and nconv and 'bwd' in self.fuse_projection
-        g = None if fuse_pb else ops.empty_cl((n, Cl, S, S, S), dev)
-        if fuse_pb:
-            # projection backward + first data-gradient convolution in one launch; then the remaining layers
-            i = nconv - 1
-            prev = (acts[i], norms[i - 1], flags) if i > 0 else None
-            g = ops.conv3d_c16_wino_projbwd(gp, self.proj_fused[1], phe, acts[nconv], norms[nconv - 1], flags,
-                                            self.wino[i][1], self.convs[i][2], prev=prev)
-            for i in range(nconv - 2, -1, -1):
-                prev = (acts[i], norms[i - 1], flags) if i > 0 else None
-                g, _ = ops.conv3d_c16_wino(g, self.wino[i][1], None, self.convs[i][2], 0, prev=prev)
+        fused_pb = self._proj_bwd_fused(gp, acts, norms, flags) if (fuse and nconv) else None
+        g = None if fused_pb is not None else ops.empty_cl((n, Cl, S, S, S), dev)
+        if fused_pb is not None:
+            g, nxt = fused_pb
+            for i in range(nxt, -1, -1):
+                g = self._conv_bwd(i, g, (acts[i], norms[i - 1], flags) if i > 0 else None, None)
         elif fuse and nconv:
             # every data-gradient kernel also applies the LeakyReLU'/PixelNorm' of the layer feeding it,
             # so no separate epilogue-backward pass touches the (N,16,S,S,S) volumes
@@ -601,18 +524,7 @@ class RenderLoopEngine:
                                             norms[nconv - 1].data_ptr(), flags, ops.SLOPE,
                                             amax[nconv].data_ptr() if amax is not None else None, s), 'lf_conv1x1_bwd_data')
             for i in range(nconv - 1, -1, -1):
-                w, b, he, _wp, wt = self.convs[i]
-                prev = (acts[i], norms[i - 1], flags) if i > 0 else None
-                if self.conv_mode == 'winograd_f16x3':
-                    g, _ = ops.conv3d_c16_wino_split(g, self.split[i][1], None, he, 0, prev=prev,
-                                                     amax_in=amax[i + 1], amax_out=amax[i])
-                elif self.split is not None:
-                    g, _ = ops.conv3d_c16_split(g, self.split[i][1], None, he, 0, prev=prev, amax_in=amax[i + 1],
-                                                amax_out=amax[i])
-                elif self.wino is not None:
-                    g, _ = ops.conv3d_c16_wino(g, self.wino[i][1], None, he, 0, prev=prev)
-                else:
-                    g = ops.conv3x3_bwd_data(g, wt, w.shape[1], he, prev)
+                g = self._conv_bwd(i, g, (acts[i], norms[i - 1], flags) if i > 0 else None, amax)
         else:
             ops._conv1x1_raw(gp, ppack_t, None, n, S * S, cout, 1, S * S * cout, 0, S * Cl, g, phe, 0,
                              yaddr=(S * S * S * Cl, Cl, Cl, S * S * Cl))

@@ -147,8 +147,13 @@ class PoseEstimator:
         # must not be dropped silently: the reference applies every scheduled weight (estimation.py:612-617)
         if any(k not in RenderLoopEngine.LOSS_KEYS + ('latent',) for k in schedules):
             return None
-        return RenderLoopEngine(ph, z_obj, target_obs, self.loss_weights, conv_mode=self.conv_mode,
-                                fuse_projection=self.fuse_projection)
+        fp = self.fuse_projection
+        wants_x = (self.conv_mode == 'winograd_f16x3' or fp is True or (isinstance(fp, (tuple, list, set)) and 'bwd' in fp)
+                   or getattr(self, 'engine_streams', 1) > 1 or getattr(self, 'engine_graph', False))
+        if wants_x:                                                # measured-and-rejected variants: experimental.py
+            from ..experimental import RenderLoopEngineX
+            return RenderLoopEngineX(ph, z_obj, target_obs, self.loss_weights, conv_mode=self.conv_mode, fuse_projection=fp)
+        return RenderLoopEngine(ph, z_obj, target_obs, self.loss_weights, conv_mode=self.conv_mode, fuse_projection=fp)
 
     def _ranking_engine(self, z_obj, target_obs):
         """One engine per (object, target) for the ranking-only estimators; the cache keeps both alive, so an address
@@ -498,7 +503,9 @@ class GradientPoseEstimator(PoseEstimator):
 
     def _engine_for(self, z_obj, target_obs, schedules=()):
         eng = super()._engine_for(z_obj, target_obs, schedules=self.loss_schedules)
-        return eng.set_streams(self.engine_streams) if eng is not None else None
+        if eng is not None and self.engine_streams > 1:
+            eng.set_streams(self.engine_streams)
+        return eng
 
     @classmethod
     def get_optimizer(cls, name, *args, **kwargs):
@@ -624,7 +631,7 @@ class GradientPoseEstimator(PoseEstimator):
             if optim_weights.get('latent', 0.0) != 0.0 or self.loss_weights.get('latent', 0.0) != 0.0:
                 # the target's latent code under every hypothesis (reference :606-608): encoder + renderer, no gradient
                 z_target_latent = self.model.compute_latent_code(st['target'], st['cam'])
-            if self.engine_graph and z_target_latent is None and not self.loss_schedules:
+            if self.engine_graph and z_target_latent is None and not self.loss_schedules and hasattr(eng, 'forward_backward_graph'):
                 losses, gparams = eng.forward_backward_graph(st['cam'], P)
             else:
                 losses, gparams = eng.forward_backward(st['cam'], need_grad=True, z_target_latent=z_target_latent, params=P)

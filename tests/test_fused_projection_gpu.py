@@ -148,7 +148,7 @@ def test_engine_with_fused_projection_equals_the_unfused_engine(S):
     opt-in) against the same engine with the separate projection launches: identical losses (the forward is bit-identical),
     camera gradients to the last bits."""
     from latentfusion_amd import synth
-    from latentfusion_amd.engine import RenderLoopEngine
+    from latentfusion_amd.experimental import RenderLoopEngineX as RenderLoopEngine   # (the fused BACKWARD form is experimental)
     from latentfusion_amd.modules.geometry import Camera
     from latentfusion_amd.observation import Observation
     from latentfusion_amd.pose import utils as pu

@@ -28,13 +28,19 @@ def prod_camera(d):
 # ---------------------------------------------------------------------------------------------
 def test_cabi_exports_every_declared_symbol():
     from latentfusion_amd import _lib
-    header = open(os.path.join(ROOT, 'include', 'lf_hip.h')).read()
-    declared = set(re.findall(r'\b(lf_[a-z0-9_]+)\s*\(', header))
-    assert declared, 'no declarations parsed'
-    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     L = _lib.lib()                               # loads (and resolves) without a GPU
-    for name in declared:
-        assert hasattr(L, name), name
+    # the product ABI (what a maintainer binds) and the experimental header (A/B switches, superseded kernels): each header
+    # declares exactly the entry points of its binding table, every one of them is exported, and the two do not overlap
+    tables = (('lf_hip.h', _lib.SIGNATURES), ('lf_hip_experimental.h', _lib.EXPERIMENTAL_SIGNATURES))
+    for fname, table in tables:
+        header = open(os.path.join(ROOT, 'include', fname)).read()
+        header = re.sub(r'/\*.*?\*/', '', header, flags=re.S)      # (comments mention functions of the other header)
+        declared = set(re.findall(r'\b(lf_[a-z0-9_]+)\s*\(', header))
+        assert declared, 'no declarations parsed'
+        assert declared == set(table), (fname, declared ^ set(table))
+        for name in declared:
+            assert hasattr(L, name), name
+    assert not set(_lib.SIGNATURES) & set(_lib.EXPERIMENTAL_SIGNATURES)
     assert L.lf_abi_version() == 1
     assert L.lf_conv3x3_cout_padded(7) == 16 and L.lf_conv3x3_cout_padded(48) == 64
     assert L.lf_conv1x1_cout_padded(200) == 256
