@@ -112,8 +112,12 @@ def pose_loss(logits, coefs, tdepth, tmask, weights, H, W):
 
 
 class RenderLoopEngine:
-    """Explicit forward+backward of N pose hypotheses through a Photographer (factor projection,
-    no occlusion / skip connections) and the fused pose loss."""
+    """Explicit forward+backward of N pose hypotheses through a Photographer and the fused pose loss.
+
+    An engine is a per-(object, target) INFERENCE object, driven from one host thread: it caches packed weights, the output of
+    the object-frame blocks and the resident volume at construction, and it freezes the renderer's trainable parameters for
+    the duration of a call (their `requires_grad` flags are restored on return).  Rebuild it after any weight update; do not
+    share the model with a concurrently running training step."""
 
     LOSS_KEYS = ('depth', 'ov_depth', 'iou', 'mask')
     EXPLICIT_DECODER = True          # A/B switch (tools/engine_ab.py): False runs a plain 2-D decoder through autograd like a generic one
@@ -160,8 +164,9 @@ class RenderLoopEngine:
         self.S = self.z.shape[-1]
         self.C = self.z.shape[1]
         self.crop = photographer.out_size
-        self.tdepth = target_obs.depth.reshape(-1).float().contiguous()
-        self.tmask = target_obs.mask.reshape(-1).float().contiguous()
+        # (the loss kernels take raw device pointers: a host-resident target must not reach them)
+        self.tdepth = target_obs.depth.reshape(-1).float().to(dev).contiguous()
+        self.tmask = target_obs.mask.reshape(-1).float().to(dev).contiguous()
         self.H, self.W = target_obs.depth.shape[-2:]
         self.set_weights(loss_weights)
         self.convs = []

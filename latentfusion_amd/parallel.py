@@ -233,8 +233,8 @@ class _Capture:
 _Identity = _Capture
 
 
-def shard_hypotheses(camera, rank=None, size=None):
-    r, s = world()
+def shard_hypotheses(camera, rank=None, size=None, group=None):
+    r, s = world(group)
     rank, size = (r if rank is None else rank), (s if size is None else size)
     b, e = shard_range(len(camera), rank, size)
     return camera[b:e], (b, e)
@@ -243,7 +243,7 @@ def shard_hypotheses(camera, rank=None, size=None):
 def gather_rows(local_rows, n_total, group=None):
     """All-gather of per-hypothesis rows (ragged over ranks) -> (n_total, ...) on every rank, in hypothesis order.
     One small collective per pose iteration: N loss scalars (+ 10 camera parameters when the ranking needs them)."""
-    rank, size = world()
+    rank, size = world(group)
     if size == 1:
         return local_rows
     counts = [shard_range(n_total, r, size) for r in range(size)]
@@ -261,11 +261,11 @@ def gather_losses(local_losses, n_total, group=None):
 
 
 def broadcast_(tensor, src=0, group=None):
-    """In-place broadcast from `src` (no-op in a single process).  Used for the few host-random quantities of the
-    estimators (GMM samples, initial hypotheses) so that every rank ranks the SAME hypotheses."""
-    rank, size = world()
+    """In-place broadcast from rank `src` OF `group` (no-op in a single process).  Used for the few host-random quantities of
+    the estimators (GMM samples, initial hypotheses) so that every rank ranks the SAME hypotheses."""
+    rank, size = world(group)
     if size > 1:
-        dist.broadcast(tensor, src=src, group=group)
+        dist.broadcast(tensor, src=_global(group, src), group=group)     # (c10d addresses the source by GLOBAL rank)
     return tensor
 
 
@@ -276,7 +276,7 @@ def allreduce_flat_(flat, group=None, bucket_bytes=64 << 20):
     """In-place mean of a flat fp32 gradient buffer over the ranks, in `bucket_bytes` pieces: a handful of
     large RCCL all-reduces (ring: bound by one xGMI link, so fewer/larger beats per-parameter traffic)
     instead of the reference's per-forward parameter broadcast (torchutils.py:133-170).  Returns `flat`."""
-    rank, size = world()
+    rank, size = world(group)
     if size == 1:
         return flat
     step = max(1, bucket_bytes // flat.element_size())
@@ -355,7 +355,7 @@ class GradientBuckets:
     def finish(self):
         """Call after backward(): reduces the buckets that are still open, waits for all, averages.  Returns the flat buffer."""
         self.armed = False
-        rank, size = world()
+        rank, size = world(self.group)
         if size > 1:
             self._drain(force=True)
             for h in self.handles:

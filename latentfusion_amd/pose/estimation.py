@@ -98,8 +98,13 @@ class PoseEstimator:
     def estimate(self, z_obj, target_obs, **kwargs):
         if len(target_obs) > 1:
             raise ValueError('The pose can only be estiamted for one observation at a time.')
-        with self._frozen_model():
-            return self._estimate(z_obj, target_obs, **kwargs)
+        try:
+            with self._frozen_model():
+                return self._estimate(z_obj, target_obs, **kwargs)
+        finally:
+            # the ranking engine of this call holds the resident volume copy, the target buffers and weight packs: it does not
+            # outlive the estimate (evaluate_samples() called directly builds one per (object, target) and keeps it)
+            self._engine_cache = None
 
     def _frozen_model(self):
         """The estimators differentiate w.r.t. the cameras only: run with the network's parameters frozen (no

@@ -841,3 +841,51 @@ def test_gradient_estimator_module_path_uses_the_fused_loss(golden):
     assert n_loss == g['rank_loss'].shape[0], n_loss
     close(stats['rank_loss'][:3], g['rank_loss'][:3], atol=1e-5, rtol=1e-4)
     assert torch.equal(torch.argmin(stats['rank_loss'], dim=1), g['argmin'])
+
+
+def test_engine_with_object_blocks_matches_module_path(golden):
+    """a Photographer WITH object-frame blocks (reference recon/models.py:410-415) -- the engine evaluates them once per
+    object at construction and renders from the cached result; losses and camera gradients equal Photographer.decode +
+    default_pose_loss through the modules, and a host-resident target is accepted (the engine moves its buffers)."""
+    from latentfusion_amd.engine import RenderLoopEngine
+    from latentfusion_amd.pose import estimation
+    from latentfusion_amd.recon.models import Photographer
+    torch.manual_seed(11)
+    ph = Photographer(in_size=16, image_config=[[16, 32], [32, 16]], camera_config=[16, 16], object_config=[16, 16],
+                      projection_type='factor', predict_color=False, predict_depth=True, predict_mask=True, scale_mode='nearest',
+                      cube_size=1.0).to(DEV)
+    with torch.no_grad():
+        for n_, p in ph.named_parameters():
+            if n_.endswith('bias'):
+                p.normal_(0, 0.1)
+    for p in ph.parameters():
+        p.requires_grad_(False)
+    assert len(ph.object_blocks) == 1
+    weights = {'depth': 1.0, 'ov_depth': 0.3, 'iou': 0.2, 'mask': 0.4}
+    g = golden('g7_adam_trace')
+    target = _target(g)
+    z_obj = torch.randn(1, 1, 16, 16, 16, 16, generator=torch.Generator().manual_seed(12)).to(DEV)
+
+    class _M:
+        photographer, device, input_size, camera_dist = ph, torch.device(DEV), 16, g['camera_dist']
+
+        @staticmethod
+        def render_latent_object(z, cam, return_latent=True, apply_mask=True):
+            y, zl, _ = ph.decode(z, cam, return_latent=return_latent, apply_mask=apply_mask)
+            return y, (zl.squeeze(0) if return_latent else zl)
+    cam0 = prod_camera(g['init']).zoom(None, 16, g['camera_dist'])
+    est = estimation.GradientPoseEstimator(model=_M, learning_rate=0.01, num_samples=len(cam0), num_iters=1, ranking_size=len(cam0),
+                                           converge_threshold=1e-6, converge_patience=10, optimizer='adam', loss_weights=weights,
+                                           use_engine=False)
+    st = est.start(z_obj, target, cam0)
+    ld, _, rank, _ = est.loss_and_grad(z_obj, target, st['cam'])
+    want_g = torch.cat((st['cam'].log_quaternion.grad, st['cam'].translation.grad, st['cam'].viewport.grad), dim=1)
+    assert RenderLoopEngine.supports(ph, weights)
+    for tgt in (target, _target(g, 'cpu')):
+        eng = RenderLoopEngine(ph, z_obj, tgt, weights)
+        losses, gparams = eng.forward_backward(cam0)
+        for i, k in enumerate(eng.LOSS_KEYS):
+            close(losses[:, i], ld[k], atol=5e-6, rtol=5e-5)
+        close(losses[:, 4], rank, atol=5e-6, rtol=5e-5)
+        rel = ((gparams - want_g).norm(dim=1) / want_g.norm(dim=1)).max().item()
+        assert rel < 2e-3, rel

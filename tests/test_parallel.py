@@ -359,3 +359,58 @@ def test_bench_refuses_a_world_size_that_is_not_the_gpus_flag():
 def test_bench_launcher_propagates_a_failing_rank():
     r, out = _run_bench(['--gpus', '2', '--launcher-selftest', '--steps', 'not-a-number'])
     assert r.returncode != 0 and not out
+
+
+# ---- helpers on a STRICT sub-group: sizes, means and source ranks are the group's, not the world's -------------
+def _subgroup_worker(rank, size, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=size)
+    try:
+        from latentfusion_amd import parallel
+        grp = dist.new_group(ranks=[1, 2])                       # (every rank of the world takes part in creating it)
+        out = None
+        if rank in (1, 2):
+            gr = rank - 1                                        # rank inside the group
+            assert parallel.world(grp) == (gr, 2)
+            b, e = parallel.shard_range(5, gr, 2)
+            rows = torch.arange(5, dtype=torch.float32)[b:e] * 10 + gr
+            gathered = parallel.gather_rows(rows, 5, grp)
+            flat = torch.arange(300, dtype=torch.float32) * (gr + 1)
+            parallel.allreduce_flat_(flat, grp, bucket_bytes=512)
+            t = torch.full((4,), float(rank))
+            parallel.broadcast_(t, src=0, group=grp)             # group rank 0 = global rank 1
+            p = torch.nn.Parameter(torch.zeros(64))
+            gbuf = torch.zeros(64)
+            p.grad = gbuf
+            bk = parallel.GradientBuckets(gbuf, [p], [0], grp, bucket_bytes=128)
+            bk.arm(True)
+            (p * float(gr + 1)).sum().backward()
+            bk.finish()
+            bk.remove()
+            out = (gathered.numpy().copy(), flat.numpy().copy(), t.numpy().copy(), gbuf.numpy().copy())
+        dist.barrier()
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_helpers_on_a_strict_subgroup_world3():
+    """gather_rows / allreduce_flat_ / broadcast_ / GradientBuckets.finish handed a 2-rank group inside a 3-rank world: the
+    gather has the group's two parts, the means divide by 2, the broadcast source is the group's rank 0 (global rank 1)."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_subgroup_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in ps:
+        p.start()
+    got = dict(q.get(timeout=180) for _ in ps)
+    for p in ps:
+        p.join(60)
+    assert got[0] is None
+    want_rows = torch.tensor([0.0, 10.0, 20.0, 31.0, 41.0])
+    for r in (1, 2):
+        gathered, flat, t, gbuf = (torch.from_numpy(v) for v in got[r])
+        assert torch.equal(gathered, want_rows)
+        assert torch.equal(flat, torch.arange(300, dtype=torch.float32) * 1.5)
+        assert torch.equal(t, torch.full((4,), 1.0))
+        assert torch.equal(gbuf, torch.full((64,), 1.5))
