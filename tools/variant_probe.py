@@ -26,6 +26,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--size', type=int, default=128)
 ap.add_argument('--iters', type=int, default=10)
 ap.add_argument('--json', default=None)
+ap.add_argument('--only', default=None, help='one variant (factor | sum | occlusion)')
+ap.add_argument('--engine-only', action='store_true')
 a = ap.parse_args()
 S, C, N, DEV = a.size, 16, 8, 'cuda'
 VARIANTS = {
@@ -44,6 +46,8 @@ torch.manual_seed(300)
 init = pu.sample_cameras_with_estimate(N, target.camera.to('cpu'))
 out = {'shape': f'SYN({S},{C}), N = {N}, adam_quick', 'variants': {}}
 for name, kw in VARIANTS.items():
+    if a.only and name != a.only:
+        continue
     torch.manual_seed(1)
     ph = Photographer(in_size=S, camera_config=[C, C], predict_color=False, predict_depth=True, predict_mask=True,
                       scale_mode='nearest', cube_size=1.0, **kw).to(DEV)
@@ -58,7 +62,7 @@ for name, kw in VARIANTS.items():
             y, zl, _ = ph.decode(z, cam, return_latent=return_latent, apply_mask=apply_mask)
             return y, (zl.squeeze(0) if return_latent else zl)
     res = {}
-    for mode, use_engine in (('engine', True), ('modules', False)):
+    for mode, use_engine in ((('engine', True),) if a.engine_only else (('engine', True), ('modules', False))):
         est = estimation.load_from_config(cfg, M, converge_patience=10 ** 6, use_engine=use_engine)
         st = est.start(z_obj, target, init.zoom(None, S, dist).to(DEV))
         assert ('engine' in st) == use_engine, (name, mode)
@@ -73,7 +77,8 @@ for name, kw in VARIANTS.items():
         res[mode + '_best_loss'] = st['ranking'][0][1]
         del est, st
         torch.cuda.empty_cache()
-    res['speedup'] = res['engine_iters_per_s'] / res['modules_iters_per_s']
+    if not a.engine_only:
+        res['speedup'] = res['engine_iters_per_s'] / res['modules_iters_per_s']
     out['variants'][name] = res
     del ph
     torch.cuda.empty_cache()
