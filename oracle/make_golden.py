@@ -1015,6 +1015,55 @@ def g25_released_arch(lf):
     print('g25: params %.1f M, loss' % (n_par / 1e6), loss)
 
 
+def g27_training_gradients(lf):
+    """BASELINE cfg 5 at a size the reference finishes in seconds: ONE generator step of the trainer (tools/train/train_reconstruct.py:
+    455-516: Sculptor.encode over the input views with the GRU fuser, Photographer.decode of the output views, hard smooth-L1 depth +
+    BCE mask reconstruction losses x 25) by the REAL reference modules on SYN(32,16), 4 input + 2 output views -- loss terms and the
+    gradient of every parameter, in fp32 and under torch.autocast(cpu, bfloat16) (the harness's stand-in for the trainer's
+    `autocast()`, which is a CUDA context).  The network and the observations are pinned by seeds (latentfusion_amd.synth: plain
+    RNG calls, no product compute), so the fixture holds reference outputs only."""
+    from torch import nn
+    from latentfusion import losses
+    from latentfusion.recon import fusion
+    from latentfusion.recon.inference import LatentFusionModel
+    from latentfusion.recon.models import Photographer, Sculptor
+    sys.path.insert(0, os.path.dirname(HERE))
+    from latentfusion_amd import synth
+    S, C, VI, VO, seed = 32, 16, 4, 2, 2700
+    sck, fck, pck, dist = synth.make_syn_checkpoints(S, C, 'gru', seed, bias_std=0.1)
+    model = LatentFusionModel(Sculptor.from_checkpoint(copy.deepcopy(sck)), fusion.from_checkpoint(copy.deepcopy(fck)),
+                              Photographer.from_checkpoint(copy.deepcopy(pck)), dist, 'cpu')
+    model.train(True)
+    obs_in = model.preprocess_observation(synth_obs(lf, VI, seed + 1))
+    obs_out = model.preprocess_observation(synth_obs(lf, VO, seed + 2))
+    mods = {'s': model.sculptor, 'f': model.fuser, 'p': model.photographer}
+    depth_crit = losses.HardPixelLoss(nn.SmoothL1Loss, k=S * S // 4)
+    mask_crit = nn.BCEWithLogitsLoss(reduction='none')
+
+    def run(autocast):
+        for m in mods.values():
+            m.zero_grad()
+        with torch.autocast('cpu', dtype=torch.bfloat16, enabled=autocast):
+            z_obj, _ = model.sculptor.encode(model.fuser, obs_in.camera, obs_in.color.unsqueeze(0), None, obs_in.mask.unsqueeze(0))
+            y, _, _ = model.photographer.decode(z_obj, obs_out.camera, interpret_logits=True)
+            l_depth = losses.reduce_loss(depth_crit(y['depth'], obs_out.depth.unsqueeze(0)))
+            l_mask = losses.reduce_loss(mask_crit(y['mask_logits'], obs_out.mask.unsqueeze(0)))
+            total = 25.0 * l_depth + 25.0 * l_mask
+        total.backward()
+        grads = {k + '.' + n: p.grad.detach().float().clone() for k, m in mods.items() for n, p in m.named_parameters()}
+        return {'depth_recon': l_depth.detach().float().clone(), 'mask_recon': l_mask.detach().float().clone(),
+                'total': total.detach().float().clone()}, grads
+    l32, g32 = run(False)
+    l16, g16 = run(True)
+    save('g27_training_gradients', {'S': S, 'C': C, 'views_in': VI, 'views_out': VO, 'seed': seed, 'bias_std': 0.1, 'camera_dist': dist,
+                                    'loss_fp32': l32, 'loss_autocast_bf16': l16, 'grad_fp32': g32, 'grad_autocast_bf16': g16})
+    import torch.nn.functional as F
+    a = torch.cat([g16[k].reshape(-1) for k in g32]).double()
+    b = torch.cat([g32[k].reshape(-1) for k in g32]).double()
+    print('g27: total fp32 %.5f bf16 %.5f; cos(bf16 grad, fp32 grad) = %.4f' % (float(l32['total']), float(l16['total']),
+                                                                               float(F.cosine_similarity(a, b, dim=0))))
+
+
 def main():
     lf = refharness.load_reference()
     import latentfusion.recon.utils  # noqa
@@ -1022,7 +1071,7 @@ def main():
     gens = [g0_preprocess, g1_camera, g2_resample, g3_block, g4_fusers, g5_decode, g6_loss, g7_g10_loop, g9_ibr,
             g11_released_like, g12_latent_code, g13_metrics, g14_initial_pose, g15_losses, g16_bop_reader, g17_api_helpers, g18_training_prep,
             g19_metropolis, g20_released_width, g21_bop_scene,
-            g22_photographer_skip, g23_ibr_generator, g24_tile_projection, g25_released_arch]
+            g22_photographer_skip, g23_ibr_generator, g24_tile_projection, g25_released_arch, g27_training_gradients]
     only = sys.argv[1:]                                  # e.g. `python oracle/make_golden.py g13` regenerates one group
     for fn in gens:
         if not only or any(fn.__name__.startswith(o + '_') or fn.__name__ == o for o in only):

@@ -309,3 +309,46 @@ def test_conv16_layers_under_the_storage_policy():
     assert cos(a[1], ref[1]) > 0.999
     for p, q in zip(a[2], ref[2]):
         assert cos(p, q) > 0.999, (p.shape, cos(p, q))
+
+
+@pytest.mark.parametrize('amp', [False, True])
+def test_generator_step_vs_the_reference_fixture(golden, amp):
+    """GeneratorStep on the HIP path against what the REAL reference computed for the same step (fixture g27, oracle/make_golden.py
+    g27_training_gradients: SYN(32,16), GRU fuser, 4 input + 2 output views, hard smooth-L1 depth + BCE mask losses x 25):
+      fp32      loss terms to 1e-4, the gradient of every parameter to 1 % rel-L2 (cosine > 0.9999);
+      autocast  loss within 2 % of the reference under torch.autocast(cpu, bf16), and the whole gradient vector at least as
+                close to the reference's fp32 gradient as the reference's own bf16 gradient is (cosine - 0.03), bf16 storage on."""
+    from latentfusion_amd import synth
+    from latentfusion_amd.modules.geometry import Camera
+    from latentfusion_amd.observation import Observation
+    from latentfusion_amd.recon import training
+    g = golden('g27_training_gradients')
+    S, C, seed = g['S'], g['C'], g['seed']
+    model, _ = synth.build_model(S, C, 'gru', seed=seed, device=DEV, bias_std=g['bias_std'])
+
+    def obs(n, sd):
+        d = synth.make_observation_data(n, sd)
+        return model.preprocess_observation(Observation(d['color'], d['depth'], d['mask'], Camera(d['intrinsic'], d['extrinsic'])).to(DEV))
+    oi, oo = obs(g['views_in'], seed + 1), obs(g['views_out'], seed + 2)
+    step = training.GeneratorStep(model.sculptor, model.fuser, model.photographer, g_depth_recon_loss_k=S * S // 4, use_amp=amp)
+    batch = {'in': {'camera': oi.camera, 'image': oi.color.unsqueeze(0), 'mask': oi.mask.unsqueeze(0)},
+             'out_gt': {'camera': oo.camera, 'depth': oo.depth.unsqueeze(0), 'mask': oo.mask.unsqueeze(0)}}
+    out = step.run_iteration(batch, is_step=False)
+    mods = {'s': model.sculptor, 'f': model.fuser, 'p': model.photographer}
+    got = {k + '.' + n: p.grad.detach().cpu() for k, m in mods.items() for n, p in m.named_parameters()}
+    ref32 = g['grad_fp32']
+    cat = lambda d: torch.cat([d[k].reshape(-1) for k in ref32]).double()      # noqa: E731
+    if not amp:
+        assert abs(float(out['depth_recon']) - float(g['loss_fp32']['depth_recon'])) < 1e-4 * float(g['loss_fp32']['depth_recon'])
+        assert abs(float(out['mask_recon']) - float(g['loss_fp32']['mask_recon'])) < 1e-4 * float(g['loss_fp32']['mask_recon'])
+        for key, want in ref32.items():
+            rel = float((got[key] - want).norm() / want.norm().clamp_min(1e-30))
+            assert rel < 1e-2, (key, rel)
+        assert F.cosine_similarity(cat(got), cat(ref32), dim=0).item() > 0.9999
+    else:
+        want16 = float(g['loss_autocast_bf16']['total'])
+        assert abs(float(out['total']) - want16) < 2e-2 * want16, (float(out['total']), want16)
+        cos_hip = F.cosine_similarity(cat(got), cat(ref32), dim=0).item()
+        cos_ref = F.cosine_similarity(cat(g['grad_autocast_bf16']), cat(ref32), dim=0).item()
+        print(f'g27 autocast: cos(HIP bf16 grad, reference fp32 grad) {cos_hip:.4f}; reference bf16 {cos_ref:.4f}')
+        assert cos_hip > cos_ref - 0.03, (cos_hip, cos_ref)
