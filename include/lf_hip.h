@@ -309,6 +309,27 @@ int lf_resample3d_bwd_vol_det_io(const void* gout, const float* coef, int kind, 
  *                              (either gradient may be NULL)
  *   lf_column_scale_fwd/bwd    out[row][:] = z[row][:] * w[row]  (z * depth_weights_resized, models.py:427-430);
  *                              bwd: gz = gout * w, gw[row] = sum_c gout * z  (gz or gw may be NULL); C % 4 == 0 */
+/* The 17th channel of the OCCLUSION module for the render-loop engine (recon/models.py:378-395 over modules/unet.py's input
+ * block, blocks.py:78-91, and the U-Net's first 3x3x3 convolution, blocks.py:152-158), 16 latent channels: the 17-channel tensors
+ * cat(z, depth coordinate) / input-block output are never built.
+ *   lf_occ_input_fwd   t = LeakyReLU(W1 [z; d] + b1) for the 17 outputs, d = linspace(-1, 1, D)[plane]: ta (outputs 0..15,
+ *                      channels-last [rows][16]) and t16 (output 16, [rows]).
+ *                      w: [17][20] = W1 * he (row = output; 16 latent inputs, depth input at [16]), b: [20]
+ *   lf_occ_conv17_fwd  pre[v][co] = sum_taps w27[tap][co] * t16[v + tap - 1], zero padding; w27: [kz*9 + ky*3 + kx][16] =
+ *                      W2[co][16][kz][ky][kx] * he.  The addend (LF_EPI_ADD) of the lf_conv3d_c16_wino launch over ta.
+ *   lf_occ_conv17_bwd  gp16[u] = LeakyReLU'(t16[u]) * sum_taps sum_co w27[tap][co] * g[u - (tap - 1)][co]
+ *   lf_occ_input_bwd   gz = g_zs * wocc[row] + W1[:16]^T (gta * LeakyReLU'(ta)) + W1[16] * gp16   (g_zs / wocc: the direct term of
+ *                      the occlusion scaling z * wocc, both NULL to leave it out); prev_y != NULL: followed by the epilogue
+ *                      backward of the layer that produced z (saved output prev_y, norm prev_norm, prev_flags), as in
+ *                      lf_conv3x3_bwd_data */
+int lf_occ_input_fwd(const float* z, const float* w, const float* b, float* ta, float* t16, int N, int D, long P, float slope,
+                     void* stream);
+int lf_occ_input_bwd(const float* gta, const float* ta, const float* gp16, const float* w, const float* g_zs, const float* wocc,
+                     float* gz, long rows, float slope, const float* prev_y, const float* prev_norm, unsigned prev_flags,
+                     void* stream);
+int lf_occ_conv17_fwd(const float* t16, const float* w27, float* pre, int N, int D, int H, int W, void* stream);
+int lf_occ_conv17_bwd(const float* g, const float* t16, const float* w27, float* gp16, int N, int D, int H, int W, float slope,
+                      void* stream);
 int lf_column_reduce_sum_fwd(const float* x, float* y, int N, int D, long P, int C, void* stream);
 int lf_column_reduce_sum_bwd(const float* gy, float* gx, int N, int D, long P, int C, void* stream);
 int lf_column_softmax_fwd(const float* logits, float* weights, float* zdepth, int N, int D, long P, void* stream);

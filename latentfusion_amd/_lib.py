@@ -71,6 +71,10 @@ SIGNATURES = {
     'lf_gru_train_stage_b': (c_int, [P, P, P, P, c_long, c_int, P]),
     'lf_gru_train_stage_b_bwd': (c_int, [P, P, P, P, P, P, P, P, P, c_long, c_int, P]),
     'lf_gru_train_stage_a_bwd': (c_int, [P, P, P, P, P, P, P, c_long, c_int, P]),
+    'lf_occ_input_fwd': (c_int, [P, P, P, P, P, c_int, c_int, c_long, c_float, P]),
+    'lf_occ_input_bwd': (c_int, [P, P, P, P, P, P, P, c_long, c_float, P, P, c_uint, P]),
+    'lf_occ_conv17_fwd': (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
+    'lf_occ_conv17_bwd': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     'lf_column_reduce_sum_fwd': (c_int, [P, P, c_int, c_int, c_long, c_int, P]),
     'lf_column_reduce_sum_bwd': (c_int, [P, P, c_int, c_int, c_long, c_int, P]),
     'lf_column_softmax_fwd': (c_int, [P, P, P, c_int, c_int, c_long, P]),

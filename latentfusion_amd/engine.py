@@ -121,6 +121,7 @@ class RenderLoopEngine:
 
     LOSS_KEYS = ('depth', 'ov_depth', 'iou', 'mask')
     EXPLICIT_DECODER = True          # A/B switch (tools/engine_ab.py): False runs a plain 2-D decoder through autograd like a generic one
+    EXPLICIT_OCCLUSION = True        # A/B switch (tools/variant_probe.py): False runs the occlusion module through autograd
 
     @staticmethod
     def supports(photographer, loss_weights):
@@ -199,6 +200,11 @@ class RenderLoopEngine:
         if self.generic_tail and self.split is not None:
             raise NotImplementedError("the split-precision conv modes drive the plain 'factor' renderer only")
         C, D = (self.convs[-1][0].shape[0] if self.convs else self.C), self.S
+        # the occlusion module on this library's kernels, sequenced here like the camera blocks (round 5); None: its
+        # architecture is not the one planned for, it runs as the module with autograd
+        self.occ = None
+        if photographer.occlusion_module is not None and self.wino is not None and C == 16 and RenderLoopEngine.EXPLICIT_OCCLUSION:
+            self.occ = self._plan_occlusion(photographer.occlusion_module)
         cout, pw = C, None
         self.proj = None
         if photographer.projection_type == 'factor':
@@ -241,7 +247,8 @@ class RenderLoopEngine:
         self.dec = None
         dec = photographer.image_decoder
         blocks2d = list(dec.down_blocks) + list(dec.up_blocks)
-        plain = (dec.input_block is None and dec.output_block is None and self.heads is not None and not self.generic_tail
+        plain = (dec.input_block is None and dec.output_block is None and self.heads is not None
+                 and (not self.generic_tail or (self.occ is not None and photographer.projection_type == 'factor'))
                  and (len(dec.up_blocks) < 2 or len(dec.down_blocks) < 2)               # no skip concatenation happens
                  and all(getattr(b, 'interpolate', True) is None for b in blocks2d) and len(blocks2d) > 0
                  and all(c.module.weight.dim() == 4 and tuple(c.module.weight.shape[2:]) == (3, 3) and c.module.weight.shape[0] <= 64
@@ -332,10 +339,118 @@ class RenderLoopEngine:
             return ops.conv3d_c16_wino(g, self.wino[i][1], None, he, 0, prev=prev)[0]
         return ops.conv3x3_bwd_data(g, wt, w.shape[1], he, prev)
 
+    def _tail_leaf(self, act_leaf, zs_leaf, zp_leaf):
+        """The tensor autograd differentiates the 2-D tail back to: the projected latent (factor projection), the scaled volume
+        (explicit occlusion + 'sum'), or the last camera block's output (the tail as modules)."""
+        if self.occ is not None:
+            return zp_leaf if self.proj is not None else zs_leaf
+        return act_leaf if self.generic_tail else zp_leaf
+
     def _proj_bwd_fused(self, gp, acts, norms, flags):
         """Hook: (gradient after the LAST block's data-gradient convolution, index of the next layer to walk) when the projection
         backward is fused into that launch; None here (experimental.RenderLoopEngineX: lf_conv3d_c16_wino_projbwd)."""
         return None
+
+    # ---- occlusion module on explicit kernels ----
+    @staticmethod
+    def _plan_occlusion(om):
+        """Weights of UNet3d(17, 1, [[17, 16], [16, 16]]) without rescaling (the occlusion module as the reference
+        constructs it, recon/models.py:305-306 over modules/unet.py, with a [[17, 16], [16, 16]] block configuration) packed for the explicit sequence, or None for any other shape:
+        input block 1x1x1 17 -> 17 (lf_occ_input_*), conv 17 -> 16 as a 16 -> 16 Winograd launch over outputs 0..15 of the input
+        block plus the 1 -> 16 convolution of its output 16 (lf_occ_conv17_*), three 16 -> 16 convolutions, output block 1x1x1 16 -> 1 without activation."""
+        from .modules.blocks import OutputBlock
+        blocks = list(om.down_blocks) + list(om.up_blocks)
+        ib, ob = om.input_block, om.output_block
+        if (ib is None or not isinstance(ob, OutputBlock) or ob.activation is not None or len(om.down_blocks) != 1
+                or len(om.up_blocks) != 1 or any(b.interpolate is not None for b in blocks)):
+            return None
+        w1, wo = ib.conv.module.weight, ob.conv.module.weight
+        convs = [c for b in blocks for c in (b.conv1, b.conv2)]
+        shapes = [tuple(c.module.weight.shape) for c in convs]
+        if (tuple(w1.shape) != (17, 17, 1, 1, 1) or tuple(wo.shape) != (1, 16, 1, 1, 1) or shapes[0] != (16, 17, 3, 3, 3)
+                or any(sh != (16, 16, 3, 3, 3) for sh in shapes[1:]) or ib.conv.bias is None or ob.conv.bias is None):
+            return None
+        dev = w1.device
+        wi = torch.zeros(17, 20, device=dev, dtype=torch.float32)
+        wi[:, :17] = w1.detach().reshape(17, 17) * ops.he_constant(w1)
+        bi = torch.zeros(20, device=dev, dtype=torch.float32)
+        bi[:17] = ib.conv.bias.detach()
+        w2 = convs[0].module.weight.detach()
+        w2a = w2[:, :16].contiguous()
+        he2 = ops.he_constant(w2)
+        w27 = (w2[:, 16].reshape(16, 27).t() * he2).float().contiguous()              # [tap][co]
+        pk = ops.pack_conv3d_c16_wino
+        first = (convs[0].bias, he2, pk(w2a), pk(w2a, transpose=True), w27)
+        rest = [(c.bias, ops.he_constant(c.module.weight), pk(c.module.weight), pk(c.module.weight, transpose=True)) for c in convs[1:]]
+        wo2 = wo.detach().reshape(1, 16)
+        head = (ob.conv.bias, ops.he_constant(wo), ops.pack_conv1x1(wo2), ops.pack_conv1x1(wo2.t().contiguous()))
+        return dict(wi=wi.contiguous(), bi=bi, first=first, rest=rest, head=head)
+
+    def _occlusion_fwd(self, zc, flags):
+        """zc: output of the last camera block (n,16,S,S,S).  Returns (zs = zc * softmax_D(occlusion logits), saved)."""
+        L = _lib.lib()
+        o, s, dev = self.occ, _s(), self.dev
+        n, _, D, H, W = zc.shape
+        P = H * W
+        ta, t16 = ops.empty_cl(zc.shape, dev), torch.empty(n, 1, D, H, W, device=dev, dtype=torch.float32)
+        with ops._timed('occ_input_fwd'):
+            check(L.lf_occ_input_fwd(zc.data_ptr(), o['wi'].data_ptr(), o['bi'].data_ptr(), ta.data_ptr(), t16.data_ptr(), n, D, P,
+                                     ops.SLOPE, s), 'lf_occ_input_fwd')
+        b2, he2, pa, _pat, w27 = o['first']
+        pre = ops.empty_cl(zc.shape, dev)
+        with ops._timed('occ_conv17_fwd'):
+            check(L.lf_occ_conv17_fwd(t16.data_ptr(), w27.data_ptr(), pre.data_ptr(), n, D, H, W, s), 'lf_occ_conv17_fwd')
+        y, nrm = ops.conv3d_c16_wino(ta, pa, b2, he2, flags, prev=(pre, None, _lib.LF_EPI_ADD), out=pre)
+        ys, ns = [y], [nrm]
+        for (b, he, pk, _pkt) in o['rest']:
+            y, nrm = ops.conv3d_c16_wino(ys[-1], pk, b, he, flags)
+            ys.append(y)
+            ns.append(nrm)
+        hb, hhe, hpk, _hpkt = o['head']
+        logits = torch.empty(n, 1, D, H, W, device=dev, dtype=torch.float32)
+        ops._conv1x1_raw(ys[-1], hpk, hb, n, D * P, 16, 1, D * P * 16, 0, 1, logits, hhe, 0)
+        wocc = torch.empty_like(logits)
+        with ops._timed('column_softmax'):
+            check(L.lf_column_softmax_fwd(logits.data_ptr(), wocc.data_ptr(), None, n, D, P, s), 'lf_column_softmax_fwd')
+        zs = ops.empty_cl(zc.shape, dev)
+        check(L.lf_column_scale_fwd(zc.data_ptr(), wocc.data_ptr(), zs.data_ptr(), n * D * P, 16, s), 'lf_column_scale_fwd')
+        return zs, (ta, t16, ys, ns, wocc)
+
+    def _occlusion_bwd(self, g_zs, zc, saved, flags, prev=None):
+        """d/d(zs) -> d/d(zc): the scaling, the softmax, the output block, the four convolutions (each data-gradient launch folds
+        in the LeakyReLU' / PixelNorm' of the layer it lands on) and the input block, plus the direct term of the scaling.
+        prev = (zc, norm, flags) of the camera-block layer that produced zc: its epilogue backward is applied on the way out."""
+        L = _lib.lib()
+        o, s, dev = self.occ, _s(), self.dev
+        ta, t16, ys, ns, wocc = saved
+        n, _, D, H, W = zc.shape
+        P = H * W
+        gw = torch.empty_like(wocc)
+        # (the direct term g_zs * wocc of the scaling joins the input block's backward below: no volume is written for it)
+        check(L.lf_column_scale_bwd(g_zs.data_ptr(), zc.data_ptr(), wocc.data_ptr(), None, gw.data_ptr(), n * D * P, 16, s),
+              'lf_column_scale_bwd')
+        gl = torch.empty_like(wocc)
+        check(L.lf_column_softmax_bwd(wocc.data_ptr(), gw.data_ptr(), None, gl.data_ptr(), n, D, P, s), 'lf_column_softmax_bwd')
+        _hb, hhe, _hpk, hpkt = o['head']
+        g = ops.empty_cl(zc.shape, dev)
+        check(L.lf_conv1x1_bwd_data(gl.data_ptr(), hpkt.data_ptr(), g.data_ptr(), n, D * P, 1, 16, D * P * 16, 16, 16, 0, hhe,
+                                    ys[-1].data_ptr(), ns[-1].data_ptr(), flags, ops.SLOPE, None, s), 'lf_conv1x1_bwd_data')
+        for i in range(len(o['rest']) - 1, -1, -1):
+            _b, he, _pk, pkt = o['rest'][i]
+            g = ops.conv3d_c16_wino(g, pkt, None, he, 0, prev=(ys[i], ns[i], flags))[0]
+        _b2, he2, _pa, pat, w27 = o['first']
+        gta = ops.conv3d_c16_wino(g, pat, None, he2, 0)[0]
+        gp16 = torch.empty_like(t16)
+        with ops._timed('occ_conv17_bwd'):
+            check(L.lf_occ_conv17_bwd(g.data_ptr(), t16.data_ptr(), w27.data_ptr(), gp16.data_ptr(), n, D, H, W, ops.SLOPE, s),
+                  'lf_occ_conv17_bwd')
+        gz = ops.empty_cl(zc.shape, dev)
+        with ops._timed('occ_input_bwd'):
+            check(L.lf_occ_input_bwd(gta.data_ptr(), ta.data_ptr(), gp16.data_ptr(), o['wi'].data_ptr(), g_zs.data_ptr(),
+                                     wocc.data_ptr(), gz.data_ptr(), n * D * P, ops.SLOPE, zc.data_ptr() if prev is not None else None,
+                                     prev[1].data_ptr() if prev is not None else None, prev[2] if prev is not None else 0, s),
+                  'lf_occ_input_bwd')
+        return gz
 
     def _forward_backward_group(self, params, intr, z_span, need_grad, grad_scale, zt=None, masked_depth=False):
         L = _lib.lib()
@@ -366,8 +481,24 @@ class RenderLoopEngine:
             acts.append(y)
             norms.append(nrm)
         Cl = acts[-1].shape[1]
-        act_leaf = None
-        if self.generic_tail:
+        act_leaf = occ_saved = zs_leaf = None
+        if self.occ is not None:
+            # occlusion weights on explicit kernels; the composite behind them: the factor projection as in the plain renderer
+            # (its own launch: the fused form reads the block's output, not the scaled one), or the 'sum' as a depth-column op
+            zs, occ_saved = self._occlusion_fwd(acts[-1], flags)
+            if self.proj is not None:
+                pw, pb, phe, ppack, ppack_t = self.proj
+                cout = pw.shape[0]
+                zp = ops.empty_cl((n, cout, S, S), dev)
+                with ops._timed('factor_project_fwd'):
+                    pnorm = ops._conv1x1_raw(zs, ppack, pb, n, S * S, Cl, S, S * S * S * Cl, S * S * Cl, cout, zp, phe, flags)
+                zp_leaf = zp.detach().requires_grad_(need_grad)
+            else:
+                zs_leaf = zs.detach().requires_grad_(need_grad)
+                with torch.set_grad_enabled(need_grad):
+                    zp_leaf = ops.column_sum(zs_leaf)
+                zp = zp_leaf
+        elif self.generic_tail:
             # occlusion weights (3-D U-Net logits -> softmax over the depth column -> scale) and / or the 'sum' composite
             # (reference recon/models.py:378-395,427-437), as in Photographer.forward, differentiated by autograd up to the
             # last camera block's output
@@ -471,7 +602,7 @@ class RenderLoopEngine:
                 gp_explicit = g2                                  # d/d(projection pre-activation): dacts[0] is zp itself
                 g_zp = None
             else:
-                g_zp, = torch.autograd.grad(logits, [act_leaf if self.generic_tail else zp_leaf], grad_outputs=[glogits])
+                g_zp, = torch.autograd.grad(logits, [self._tail_leaf(act_leaf, zs_leaf, zp_leaf)], grad_outputs=[glogits])
         else:
             cf_leaf = coefs.detach().requires_grad_(need_grad)
             with torch.set_grad_enabled(need_grad):
@@ -485,16 +616,30 @@ class RenderLoopEngine:
                 objective = total.mean()                     # the optimised quantity (estimation.py:616-617)
             if not need_grad:
                 return losses, None
-            g_zp, g_cf = torch.autograd.grad(objective, [act_leaf if self.generic_tail else zp_leaf, cf_leaf])
+            g_zp, g_cf = torch.autograd.grad(objective, [self._tail_leaf(act_leaf, zs_leaf, zp_leaf), cf_leaf])
 
         # ---- 3-D backward (data gradients only) ----
         fuse = (Cl == 16 and self.C == 16 and all(w.shape[0] == 16 and w.shape[1] == 16 for w, *_ in self.convs))
         nconv = len(self.convs)
         if self.generic_tail:
+            if self.occ is not None:
+                # d/d(scaled volume): the projection's data gradient (factor) or autograd's column-sum gradient ('sum'),
+                # then the occlusion module's explicit backward
+                if self.proj is not None:
+                    gp = gp_explicit if (explicit and gp_explicit is not None) else ops._epilogue_bwd(ops.cl(g_zp), zp, pnorm, flags)
+                    g_zs = ops.empty_cl((n, Cl, S, S, S), dev)
+                    with ops._timed('factor_project_bwd'):
+                        ops._conv1x1_raw(gp, ppack_t, None, n, S * S, cout, 1, S * S * cout, 0, S * Cl, g_zs, phe, 0,
+                                         yaddr=(S * S * S * Cl, Cl, Cl, S * S * Cl))
+                else:
+                    g_zs = ops.cl(g_zp)
+                landed = fuse and nconv > 0
+                g_zp = self._occlusion_bwd(g_zs, acts[-1], occ_saved, flags, (acts[nconv], norms[nconv - 1], flags) if landed else None)
             # g_zp is d/d(output of the last camera block); from here the explicit data-gradient chain
             g = ops.cl(g_zp)
             if fuse and nconv:
-                g = ops._epilogue_bwd(g, acts[nconv], norms[nconv - 1], flags)
+                if self.occ is None:
+                    g = ops._epilogue_bwd(g, acts[nconv], norms[nconv - 1], flags)
                 for i in range(nconv - 1, -1, -1):
                     w, b, he, _wp, wt = self.convs[i]
                     prev = (acts[i], norms[i - 1], flags) if i > 0 else None

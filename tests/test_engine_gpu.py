@@ -889,3 +889,131 @@ def test_engine_with_object_blocks_matches_module_path(golden):
         close(losses[:, 4], rank, atol=5e-6, rtol=5e-5)
         rel = ((gparams - want_g).norm(dim=1) / want_g.norm(dim=1)).max().item()
         assert rel < 2e-3, rel
+
+
+def test_occlusion_seventeenth_channel_kernels():
+    """lf_occ_input_fwd / _bwd and lf_occ_conv17_fwd / _bwd against the expressions they stand for (reference
+    recon/models.py:381-384 over the U-Net's input block, modules/blocks.py:78-91, and the first 3x3x3 convolution,
+    blocks.py:152-158): LeakyReLU(conv1x1(cat(z, depth coordinate)) * he + b) with its 17 outputs written as a 16-channel volume
+    and a scalar volume, the 1 -> 16 convolution of the latter, and their data gradients; fp64 expressions as the yardstick.
+    Ragged sizes (W not a multiple of 4, one-plane volumes)."""
+    from latentfusion_amd import _lib, ops
+    from latentfusion_amd.recon.utils import get_normalized_voxel_depth
+    F = torch.nn.functional
+    L = _lib.lib()
+    gen = torch.Generator().manual_seed(5)
+    s = torch.cuda.current_stream().cuda_stream
+    for (n, D, H, W) in ((3, 12, 6, 10), (2, 1, 5, 7), (1, 4, 4, 64)):
+        z = ops.cl(torch.randn(n, 16, D, H, W, generator=gen).to(DEV))
+        w = torch.randn(17, 17, generator=gen).to(DEV) * 0.4
+        b = torch.randn(17, generator=gen).to(DEV) * 0.2
+        wi = torch.zeros(17, 20, device=DEV)
+        wi[:, :17] = w
+        bi = torch.zeros(20, device=DEV)
+        bi[:17] = b
+        ta, t16 = ops.empty_cl(z.shape, DEV), torch.empty(n, 1, D, H, W, device=DEV)
+        _lib.check(L.lf_occ_input_fwd(z.data_ptr(), wi.data_ptr(), bi.data_ptr(), ta.data_ptr(), t16.data_ptr(), n, D, H * W, 0.2, s), 'fwd')
+        x17 = torch.cat((z, get_normalized_voxel_depth(z)), dim=1).double().requires_grad_(True)
+        t = F.leaky_relu(torch.einsum('oc,ncdhw->nodhw', w.double(), x17) + b.double().view(1, 17, 1, 1, 1), 0.2)
+        close(ta, t[:, :16].float(), atol=2e-6, rtol=1e-5)
+        close(t16, t[:, 16:].float(), atol=2e-6, rtol=1e-5)
+        # 1 -> 16 convolution of the scalar volume and its data gradient
+        w2 = torch.randn(16, 1, 3, 3, 3, generator=gen).to(DEV) * 0.3
+        w27 = w2.reshape(16, 27).t().contiguous()
+        pre = ops.empty_cl(z.shape, DEV)
+        _lib.check(L.lf_occ_conv17_fwd(t16.data_ptr(), w27.data_ptr(), pre.data_ptr(), n, D, H, W, s), 'conv17 fwd')
+        t16d = t16.double().requires_grad_(True)
+        want_pre = F.conv3d(t16d, w2.double(), padding=1)
+        close(pre, want_pre.float(), atol=5e-6, rtol=1e-5)
+        g = ops.cl(torch.randn(n, 16, D, H, W, generator=gen).to(DEV))
+        gp16 = torch.empty_like(t16)
+        _lib.check(L.lf_occ_conv17_bwd(g.data_ptr(), t16.data_ptr(), w27.data_ptr(), gp16.data_ptr(), n, D, H, W, 0.2, s), 'conv17 bwd')
+        gt16, = torch.autograd.grad(want_pre, t16d, g.double())
+        want_gp16 = gt16 * torch.where(t16d > 0, 1.0, 0.2)
+        close(gp16, want_gp16.float(), atol=1e-5, rtol=1e-5)
+        # input block backward with and without the direct term of the scaling
+        gta = ops.cl(torch.randn(n, 16, D, H, W, generator=gen).to(DEV))
+        g_zs = ops.cl(torch.randn(n, 16, D, H, W, generator=gen).to(DEV))
+        wocc = torch.rand(n, 1, D, H, W, generator=gen).to(DEV)
+        gz = ops.empty_cl(z.shape, DEV)
+        _lib.check(L.lf_occ_input_bwd(gta.data_ptr(), ta.data_ptr(), gp16.data_ptr(), wi.data_ptr(), g_zs.data_ptr(), wocc.data_ptr(),
+                                      gz.data_ptr(), n * D * H * W, 0.2, None, None, 0, s), 'bwd')
+        g17 = torch.cat((gta.double(), gt16), dim=1)
+        want, = torch.autograd.grad(t, x17, g17)
+        close(gz, (want[:, :16] + g_zs.double() * wocc.double()).float(), atol=1e-5, rtol=1e-5)
+        gz2 = ops.empty_cl(z.shape, DEV)
+        _lib.check(L.lf_occ_input_bwd(gta.data_ptr(), ta.data_ptr(), gp16.data_ptr(), wi.data_ptr(), None, None,
+                                      gz2.data_ptr(), n * D * H * W, 0.2, None, None, 0, s), 'bwd')
+        close(gz2, want[:, :16].float(), atol=1e-5, rtol=1e-5)
+        # ... followed by the epilogue backward of the layer that produced z (z = PixelNorm(LeakyReLU(pre)))
+        prez = torch.randn(n, 16, D, H, W, generator=gen).to(DEV).double().requires_grad_(True)
+        a_ = F.leaky_relu(prez, 0.2)
+        nrm = (a_.pow(2).mean(dim=1, keepdim=True) + 1e-8).sqrt()
+        yz = a_ / nrm
+        want3, = torch.autograd.grad(yz, prez, want[:, :16])
+        yz32, nrm32 = ops.cl(yz.detach().float()), nrm.detach().float().reshape(-1).contiguous()
+        gz3 = ops.empty_cl(z.shape, DEV)
+        _lib.check(L.lf_occ_input_bwd(gta.data_ptr(), ta.data_ptr(), gp16.data_ptr(), wi.data_ptr(), None, None, gz3.data_ptr(),
+                                      n * D * H * W, 0.2, yz32.data_ptr(), nrm32.data_ptr(), 3, s), 'bwd')
+        close(gz3, want3.float(), atol=2e-5, rtol=2e-5)
+
+
+@pytest.mark.parametrize('projection', ['factor', 'sum'])
+def test_engine_occlusion_module_on_explicit_kernels(golden, projection):
+    """The 16-channel occlusion renderer (UNet3d(17, 1, [[17, 16], [16, 16]]), reference recon/models.py:305-306,378-395,427-430)
+    sequenced by the engine on explicit kernels -- input block without the 17-channel concatenation, the 17 -> 16 convolution as
+    two 16-channel Winograd launches, every data gradient with the previous layer's epilogue backward folded in -- against (a) the
+    same engine with the occlusion module run as modules under autograd and (b) the estimator's module path."""
+    from latentfusion_amd.engine import RenderLoopEngine
+    from latentfusion_amd.pose import estimation
+    from latentfusion_amd.recon.models import Photographer
+    g = golden('g7_adam_trace')
+    target = _target(g)
+    S = 32
+    torch.manual_seed(11)
+    ph = Photographer(in_size=S, camera_config=[16, 16], object_config=[16, 16], occlusion_config=[[17, 16], [16, 16]],
+                      image_config=[[16, 32], [32, 16]], projection_type=projection, predict_color=False, predict_depth=True,
+                      predict_mask=True, scale_mode='nearest', cube_size=1.0).to(DEV)
+    with torch.no_grad():
+        for name, p in ph.named_parameters():
+            if name.endswith('bias'):
+                p.normal_(0.0, 0.1)
+    for p in ph.parameters():
+        p.requires_grad_(False)
+    weights = {'depth': 1.0, 'ov_depth': 0.3, 'iou': 0.2, 'mask': 0.4}
+    z_obj = torch.randn(1, 1, 16, S, S, S, generator=torch.Generator().manual_seed(3)).to(DEV)
+    cam0 = prod_camera(g['init']).zoom(None, S, 1.0)
+    eng = RenderLoopEngine(ph, z_obj, target, weights)
+    assert eng.occ is not None and eng.generic_tail and (eng.dec is not None) == (projection == 'factor')
+    losses, gparams = eng.forward_backward(cam0)
+    again = eng.forward_backward(cam0)
+    assert torch.equal(again[0], losses) and torch.equal(again[1], gparams)
+    RenderLoopEngine.EXPLICIT_OCCLUSION = False
+    try:
+        ref_eng = RenderLoopEngine(ph, z_obj, target, weights)
+    finally:
+        RenderLoopEngine.EXPLICIT_OCCLUSION = True
+    assert ref_eng.occ is None
+    want_l, want_g = ref_eng.forward_backward(cam0)
+    close(losses[:, :5], want_l[:, :5], atol=5e-6, rtol=5e-5)
+    rel = ((gparams - want_g).norm(dim=1) / want_g.norm(dim=1)).max().item()
+    assert rel < 1e-3, rel
+
+    class _M:
+        photographer, device, input_size, camera_dist = ph, torch.device(DEV), S, 1.0
+
+        @staticmethod
+        def render_latent_object(z, cam, return_latent=True, apply_mask=True):
+            y, zl, _ = ph.decode(z, cam, return_latent=return_latent, apply_mask=apply_mask)
+            return y, (zl.squeeze(0) if return_latent else zl)
+    est = estimation.GradientPoseEstimator(model=_M, learning_rate=0.01, num_samples=len(cam0), num_iters=1, ranking_size=len(cam0),
+                                           converge_threshold=1e-6, converge_patience=10, optimizer='adam', loss_weights=weights,
+                                           use_engine=False)
+    st = est.start(z_obj, target, cam0.to(DEV))
+    ld, _, rank, _ = est.loss_and_grad(z_obj, target, st['cam'])
+    mod_g = torch.cat((st['cam'].log_quaternion.grad, st['cam'].translation.grad, st['cam'].viewport.grad), dim=1)
+    close(losses[:, 4], rank, atol=5e-6, rtol=5e-5)
+    rel = ((gparams - mod_g).norm(dim=1) / mod_g.norm(dim=1)).max().item()
+    assert rel < 2e-3, rel
+    fwd_only, none = eng.forward_backward(cam0, need_grad=False)
+    assert none is None and torch.equal(fwd_only, losses)
