@@ -287,10 +287,14 @@ int lf_gru_train_stage_a_bwd(const void* grh, const void* rpre, const float* h, 
 
 /* Storage-type variants of the 16-channel resampler for the training step (io bit 0: the source, bit 1: the destination is a
  * bf16 channels-last volume; same fp32 interpolation / same fixed-point sums as lf_resample3d_fwd / lf_resample3d_bwd_vol_det
- * with C = 16; scratch: lf_resample3d_bwd_vol_det_io_scratch_bytes, the box lists of the tiled splat only). */
+ * with C = 16).  The splat runs in BINNED form: the output voxels are first listed under the source tiles their corners touch
+ * (count / scan / fill, <= 8 entries per voxel), then one workgroup per tile adds exactly its lists into 64-bit LDS accumulators
+ * -- same integers, bit-identical to the tile / atomic forms of lf_resample3d_bwd_vol_det (3.7 -> 2.5 ms at 8 x 128^3).  A volume
+ * per sample (vol_n == N) is processed in passes of as many samples as 512 MB of lists hold; one shared volume (vol_n == 1)
+ * needs all samples in one pass and otherwise takes the tile form.  scratch: lf_resample3d_bwd_vol_det_io_scratch_bytes. */
 int lf_resample3d_fwd_io(const void* vol, int vol_n, const float* coef, int kind, void* out, int N, int D, int H, int W,
                          int io, void* stream);
-size_t lf_resample3d_bwd_vol_det_io_scratch_bytes(int N, int D, int H, int W);
+size_t lf_resample3d_bwd_vol_det_io_scratch_bytes(int vol_n, int N, int D, int H, int W);
 int lf_resample3d_bwd_vol_det_io(const void* gout, const float* coef, int kind, void* gvol, int vol_n, void* scratch,
                                  size_t scratch_bytes, int N, int D, int H, int W, int io, void* stream);
 

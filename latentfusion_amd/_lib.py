@@ -96,7 +96,7 @@ SIGNATURES = {
     'lf_epilogue_bwd_c16_scratch_bytes': (c_size_t, [c_long]),
     'lf_epilogue_bwd_c16': (c_int, [P, P, P, P, P, P, c_size_t, c_long, c_uint, c_float, c_int, P]),
     'lf_resample3d_fwd_io': (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
-    'lf_resample3d_bwd_vol_det_io_scratch_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
+    'lf_resample3d_bwd_vol_det_io_scratch_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     'lf_resample3d_bwd_vol_det_io': (c_int, [P, P, c_int, P, c_int, P, c_size_t, c_int, c_int, c_int, c_int, c_int, P]),
     'lf_resize_fwd': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     'lf_resize_bwd': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),

@@ -846,9 +846,18 @@ __global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x
   if ((threadIdx.x & 63) == 0 && m > 0.f && m < 3.0e38f) atomicMax(out, __float_as_uint(m));   // max is order-independent
 }
 
+// (n a multiple of 16 and x 16-byte aligned: channels-last 16-channel records; a lane reads 8 values per load)
 __global__ void __launch_bounds__(256) absmax_bf16_kernel(const __bf16* __restrict__ x, long n, unsigned* __restrict__ out) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   float m = 0.f;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf((float)x[i]));
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n / 8; i += (long)gridDim.x * 256) {
+    const u32x4 r = ((const u32x4*)x)[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                                  // |bf16| as fp32: the 16 bits shifted into the high half, sign cleared
+      m = fmaxf(m, __uint_as_float((r[k] << 16) & 0x7fffffffu));
+      m = fmaxf(m, __uint_as_float(r[k] & 0x7fff0000u));
+    }
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
   if ((threadIdx.x & 63) == 0 && m > 0.f && m < 3.0e38f) atomicMax(out, __float_as_uint(m));
@@ -1065,7 +1074,167 @@ __global__ void __launch_bounds__(256) splat_tile_kernel(const float* __restrict
   }
 }
 
-int g_splat_variant = 2;      // deterministic splat (lf_set_tuning key 4): 1 = global 64-bit atomics, 2 = source tiles in LDS (C == 16)
+// ---- binned form of the same sums (round 5: the camera -> object splat of the training step, a volume per sample, and the
+// object -> camera one, all samples into one volume).  The tile form above finds the output voxels that touch a source tile by culling boxes: at 128^3 a workgroup
+// walks 512 super-block boxes and then re-evaluates 40-75 blocks of 64 samples of which a tenth lands in its tile (12.4 ms for
+// 32 views, the largest kernel of the step).  Here the output voxels are BINNED by the source tiles their corners touch first
+// (count, scan, fill: 1.6 list entries per voxel on average, 8 at most), and a tile's workgroup evaluates exactly its list:
+//   bin<FILL = false>  per output voxel: the <= 8 distinct tiles of its corner voxels, one wave-aggregated atomic add per tile
+//                      and wave on the tile's counter;
+//   scan               exclusive prefix of a sample's tile counters;
+//   bin<FILL = true>   the same walk, now storing the voxel (z << 20 | y << 10 | x) at offset[tile] + slot;
+//   binned tile        64-bit LDS accumulators as above, one LANE per list entry (all 16 channels), conversion and store as above.
+// The order of a list depends on the atomics; the integer sums do not: bit-identical to the other two forms.
+template <int KIND, bool FILL>
+__global__ void __launch_bounds__(256) splat_bin_kernel(const float* __restrict__ coef, unsigned* __restrict__ cnt,
+                                                        const unsigned* __restrict__ off, unsigned* __restrict__ list, int n0, long nvox,
+                                                        long cap, int ntiles, int ntx, int nty, int D, int H, int W, Steps st) {
+  const int lane = threadIdx.x & 63;
+  const int nl = blockIdx.y;                                       // sample within the chunk
+  // a wave takes a 4x4x4 block of output voxels: its samples land in one or two tiles per axis (a row of 64 voxels would
+  // cross four to eight), so the aggregation loop below runs once or twice per corner combination
+  const int nbx = (W + 3) >> 2, nby = (H + 3) >> 2, nbz = (D + 3) >> 2;
+  const long blk = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const bool wave_live = blk < (long)nbx * nby * nbz;
+  const long bq = wave_live ? blk : 0;
+  const int x = (int)(bq % nbx) * 4 + (lane & 3), y = (int)((bq / nbx) % nby) * 4 + ((lane >> 2) & 3), z = (int)(bq / ((long)nbx * nby)) * 4 + (lane >> 4);
+  const bool live = wave_live && x < W && y < H && z < D;
+  const SplatTap t = splat_eval<KIND>(coef + (long)(n0 + nl) * LF_MAP_COEFS, min(x, W - 1), min(y, H - 1), min(z, D - 1), W, H, D, st);
+  const int tx[2] = {t.x0 / STX, t.x1 / STX}, ty[2] = {t.y0 / STY, t.y1 / STY}, tz[2] = {t.z0 / STZ, t.z1 / STZ};
+  unsigned* c = cnt + (long)nl * ntiles;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int kx = k & 1, ky = (k >> 1) & 1, kz = k >> 2;
+    // a combination is a NEW tile iff every axis it takes the upper corner on really changes tile there
+    const bool act = live && (!kx || tx[1] != tx[0]) && (!ky || ty[1] != ty[0]) && (!kz || tz[1] != tz[0]);
+    const int tile = (tz[kz] * nty + ty[ky]) * ntx + tx[kx];
+    unsigned long long todo = __ballot(act);
+    while (todo) {                                                 // (wave-uniform loop: one atomic per distinct tile and wave)
+      const int leader = __builtin_ctzll(todo);
+      const int lt = __shfl(tile, leader, 64);
+      const unsigned long long same = __ballot(act && tile == lt);
+      unsigned base = 0;
+      if (lane == leader) base = atomicAdd(c + lt, (unsigned)__builtin_popcountll(same));
+      if (FILL) {
+        base = __shfl(base, leader, 64);
+        if (act && tile == lt) {
+          const unsigned slot = base + (unsigned)__builtin_popcountll(same & ((1ull << lane) - 1ull));
+          list[(long)nl * cap + off[(long)nl * ntiles + lt] + slot] = ((unsigned)z << 20) | ((unsigned)y << 10) | (unsigned)x;
+        }
+      }
+      todo &= ~same;
+    }
+  }
+}
+
+// exclusive prefix sums of each sample's tile counters (one workgroup per sample)
+__global__ void __launch_bounds__(256) splat_scan_kernel(const unsigned* __restrict__ cnt, unsigned* __restrict__ off, int ntiles) {
+  __shared__ unsigned part[256];
+  const unsigned* c = cnt + (long)blockIdx.x * ntiles;
+  unsigned* o = off + (long)blockIdx.x * ntiles;
+  const int per = (ntiles + 255) / 256, b = threadIdx.x * per, e = min(b + per, ntiles);
+  unsigned sum = 0;
+  for (int i = b; i < e; ++i) sum += c[i];
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned run = 0;
+    for (int i = 0; i < 256; ++i) { const unsigned p = part[i]; part[i] = run; run += p; }
+  }
+  __syncthreads();
+  unsigned run = part[threadIdx.x];
+  for (int i = b; i < e; ++i) { o[i] = run; run += c[i]; }
+}
+
+template <int KIND, int IO>
+__global__ void __launch_bounds__(256) splat_binned_tile_kernel(const float* __restrict__ gout, const float* __restrict__ coef,
+                                                                const unsigned* __restrict__ cnt, const unsigned* __restrict__ off,
+                                                                const unsigned* __restrict__ list, const unsigned* __restrict__ amax,
+                                                                float* __restrict__ gvol, int n0, int m, int shared, long nvox, long cap,
+                                                                int ntiles, int ntx, int nty, int D, int H, int W, Steps st) {
+  __shared__ unsigned long long acc[STZ * STY * STX * SACC];
+  const int tid = threadIdx.x;
+  const int tile = blockIdx.x;
+  // a volume per sample: blockIdx.y is the sample; one volume shared by the m samples: the workgroup walks their m lists
+  const int nl_first = shared ? 0 : (int)blockIdx.y, nl_last = shared ? m : (int)blockIdx.y + 1;
+  const long n_out = shared ? 0 : n0 + (long)blockIdx.y;
+  const int tx0 = (tile % ntx) * STX, ty0 = ((tile / ntx) % nty) * STY, tz0 = (tile / (ntx * nty)) * STZ;
+  unsigned total = 0;
+  for (int nl = nl_first; nl < nl_last; ++nl) total |= cnt[(long)nl * ntiles + tile];
+  if (total == 0) {                                                // nothing lands here (more than half of the camera volume's tiles
+    const int lx = tid % STX, ly = (tid / STX) % STY, lz = tid / (STX * STY);   // when the object fills part of it): zeros, no LDS pass
+    const int x = tx0 + lx, y = ty0 + ly, z = tz0 + lz;
+    if (x < W && y < H && z < D) {
+      constexpr int OREC = (IO & 2) ? 32 : 64;
+      f32x4* dst = (f32x4*)((char*)gvol + (n_out * nvox + (((long)z * H + y) * W + x)) * OREC);
+#pragma unroll
+      for (int k = 0; k < OREC / 16; ++k) dst[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    return;
+  }
+  for (int i = tid; i < STZ * STY * STX * SACC; i += 256) acc[i] = 0ull;
+  const float scale = fixed_scale(amax);
+  __syncthreads();
+  // a lane quad per list entry, four channels each (as the tile form: the lanes of one atomic instruction then spread over 16
+  // records x 4 slots; one lane per entry measured 2.7x slower -- clamped samples pile up on border voxels and 64 lanes on one
+  // address serialise); corners of weight zero (the far corner on an axis a sample was clamped on) add nothing and are skipped
+  const int q = tid & 3;
+  for (int nl = nl_first; nl < nl_last; ++nl) {
+    const float* cf = coef + (long)(n0 + nl) * LF_MAP_COEFS;
+    const char* gs = (const char*)gout + (long)(n0 + nl) * nvox * ((IO & 1) ? 32 : 64);
+    const unsigned count = cnt[(long)nl * ntiles + tile];
+    const unsigned* mine = list + (long)nl * cap + off[(long)nl * ntiles + tile];
+    for (unsigned i = tid >> 2; i < count; i += 64) {
+      const unsigned pk = mine[i];                                  // z << 20 | y << 10 | x
+      const int x = (int)(pk & 1023u), y = (int)((pk >> 10) & 1023u), z = (int)(pk >> 20);
+      const long v = ((long)z * H + y) * W + x;
+      const SplatTap t = splat_eval<KIND>(cf, x, y, z, W, H, D, st);
+      f32x4 g4;
+      if constexpr ((IO & 1) != 0) g4 = __builtin_convertvector(*(const bf16x4r*)(gs + (long)v * 32 + q * 8), f32x4);
+      else g4 = *(const f32x4*)(gs + (long)v * 64 + q * 16);
+      g4 = g4 * scale;
+#define SPLAT_B(Z, Y, X, WI) do { \
+        const int lz_ = (Z) - tz0, ly_ = (Y) - ty0, lx_ = (X) - tx0; \
+        if (t.w[WI] != 0.f && (unsigned)lz_ < (unsigned)STZ && (unsigned)ly_ < (unsigned)STY && (unsigned)lx_ < (unsigned)STX) { \
+          unsigned long long* d_ = acc + ((lz_ * STY + ly_) * STX + lx_) * SACC + q * 4; \
+          _Pragma("unroll") for (int e = 0; e < 4; ++e) atomicAdd(d_ + e, fixed_round(g4[e] * t.w[WI])); \
+        } } while (0)
+      SPLAT_B(t.z0, t.y0, t.x0, 0); SPLAT_B(t.z0, t.y0, t.x1, 1);
+      SPLAT_B(t.z0, t.y1, t.x0, 2); SPLAT_B(t.z0, t.y1, t.x1, 3);
+      SPLAT_B(t.z1, t.y0, t.x0, 4); SPLAT_B(t.z1, t.y0, t.x1, 5);
+      SPLAT_B(t.z1, t.y1, t.x0, 6); SPLAT_B(t.z1, t.y1, t.x1, 7);
+#undef SPLAT_B
+    }
+  }
+  __syncthreads();
+  const int lx = tid % STX, ly = (tid / STX) % STY, lz = tid / (STX * STY);
+  const int x = tx0 + lx, y = ty0 + ly, z = tz0 + lz;
+  if (x < W && y < H && z < D) {
+    constexpr int OREC = (IO & 2) ? 32 : 64;
+    char* dst = (char*)gvol + (n_out * nvox + (((long)z * H + y) * W + x)) * OREC;
+    const double inv = (double)scale;
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) {
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (float)((double)(long long)acc[tid * SACC + c4 * 4 + e] / inv);
+      if constexpr ((IO & 2) != 0) *(bf16x4r*)(dst + c4 * 8) = __builtin_convertvector(o, bf16x4r);
+      else *(f32x4*)(dst + c4 * 16) = o;
+    }
+  }
+}
+
+// samples per pass of the binned form: the lists are sized for the worst case (8 entries per voxel), 512 MB at most
+int g_splat_chunk_cap = 0;                                        // lf_set_tuning key 6: samples per pass at most (0 = by memory only)
+inline int splat_bin_chunk(int N, long nvox) {
+  long cv = (512L << 20) / (nvox * 32);
+  if (cv < 1) cv = 1;
+  if (g_splat_chunk_cap > 0 && cv > g_splat_chunk_cap) cv = g_splat_chunk_cap;
+  return (int)(cv < N ? cv : N);
+}
+
+int g_splat_variant = 2;      // deterministic splat (lf_set_tuning key 4): 1 = global 64-bit atomics, 2 = source tiles in LDS (C == 16;
+                              // lf_resample3d_bwd_vol_det_io: binned lists when every sample has its own volume), 3 = as 2 without the binned form
 
 bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
@@ -1266,7 +1435,12 @@ extern "C" int lf_set_tuning(int key, int value) {
   }
   if (key == 4) {
     const int prev = g_splat_variant;
-    if (value == 1 || value == 2) g_splat_variant = value;
+    if (value >= 1 && value <= 3) g_splat_variant = value;
+    return prev;
+  }
+  if (key == 6) {
+    const int prev = g_splat_chunk_cap;
+    if (value >= 0) g_splat_chunk_cap = value;
     return prev;
   }
   if (key == 3) return lf_internal_fused_set_cfg(value);            // fused wide-conv GEMM: workgroup shape 0..3, -1 = by shape
@@ -1300,7 +1474,7 @@ extern "C" int lf_resample3d_bwd_vol_det(const float* gout, const float* coef, i
   const long nblk = (long)nbx * nby * nbz;
   const int ntx = (W + STX - 1) / STX, nty = (H + STY - 1) / STY, ntz = (D + STZ - 1) / STZ;
   const int nsx = (nbx + 3) / 4, nsy = (nby + 3) / 4, nsz = (nbz + 3) / 4, nsb = nsx * nsy * nsz;
-  if (g_splat_variant == 2 && C == 16 && lf_aligned16(gout) && lf_aligned16(gvol) && D < 0x7fff && H < 0x7fff && W < 0x7fff &&
+  if (g_splat_variant >= 2 && C == 16 && lf_aligned16(gout) && lf_aligned16(gvol) && D < 0x7fff && H < 0x7fff && W < 0x7fff &&
       nblk < 0x7fffffffL / 4 && (long)ntx * nty * ntz < 0x7fffffffL && N <= 65535 &&
       scratch_bytes >= 256 + (size_t)N * (nblk + nsb) * sizeof(uint3)) {
     // tiled form: scratch = [amax (256 B)] [block boxes: N x blocks x 12 B] [super-block boxes: N x super-blocks x 12 B]
@@ -1366,13 +1540,26 @@ extern "C" int lf_resample3d_fwd_io(const void* vol, int vol_n, const float* coe
   return lf_launch_status();
 }
 
-// scratch of the tiled form alone: [amax (256 B)] [block boxes] [super-block boxes] (a few MB; the generic entry point also
-// reserves the fixed-point volume of its atomic form)
-extern "C" size_t lf_resample3d_bwd_vol_det_io_scratch_bytes(int N, int D, int H, int W) {
+// scratch: the tile form: [amax (256 B)] [block boxes] [super-block boxes] (a few MB); the binned form: [amax (256 B)]
+// [counters | cursors | offsets: 3 x chunk x tiles u32] [lists: chunk x voxels x 8 u32], chunk = samples per pass (lists of at
+// most 512 MB)
+static bool splat_binned_ok(int vol_n, int N, int D, int H, int W) {
+  if (g_splat_variant == 3 || W > 1024 || H > 1024 || D > 4096) return false;
+  // a volume per sample: passes of `chunk` samples; one shared volume: its tile accumulators live for ONE pass, all samples in it
+  return vol_n == N || splat_bin_chunk(N, (long)D * H * W) == N;
+}
+
+extern "C" size_t lf_resample3d_bwd_vol_det_io_scratch_bytes(int vol_n, int N, int D, int H, int W) {
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
   const long nbx = (W + 3) / 4, nby = (H + 3) / 4, nbz = (D + 3) / 4;
   const long nsb = ((nbx + 3) / 4) * ((nby + 3) / 4) * ((nbz + 3) / 4);
-  return 256 + (size_t)N * (size_t)(nbx * nby * nbz + nsb) * sizeof(uint3);
+  const size_t boxes = 256 + (size_t)N * (size_t)(nbx * nby * nbz + nsb) * sizeof(uint3);
+  const long nvox = (long)D * H * W;
+  const long nt = (long)((W + STX - 1) / STX) * ((H + STY - 1) / STY) * ((D + STZ - 1) / STZ);
+  const long cv = splat_bin_chunk(N, nvox);
+  const size_t lists = 256 + (size_t)(3 * cv * nt * 4) + (size_t)(cv * nvox * 32);
+  // (sized for either form: lf_set_tuning may switch between them after the caller asked)
+  return boxes > lists ? boxes : lists;
 }
 
 extern "C" int lf_resample3d_bwd_vol_det_io(const void* gout, const float* coef, int kind, void* gvol, int vol_n, void* scratch,
@@ -1380,10 +1567,55 @@ extern "C" int lf_resample3d_bwd_vol_det_io(const void* gout, const float* coef,
   lf_clear_error();
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || io < 0 || io > 3) return LF_EINVAL;
   if ((vol_n != 1 && vol_n != N) || (kind != LF_MAP_O2C && kind != LF_MAP_C2O)) return LF_EINVAL;
-  if (scratch == nullptr || scratch_bytes < lf_resample3d_bwd_vol_det_io_scratch_bytes(N, D, H, W)) return LF_ENOSPC;
+  if (scratch == nullptr || scratch_bytes < lf_resample3d_bwd_vol_det_io_scratch_bytes(vol_n, N, D, H, W)) return LF_ENOSPC;
   if ((((uintptr_t)scratch) & 7u) != 0 || !lf_aligned16(gout) || !lf_aligned16(gvol)) return LF_EALIGN;
   hipStream_t s = (hipStream_t)stream;
   const long ng = (long)D * H * W * 16 * N;
+  if (splat_binned_ok(vol_n, N, D, H, W)) {
+    // binned form (list entries pack z | y | x into 12 + 10 + 10 bits)
+    const long nvox = (long)D * H * W;
+    const int ntx = (W + STX - 1) / STX, nty = (H + STY - 1) / STY, ntz = (D + STZ - 1) / STZ;
+    const long nt = (long)ntx * nty * ntz;
+    if (nvox >= 0xffffffffL || nt >= 0x7fffffffL || N > 65535) return LF_EINVAL;
+    const int cv = splat_bin_chunk(N, nvox);
+    const long cap = nvox * 8;
+    unsigned* amax = (unsigned*)scratch;
+    unsigned* cnt = (unsigned*)((char*)scratch + 256);
+    unsigned* cur = cnt + (size_t)cv * nt;
+    unsigned* off = cur + (size_t)cv * nt;
+    unsigned* list = off + (size_t)cv * nt;
+    hipError_t e = hipMemsetAsync(scratch, 0, 256, s);
+    if (e != hipSuccess) return (int)e;
+    if (io & 1) hipLaunchKernelGGL(absmax_bf16_kernel, dim3((unsigned)min((ng + 255) / 256, 4096L)), dim3(256), 0, s, (const __bf16*)gout, ng, amax);
+    else hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)min((ng + 255) / 256, 4096L)), dim3(256), 0, s, (const float*)gout, ng, amax);
+    const Steps stp = make_steps(D, H, W);
+    typedef void (*tile_t)(const float*, const float*, const unsigned*, const unsigned*, const unsigned*, const unsigned*, float*, int, int,
+                           int, long, long, int, int, int, int, int, int, Steps);
+    static const tile_t tiles[2][4] = {
+        {splat_binned_tile_kernel<LF_MAP_O2C, 0>, splat_binned_tile_kernel<LF_MAP_O2C, 1>, splat_binned_tile_kernel<LF_MAP_O2C, 2>,
+         splat_binned_tile_kernel<LF_MAP_O2C, 3>},
+        {splat_binned_tile_kernel<LF_MAP_C2O, 0>, splat_binned_tile_kernel<LF_MAP_C2O, 1>, splat_binned_tile_kernel<LF_MAP_C2O, 2>,
+         splat_binned_tile_kernel<LF_MAP_C2O, 3>}};
+    for (int n0 = 0; n0 < N; n0 += cv) {
+      const int m = min(cv, N - n0);
+      e = hipMemsetAsync(cnt, 0, (size_t)2 * cv * nt * 4, s);
+      if (e != hipSuccess) return (int)e;
+      const dim3 gbin((unsigned)(((long)((W + 3) / 4) * ((H + 3) / 4) * ((D + 3) / 4) + 3) / 4), (unsigned)m);
+      if (kind == LF_MAP_O2C) {
+        hipLaunchKernelGGL((splat_bin_kernel<LF_MAP_O2C, false>), gbin, dim3(256), 0, s, coef, cnt, off, list, n0, nvox, cap, (int)nt, ntx, nty, D, H, W, stp);
+        hipLaunchKernelGGL(splat_scan_kernel, dim3((unsigned)m), dim3(256), 0, s, cnt, off, (int)nt);
+        hipLaunchKernelGGL((splat_bin_kernel<LF_MAP_O2C, true>), gbin, dim3(256), 0, s, coef, cur, off, list, n0, nvox, cap, (int)nt, ntx, nty, D, H, W, stp);
+      } else {
+        hipLaunchKernelGGL((splat_bin_kernel<LF_MAP_C2O, false>), gbin, dim3(256), 0, s, coef, cnt, off, list, n0, nvox, cap, (int)nt, ntx, nty, D, H, W, stp);
+        hipLaunchKernelGGL(splat_scan_kernel, dim3((unsigned)m), dim3(256), 0, s, cnt, off, (int)nt);
+        hipLaunchKernelGGL((splat_bin_kernel<LF_MAP_C2O, true>), gbin, dim3(256), 0, s, coef, cur, off, list, n0, nvox, cap, (int)nt, ntx, nty, D, H, W, stp);
+      }
+      const int shared = vol_n == 1 && N > 1;
+      hipLaunchKernelGGL(tiles[kind == LF_MAP_O2C ? 0 : 1][io], dim3((unsigned)nt, (unsigned)(shared ? 1 : m)), dim3(256), 0, s, (const float*)gout,
+                         coef, cnt, off, list, amax, (float*)gvol, n0, m, shared, nvox, cap, (int)nt, ntx, nty, D, H, W, stp);
+    }
+    return lf_launch_status();
+  }
   const int nbx = (W + 3) / 4, nby = (H + 3) / 4, nbz = (D + 3) / 4;
   const long nblk = (long)nbx * nby * nbz;
   const int ntx = (W + STX - 1) / STX, nty = (H + STY - 1) / STY, ntz = (D + STZ - 1) / STZ;

@@ -96,7 +96,7 @@ class _ResampleAC(torch.autograd.Function):
         g = cl(gout)
         n, C, D, H, W = g.shape
         gv = empty_cl16((vol_n, 16, D, H, W), g.device, vdtype == torch.bfloat16)
-        nb = L.lf_resample3d_bwd_vol_det_io_scratch_bytes(n, D, H, W)
+        nb = L.lf_resample3d_bwd_vol_det_io_scratch_bytes(vol_n, n, D, H, W)
         scr = torch.empty(nb // 8 + 1, device=g.device, dtype=torch.int64)
         io = (1 if g.dtype == torch.bfloat16 else 0) | (2 if gv.dtype == torch.bfloat16 else 0)
         with _timed('resample_bwd_vol', f'{kind}:{n}:io{io}'):

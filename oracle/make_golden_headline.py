@@ -1,6 +1,9 @@
 """Generates tests/golden/g26_headline_trace.pt from the REAL reference at the HEADLINE shape (build container only).
 
     python oracle/make_golden_headline.py [T]          # T = pose iterations (default 100 = the adam_quick preset's length)
+    python oracle/make_golden_headline.py T TARGET_SEED INIT_SEED NAME     # further seeds of the target frame / the initial
+                                                                           # hypotheses -> tests/golden/NAME.pt (same object; the
+                                                                           # latent volume is not stored again)
 
 BASELINE cfg 2 exactly as bench.py runs it: SYN(128,16) with the GRU fuser (weights seed 0), 16 reference views (seed 100),
 one target frame (seed 200), 8 initial hypotheses (seed 300), configs/adam_quick.toml.  The REFERENCE (imported from
@@ -29,7 +32,12 @@ SEED_MODEL, SEED_REF, SEED_TARGET, SEED_INIT = 0, 100, 200, 300
 
 
 def main():
+    global SEED_TARGET, SEED_INIT
     T = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    name = 'g26_headline_trace'
+    if len(sys.argv) > 4:
+        SEED_TARGET, SEED_INIT, name = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    lean = name != 'g26_headline_trace'
     refharness.load_reference()
     import tomli
     from latentfusion.modules.geometry import Camera
@@ -101,7 +109,10 @@ def main():
         'hist_viewport': torch.stack([c.viewport for _, c in hist]),
         'best': cam_dict(best), 'reference_seconds_per_iteration': el / T, 'reference_threads': torch.get_num_threads(),
     }
-    save('g26_headline_trace', out)
+    if lean:
+        for k in ('z_obj_sub', 'z_obj_channel_mean', 'z_obj_channel_sq'):
+            del out[k]
+    save(name, out)
     top2 = torch.sort(rank, dim=1).values
     print('argmin per iteration:', out['argmin'].tolist())
     print('min top-2 gap: %.3e' % float((top2[:, 1] - top2[:, 0]).min()))

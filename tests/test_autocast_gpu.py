@@ -232,8 +232,8 @@ def test_resampler_bf16_storage_variants():
         g = ops.cl(ops.round_bf16((torch.randn(N, 16, S, S, S, generator=gen) * 1e-2).to(DEV)))
         ref = ops.empty_cl((N, 16, S, S, S), DEV)
         _lib.check(L.lf_resample3d_fwd(vol.data_ptr(), N, cf.data_ptr(), kind, ref.data_ptr(), N, S, S, S, 16, s), 'fwd')
-        nb = L.lf_resample3d_bwd_vol_det_scratch_bytes(N, S, S, S, 16)
-        assert L.lf_resample3d_bwd_vol_det_io_scratch_bytes(N, S, S, S) <= nb
+        nb = max(L.lf_resample3d_bwd_vol_det_scratch_bytes(N, S, S, S, 16), L.lf_resample3d_bwd_vol_det_io_scratch_bytes(N, N, S, S, S),
+                 L.lf_resample3d_bwd_vol_det_io_scratch_bytes(1, N, S, S, S))
         scr = torch.empty(nb // 8 + 1, device=DEV, dtype=torch.int64)
         gref = ops.empty_cl((N, 16, S, S, S), DEV)
         _lib.check(L.lf_resample3d_bwd_vol_det(g.data_ptr(), cf.data_ptr(), kind, gref.data_ptr(), N, scr.data_ptr(), scr.numel() * 8,
@@ -247,7 +247,36 @@ def test_resampler_bf16_storage_variants():
             gv = ops.empty_cl16((N, 16, S, S, S), DEV, bool(io & 2))
             _lib.check(L.lf_resample3d_bwd_vol_det_io(gi.data_ptr(), cf.data_ptr(), kind, gv.data_ptr(), N, scr.data_ptr(), scr.numel() * 8,
                                                       N, S, S, S, io, s), 'bwd io')
-            assert torch.equal(gv, gref.to(torch.bfloat16) if io & 2 else gref), (kind, io)
+            assert torch.equal(gv, gref.to(torch.bfloat16) if io & 2 else gref), (kind, io)     # (binned form: a volume per sample)
+            prev = L.lf_set_tuning(4, 3)                                                        # ... and the tile form of the same call
+            try:
+                gv3 = ops.empty_cl16((N, 16, S, S, S), DEV, bool(io & 2))
+                _lib.check(L.lf_resample3d_bwd_vol_det_io(gi.data_ptr(), cf.data_ptr(), kind, gv3.data_ptr(), N, scr.data_ptr(),
+                                                          scr.numel() * 8, N, S, S, S, io, s), 'bwd io')
+            finally:
+                L.lf_set_tuning(4, prev)
+            assert torch.equal(gv3, gv), (kind, io)
+            prev = L.lf_set_tuning(6, 2)                                                        # ... and the binned form in two passes
+            try:
+                gv2 = ops.empty_cl16((N, 16, S, S, S), DEV, bool(io & 2))
+                _lib.check(L.lf_resample3d_bwd_vol_det_io(gi.data_ptr(), cf.data_ptr(), kind, gv2.data_ptr(), N, scr.data_ptr(),
+                                                          scr.numel() * 8, N, S, S, S, io, s), 'bwd io')
+            finally:
+                L.lf_set_tuning(6, prev)
+            assert torch.equal(gv2, gv), (kind, io)
+        # one volume shared by the samples (the renderer's transform): binned form (all samples in one pass) == tile form == fp32 entry
+        gref1 = ops.empty_cl((1, 16, S, S, S), DEV)
+        _lib.check(L.lf_resample3d_bwd_vol_det(g.data_ptr(), cf.data_ptr(), kind, gref1.data_ptr(), 1, scr.data_ptr(), scr.numel() * 8,
+                                               N, S, S, S, 16, s), 'bwd')
+        for variant in (2, 3):
+            prev = L.lf_set_tuning(4, variant)
+            try:
+                gv1 = ops.empty_cl16((1, 16, S, S, S), DEV, False)
+                _lib.check(L.lf_resample3d_bwd_vol_det_io(_b16(g).data_ptr(), cf.data_ptr(), kind, gv1.data_ptr(), 1, scr.data_ptr(),
+                                                          scr.numel() * 8, N, S, S, S, 1, s), 'bwd io')
+            finally:
+                L.lf_set_tuning(4, prev)
+            assert torch.equal(gv1, gref1), (kind, variant)
 
 
 @pytest.mark.parametrize('flags', [0, 1, 3])

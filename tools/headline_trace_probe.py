@@ -3,7 +3,7 @@
 oracle/make_golden_headline.py from the imported reference): 16-view reconstruction at 128^3, the renders of iteration 0, and
 the adam_quick loop iteration by iteration over the fixture's length (the preset's 100 iterations).
 
-    python tools/headline_trace_probe.py [out.json]
+    python tools/headline_trace_probe.py [out.json [fixture name, default g26_headline_trace]]
 
 Reports, per iteration: max relative difference of the N rank losses, whether the argmin / the full ranking agree, the
 reference's top-2 gap; and the summary figures: first iteration whose ranking differs, first whose argmin differs, the
@@ -18,12 +18,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def compare(dev='cuda'):
+def compare(dev='cuda', name='g26_headline_trace'):
     from latentfusion_amd import synth
     from latentfusion_amd.modules.geometry import Camera
     from latentfusion_amd.observation import Observation
     from latentfusion_amd.pose import estimation
-    g = torch.load(os.path.join(ROOT, 'tests', 'golden', 'g26_headline_trace.pt'), weights_only=False)
+    g = torch.load(os.path.join(ROOT, 'tests', 'golden', name + '.pt'), weights_only=False)
     S, C, V, N, T = g['S'], g['C'], g['V'], g['N'], g['T']
     sd = g['seeds']
     model, cks = synth.build_model(S, C, 'gru', seed=sd['model'], device=dev)
@@ -36,10 +36,11 @@ def compare(dev='cuda'):
     target = obs(1, sd['target'])
     out = {'fixture': {'S': S, 'C': C, 'V': V, 'N': N, 'T': T, 'reference_s_per_iteration': g['reference_seconds_per_iteration'],
                        'reference_threads': g['reference_threads']}}
-    zs = z[..., ::4, ::4, ::4].cpu()
-    scale = float(g['z_obj_absmax'])
-    out['volume'] = {'max_abs_diff_over_absmax': float((zs - g['z_obj_sub']).abs().max()) / scale,
-                     'rel_l2': float((zs - g['z_obj_sub']).norm() / g['z_obj_sub'].norm())}
+    if 'z_obj_sub' in g:                                           # (the further-seed fixtures share g26's object)
+        zs = z[..., ::4, ::4, ::4].cpu()
+        scale = float(g['z_obj_absmax'])
+        out['volume'] = {'max_abs_diff_over_absmax': float((zs - g['z_obj_sub']).abs().max()) / scale,
+                         'rel_l2': float((zs - g['z_obj_sub']).norm() / g['z_obj_sub'].norm())}
     c = g['init']
     init = Camera(c['K'].to(dev), None, c['z_span'], c['viewport'].to(dev), width=c['width'], height=c['height'],
                   log_quaternion=c['log_q'].to(dev), translation=c['t'].to(dev))
@@ -85,12 +86,12 @@ def compare(dev='cuda'):
 
 
 if __name__ == '__main__':
-    res = compare()
+    res = compare(name=sys.argv[2] if len(sys.argv) > 2 else 'g26_headline_trace')
     txt = json.dumps(res, indent=1)
     if len(sys.argv) > 1:
         open(sys.argv[1], 'w').write(txt)
     t = res['trace']
     print(json.dumps({k: v for k, v in t.items() if k != 'per_iteration'}))
-    print(json.dumps(res['volume']), json.dumps(res['iteration0_renders']))
+    print(json.dumps(res.get('volume')), json.dumps(res['iteration0_renders']))
     for r in t['per_iteration'][:12] + t['per_iteration'][-3:]:
         print(r)
