@@ -61,7 +61,7 @@ def parse(argv=None):
                          'the HIP loop from the same start (trace_parity_at_full_size)')
     ap.add_argument('--no-alt', action='store_true', help='skip the secondary f16x3 measurement')
     ap.add_argument('--no-graph', action='store_true', help='(accepted, no effect: the hipGraph block moved to tools/engine_ab.py)')
-    ap.add_argument('--repeats', type=int, default=25,
+    ap.add_argument('--repeats', type=int, default=30,
                     help='the timed region (exactly --steps iterations between barriers) is run this many times back to back; '
                          '`value` is steps / MEDIAN block time, every block time is reported (box-to-box and run-to-run '
                          'spread of a 0.1 s region is a few per cent)')
