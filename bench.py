@@ -85,6 +85,8 @@ def parse(argv=None):
     ap.add_argument('--no-cfg5', action='store_true',
                     help='skip the secondary cfg 5 block (one bf16-autocast generator training step, 32 + 8 views, SYN(128,16))')
     ap.add_argument('--cfg5-steps', type=int, default=3)
+    ap.add_argument('--no-variants', action='store_true',
+                    help="skip the secondary block with the 'sum' and occlusion renderer variants on the engine")
     ap.add_argument('--launcher-selftest', action='store_true',
                     help='run only the rank plumbing (spawn / process group / one all-reduce on HOST tensors over gloo) and '
                          'print a JSON line with n_gpus and ranks_seen: the CPU test of the N-rank path (tests/test_parallel.py)')
@@ -322,6 +324,53 @@ def cfg3_report(a, dev):
                     break
             except Exception:                                       # noqa: BLE001
                 continue
+    return out
+
+
+def variants_report(a, dev):
+    """Secondary block (never `value`): the reference's other two renderer variants on the render-loop engine, same loop shape as the
+    headline (SYN(128,16), N = 8, adam_quick; seeded random renderer) -- the 'sum' projection and the occlusion module
+    (reference recon/models.py:378-395,427-437; round 5: the occlusion U-Net on explicit kernels, engine._plan_occlusion)."""
+    from latentfusion_amd import consts, synth
+    from latentfusion_amd.modules.geometry import Camera
+    from latentfusion_amd.observation import Observation
+    from latentfusion_amd.pose import estimation, utils as pu
+    from latentfusion_amd.recon.utils import optimal_camera_dist
+    from latentfusion_amd.recon.models import Photographer
+    S, C, N, K = 128, 16, 8, 10
+    td = synth.make_observation_data(1, seed=200)
+    target = Observation(td['color'], td['depth'], td['mask'], Camera(td['intrinsic'], td['extrinsic'])).to(dev)
+    z_obj = torch.randn(1, 1, C, S, S, S, generator=torch.Generator().manual_seed(0)).to(dev)
+    cdist = optimal_camera_dist(consts.INTRINSIC[1][1], S, 0.5, slack=128 / S)
+    cfg = estimation._load_toml(os.path.join(ROOT, 'configs', 'adam_quick.toml'))
+    cfg['args']['num_samples'] = cfg['args']['ranking_size'] = N
+    torch.manual_seed(300)
+    init = pu.sample_cameras_with_estimate(N, target.camera.to('cpu'))
+    out = {'workload': f'SYN({S},{C}) renderer with seeded random weights, N = {N}, adam_quick, {K} timed iterations after 2 warm-up'}
+    for name, kw in (('sum', dict(projection_type='sum', object_config=[], occlusion_config=False)),
+                     ('occlusion', dict(projection_type='factor', object_config=[16, 16], occlusion_config=[[17, 16], [16, 16]]))):
+        torch.manual_seed(1)
+        ph = Photographer(in_size=S, camera_config=[C, C], predict_color=False, predict_depth=True, predict_mask=True,
+                          scale_mode='nearest', cube_size=1.0, image_config=[[16, 32], [32, 16]], **kw).to(dev)
+        for p in ph.parameters():
+            p.requires_grad_(False)
+
+        class M:                                                      # the facade surface the estimator touches
+            photographer, device, input_size, camera_dist = ph, torch.device(dev), S, cdist
+        est = estimation.load_from_config(cfg, M, converge_patience=10 ** 6)
+        st = est.start(z_obj, target, init.zoom(None, S, cdist).to(dev))
+        for _ in range(2):
+            est.iterate(st)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            est.iterate(st)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        out[name] = {'iters_per_s': K / el, 'ms_per_iteration': el / K * 1e3, 'on_engine': 'engine' in st,
+                     'explicit_occlusion_kernels': bool(getattr(st.get('engine'), 'occ', None) is not None)}
+        del est, st, ph
+        torch.cuda.empty_cache()
     return out
 
 
@@ -838,6 +887,13 @@ def main():
         except Exception as e:                                       # noqa: BLE001  (auxiliary: never loses the headline)
             cfg5 = {'error': f'{type(e).__name__}: {e}'[:300]}
 
+    variants = None
+    if world == 1 and not a.no_variants:
+        try:
+            variants = variants_report(a, dev)
+        except Exception as e:                                       # noqa: BLE001  (auxiliary: never loses the headline)
+            variants = {'error': f'{type(e).__name__}: {e}'[:300]}
+
     # RCCL on this box: under a launcher the process group above IS an RCCL communicator; a plain `python bench.py` run
     # initialises a world-size-1 group here (after the timed regions, so it cannot touch the number) and runs one
     # all-reduce of a latent-volume-sized tensor through it
@@ -965,6 +1021,8 @@ def main():
         out['cfg5'] = cfg5
     if ref_trace is not None:
         out['reference_trace_parity'] = ref_trace
+    if variants is not None:
+        out['renderer_variants'] = variants
     if pipelined is not None:
         out['pipelined_gru_build'] = pipelined
     if hyp is not None:
