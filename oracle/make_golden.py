@@ -1064,6 +1064,48 @@ def g27_training_gradients(lf):
                                                                                float(F.cosine_similarity(a, b, dim=0))))
 
 
+def g28_occlusion16(lf):
+    """The 16-channel OCCLUSION renderer (reference recon/models.py:305-306,378-395,427-430: UNet3d(17, 1, [[17, 16], [16, 16]]) over
+    cat(z, depth coordinate), softmax over D, z * weights) under the adam_quick loop, 'factor' and 'sum' composites: what the
+    reference's own Photographer + GradientPoseEstimator produce -- the render-loop engine sequences exactly this architecture on
+    explicit kernels since round 5 (engine._plan_occlusion), so it gets its own reference-made fixture."""
+    from latentfusion.pose import estimation, utils as pu
+    from latentfusion.recon.inference import LatentFusionModel
+    import tomli
+    S, C, N, T = 32, 16, 6, 6
+    dist = lf.recon.utils.optimal_camera_dist(615.4991, S, 0.5, slack=128 / S)
+    z_obj = torch.randn(1, 1, C, S, S, S, generator=torch.Generator().manual_seed(31))
+    target = synth_obs(lf, 1, seed=32)
+    torch.manual_seed(33)
+    init = pu.sample_cameras_with_estimate(N, target.camera)
+    with open('/root/reference/configs/adam_quick.toml', 'rb') as f:
+        cfg = tomli.load(f)
+    cfg['args']['num_iters'] = T
+    cfg['args']['num_samples'] = cfg['args']['ranking_size'] = N
+    out = {'S': S, 'C': C, 'camera_dist': dist, 'cfg': cfg, 'z_obj': z_obj.clone(), 'target': obs_dict(target, lite=True),
+           'init': cam_dict(init), 'variants': {}}
+    for proj in ('factor', 'sum'):
+        sc, fu, ph = syn_ckpts(lf, S, C, seed=30, occlusion_config=[[17, 16], [16, 16]], object_config=[C, C], projection_type=proj)
+        model = LatentFusionModel(sc, fu, ph, dist, 'cpu')
+        for m in (sc, fu, ph):
+            for p_ in m.parameters():
+                p_.requires_grad_(False)
+        zoomed = init.zoom(None, model.input_size, model.camera_dist)
+        with torch.no_grad():
+            y0, _ = model.render_latent_object(z_obj, zoomed, return_latent=True)
+        est = estimation.load_from_config(copy.deepcopy(cfg), model, track_stats=True, return_camera_history=True)
+        best, stats, hist = est.estimate(z_obj, target, camera=init)
+        out['variants'][proj] = {
+            'photographer': ck(ph),
+            'iter0': {k: y0[k].squeeze(0).clone() for k in ('depth_logits', 'mask_logits')},
+            'rank_loss': stats['rank_loss'].clone(), 'depth_loss': stats['depth_loss'].clone(),
+            'ov_depth_loss': stats['ov_depth_loss'].clone(), 'iou_loss': stats['iou_loss'].clone(), 'mask_loss': stats['mask_loss'].clone(),
+            'argmin': torch.argmin(stats['rank_loss'], dim=1),
+            'hist_log_q': torch.stack([c.log_quaternion for _, c in hist]), 'hist_t': torch.stack([c.translation for _, c in hist]),
+            'best': cam_dict(best)}
+    save('g28_occlusion16', out)
+
+
 def main():
     lf = refharness.load_reference()
     import latentfusion.recon.utils  # noqa
@@ -1071,7 +1113,7 @@ def main():
     gens = [g0_preprocess, g1_camera, g2_resample, g3_block, g4_fusers, g5_decode, g6_loss, g7_g10_loop, g9_ibr,
             g11_released_like, g12_latent_code, g13_metrics, g14_initial_pose, g15_losses, g16_bop_reader, g17_api_helpers, g18_training_prep,
             g19_metropolis, g20_released_width, g21_bop_scene,
-            g22_photographer_skip, g23_ibr_generator, g24_tile_projection, g25_released_arch, g27_training_gradients]
+            g22_photographer_skip, g23_ibr_generator, g24_tile_projection, g25_released_arch, g27_training_gradients, g28_occlusion16]
     only = sys.argv[1:]                                  # e.g. `python oracle/make_golden.py g13` regenerates one group
     for fn in gens:
         if not only or any(fn.__name__.startswith(o + '_') or fn.__name__ == o for o in only):

@@ -1017,3 +1017,44 @@ def test_engine_occlusion_module_on_explicit_kernels(golden, projection):
     assert rel < 2e-3, rel
     fwd_only, none = eng.forward_backward(cam0, need_grad=False)
     assert none is None and torch.equal(fwd_only, losses)
+
+
+@pytest.mark.parametrize('proj', ['factor', 'sum'])
+def test_g28_occlusion16_loop_on_hip(golden, proj):
+    """The explicit-kernel occlusion renderer against the REFERENCE ITSELF (golden g28: the reference's Photographer with
+    UNet3d(17, 1, [[17, 16], [16, 16]]) under its GradientPoseEstimator, 6 hypotheses x 6 iterations of adam_quick at 32^3 x 16):
+    iteration-0 logits, the rank-loss trace, identical argmin at every iteration."""
+    from latentfusion_amd.engine import RenderLoopEngine
+    from latentfusion_amd.pose import estimation
+    from latentfusion_amd.recon.models import Photographer
+    g = golden('g28_occlusion16')
+    r = g['variants'][proj]
+    ph = Photographer.from_checkpoint(r['photographer']).to(DEV)
+    for p in ph.parameters():
+        p.requires_grad_(False)
+    S = g['S']
+
+    class _M:
+        photographer, device, input_size, camera_dist = ph, torch.device(DEV), S, g['camera_dist']
+
+        @staticmethod
+        def render_latent_object(z, cam, return_latent=True, apply_mask=True):
+            y, zl, _ = ph.decode(z, cam, return_latent=return_latent, apply_mask=apply_mask)
+            return y, (zl.squeeze(0) if return_latent else zl)
+    z_obj = g['z_obj'].to(DEV)
+    target = _target(g, 'cpu')
+    init = prod_camera(g['init'], 'cpu')
+    with torch.no_grad():
+        y0, _ = _M.render_latent_object(z_obj, init.zoom(None, S, g['camera_dist']).to(DEV))
+    for k in ('depth_logits', 'mask_logits'):
+        close(y0[k].squeeze(0), r['iter0'][k], atol=1e-4, rtol=1e-3)
+    eng = RenderLoopEngine(ph, z_obj, target.to(DEV), dict(g['cfg']['loss_weights']))
+    assert eng.occ is not None and (eng.dec is not None) == (proj == 'factor')
+    est = estimation.load_from_config(copy.deepcopy(g['cfg']), _M, track_stats=True, return_camera_history=True)
+    best, stats, hist = est.estimate(z_obj, target, camera=init)
+    # (same inputs at iteration 0; afterwards Adam's normalised steps amplify fp32 rounding, as in g7 / g26)
+    close(stats['rank_loss'][:1], r['rank_loss'][:1], atol=1e-6, rtol=2e-5)
+    close(stats['rank_loss'][:3], r['rank_loss'][:3], atol=1e-5, rtol=1e-3)
+    close(stats['rank_loss'], r['rank_loss'], atol=1e-4, rtol=1e-2)
+    assert torch.argmin(stats['rank_loss'], dim=1).tolist() == r['argmin'].tolist()
+    close(torch.stack([c.log_quaternion for _, c in hist]), r['hist_log_q'], atol=2e-2, rtol=0)
