@@ -84,7 +84,7 @@ def parse(argv=None):
     ap.add_argument('--cfg3-iters', type=int, default=10)
     ap.add_argument('--no-cfg5', action='store_true',
                     help='skip the secondary cfg 5 block (one bf16-autocast generator training step, 32 + 8 views, SYN(128,16))')
-    ap.add_argument('--cfg5-steps', type=int, default=3)
+    ap.add_argument('--cfg5-steps', type=int, default=5)
     ap.add_argument('--no-variants', action='store_true',
                     help="skip the secondary block with the 'sum' and occlusion renderer variants on the engine")
     ap.add_argument('--launcher-selftest', action='store_true',
@@ -380,7 +380,7 @@ def cfg5_report(a, dev):
     32 input views encoded and fused, 8 output views rendered, hard smooth-L1 depth + BCE mask losses, backward through every
     kernel (data, weight and bias gradients, deterministic volume splat), flat Adam -- under the bf16 autocast policy
     (ops.autocast; `--use-amp` of the reference).  One GPU: the data-parallel half (bucketed RCCL gradient all-reduce) needs
-    more devices.  Reported: wall time per step (mean of `--cfg5-steps` steps after one warm-up), peak device memory, the
+    more devices.  Reported: wall time per step (MEDIAN of `--cfg5-steps` steps after one warm-up; every step time is listed), peak device memory, the
     launch time and HBM fraction of the dominant training kernel from HIP events in one extra step, and whether two fresh
     runs of the same steps agree bit for bit."""
     from latentfusion_amd import ops, synth
@@ -428,10 +428,11 @@ def cfg5_report(a, dev):
     identical = losses == losses2 and bool(torch.equal(params_after, step2.flat.data))
     del step2, batch2, params_after
     torch.cuda.empty_cache()
-    ms = sum(times[1:]) / K * 1e3
+    ms = sorted(times[1:])[(K - 1) // 2] * 1e3                     # median step (a single step can catch an allocator / clock hiccup)
     out = {'workload': f'one generator training step (reference tools/train/train_reconstruct.py:421-535) on SYN({S},{C}), GRU fuser: '
                        f'{Vi} input views + {Vo} output views, bf16 autocast policy, flat Adam; 1 GPU (no data-parallel all-reduce)',
            'ms_per_step': ms, 'steps_per_s': 1e3 / ms, 'steps_timed': K, 'step_ms': [t * 1e3 for t in times[1:]],
+           'mean_step_ms': sum(times[1:]) / K * 1e3,
            'first_step_ms': times[0] * 1e3, 'peak_mem_GB': peak, 'params': n_par, 'loss': losses,
            'run_to_run_identical': bool(identical), 'dtype': 'bf16 MFMA operands (autocast policy), fp32 accumulation / master weights / Adam'}
     # roofline of the dominant training kernel: the bf16 ring convolution on ONE 128^3 x 16 volume (the ConvGRU recurrence

@@ -44,6 +44,9 @@ TRAIN_KERNELS = collections.OrderedDict([
     ('epilogue_bwd_c16_kernel', (('epilogue_bwd_c16_kernel<7>', 'epilogue_bwd_c16_kernelILi7E'), 3 * V // 2 + V // 16)),
     ('resample_fwd_c16_kernel', (('resample_fwd_c16_kernel<1, 3>', 'resample_fwd_c16_kernelILi1ELi3E'), V)),
     ('splat_tile_kernel', (('splat_tile_kernel<1, 3>', 'splat_tile_kernelILi1ELi3E'), V)),
+    # round 5, binned form: + the lists (1.6 entries of 4 B per voxel, written by the fill pass and read here)
+    ('splat_binned_tile_kernel', (('splat_binned_tile_kernel<1, 3>', 'splat_binned_tile_kernelILi1ELi3E'), V + 8 * 128 ** 3 * 7)),
+    ('splat_bin_kernel_fill', (('splat_bin_kernel<1, true>', 'splat_bin_kernelILi1ELb1E'), 8 * 128 ** 3 * 7)),
     ('lift_norm_unfold_kernel', ('lift_norm_unfold_kernel', V + V // 2)),
     ('lift_bwd_fused_kernel', ('lift_bwd_fused_kernel', 2 * V)),
 ])
@@ -53,6 +56,17 @@ SPLIT = {'conv3d_c16_wino_kernel': (('forward form', 2 * 8 * 16 * 128 ** 3 * 4 +
                                     ('data-gradient form + fused previous-layer backward', 3 * 8 * 16 * 128 ** 3 * 4 + 8 * 128 ** 3 * 4))}
 SOURCES = ['conv_wino.hip', 'conv.hip', 'conv_split.hip', 'resample.hip', 'pointwise.hip', 'reduce.hip']
 TRAIN_SOURCES = ['conv_split.hip', 'wgrad.hip', 'resample.hip', 'pointwise.hip', 'gru.hip']
+# --cfg3: the released architecture's kernels inside the cross_entropy_linemod loop (tools/pmc_collect_cfg3.sh over
+# tools/cfg3_probe.py; no calibration copy in that run: FETCH_SIZE x 2, WRITE_SIZE x 1 as calibrated in the other two)
+CFG3_KERNELS = collections.OrderedDict([
+    # 3-D 256 -> 256 @ 16^3, N = 128: x in + y out (0.537 GB each) + U (17 MB); V (4.3 GB) is an intermediate, not algorithmic
+    ('wino_fused_kernel<3>', (('wino_fused_kernel<3, 4, 2, 2, 2>',), 2 * 128 * 256 * 16 ** 3 * 4 + 64 * 256 * 256 * 4)),
+    ('wino_fused_kernel<2>', (('wino_fused_kernel<2, 4, 2, 2, 4>',), 1)),
+    ('wino_fused_kernel<2> (1 x 8)', (('wino_fused_kernel<2, 1, 8, 4, 2>',), 1)),
+    ('wino3d_input_kernel', ('wino3d_input_kernel', 1)),
+    ('wino2d_input_kernel', ('wino2d_input_kernel', 1)),
+])
+CFG3_SOURCES = ['wino_fused.hip', 'wino_gemm.hip']
 
 
 def source_hashes(sources=None):
@@ -101,9 +115,11 @@ def main(dirname, prefix, kernels=None, probe='tools/hbm_probe.py', sources=None
     corr = (GiB / 1024.0) / mean(calf) if calf else 2.0
     wcorr = (GiB / 1024.0) / mean(calw) if calw else 1.0
     lines = [f'# PMC counters per launch (means over the dispatches of {probe}), from {dirname}',
-             '# bench shape SYN(128,16), N = 8: 8 x 128^3 voxels x 16 channels fp32 per volume',
+             '# ' + ('released architecture (cfg 3): 128 renders per iteration' if kernels is CFG3_KERNELS else 'bench shape SYN(128,16), N = 8: 8 x 128^3 voxels x 16 channels per volume'),
              f'# FETCH_SIZE correction (1 GiB copy in the same run): x{corr:.4f};  WRITE_SIZE: x{wcorr:.4f}', '']
-    hbm = {'shape': 'N=8, C=16, S=128 (SYN(128,16) bench shape), ' + ('bf16 storage (32 B per voxel record)' if sources else 'fp32'), 'collected': 'tools/pmc_collect.sh (separate --pmc passes)',
+    shape = ('released architecture, cross_entropy_linemod: N = 128 renders, 3-D 256 -> 256 @ 16^3 (wino_fused_kernel<3>)' if kernels is CFG3_KERNELS
+             else 'N=8, C=16, S=128 (SYN(128,16) bench shape), ' + ('bf16 storage (32 B per voxel record)' if sources else 'fp32'))
+    hbm = {'shape': shape, 'collected': 'tools/pmc_collect*.sh (separate --pmc passes)',
            'fetch_correction': corr, 'write_correction': wcorr, 'source_sha256': source_hashes(sources), 'kernels': {}}
     for key, (sub, alg) in kernels.items():
         k = find(data, sub)
@@ -139,15 +155,18 @@ def summarise(lines, hbm, key, vkey, k, alg, c, corr, wcorr):
             d.append(f"L2 hit rate = {c['TCC_HIT_sum'] / (c['TCC_HIT_sum'] + c['TCC_MISS_sum']):.3f}")
         if c.get('FETCH_SIZE') is not None and c.get('WRITE_SIZE') is not None:
             rb, wb = c['FETCH_SIZE'] * 1024 * corr, c['WRITE_SIZE'] * 1024 * wcorr
-            d.append(f'HBM bytes per launch = {rb / 1e9:.3f} GB read + {wb / 1e9:.3f} GB written = {(rb + wb) / 1e9:.3f} GB '
-                     f'({(rb + wb) / alg:.2f}x the algorithmic {alg / 1e9:.3f} GB)')
+            known = alg is not None and alg > 1                      # (mean over launches of many shapes: no single algorithmic figure)
+            d.append(f'HBM bytes per launch = {rb / 1e9:.3f} GB read + {wb / 1e9:.3f} GB written = {(rb + wb) / 1e9:.3f} GB'
+                     + (f' ({(rb + wb) / alg:.2f}x the algorithmic {alg / 1e9:.3f} GB)' if known else ' (mean over launches of several shapes)'))
             hbm['kernels'][key] = {'kernel_name': k[:160], 'read_bytes': rb, 'write_bytes': wb, 'bytes_per_launch': rb + wb,
-                                   'algorithmic_bytes_per_launch': alg}
+                                   'algorithmic_bytes_per_launch': alg if known else None}
         lines += ['   ' + x for x in d] + ['']
 
 
 if __name__ == '__main__':
     if sys.argv[1] == '--train':
         main(sys.argv[2], sys.argv[3], TRAIN_KERNELS, 'tools/train_kernels_probe.py', TRAIN_SOURCES)
+    elif sys.argv[1] == '--cfg3':
+        main(sys.argv[2], sys.argv[3], CFG3_KERNELS, 'tools/cfg3_probe.py (means over ALL launches of a kernel in the loop)', CFG3_SOURCES)
     else:
         main(sys.argv[1], sys.argv[2])
