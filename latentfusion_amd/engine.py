@@ -539,11 +539,13 @@ class RenderLoopEngine:
             ops._conv1x1_raw(dacts[-1], hpk, hb, n, hh * ww, hw.shape[1], 1, hh * ww * hw.shape[1], 0, hw.shape[0], logits, hhe, 0)
         else:
             with torch.set_grad_enabled(need_grad):
-                yimg = self.ph.image_decoder(zp_leaf)
+                yimg, rescale = self.ph.decode_features(zp_leaf)      # (a final nearest up-sampling is owed to the logits)
                 if self.heads is not None:
                     logits = ops.conv1x1(yimg, self.heads[0], self.heads[1])
                 else:
                     logits = torch.cat([ob(yimg) for ob in self.ph.output_blocks], dim=1)
+                if rescale is not None:
+                    logits = rescale(logits)
         if zt is None or not need_grad:
             # the optimised quantity is mean_n(total) (estimation.py:616-617): lf_pose_loss_fwd already leaves the sums'
             # gradients for exactly that, so the loss needs no autograd node -- logits -> loss -> d/d(logits, coefficients)

@@ -97,7 +97,9 @@ class Block(nn.Module):
         if scale_factor != 1.0 and scale_factor is not None:
             self.interpolate = Interpolate(scale_factor, mode=scale_mode)
 
-    def forward(self, x):
+    def forward(self, x, rescale=True):
+        """rescale=False leaves the block's resize to the caller (a nearest up-sampling commutes with the pointwise layers behind
+        it: Photographer.decode_features)."""
         x = self.conv1(x, fuse_act=True, fuse_norm=True)
         x = self.conv2(x, fuse_act=True, fuse_norm=True)
-        return self.interpolate(x) if self.interpolate else x
+        return self.interpolate(x) if (self.interpolate and rescale) else x

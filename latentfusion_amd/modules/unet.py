@@ -59,9 +59,13 @@ class BaseUNet(nn.Module):
     def output_size(self, in_size):
         return self.bottleneck_size(in_size) * (2 ** (self.block_config[1].count('I') + self.block_config[1].count('U')))
 
-    def forward(self, z, z_inject=None, return_intermediate=False):
+    def forward(self, z, z_inject=None, return_intermediate=False, defer_last_rescale=False):
+        """defer_last_rescale=True (no output block): the LAST up block runs without its resize, which the caller applies after
+        the layers it commutes with."""
         if z_inject is not None:
             raise NotImplementedError('z_inject is unused on the reconstruct-and-render path')
+        if defer_last_rescale and (self.output_block is not None or not len(self.up_blocks)):
+            raise ValueError('defer_last_rescale needs a decoder that ends in an up block')
         if self.input_block is not None:
             z = self.input_block(z)
         mids = []                                   # deepest first
@@ -71,7 +75,7 @@ class BaseUNet(nn.Module):
         for i, blk in enumerate(self.up_blocks):
             if 1 <= i < len(mids):
                 z = torch.cat((z, mids[i]), dim=1)
-            z = blk(z)
+            z = blk(z, rescale=False) if (defer_last_rescale and i == len(self.up_blocks) - 1) else blk(z)
         if isinstance(self.output_block, OutputBlock):
             z = self.output_block(z)
         elif self.output_block is not None:

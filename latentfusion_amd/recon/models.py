@@ -234,9 +234,27 @@ class Photographer(_Checkpointed):
             z = ops.column_sum(z)
         elif self.projection_type == 'factor':
             z = self.projection_block(z)
-        y = self.image_decoder(z)
+        y, rescale = self.decode_features(z)
         y = torch.cat([ob(y) for ob in self.output_blocks], dim=1)
+        if rescale is not None:
+            y = rescale(y)
         return y, (z if return_latent else None), z_depth
+
+    def decode_features(self, z):
+        """The 2-D decoder on the projected latent: (features, rescale) where `rescale` is None or the resize the caller owes the
+        LOGITS.  When the decoder ends in an up-sampling (the released architecture: ..., 'U', 64 at 128^2 -> 256^2,
+        tools/train/train.sh:28-66; the reference's 2-D U-Nets resize bilinearly, modules/blocks.py:10-75) and the output blocks
+        are pointwise convolutions without activation (reference recon/models.py:316-327, blocks.py:108-119), the resize commutes
+        with them: it is a linear map over space whose weights sum to one, they are affine over channels, so
+        heads(resize(x)) = resize(heads(x)) -- bit for bit with nearest neighbours, to fp32 rounding with bilinear weights.  The
+        heads then run on a quarter of the pixels and the 64-channel 256^2 tensor (2.1 GB for the 128 renders of a cross-entropy
+        iteration) is never written."""
+        dec = self.image_decoder
+        last = dec.up_blocks[-1] if len(dec.up_blocks) else None
+        if (last is not None and dec.output_block is None and last.interpolate is not None and last.interpolate.mode in ('nearest', 'bilinear')
+                and all(getattr(ob, 'activation', None) is None and getattr(ob.conv, 'kernel_size', 0) == 1 for ob in self.output_blocks)):
+            return dec(z, defer_last_rescale=True), last.interpolate
+        return dec(z), None
 
     @staticmethod
     def _checked(block, z):

@@ -634,3 +634,44 @@ def test_wgrad_bf16_storage_variants():
         outs[io] = gw
     for io in (1, 2, 3):
         assert torch.equal(outs[io], outs[0]), io
+
+
+def test_heads_commute_with_the_final_upsampling():
+    """Photographer.decode_features: a 2-D decoder that ends in an up-sampling (the released architecture's last 'U') hands that
+    resize to the LOGITS -- the pointwise output blocks (reference recon/models.py:316-327, blocks.py:108-119) run before it.  A
+    resize is linear over space with weights that sum to one, the heads are affine over channels: the two orders agree to fp32
+    rounding (bilinear, the mode of the reference's 2-D U-Nets), logits and gradients."""
+    from latentfusion_amd.modules.geometry import Camera
+    from latentfusion_amd.recon.models import Photographer
+    from latentfusion_amd import synth
+    torch.manual_seed(5)
+    S, N = 16, 3
+    td = synth.make_observation_data(N, seed=3)
+    cam = Camera(td['intrinsic'], td['extrinsic']).zoom(None, S, 2.0).to(DEV)
+    ph = Photographer(in_size=S, camera_config=[16, 16], object_config=[], image_config=[[16, 'D', 32], [32, 'U', 24, 'U', 12]],
+                      predict_color=False, predict_depth=True, predict_mask=True, scale_mode='nearest', cube_size=1.0).to(DEV)
+    with torch.no_grad():
+        for name, p in ph.named_parameters():
+            if name.endswith('bias'):
+                p.normal_(0.0, 0.1)
+    assert ph.image_decoder.up_blocks[-1].interpolate.mode == 'bilinear'
+    z = torch.randn(1, 1, 16, S, S, S, generator=torch.Generator().manual_seed(8)).to(DEV).requires_grad_(True)
+    z2d = torch.randn(N, 16, S, S, generator=torch.Generator().manual_seed(9)).to(DEV)
+    feats, rescale = ph.decode_features(z2d)
+    assert rescale is ph.image_decoder.up_blocks[-1].interpolate
+    assert feats.shape[-1] == S and feats.shape[1] == 12 and ph.image_decoder(z2d).shape[-1] == 2 * S
+    y, _, _ = ph.decode(z, cam, interpret_logits=False)
+    assert y.shape[-2:] == (2 * S, 2 * S)
+    wts = torch.linspace(-1, 1, y.numel(), device=DEV).view_as(y)
+    gz, = torch.autograd.grad((y * wts).sum(), z)
+    # the reference order: decoder with its resize, then the output blocks
+    z_ = z.detach().clone().requires_grad_(True)
+    orig = Photographer.decode_features
+    Photographer.decode_features = lambda self, zz: (self.image_decoder(zz), None)
+    try:
+        y_ref, _, _ = ph.decode(z_, cam, interpret_logits=False)
+    finally:
+        Photographer.decode_features = orig
+    close(y, y_ref, atol=2e-6 * y_ref.abs().max().item(), rtol=1e-5)
+    gz_ref, = torch.autograd.grad((y_ref * wts).sum(), z_)
+    close(gz, gz_ref, atol=1e-5 * gz_ref.abs().max().item(), rtol=1e-4)
