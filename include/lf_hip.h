@@ -322,6 +322,8 @@ int lf_resample3d_bwd_vol_det_io(const void* gout, const float* coef, int kind, 
  *   lf_occ_conv17_fwd  pre[v][co] = sum_taps w27[tap][co] * t16[v + tap - 1], zero padding; w27: [kz*9 + ky*3 + kx][16] =
  *                      W2[co][16][kz][ky][kx] * he.  The addend (LF_EPI_ADD) of the lf_conv3d_c16_wino launch over ta.
  *   lf_occ_conv17_bwd  gp16[u] = LeakyReLU'(t16[u]) * sum_taps sum_co w27[tap][co] * g[u - (tap - 1)][co]
+ *                      (both on v_mfma_f32_16x16x4_f32: the forward as a 16 x 27 by 27 x voxels product, the backward as
+ *                      h[tap][voxel] = W g per z plane into LDS followed by the shifted sums)
  *   lf_occ_input_bwd   gz = g_zs * wocc[row] + W1[:16]^T (gta * LeakyReLU'(ta)) + W1[16] * gp16   (g_zs / wocc: the direct term of
  *                      the occlusion scaling z * wocc, both NULL to leave it out); prev_y != NULL: followed by the epilogue
  *                      backward of the layer that produced z (saved output prev_y, norm prev_norm, prev_flags), as in

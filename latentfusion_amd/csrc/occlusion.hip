@@ -103,108 +103,144 @@ __global__ void __launch_bounds__(256) occ_input_bwd_kernel(const f32x4* __restr
 }
 
 // pre[v][co] = sum_taps w27[tap][co] * t16[v + tap - 1]  (zero padding), w27 = W2[:, 16] * he as [kz*9 + ky*3 + kx][16].
-// One lane per voxel, all 16 outputs (the weights are wave-uniform: scalar loads); the loads are unconditional on clamped
-// addresses (no branch separates them: a lane has its 27 loads in flight together) and the records go out through an LDS
-// transpose so that each store instruction of a wave covers 1 KB of consecutive bytes.
+// A 16 x 27 by 27 x voxels product on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32: M = the 16 outputs, N = 16 consecutive voxels,
+// K = 28 tap slots in 7 steps, the last slot zero): lane (n = lane & 15, kg = lane >> 4) holds the A entry W[tap 4s + kg][co n]
+// of every step for the whole kernel, loads ONE neighbour value per step as its B entry (voxel n, tap 4s + kg; unconditional
+// load from a safe address, zero by select), and ends with outputs 4 kg .. 4 kg + 3 of voxel n -- a channels-last quarter record,
+// so a wave's store covers 1 KB of consecutive bytes without a transpose.  (The VALU form -- 432 FMAs and 27 loads per voxel
+// lane -- took 0.68 ms at 8 x 64^3; this one is bound by the 64 B per voxel it writes.)
+constexpr int C17_GPW = 8;                                        // groups of 16 voxels per wave
 __global__ void __launch_bounds__(256) occ_conv17_fwd_kernel(const float* __restrict__ t16, const float* __restrict__ w27,
-                                                             f32x4* __restrict__ pre, int N, int D, int H, int W) {
-  __shared__ __attribute__((aligned(16))) float st[4][64 * 20];
-  const long rows = (long)N * D * H * W;
-  const long row = (long)blockIdx.x * 256 + threadIdx.x;
-  const bool live = row < rows;
-  const long rc = live ? row : rows - 1;
-  const int x = (int)(rc % W), y = (int)((rc / W) % H), zc = (int)((rc / ((long)W * H)) % D);
-  const long plane0 = rc - ((long)zc * H + y) * W - x;             // first voxel of this sample
-  float acc[16];
+                                                             f32x4* __restrict__ pre, int D, int H, int W, long rows, long groups) {
+  const int lane = threadIdx.x & 63, n = lane & 15, kg = lane >> 4;
+  const long g0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * C17_GPW;
+  if (g0 >= groups) return;                                        // (wave-uniform)
+  float a[7];
+  int dz[7], dy[7], dx[7], dl[7];
 #pragma unroll
-  for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+  for (int s = 0; s < 7; ++s) {
+    const int tap = 4 * s + kg;
+    const bool tv = tap < 27;
+    a[s] = tv ? w27[tap * 16 + n] : 0.f;
+    const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
+    dz[s] = tv ? kz - 1 : 9999;                                    // (an impossible offset: slot 27 is never in range)
+    dy[s] = ky - 1;
+    dx[s] = kx - 1;
+    dl[s] = ((kz - 1) * H + (ky - 1)) * W + (kx - 1);
+  }
+  long v = g0 * 16 + n;
+  int x = (int)(v % W), y = (int)((v / W) % H), z = (int)((v / ((long)W * H)) % D);
+  for (int gi = 0; gi < C17_GPW; ++gi) {
+    if (g0 + gi >= groups) break;                                  // (wave-uniform)
+    const bool live = v < rows;
+    float b[7];
 #pragma unroll
-  for (int kz = 0; kz < 3; ++kz) {
-    const int zz = zc + kz - 1;
-    const int zq = min(max(zz, 0), D - 1);
+    for (int s = 0; s < 7; ++s) {
+      const bool ok = live && (unsigned)(z + dz[s]) < (unsigned)D && (unsigned)(y + dy[s]) < (unsigned)H && (unsigned)(x + dx[s]) < (unsigned)W;
+      const float t = t16[ok ? v + dl[s] : (live ? v : 0)];
+      b[s] = ok ? t : 0.f;
+    }
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int yy = y + ky - 1;
-      const int yq = min(max(yy, 0), H - 1);
-      const bool okzy = zz >= 0 && zz < D && yy >= 0 && yy < H;
-      const long line = plane0 + ((long)zq * H + yq) * W;
-#pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int xx = x + kx - 1;
-        const float v = t16[line + min(max(xx, 0), W - 1)];
-        const float t = (okzy && xx >= 0 && xx < W) ? v : 0.f;
-        const float* wr = w27 + ((kz * 3 + ky) * 3 + kx) * 16;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) acc[c] += wr[c] * t;
+    for (int s = 0; s < 7; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
+    if (live) pre[v * 4 + kg] = acc;
+    v += 16;
+    x += 16;
+    while (x >= W) {
+      x -= W;
+      if (++y >= H) {
+        y = 0;
+        if (++z >= D) z = 0;
       }
     }
-  }
-  const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) *(f32x4*)(&st[wv][l * 20 + k * 4]) = (f32x4){acc[k * 4], acc[k * 4 + 1], acc[k * 4 + 2], acc[k * 4 + 3]};
-  __syncthreads();
-  const long row0 = (long)blockIdx.x * 256 + wv * 64;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int v = (l >> 2) + 16 * k;
-    if (row0 + v < rows) pre[(row0 + v) * 4 + (l & 3)] = *(const f32x4*)(&st[wv][v * 20 + (l & 3) * 4]);
   }
 }
 
-// gp16[u] = lrelu'(t16[u]) * sum_taps sum_co w27[tap][co] * g[u - (tap - 1)][co]: a lane takes FOUR voxels along W and a
-// quarter of the channels (each loaded record serves up to three outputs), then a fixed-order butterfly over the four lanes.
-// Branch-free like the forward: clamped addresses, out-of-range records replaced by zeros.
+// gp16[u] = lrelu'(t16[u]) * sum_taps sum_co w27[tap][co] * g[u - (tap - 1)][co], in two stages per z plane:
+//   A  h[tap][v] = sum_co w27[tap][co] g[v][co] for the 18 x 18 voxels around a 16 x 16 footprint, on the fp32 matrix pipe
+//      (v_mfma_f32_16x16x4_f32: M = 32 tap slots in two blocks, N = 16 voxels, K = the 16 channels; a lane's B entries are the
+//      four floats of the quarter record it loads), written to LDS as [tap][voxel];
+//   B  every thread owns one (y, x) of the footprint and adds the nine h values of each kz that land on it to the running sums
+//      of the output planes p - 1, p, p + 1; a plane is complete -- and stored, times lrelu'(t16) -- once the plane behind it
+//      has been added.
+// A workgroup walks C17_ZR output planes down z, so every gradient record is loaded (18 / 16)^2 (1 + 2 / C17_ZR) = 1.4 times
+// instead of 13.5 times by the lane-per-quarter form it replaces (0.89 ms at 8 x 64^3, bound by those loads).
+constexpr int C17_ZR = 16, C17_HS = 336;                         // planes per workgroup; LDS slots per tap (324 halo voxels, padded to 21 x 16)
 __global__ void __launch_bounds__(256) occ_conv17_bwd_kernel(const f32x4* __restrict__ g, const float* __restrict__ t16,
                                                              const float* __restrict__ w27, float* __restrict__ gp16,
-                                                             int N, int D, int H, int W, int W4, float slope) {
-  __shared__ __attribute__((aligned(16))) float sw[27 * 16];
-  for (int i = threadIdx.x; i < 27 * 16; i += 256) sw[i] = w27[i];
-  __syncthreads();
-  const long groups = (long)N * D * H * W4;
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  const int q = (int)(i & 3);
-  const bool live = (i >> 2) < groups;
-  const long grp = live ? (i >> 2) : groups - 1;
-  const int x0 = (int)(grp % W4) * 4, y = (int)((grp / W4) % H), zc = (int)((grp / ((long)W4 * H)) % D);
-  const long n = grp / ((long)W4 * H * D);
-  float o[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1                                                   // (a real loop: 18 records in flight per lane, not 54)
-  for (int kz = 0; kz < 3; ++kz) {
-    const int zz = zc - (kz - 1);
-    const int zq = min(max(zz, 0), D - 1);
+                                                             int D, int H, int W, int nzr, int nty, int ntx, float slope) {
+  __shared__ float hT[28 * C17_HS];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, kg = lane >> 4;
+  int b = blockIdx.x;
+  const int bx = b % ntx; b /= ntx;
+  const int by = b % nty; b /= nty;
+  const int bz = b % nzr;
+  const long smp = b / nzr;
+  const int x0 = bx * 16, y0 = by * 16, z0 = bz * C17_ZR;
+  // A operands: block blk, step s: W[tap = 16 blk + n][co = 4 kg + s]
+  float a[2][4];
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int yy = y - (ky - 1);
-      const int yq = min(max(yy, 0), H - 1);
-      const bool okzy = zz >= 0 && zz < D && yy >= 0 && yy < H;
-      const long line = ((n * D + zq) * H + yq) * (long)W;
-      f32x4 wv[3];
+  for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) wv[kx] = *(const f32x4*)(sw + ((kz * 3 + ky) * 3 + kx) * 16 + q * 4);
+    for (int s = 0; s < 4; ++s) {
+      const int tap = 16 * blk + n;
+      a[blk][s] = tap < 27 ? w27[tap * 16 + 4 * kg + s] : 0.f;
+    }
+  const int ty = tid >> 4, tx = tid & 15;                          // stage B: this thread's output column
+  const bool col_ok = y0 + ty < H && x0 + tx < W;
+  const long vol = (long)D * H * W;
+  float accm = 0.f, acc0 = 0.f, accp = 0.f;                        // sums of output planes p - 1, p, p + 1
+  for (int p = z0 - 1; p <= z0 + C17_ZR && p <= D; ++p) {
+    const bool plane_in = p >= 0 && p < D;                         // (workgroup-uniform)
+    if (plane_in) {
+      // ---- stage A: 21 groups of 16 halo voxels, wave wv takes groups wv, wv + 4, ...
+      for (int grp = wv; grp < C17_HS / 16; grp += 4) {
+        const int q = grp * 16 + n;                                // halo slot of this lane's voxel
+        const int yy = y0 - 1 + q / 18, xx = x0 - 1 + q % 18;
+        const bool ok = q < 324 && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+        const long v = smp * vol + ((long)p * H + (ok ? yy : 0)) * W + (ok ? xx : 0);
+        f32x4 r = g[v * 4 + kg];
+        if (!ok) r = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 d0 = (f32x4){0.f, 0.f, 0.f, 0.f}, d1 = d0;
 #pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        const int xp = x0 + j - 1;                               // position of the loaded record
-        f32x4 r = g[(line + min(max(xp, 0), W - 1)) * 4 + q];
-        if (!(okzy && xp >= 0 && xp < W)) r = (f32x4){0.f, 0.f, 0.f, 0.f};           // (a select, not a branch around the load)
+        for (int s = 0; s < 4; ++s) {
+          d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][s], r[s], d0, 0, 0, 0);
+          d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][s], r[s], d1, 0, 0, 0);
+        }
 #pragma unroll
-        for (int oi = 0; oi < 4; ++oi) {
-          const int kx = oi - j + 2;                             // xp = (x0 + oi) - (kx - 1)
-          if (kx < 0 || kx > 2) continue;
-          o[oi] += wv[kx][0] * r[0] + wv[kx][1] * r[1] + wv[kx][2] * r[2] + wv[kx][3] * r[3];
+        for (int i = 0; i < 4; ++i) {
+          hT[(4 * kg + i) * C17_HS + q] = d0[i];                   // taps 0..15
+          if (16 + 4 * kg + i < 28) hT[(16 + 4 * kg + i) * C17_HS + q] = d1[i];   // taps 16..27 (27 = the zero slot)
         }
       }
     }
-  }
+    __syncthreads();
+    if (plane_in) {
+      // ---- stage B: source voxel of tap (kz, ky, kx) for output (ty, tx) = halo slot (ty + 2 - ky, tx + 2 - kx) of this plane
+      float sm = 0.f, s0 = 0.f, sp = 0.f;
 #pragma unroll
-  for (int oi = 0; oi < 4; ++oi) {
-    o[oi] += __shfl_xor(o[oi], 1, 64);
-    o[oi] += __shfl_xor(o[oi], 2, 64);
-  }
-  const float mine = q == 0 ? o[0] : q == 1 ? o[1] : q == 2 ? o[2] : o[3];
-  const int xo = x0 + q;
-  if (live && xo < W) {
-    const long u = ((n * D + zc) * H + y) * (long)W + xo;
-    gp16[u] = t16[u] > 0.f ? mine : mine * slope;
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int slot = (ty + 2 - ky) * 18 + (tx + 2 - kx);
+          sm += hT[(0 * 9 + ky * 3 + kx) * C17_HS + slot];
+          s0 += hT[(1 * 9 + ky * 3 + kx) * C17_HS + slot];
+          sp += hT[(2 * 9 + ky * 3 + kx) * C17_HS + slot];
+        }
+      accm += sm;
+      acc0 += s0;
+      accp += sp;
+    }
+    // output plane p - 1 has now received planes p - 2, p - 1, p
+    const int zo = p - 1;
+    if (col_ok && zo >= z0 && zo < z0 + C17_ZR && zo < D) {
+      const long u = smp * vol + ((long)zo * H + (y0 + ty)) * W + (x0 + tx);
+      gp16[u] = t16[u] > 0.f ? accm : accm * slope;
+    }
+    accm = acc0;
+    acc0 = accp;
+    accp = 0.f;
+    __syncthreads();
   }
 }
 
@@ -242,8 +278,9 @@ extern "C" int lf_occ_conv17_fwd(const float* t16, const float* w27, float* pre,
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || !t16 || !w27 || !pre) return LF_EINVAL;
   if (!lf_aligned16(pre)) return LF_EALIGN;
   const long rows = (long)N * D * H * W;
-  hipLaunchKernelGGL(occ_conv17_fwd_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, t16, w27, (f32x4*)pre,
-                     N, D, H, W);
+  const long groups = (rows + 15) / 16;
+  hipLaunchKernelGGL(occ_conv17_fwd_kernel, dim3((unsigned)((groups + 4 * C17_GPW - 1) / (4 * C17_GPW))), dim3(256), 0, (hipStream_t)stream, t16,
+                     w27, (f32x4*)pre, D, H, W, rows, groups);
   return lf_launch_status();
 }
 
@@ -252,9 +289,10 @@ extern "C" int lf_occ_conv17_bwd(const float* g, const float* t16, const float* 
   lf_clear_error();
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || !g || !t16 || !w27 || !gp16) return LF_EINVAL;
   if (!lf_aligned16(g)) return LF_EALIGN;
-  const int W4 = (W + 3) / 4;
-  const long groups = (long)N * D * H * W4;
-  hipLaunchKernelGGL(occ_conv17_bwd_kernel, dim3((unsigned)((groups * 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const f32x4*)g, t16,
-                     w27, gp16, N, D, H, W, W4, slope);
+  const int nzr = (D + C17_ZR - 1) / C17_ZR, nty = (H + 15) / 16, ntx = (W + 15) / 16;
+  const long blocks = (long)N * nzr * nty * ntx;
+  if (blocks >= 0x7fffffffL) return LF_EINVAL;
+  hipLaunchKernelGGL(occ_conv17_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const f32x4*)g, t16, w27, gp16, D, H, W,
+                     nzr, nty, ntx, slope);
   return lf_launch_status();
 }
