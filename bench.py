@@ -292,7 +292,7 @@ def cfg3_report(a, dev):
         runs.append(time.perf_counter() - t0)
         if rep == 2:
             timer, ops.KERNEL_TIMER = ops.KERNEL_TIMER, None
-    on_engine = est._engine_cache is not None and est._engine_cache[2] is not None
+    on_engine = bool(getattr(est, 'last_scored_on_engine', False))   # (estimate() drops its engine on return)
     el = min(runs[1:2])                                            # the un-instrumented warm run
     d3 = [e0.elapsed_time(e1) for n_, e0, e1 in timer if n_ == 'wino3d_fused']
     Cw, Sw = 256, 16
@@ -419,6 +419,13 @@ def cfg5_report(a, dev):
     step.run_iteration(batch)
     torch.cuda.synchronize()
     timer, ops.KERNEL_TIMER, ops.KERNEL_TIMER_TAGS = ops.KERNEL_TIMER, None, None
+    # algorithmic bytes of the STEP: one more untimed step with the library's byte accounting on (_lib.BYTE_LOG: per launch,
+    # the sizes of its input / output tensors, each once, scratch excluded)
+    from latentfusion_amd import _lib
+    _lib.BYTE_LOG = {}
+    step.run_iteration(batch)
+    torch.cuda.synchronize()
+    byte_log, _lib.BYTE_LOG = _lib.BYTE_LOG, None
     n_par = sum(q.numel() for q in step.flat.params)
     del step, batch
     torch.cuda.empty_cache()
@@ -435,6 +442,15 @@ def cfg5_report(a, dev):
            'mean_step_ms': sum(times[1:]) / K * 1e3,
            'first_step_ms': times[0] * 1e3, 'peak_mem_GB': peak, 'params': n_par, 'loss': losses,
            'run_to_run_identical': bool(identical), 'dtype': 'bf16 MFMA operands (autocast policy), fp32 accumulation / master weights / Adam'}
+    step_bytes = float(sum(v[1] for v in byte_log.values()))
+    top = sorted(byte_log.items(), key=lambda kv: -kv[1][1])[:12]
+    out['roofline_step'] = {
+        'bound': 'hbm', 'algorithmic_bytes_per_step': step_bytes, 'library_launches_per_step': int(sum(v[0] for v in byte_log.values())),
+        'hbm_floor_ms': step_bytes / (HBM_PEAK_GBS * 1e9) * 1e3, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+        'achieved': step_bytes / (ms * 1e-3) / 1e9, 'frac': step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        'how': 'sum over the library launches of one step of the sizes of each launch\'s input and output tensors (each once; scratch and '
+               'the few ATen element-wise launches excluded), divided by the median step time and 8 TB/s',
+        'largest_entry_points_GB': {k: {'launches': v[0], 'GB': v[1] / 1e9} for k, v in top}}
     # roofline of the dominant training kernel: the bf16 ring convolution on ONE 128^3 x 16 volume (the ConvGRU recurrence
     # launches it ~370 times per step); algorithmic bytes = input + output (+ the addend of the gates' sum form), fp32
     vol = C * S ** 3 * 4
@@ -748,10 +764,8 @@ def main():
 
     # ---- roofline of the dominant kernel (fused conv3d 16->16 block step; 2 forward + 2 data-gradient launches per
     # iteration), from HIP events recorded on the launch stream inside the timed region -------------------------------
-    name = {'fp32': f'conv3x3_3d_{C}x{C}', 'winograd': 'conv3d_c16_wino', 'f16x3': 'conv3d_c16_split',
-            'winograd_f16x3': 'conv3d_c16_wino_split'}[a.conv_mode]
-    kname = {'fp32': 'conv3d_c16_persistent_kernel', 'winograd': 'conv3d_c16_wino_kernel',
-             'f16x3': 'conv3d_c16_f16x3_kernel', 'winograd_f16x3': 'conv3d_c16_wino_f16x3_kernel'}[a.conv_mode]
+    name = {'fp32': f'conv3x3_3d_{C}x{C}', 'winograd': 'conv3d_c16_wino', 'f16x3': 'conv3d_c16_split'}[a.conv_mode]
+    kname = {'fp32': 'conv3d_c16_persistent_kernel', 'winograd': 'conv3d_c16_wino_kernel', 'f16x3': 'conv3d_c16_f16x3_kernel'}[a.conv_mode]
 
     def avg_ms(tag):
         d = [e0.elapsed_time(e1) for n_, e0, e1 in timer if n_ == tag]
@@ -760,7 +774,7 @@ def main():
     nvox = N * S ** 3
     alg_flops = 2.0 * 27 * C * C * nvox                            # direct-convolution count
     alg_bytes = (2 * C + 1) * nvox * 4                             # read x, write y and one norm float per voxel
-    wino = a.conv_mode in ('winograd', 'winograd_f16x3')
+    wino = a.conv_mode == 'winograd'
     exec_flops = alg_flops * (64.0 / 216.0 if wino else 1.0) * (1.0 if a.conv_mode in ('fp32', 'winograd') else 3.0)
     # price against the pipe the products run on: fp32 MFMA for the all-fp32 kernels, dense f16 MFMA for the split ones
     peak = FP32_MFMA_PEAK_TFLOPS if a.conv_mode in ('fp32', 'winograd') else F16_MFMA_PEAK_TFLOPS
@@ -1028,6 +1042,28 @@ def main():
         out['pipelined_gru_build'] = pipelined
     if hyp is not None:
         out['hypothesis_sharded_one_object'] = hyp
+    # LAST in the line (the driver keeps the line's tail): every secondary claim of DESIGN.md in one compact object
+    def dig(d, *ks):
+        for k_ in ks:
+            if not isinstance(d, dict) or k_ not in d:
+                return None
+            d = d[k_]
+        return d
+    tr = dig(ref_trace, 'trace') or {}
+    out['summary'] = {
+        'headline_iters_per_s': out.get('value'), 'headline_roofline_frac': dig(out, 'roofline', 'frac'),
+        'cpu_baseline_iters_per_s': dig(out, 'cpu_baseline', 'value'),
+        'cfg3_iters_per_s': dig(cfg3, 'value'), 'cfg3_roofline_frac': dig(cfg3, 'roofline', 'frac'),
+        'cfg3_scored_on_fused_engine': dig(cfg3, 'scored_on_fused_engine'),
+        'cfg5_ms_per_step': dig(cfg5, 'ms_per_step'), 'cfg5_peak_mem_GB': dig(cfg5, 'peak_mem_GB'),
+        'cfg5_roofline_step_frac': dig(cfg5, 'roofline_step', 'frac'), 'cfg5_step_GB': (dig(cfg5, 'roofline_step', 'algorithmic_bytes_per_step') or 0) / 1e9 or None,
+        'cfg5_run_to_run_identical': dig(cfg5, 'run_to_run_identical'),
+        'renderer_variants_iters_per_s': {k: dig(variants, k, 'iters_per_s') for k in ('sum', 'occlusion')} if variants else None,
+        'reference_trace': {k: tr.get(k) for k in ('first_iteration_argmin_differs', 'max_rel_diff_all', 'final_top1_equal',
+                                                     'argmin_mismatch_at_clear_gap')} if tr else None,
+        'reference_self_deviation': {k: dig(tr, 'reference_self_deviation', k) for k in (
+            'control_threads', 'first_iteration_references_disagree_on_argmin', 'hip_argmin_mismatch_where_references_agree',
+            'max_hip_dev_over_windowed_ref_dev', 'hip_dev_over_ref_dev_at_9')} if dig(tr, 'reference_self_deviation') else None}
     print(json.dumps(out), flush=True)
 
 

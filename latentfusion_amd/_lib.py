@@ -177,6 +177,29 @@ _ERR = {-1: 'LF_EINVAL (bad size/flag combination)', -2: 'LF_EALIGN (alignment /
         -3: 'LF_ENOSPC (scratch too small)'}
 
 
+# Algorithmic-byte accounting of a step (bench.py `cfg5.roofline_step`): while BYTE_LOG is a dict, every tensor whose pointer the
+# operator wrappers hand to the library (ops._ptr) is noted, and `check` -- called once per launch -- closes the launch:
+# BYTE_LOG[entry point] = [launches, bytes], bytes = the sizes of the launch's input / output tensors, each once (scratch
+# buffers excluded) = what the launch has to move through HBM at least.  None: no cost beyond one comparison per pointer.
+BYTE_LOG = None
+_PENDING = [0]
+
+
+def note_bytes(t, scratch=False):
+    if BYTE_LOG is not None and not scratch:
+        n = t.numel() * t.element_size()
+        try:                                            # (an expanded view is read once, not numel() times)
+            n = min(n, t.untyped_storage().nbytes() - t.storage_offset() * t.element_size())
+        except Exception:                               # noqa: BLE001
+            pass
+        _PENDING[0] += n
+
+
 def check(rc, what):
+    if BYTE_LOG is not None:
+        e = BYTE_LOG.setdefault(what, [0, 0])
+        e[0] += 1
+        e[1] += _PENDING[0]
+        _PENDING[0] = 0
     if rc != 0:
         raise LFHipError(f'{what} failed: {_ERR.get(rc, "hipError " + str(rc))}')

@@ -569,13 +569,10 @@ extern "C" int lf_conv3d_c16_split(const float* x, const void* wsplit, const flo
   typedef void (*kern_t)(const float*, const void*, const float*, float*, float*, int, int, int, int, int, int, int, int, float,
                          unsigned, float, float, const float*, const float*, unsigned, const float*, float*, int);
   static const kern_t kerns[2] = {conv3d_c16_f16x3_kernel<false, 3>, conv3d_c16_f16x3_kernel<true, 3>};
-  static bool attr_set = false;
-  if (!attr_set) {
-    for (int i = 0; i < 2; ++i) {
-      hipError_t e = hipFuncSetAttribute((const void*)kerns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-      if (e != hipSuccess) return (int)e;
-    }
-    attr_set = true;
+  static lf_devmask_t attr_set[2];
+  for (int i = 0; i < 2; ++i) {
+    hipError_t e = lf_ensure_dyn_lds(attr_set[i], (const void*)kerns[i], (int)shmem);
+    if (e != hipSuccess) return (int)e;
   }
   const long want = (long)SPLIT_WGS * cus;                        // two resident workgroups per CU
   const unsigned grid = (unsigned)(pt < want ? pt : want);

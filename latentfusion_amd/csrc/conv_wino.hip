@@ -896,11 +896,10 @@ int launch_wino(K kernel, const float* x, const void* upack, const float* bias, 
            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
   }
   const size_t shmem = (size_t)LDSw;
-  static bool attr_set = false;                                 // (one instance per kernel: the template is per K)
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+  static lf_devmask_t attr_set;                                   // (one instance per kernel: the template is per K)
+  {
+    hipError_t e = lf_ensure_dyn_lds(attr_set, (const void*)kernel, (int)shmem);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
   }
   const long want = 2L * cus;                                     // two resident workgroups per CU
   const long units = COLUMNS ? pt / ptz : pt;                     // (the fused forms hand out whole columns of tiles)

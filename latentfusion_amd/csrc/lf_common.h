@@ -20,6 +20,21 @@ static inline int lf_launch_status() {
 
 static inline bool lf_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, DEVICE): `done` keeps one bit per device ordinal, so a
+// process that drives several GPUs (one host thread each, e.g. autograd's per-device backward threads) sets it on each of
+// them, and concurrent first launches at worst set it twice.
+#include <atomic>
+typedef std::atomic<unsigned long long> lf_devmask_t;
+static inline hipError_t lf_ensure_dyn_lds(lf_devmask_t& done, const void* fn, int bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+  return e;
+}
+
 __device__ __forceinline__ float lf_wave_sum(float v) {
   // fixed-order butterfly over the 64 lanes of a wavefront (deterministic)
 #pragma unroll

@@ -487,11 +487,10 @@ extern "C" int lf_lift_norm_unfold(const float* src, void* dst, float* norm_out,
   const dim3 grid((unsigned)((P + FT - 1) / FT), (unsigned)N);
   typedef void (*kern_t)(const float*, void*, float*, long, int, int, float);
   const kern_t k = out_bf16 ? (kern_t)lift_norm_unfold_kernel<true> : (kern_t)lift_norm_unfold_kernel<false>;
-  static bool attr[2] = {false, false};
-  if (!attr[out_bf16 ? 1 : 0] && shmem > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+  static lf_devmask_t attr[2];
+  if (shmem > 48 * 1024) {
+    hipError_t e = lf_ensure_dyn_lds(attr[out_bf16 ? 1 : 0], (const void*)k, 150 * 1024);
     if (e != hipSuccess) return (int)e;
-    attr[out_bf16 ? 1 : 0] = true;
   }
   hipLaunchKernelGGL(k, grid, dim3(256), shmem, (hipStream_t)stream, src, dst, norm_out, P, C0, S, eps);
   return lf_launch_status();
@@ -507,11 +506,10 @@ extern "C" int lf_lift_bwd(const void* gvol, const void* yvol, const float* norm
   const dim3 grid((unsigned)((P + FT - 1) / FT), (unsigned)N);
   typedef void (*kern_t)(const void*, const void*, const float*, float*, long, int, int, float, int);
   static const kern_t kerns[4] = {lift_bwd_fused_kernel<0>, lift_bwd_fused_kernel<1>, lift_bwd_fused_kernel<2>, lift_bwd_fused_kernel<3>};
-  static bool attr[4] = {false, false, false, false};
-  if (!attr[io] && shmem > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)kerns[io], hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+  static lf_devmask_t attr[4];
+  if (shmem > 48 * 1024) {
+    hipError_t e = lf_ensure_dyn_lds(attr[io], (const void*)kerns[io], 150 * 1024);
     if (e != hipSuccess) return (int)e;
-    attr[io] = true;
   }
   hipLaunchKernelGGL(kerns[io], grid, dim3(256), shmem, (hipStream_t)stream, gvol, yvol, norm, gp, P, C0, S, slope, round_bf16);
   return lf_launch_status();

@@ -572,11 +572,10 @@ extern "C" int lf_conv_bwd_weight(const float* x, const float* gpre, float* gw, 
     const long pt = (long)ptx * pty * ptz * N;
     if (pt > 0x7fffffffL) return LF_EINVAL;
     const size_t shmem = (size_t)2 * WBUF;
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute((const void*)wgrad3d_c16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    static lf_devmask_t attr_set;
+    {
+      hipError_t e = lf_ensure_dyn_lds(attr_set, (const void*)wgrad3d_c16_kernel, (int)shmem);
       if (e != hipSuccess) return (int)e;
-      attr_set = true;
     }
     hipStream_t s = (hipStream_t)stream;
     // every workgroup writes its 8 x 27 x 256 partials (zeros when it has no tiles), so the grid is always `cus`
@@ -637,13 +636,10 @@ static int wgrad_bf16_launch(const void* x, const void* gpre, float* gw, void* s
   const size_t shmem = (size_t)BLDS;
   typedef void (*kern_t)(const float*, const float*, float*, int, int, int, int, int, int, int, int);
   static const kern_t kerns[4] = {wgrad3d_c16_bf16_kernel<0>, wgrad3d_c16_bf16_kernel<1>, wgrad3d_c16_bf16_kernel<2>, wgrad3d_c16_bf16_kernel<3>};
-  static bool attr_set = false;
-  if (!attr_set) {
-    for (int i = 0; i < 4; ++i) {
-      hipError_t e = hipFuncSetAttribute((const void*)kerns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-      if (e != hipSuccess) return (int)e;
-    }
-    attr_set = true;
+  static lf_devmask_t attr_set[4];
+  {
+    hipError_t e = lf_ensure_dyn_lds(attr_set[io], (const void*)kerns[io], (int)shmem);
+    if (e != hipSuccess) return (int)e;
   }
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(kerns[io], dim3(nb), dim3(256), shmem, s, (const float*)x, (const float*)gpre, (float*)scratch, N, D, H, W, ptx, pty, ptz, (int)pt);

@@ -344,11 +344,10 @@ static int launch_fused(dim3 grid, hipStream_t s, const float* V, const float* U
                         int tx, int D, int H, int W, int Cin, int Cout, int CoutP, float he, unsigned flags, float slope,
                         float* partial, long ysize) {
   constexpr int lds = NSTAGE * (WM * BA * 16 + WN * BB * 16) * 128;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)wino_fused_kernel<DIMS, WM, WN, BA, BB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  static lf_devmask_t attr_set;
+  {
+    hipError_t e = lf_ensure_dyn_lds(attr_set, (const void*)wino_fused_kernel<DIMS, WM, WN, BA, BB>, lds);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
   }
   hipLaunchKernelGGL((wino_fused_kernel<DIMS, WM, WN, BA, BB>), grid, dim3(WM * WN * 64), lds, s, V, U2, bias, y, T, tz, ty, tx, D, H, W,
                      Cin, Cout, CoutP, he, flags, slope, partial, ysize);

@@ -155,7 +155,9 @@ def empty_cl(shape, device):
     return torch.empty(shape, device=device, dtype=torch.float32, memory_format=fmt)
 
 
-def _ptr(t):
+def _ptr(t, scratch=False):
+    if _lib.BYTE_LOG is not None:
+        _lib.note_bytes(t, scratch)
     return t.data_ptr()
 
 
@@ -441,7 +443,7 @@ def conv_wino_fused(x, U2, cout, bias, he, flags):
     scr = torch.empty(nscr // 4, device=x.device, dtype=torch.float32) if nscr else None
     with _timed(f'wino{dims}d_fused'):
         check(L.lf_wino_fused_gemm(_ptr(V), _ptr(U2), _ptr(bias) if bias is not None else None, _ptr(y),
-                                   _ptr(scr) if scr is not None else None, nscr, dims, N, D, H, W, cin,
+                                   _ptr(scr, True) if scr is not None else None, nscr, dims, N, D, H, W, cin,
                                    cout, he, flags & LF_EPI_LRELU, SLOPE, _stream()), 'lf_wino_fused_gemm')
     del V
     norm = None
@@ -516,14 +518,14 @@ class _Resample(torch.autograd.Function):
             gcoef = torch.empty(n, 18, device=g.device, dtype=torch.float32)
             nbytes = L.lf_resample3d_bwd_coef_scratch_bytes(n, D, H, W)
             scratch = torch.empty(max(nbytes, 4) // 4 + 1, device=g.device, dtype=torch.float32)
-            check(L.lf_resample3d_bwd_coef(_ptr(g), _ptr(v), ctx.vol_n, _ptr(cf), _ptr(gcoef), _ptr(scratch),
+            check(L.lf_resample3d_bwd_coef(_ptr(g), _ptr(v), ctx.vol_n, _ptr(cf), _ptr(gcoef), _ptr(scratch, True),
                                            scratch.numel() * 4, n, D, H, W, C, _stream()), 'lf_resample3d_bwd_coef')
         if ctx.needs_input_grad[0]:
             if DETERMINISTIC_SPLAT:
                 gv = empty_cl((ctx.vol_n, C, D, H, W), g.device)
                 nb = L.lf_resample3d_bwd_vol_det_scratch_bytes(ctx.vol_n, D, H, W, C)
                 scr = torch.empty(nb // 8 + 1, device=g.device, dtype=torch.int64)
-                check(L.lf_resample3d_bwd_vol_det(_ptr(g), _ptr(cf), ctx.kind, _ptr(gv), ctx.vol_n, _ptr(scr), scr.numel() * 8,
+                check(L.lf_resample3d_bwd_vol_det(_ptr(g), _ptr(cf), ctx.kind, _ptr(gv), ctx.vol_n, _ptr(scr, True), scr.numel() * 8,
                                                   n, D, H, W, C, _stream()), 'lf_resample3d_bwd_vol_det')
             else:
                 gv = empty_cl((ctx.vol_n, C, D, H, W), g.device).zero_()

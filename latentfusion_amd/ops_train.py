@@ -100,7 +100,7 @@ class _ResampleAC(torch.autograd.Function):
         scr = torch.empty(nb // 8 + 1, device=g.device, dtype=torch.int64)
         io = (1 if g.dtype == torch.bfloat16 else 0) | (2 if gv.dtype == torch.bfloat16 else 0)
         with _timed('resample_bwd_vol', f'{kind}:{n}:io{io}'):
-            check(L.lf_resample3d_bwd_vol_det_io(_ptr(g), _ptr(cf), kind, _ptr(gv), vol_n, _ptr(scr), scr.numel() * 8, n, D, H, W, io,
+            check(L.lf_resample3d_bwd_vol_det_io(_ptr(g), _ptr(cf), kind, _ptr(gv), vol_n, _ptr(scr, True), scr.numel() * 8, n, D, H, W, io,
                                                  _stream()), 'lf_resample3d_bwd_vol_det_io')
         if gv.shape[0] == vshape[0]:
             return gv, None, None
@@ -128,7 +128,7 @@ def bias_grad(gp, dims):
     gb = torch.empty(1, cout, 1, device=gp.device, dtype=torch.float32)
     nbytes = L.lf_conv_bwd_weight_scratch_bytes(0, N, D, H, W, 0, cout)
     scratch = torch.empty(nbytes // 4 + 1, device=gp.device, dtype=torch.float32)
-    check(L.lf_conv_bwd_weight(None, _ptr(gp), _ptr(gb), _ptr(scratch), scratch.numel() * 4, 0, N, D, H, W, 0, cout,
+    check(L.lf_conv_bwd_weight(None, _ptr(gp), _ptr(gb), _ptr(scratch, True), scratch.numel() * 4, 0, N, D, H, W, 0, cout,
                                1.0, _stream()), 'lf_conv_bwd_weight')
     return gb.reshape(cout)
 
@@ -181,14 +181,14 @@ def conv_bwd_weight(x, gp, dims, cin, he, want_bias=True, bf16=None):
     scratch = torch.empty(nbytes // 4 + 1, device=gp.device, dtype=torch.float32)
     if bf16 and _wgrad_bf16_ok(gp, dims, cin, cout):
         # autocast: both operands are bf16 values -- the bf16 MFMA forms the same exact products 8x faster
-        check(L.lf_conv_bwd_weight_bf16(_ptr(x), _ptr(gp), _ptr(gw), _ptr(scratch), scratch.numel() * 4, dims, N, D, H, W, cin, cout,
+        check(L.lf_conv_bwd_weight_bf16(_ptr(x), _ptr(gp), _ptr(gw), _ptr(scratch, True), scratch.numel() * 4, dims, N, D, H, W, cin, cout,
                                         he, _stream()), 'lf_conv_bwd_weight_bf16')
     else:
-        check(L.lf_conv_bwd_weight(_ptr(x), _ptr(gp), _ptr(gw), _ptr(scratch), scratch.numel() * 4, dims, N, D, H, W, cin, cout,
+        check(L.lf_conv_bwd_weight(_ptr(x), _ptr(gp), _ptr(gw), _ptr(scratch, True), scratch.numel() * 4, dims, N, D, H, W, cin, cout,
                                    he, _stream()), 'lf_conv_bwd_weight')
     if not want_bias:
         return gw, None
-    check(L.lf_conv_bwd_weight(None, _ptr(gp), _ptr(gb), _ptr(scratch), scratch.numel() * 4, 0, N, D, H, W, 0, cout,
+    check(L.lf_conv_bwd_weight(None, _ptr(gp), _ptr(gb), _ptr(scratch, True), scratch.numel() * 4, 0, N, D, H, W, 0, cout,
                                1.0, _stream()), 'lf_conv_bwd_weight')
     return gw, gb.reshape(cout)
 
@@ -211,7 +211,7 @@ def epilogue_bwd_c16(gy, y, norm, flags, want_bias, out_bf16=True):
     io = (1 if gy.dtype == torch.bfloat16 else 0) | (2 if (y is not None and y.dtype == torch.bfloat16) else 0) | (4 if out_bf16 else 0)
     with _timed('epilogue_bwd_c16', f'{rows}:io{io}'):
         check(L.lf_epilogue_bwd_c16(_ptr(gy), _ptr(y) if y is not None else None, _ptr(norm) if norm is not None else None, _ptr(gp),
-                                    _ptr(gb) if gb is not None else None, _ptr(scr) if scr is not None else None,
+                                    _ptr(gb) if gb is not None else None, _ptr(scr, True) if scr is not None else None,
                                     scr.numel() * 4 if scr is not None else 0, rows, flags, SLOPE, io, _stream()), 'lf_epilogue_bwd_c16')
     return gp, gb
 
@@ -264,7 +264,7 @@ class _Conv16AC(torch.autograd.Function):
                     side = side_stream(gp.device)
                     side.wait_stream(main)                    # gp (and the allocations above) are ready
                 with torch.cuda.stream(side) if side is not None else _timed('wgrad3d_c16_bf16', f'{N}:io{io}'):
-                    check(L.lf_conv_bwd_weight_bf16_io(_ptr(x_saved), _ptr(gp), _ptr(gwt), _ptr(scr), scr.numel() * 4, 3, N, D, H, W, 16, 16,
+                    check(L.lf_conv_bwd_weight_bf16_io(_ptr(x_saved), _ptr(gp), _ptr(gwt), _ptr(scr, True), scr.numel() * 4, 3, N, D, H, W, 16, 16,
                                                        ctx.he, io, _stream()), 'lf_conv_bwd_weight_bf16_io')
                     if side is not None:
                         done = torch.cuda.Event()
@@ -473,6 +473,8 @@ class _GruFuse(torch.autograd.Function):
         zz = _dense_views(z)                                      # (V,16,D,H,W) channels-last, fp32 or bf16 storage
         D, H, W = zz.shape[2:]
         ac = ops.AUTOCAST is not None
+        if not ac:
+            zz = _f32(zz)                                         # (a bf16-stored stack fused OUTSIDE the policy: the fp32 kernels read 64 B records)
         T16 = ac                                                  # bf16 storage of the once-per-step tensors
         he = he_constant(wu)
         gates = ((wu, bu), (wr, br), (wo, bo))
@@ -555,12 +557,12 @@ class _GruFuse(torch.autograd.Function):
         def wgrad(x, gp, dst):
             if ac and fast:
                 io = (1 if x.dtype == torch.bfloat16 else 0) | (2 if gp.dtype == torch.bfloat16 else 0)
-                check(L.lf_conv_bwd_weight_bf16_io(_ptr(x), _ptr(gp), _ptr(dst), _ptr(scratch), scratch.numel() * 4, 3, 1, D, H, W,
+                check(L.lf_conv_bwd_weight_bf16_io(_ptr(x), _ptr(gp), _ptr(dst), _ptr(scratch, True), scratch.numel() * 4, 3, 1, D, H, W,
                                                    16, 16, he, io, _stream()), 'lf_conv_bwd_weight_bf16_io')
             else:
                 xf = round_bf16(x.float()) if ac else x
                 gf = round_bf16(gp.float()) if ac else gp
-                check(L.lf_conv_bwd_weight(_ptr(xf), _ptr(gf), _ptr(dst), _ptr(scratch), scratch.numel() * 4, 3, 1, D, H, W, 16, 16,
+                check(L.lf_conv_bwd_weight(_ptr(xf), _ptr(gf), _ptr(dst), _ptr(scratch, True), scratch.numel() * 4, 3, 1, D, H, W, 16, 16,
                                            he, _stream()), 'lf_conv_bwd_weight')
         gh1 = empty_cl(shape1, dev)
         gh12 = empty_cl(shape1, dev)

@@ -76,6 +76,7 @@ class PoseEstimator:
         # hypotheses when the renderer and the loss are of the kind it sequences; False selects the generic module path
         self.use_engine, self.conv_mode, self.fuse_projection = use_engine, conv_mode, fuse_projection
         self._engine_cache = None
+        self.last_scored_on_engine = False
         self.shard_hypotheses = bool(shard_hypotheses)
         self.ranking_size = ranking_size
         self.loss_func = default_pose_loss if loss_func is None else loss_func
@@ -166,6 +167,7 @@ class PoseEstimator:
         c = self._engine_cache
         if c is None or c[0] is not z_obj or c[1] is not target_obs:
             self._engine_cache = c = (z_obj, target_obs, self._engine_for(z_obj, target_obs))
+            self.last_scored_on_engine = c[2] is not None         # (outlives the cache entry: bench.py reports it)
         return c[2]
 
     def _score_samples(self, z_obj, target_obs, cameras, z_target_latent=None):
@@ -282,7 +284,9 @@ class CrossEntropyPoseEstimator(PoseEstimator):
             gmm = self._create_gmm(self._camera_to_params(cameras).cpu())
             if self._track_best_items(ranking, step, list(cameras), losses.tolist()) > 0:
                 history.append((losses, Camera.cat([c for c, _, _ in ranking])))
-        out = Camera.cat([c for c, _, _ in ranking])
+        # the ranked cameras go back to the estimator's device, as the reference builds them (:381): the same return type on
+        # one rank (where the sampler keeps its cameras on the host, _refine_pose) and when sharded
+        out = Camera.cat([c for c, _, _ in ranking]).to(self.device)
         return (out, history) if self.return_camera_history else out
 
     def evaluate_samples(self, z_obj, target_obs, cameras):

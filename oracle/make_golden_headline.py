@@ -4,6 +4,12 @@
     python oracle/make_golden_headline.py T TARGET_SEED INIT_SEED NAME     # further seeds of the target frame / the initial
                                                                            # hypotheses -> tests/golden/NAME.pt (same object; the
                                                                            # latent volume is not stored again)
+    python oracle/make_golden_headline.py 30 200 300 g26n_headline_trace_threads3 --threads 3
+                                                                           # the NOISE-FLOOR CONTROL: the same reference run on
+                                                                           # the same seeds as g26 with another thread count
+                                                                           # (ATen's reductions split differently): the
+                                                                           # reference-vs-reference deviation the loop
+                                                                           # tolerances of the GPU tests are anchored to
 
 BASELINE cfg 2 exactly as bench.py runs it: SYN(128,16) with the GRU fuser (weights seed 0), 16 reference views (seed 100),
 one target frame (seed 200), 8 initial hypotheses (seed 300), configs/adam_quick.toml.  The REFERENCE (imported from
@@ -33,6 +39,11 @@ SEED_MODEL, SEED_REF, SEED_TARGET, SEED_INIT = 0, 100, 200, 300
 
 def main():
     global SEED_TARGET, SEED_INIT
+    threads = os.cpu_count() or 8
+    if '--threads' in sys.argv:
+        i = sys.argv.index('--threads')
+        threads = int(sys.argv[i + 1])
+        del sys.argv[i:i + 2]
     T = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     name = 'g26_headline_trace'
     if len(sys.argv) > 4:
@@ -47,7 +58,7 @@ def main():
     from latentfusion.recon.inference import LatentFusionModel
     from latentfusion.recon.models import Photographer, Sculptor
     from latentfusion_amd import synth                       # seeded inputs only: no product compute is used
-    torch.set_num_threads(os.cpu_count() or 8)
+    torch.set_num_threads(threads)
 
     sck, fck, pck, dist = synth.make_syn_checkpoints(S, C, 'gru', SEED_MODEL)
     model = LatentFusionModel(Sculptor.from_checkpoint(copy.deepcopy(sck)), fusion.from_checkpoint(copy.deepcopy(fck)),

@@ -3,7 +3,7 @@
 oracle/make_golden_headline.py from the imported reference): 16-view reconstruction at 128^3, the renders of iteration 0, and
 the adam_quick loop iteration by iteration over the fixture's length (the preset's 100 iterations).
 
-    python tools/headline_trace_probe.py [out.json [fixture name, default g26_headline_trace]]
+    python tools/headline_trace_probe.py [out.json [fixture name, default g26_headline_trace]] [--conv-mode fp32|f16x3|winograd]
 
 Reports, per iteration: max relative difference of the N rank losses, whether the argmin / the full ranking agree, the
 reference's top-2 gap; and the summary figures: first iteration whose ranking differs, first whose argmin differs, the
@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def compare(dev='cuda', name='g26_headline_trace'):
+def compare(dev='cuda', name='g26_headline_trace', conv_mode=None, control='g26n_headline_trace_threads3'):
     from latentfusion_amd import synth
     from latentfusion_amd.modules.geometry import Camera
     from latentfusion_amd.observation import Observation
@@ -55,10 +55,18 @@ def compare(dev='cuda', name='g26_headline_trace'):
     out['iteration0_renders'] = r0
     cfg = dict(g['cfg'])
     cfg['args'] = dict(cfg['args'])
-    est = estimation.load_from_config(cfg, model, track_stats=True)
+    est = estimation.load_from_config(cfg, model, track_stats=True, **({'conv_mode': conv_mode} if conv_mode else {}))
     _, stats = est.estimate(z, target, camera=init.to('cpu'))
     got, ref = stats['rank_loss'].cpu(), g['rank_loss']
     k = min(len(got), len(ref))
+    # the noise-floor control: the reference against ITSELF on the same seeds with another thread count (g26n, written by
+    # oracle/make_golden_headline.py --threads 3): per iteration, the reference's own deviation and HIP's as a multiple of it
+    ctl_path = os.path.join(ROOT, 'tests', 'golden', control + '.pt')
+    ctl = torch.load(ctl_path, weights_only=False) if (name == 'g26_headline_trace' and os.path.exists(ctl_path)) else None
+    ref_dev = None
+    if ctl is not None:
+        kc = min(k, len(ctl['rank_loss']))
+        ref_dev = ((ctl['rank_loss'][:kc] - ref[:kc]).abs() / ref[:kc].abs().clamp_min(1e-30)).max(dim=1).values
     rows, rank_first, arg_first, clear_mismatch = [], None, None, []
     for i in range(k):
         srt = torch.sort(ref[i]).values
@@ -74,6 +82,10 @@ def compare(dev='cuda', name='g26_headline_trace'):
             clear_mismatch.append(i)
         rows.append({'iteration': i, 'rank_loss_max_rel_diff': rel, 'argmin_equal': a_eq, 'ranking_equal': r_eq, 'reference_top2_rel_gap': gap,
                      'best_loss_hip': float(got[i].min()), 'best_loss_reference': float(ref[i].min())})
+        if ref_dev is not None and i < len(ref_dev):
+            rows[-1]['reference_self_deviation'] = float(ref_dev[i])
+            rows[-1]['hip_dev_over_ref_dev'] = rel / max(float(ref_dev[i]), 1e-30)
+            rows[-1]['references_agree_on_argmin'] = bool(torch.argmin(ctl['rank_loss'][i]) == torch.argmin(ref[i]))
     out['trace'] = {'iterations': k, 'first_iteration_ranking_differs': rank_first, 'first_iteration_argmin_differs': arg_first,
                     'argmin_equal_count': sum(r['argmin_equal'] for r in rows),
                     'iterations_with_clear_gap': sum(r['reference_top2_rel_gap'] > 1e-3 for r in rows),
@@ -82,11 +94,32 @@ def compare(dev='cuda', name='g26_headline_trace'):
                     'final_best_loss_reference': rows[-1]['best_loss_reference'],
                     'max_rel_diff_first_5': max(r['rank_loss_max_rel_diff'] for r in rows[:5]),
                     'max_rel_diff_all': max(r['rank_loss_max_rel_diff'] for r in rows), 'per_iteration': rows}
+    if ref_dev is not None:
+        kc = len(ref_dev)
+        both = [r for r in rows[:kc] if r['references_agree_on_argmin']]
+        out['trace']['reference_self_deviation'] = {
+            'control': control, 'control_threads': int(ctl['reference_threads']), 'iterations': kc,
+            'per_iteration': [float(v) for v in ref_dev],
+            'first_iteration_references_disagree_on_argmin': next((r['iteration'] for r in rows[:kc] if not r['references_agree_on_argmin']), None),
+            'iterations_references_agree_on_argmin': len(both),
+            'hip_argmin_mismatch_where_references_agree': [r['iteration'] for r in both if not r['argmin_equal']],
+            # windowed: Adam amplifies a rounding difference exponentially over the first iterations, so one iteration's
+            # deviation is compared with the control's largest over iterations i-2 .. i+2
+            'max_hip_dev_over_windowed_ref_dev': max(
+                rows[i]['rank_loss_max_rel_diff'] / max(float(ref_dev[max(0, i - 2):i + 3].max()), 1e-30) for i in range(kc)),
+            'hip_dev_over_ref_dev_at_9': rows[9].get('hip_dev_over_ref_dev') if kc > 9 else None}
+    if conv_mode:
+        out['conv_mode'] = conv_mode
     return out
 
 
 if __name__ == '__main__':
-    res = compare(name=sys.argv[2] if len(sys.argv) > 2 else 'g26_headline_trace')
+    cm = None
+    if '--conv-mode' in sys.argv:
+        i = sys.argv.index('--conv-mode')
+        cm = sys.argv[i + 1]
+        del sys.argv[i:i + 2]
+    res = compare(name=sys.argv[2] if len(sys.argv) > 2 else 'g26_headline_trace', conv_mode=cm)
     txt = json.dumps(res, indent=1)
     if len(sys.argv) > 1:
         open(sys.argv[1], 'w').write(txt)
