@@ -223,6 +223,35 @@ int lf_conv3d_c16_ring_bf16_io(const void* x, const void* wpack, const float* bi
                                int N, int D, int H, int W, float he, unsigned flags, float slope, float eps,
                                const void* addend, int round_out, int io, void* stream);
 
+/* MULTI-OUTPUT form of the bf16 ring convolution for the ConvGRU recurrence of the training step (round 6; reference
+ * modules/gru.py:30-43 under recon/fusion.py:188-197, autograd of the same lines): ONE staged input volume x (bf16 records,
+ * or fp32 with x_bf16 = 0) is convolved with `ngroups` (1 or 2) weight packs (wpack = the packs of
+ * lf_conv3d_c16_ring_bf16 back to back) into `ngroups` outputs; per group g the epilogue is
+ *     y_g = fma(conv_g, he, add_g)                       add_g fp32 or (LF_RING_ADD_BF16) bf16, NULL = no addend
+ *     y_g = bf16(bf16(conv_g) * he)                      LF_RING_ROUND: what autocast's half-precision convolution returns
+ * stored as fp32 or (LF_RING_OUT_BF16) bf16 records; addend_per_sample = 0: one addend volume for all N samples.
+ * `extra` folds an element-wise stage of the recurrence into the epilogue of the convolution that owns the same voxels:
+ *   LF_RING_EX_RH    (fp32 x = h, the LAST group = reset gate stored as bf16): o2 = bf16(h * sigmoid(y_last as stored))
+ *   LF_RING_EX_BLEND (ngroups 1, y_0 = candidate stored as bf16; e0 = h fp32, e1 = update pre-activation bf16):
+ *                    o2 (fp32) = h (1 - u) + y_0 u,  u = sigmoid(e1)
+ *   LF_RING_EX_ABWD  (group 0 = LF_RING_ROUND | LF_RING_ADD_BF16 with add_0 = reset pre-activation, NOT added;
+ *                    e0 = h fp32, e1 = gh1 fp32): g = group 0's result is not stored; y_0 (bf16) = g h r (1 - r),
+ *                    o2 (fp32) = e1 + g r,  r = sigmoid(add_0).  y_0 may alias add_0.
+ * In-place addends (y_g == add_g) are allowed.  Only the combinations the recurrence launches are instantiated (LF_EINVAL
+ * otherwise): no extra with (bf16 x, 1 or 2 groups) or (fp32 x, 1 group); EX_RH and EX_ABWD with 1 or 2 groups; EX_BLEND with 1.
+ * D*H*W*64 < 2^31. */
+#define LF_RING_ADD_BF16 1u
+#define LF_RING_OUT_BF16 2u
+#define LF_RING_ROUND 4u
+#define LF_RING_EX_NONE 0
+#define LF_RING_EX_RH 1
+#define LF_RING_EX_BLEND 2
+#define LF_RING_EX_ABWD 3
+int lf_conv3d_c16_ring_multi(const void* x, int x_bf16, const void* wpack, int ngroups,
+                             void* y0, const void* add0, unsigned flags0, void* y1, const void* add1, unsigned flags1,
+                             int extra, const void* e0, const void* e1, void* o2,
+                             int N, int D, int H, int W, float he, int addend_per_sample, void* stream);
+
 /* Winograd F(2x2x2,3x3x3) for wide (>= 64-channel) 3-D convolutions, stage 1: the input transform.  x channels-last;
  * V [64][T][Cin], T = lf_wino3d_tiles(N, D, H, W), frequency f = (a*4 + b)*4 + c (z, y, x).  Cin a multiple of 4.
  * Stages 2 + 3: lf_wino_fused_gemm below. */
@@ -284,6 +313,9 @@ int lf_gru_train_stage_b_bwd(const float* g, const float* h, const void* upre, c
                              void* gc, float* acc_u, float* acc_o, long n, int bf16, void* stream);
 int lf_gru_train_stage_a_bwd(const void* grh, const void* rpre, const float* h, const float* gh1, void* grpre, float* gh12,
                              float* acc_r, long n, int bf16, void* stream);
+/* dst[i] (+= if accumulate) sum over `views` bf16 arrays of n elements each (src = the arrays back to back), in order:
+ * the sum over the recurrence's steps of a stored gate gradient (bias / coordinate-channel weight gradients). n % 4 == 0. */
+int lf_sum_views_bf16(const void* src, float* dst, long n, int views, int accumulate, void* stream);
 
 /* Storage-type variants of the 16-channel resampler for the training step (io bit 0: the source, bit 1: the destination is a
  * bf16 channels-last volume; same fp32 interpolation / same fixed-point sums as lf_resample3d_fwd / lf_resample3d_bwd_vol_det

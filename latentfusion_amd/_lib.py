@@ -13,6 +13,8 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'liblf_hip.so')
 LF_EPI_LRELU = 1
 LF_EPI_PIXELNORM = 2
 LF_EPI_ADD = 4
+LF_RING_ADD_BF16, LF_RING_OUT_BF16, LF_RING_ROUND = 1, 2, 4
+LF_RING_EX_NONE, LF_RING_EX_RH, LF_RING_EX_BLEND, LF_RING_EX_ABWD = 0, 1, 2, 3
 LF_IO_IN_BF16, LF_IO_OUT_BF16, LF_IO_ADDEND_BF16 = 1, 2, 4
 LF_MAP_O2C = 0
 LF_MAP_C2O = 1
@@ -54,6 +56,7 @@ SIGNATURES = {
     'lf_conv3d_c16_ring_bf16_wpack_elems': (c_size_t, []),
     'lf_conv3d_c16_ring_bf16': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint, c_float, c_float, P, c_int, P]),
     'lf_conv3d_c16_ring_bf16_io': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint, c_float, c_float, P, c_int, c_int, P]),
+    'lf_conv3d_c16_ring_multi': (c_int, [P, c_int, P, c_int, P, P, c_uint, P, P, c_uint, c_int, P, P, P, c_int, c_int, c_int, c_int, c_float, c_int, P]),
     'lf_wino3d_tiles': (c_long, [c_int, c_int, c_int, c_int]),
     'lf_wino3d_input_transform': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'lf_wino_fused_cout_padded': (c_int, [c_int]),
@@ -71,6 +74,7 @@ SIGNATURES = {
     'lf_gru_train_stage_b': (c_int, [P, P, P, P, c_long, c_int, P]),
     'lf_gru_train_stage_b_bwd': (c_int, [P, P, P, P, P, P, P, P, P, c_long, c_int, P]),
     'lf_gru_train_stage_a_bwd': (c_int, [P, P, P, P, P, P, P, c_long, c_int, P]),
+    'lf_sum_views_bf16': (c_int, [P, P, c_long, c_int, c_int, P]),
     'lf_occ_input_fwd': (c_int, [P, P, P, P, P, c_int, c_int, c_long, c_float, P]),
     'lf_occ_input_bwd': (c_int, [P, P, P, P, P, P, P, c_long, c_float, P, P, c_uint, P]),
     'lf_occ_conv17_fwd': (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),

@@ -5,10 +5,10 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ['resample.hip', 'conv.hip', 'pointwise.hip', 'image.hip', 'optim.hip', 'resize.hip', 'conv_split.hip', 'conv_wino.hip', 'wgrad.hip', 'sample2d.hip', 'gru.hip', 'wino_gemm.hip', 'reduce.hip', 'wino_fused.hip', 'conv_bf16.hip', 'occlusion.hip']
+SOURCES = ['resample.hip', 'conv.hip', 'pointwise.hip', 'image.hip', 'optim.hip', 'resize.hip', 'conv_split.hip', 'conv_wino.hip', 'wgrad.hip', 'sample2d.hip', 'gru.hip', 'wino_gemm.hip', 'reduce.hip', 'wino_fused.hip', 'conv_bf16.hip', 'occlusion.hip', 'conv_gru.hip']
 LIB = os.path.join(HERE, 'liblf_hip.so')
-# per-file extras (conv_split.hip: see split_piece there)
-EXTRA = {'conv_split.hip': ['-fno-slp-vectorize']}
+# per-file extras (conv_split.hip: see split_piece there; conv_gru.hip: see the note on packed fp32 arithmetic at its top)
+EXTRA = {'conv_split.hip': ['-fno-slp-vectorize'], 'conv_gru.hip': ['-fno-slp-vectorize']}
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function']
 
 
@@ -24,7 +24,7 @@ def needs_build():
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(HERE, s) for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
-    deps += [os.path.join(HERE, 'lf_common.h'), os.path.join(HERE, 'resample_staged.inc'),
+    deps += [os.path.join(HERE, 'lf_common.h'), os.path.join(HERE, 'resample_staged.inc'), os.path.join(HERE, 'ring_tile.h'),
              os.path.join(HERE, '..', '..', 'include', 'lf_hip.h'), os.path.join(HERE, '..', '..', 'include', 'lf_hip_experimental.h')]
     return any(os.path.getmtime(d) > t for d in deps)
 

@@ -159,10 +159,12 @@ __global__ void __launch_bounds__(256) gru_train_b_kernel(const f32x4* __restric
   h_out[i] = o;
 }
 
+// (gupre may alias upre and gc may alias cand -- round 6 writes the gate gradients over the saved pre-activations: these four
+// pointers carry no __restrict__, every load of a thread precedes its stores)
 template <typename T>
 __global__ void __launch_bounds__(256) gru_train_b_bwd_kernel(const f32x4* __restrict__ g, const f32x4* __restrict__ h,
-                                                              const void* __restrict__ upre, const void* __restrict__ cand,
-                                                              f32x4* __restrict__ gh1, void* __restrict__ gupre, void* __restrict__ gc,
+                                                              const void* upre, const void* cand,
+                                                              f32x4* __restrict__ gh1, void* gupre, void* gc,
                                                               f32x4* __restrict__ acc_u, f32x4* __restrict__ acc_o, long n4) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n4) return;
@@ -190,7 +192,35 @@ __global__ void __launch_bounds__(256) gru_train_a_bwd_kernel(const void* __rest
   if (acc_r != nullptr) acc_r[i] += grp;
 }
 
+// dst[i] (+)= sum over the n volumes of src[v][i], in view order (deterministic): the sum over the recurrence's steps of a gate
+// gradient, which is all the bias and the coordinate-channel weight gradients of that gate need
+__global__ void __launch_bounds__(256) sum_views_bf16_kernel(const bf16x4g* __restrict__ src, f32x4* __restrict__ dst, long n4, int nv,
+                                                             int accumulate) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  f32x4 s = accumulate ? dst[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+  int v = 0;
+  for (; v + 4 <= nv; v += 4) {                                   // four loads in flight
+    const bf16x4g a = src[(long)v * n4 + i], b = src[(long)(v + 1) * n4 + i], c = src[(long)(v + 2) * n4 + i], d = src[(long)(v + 3) * n4 + i];
+    s += __builtin_convertvector(a, f32x4);
+    s += __builtin_convertvector(b, f32x4);
+    s += __builtin_convertvector(c, f32x4);
+    s += __builtin_convertvector(d, f32x4);
+  }
+  for (; v < nv; ++v) s += __builtin_convertvector(src[(long)v * n4 + i], f32x4);
+  dst[i] = s;
+}
+
 }  // namespace
+
+extern "C" int lf_sum_views_bf16(const void* src, float* dst, long n, int views, int accumulate, void* stream) {
+  lf_clear_error();
+  if (n <= 0 || (n & 3) || views <= 0 || src == nullptr || dst == nullptr) return LF_EINVAL;
+  if (!lf_aligned16(src) || !lf_aligned16(dst)) return LF_EALIGN;
+  hipLaunchKernelGGL(sum_views_bf16_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16x4g*)src, (f32x4*)dst, n / 4, views, accumulate ? 1 : 0);
+  return lf_launch_status();
+}
 
 extern "C" int lf_lstm_cell_fwd(const float* cc, const float* c_cur, float* h_next, float* c_next, long nvox, int Ch, void* stream) {
   lf_clear_error();

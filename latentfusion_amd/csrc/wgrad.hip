@@ -231,6 +231,9 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#ifndef WG_ABL
+#define WG_ABL 0                                                 // ablations (tools/wgrad_ab.py): 1 no contraction, 2 no commit to LDS, 4 no loads
+#endif
 constexpr int BRING = 6;                                         // z-plane slots: 4 being read + 2 being filled
 constexpr int BRS = 48;                                          // bytes per halo row: 18 bf16 (+6)
 constexpr int BPL = WHY * BRS;                                   // 480 B per plane slot and channel
@@ -427,12 +430,12 @@ __global__ void __launch_bounds__(256, 2) wgrad3d_c16_bf16_kernel(
       if (on) {
         if (!slide) column(nx, ny, nn);
         // the two planes the next tile adds (slide: its halo planes 2, 3; new column: its planes 0, 1) and its gpre block
-        issue(nz * WTZ - 1 + (slide ? 2 : 0), nz * WTZ, true);
+        if (!(WG_ABL & 4)) issue(nz * WTZ - 1 + (slide ? 2 : 0), nz * WTZ, true);
       }
       __builtin_amdgcn_sched_barrier(0);
-      contract(rot, gsel);
+      if (!(WG_ABL & 1)) contract(rot, gsel);
       __builtin_amdgcn_sched_barrier(0);
-      if (on) commit(bmod6(rot + 4), bmod6(rot + 5), gsel ^ 1, true);
+      if (on && !(WG_ABL & 2)) commit(bmod6(rot + 4), bmod6(rot + 5), gsel ^ 1, true);
       __syncthreads();                                          // this tile's planes 0, 1 are free; the new planes are visible
       if (on && !slide) {
         // bottom of a new column: what arrived are its planes 0, 1 (slots rot+4, rot+5); planes 2, 3 go to the slots this

@@ -16,6 +16,19 @@ from .ops import (PN_EPS, SLOPE, _ac_in, _cached, _conv1x1_raw, _dense_views, _f
 # workgroups (62 KB of LDS each) plus one ring-convolution workgroup (35 KB): the weight gradient of a layer -- nothing in the
 # backward chain waits for it -- runs beside the data-gradient convolution of the same layer instead of in front of it.
 WGRAD_STREAM = True
+# The ConvGRU recurrence of the training step on the multi-output ring kernels (round 6, csrc/conv_gru.hip); False: the
+# one-output kernels + stage kernels of round 5 (kept: fp32 storage / no autocast take that path anyway)
+GRU_RING = True
+GRU_WGRAD_CHUNK = 8                                               # steps per multi-volume weight-gradient launch (0: one launch over all steps, after the chain)
+# 1: one-output launches on the sequential chain (two workgroups per CU overlap their phases), everything that does not depend
+# on the state batched over the views before / after the loop; 2: two outputs per staged halo (one 8-wave workgroup per CU --
+# measured slower: its waves run in lock-step, profiles/r06_gru_ring_ab.txt)
+GRU_RING_GROUPS = 1
+RING_DGRAD = True                                                 # data gradients of the 16 -> 16 layers on the same kernel family
+import os as _os                                                  # (A/B switches of tools/train_probe.py)
+GRU_WGRAD_CHUNK = int(_os.environ.get('LF_GRU_WGRAD_CHUNK', GRU_WGRAD_CHUNK))
+GRU_RING_GROUPS = int(_os.environ.get('LF_GRU_RING_GROUPS', GRU_RING_GROUPS))
+RING_DGRAD = bool(int(_os.environ.get('LF_RING_DGRAD', int(RING_DGRAD))))
 
 
 _SIDE = {}
@@ -273,7 +286,13 @@ class _Conv16AC(torch.autograd.Function):
                             t.record_stream(side)
             if ctx.needs_input_grad[0]:
                 pack_t = _pk(w, 'a3b', lambda t: pack_conv3d_c16_ring_bf16(w3(t), transpose=True))
-                gx, _ = conv3d_c16_ring_bf16_io(gp, pack_t, None, ctx.he, 0, 1, out_bf16=ctx.xdtype == torch.bfloat16)
+                if RING_DGRAD and gp.dtype == torch.bfloat16 and ctx.xdtype == torch.bfloat16:
+                    # the same sums and roundings on the one-group ring kernel with a compile-time epilogue (csrc/conv_gru.hip):
+                    # bit-identical, 32 instead of 53 us per 128^3 volume
+                    gx = torch.empty_like(gp)
+                    ring_multi(gp, pack_t.reshape(1, 14, 16, 32), ctx.he, [(gx, None, True)])
+                else:
+                    gx, _ = conv3d_c16_ring_bf16_io(gp, pack_t, None, ctx.he, 0, 1, out_bf16=ctx.xdtype == torch.bfloat16)
             if ctx.needs_input_grad[1]:
                 if done is not None:
                     torch.cuda.current_stream().wait_event(done)
@@ -370,6 +389,29 @@ class _Conv3x3Sum16(torch.autograd.Function):
                     gb = bias_grad(gy_full, 3)
         return (gw if ctx.needs_input_grad[0] else None, gb if ctx.needs_input_grad[1] else None, None,
                 gy_full if ctx.needs_input_grad[3] else None, *gparts)
+
+
+def ring_multi(x, wpacks, he, outs, extra=0, e0=None, e1=None, o2=None, addend_per_sample=True):
+    """lf_conv3d_c16_ring_multi: ONE staged (N,16,D,H,W) channels-last volume `x` (bf16 or fp32 storage) convolved with 1 or 2
+    ring-kernel weight packs.  wpacks: the packs back to back ((ngroups,14,16,32) bf16); outs: per group (y, addend or None, round)
+    -- y / addend fp32 or bf16 channels-last volumes (their dtypes select the storage flags), round: bf16(bf16(conv) * he) instead
+    of fma(conv, he, addend).  extra / e0 / e1 / o2: the fused element-wise stage (LF_RING_EX_*, include/lf_hip.h)."""
+    L = _lib.lib()
+    N, _, D, H, W = x.shape
+    ng = len(outs)
+    assert wpacks.dtype == torch.bfloat16 and wpacks.numel() == ng * 14 * 512 and wpacks.is_contiguous()
+    args = []
+    for y, add, rnd in outs:
+        fl = ((_lib.LF_RING_OUT_BF16 if y.dtype == torch.bfloat16 else 0) | (_lib.LF_RING_ROUND if rnd else 0)
+              | (_lib.LF_RING_ADD_BF16 if (add is not None and add.dtype == torch.bfloat16) else 0))
+        args += [_ptr(y), _ptr(add) if add is not None else None, fl]
+    if ng == 1:
+        args += [None, None, 0]
+    with _timed('conv3d_c16_ring_multi', f'{ng}:{extra}:{N}'):
+        check(L.lf_conv3d_c16_ring_multi(_ptr(x), int(x.dtype == torch.bfloat16), _ptr(wpacks), ng, *args, extra,
+                                         _ptr(e0) if e0 is not None else None, _ptr(e1) if e1 is not None else None,
+                                         _ptr(o2) if o2 is not None else None, N, D, H, W, he, int(bool(addend_per_sample)), _stream()),
+              'lf_conv3d_c16_ring_multi')
 
 
 class _GruGates(torch.autograd.Function):
@@ -498,6 +540,46 @@ class _GruFuse(torch.autograd.Function):
         n = zz[0].numel()
         s = _stream()
         base = [conv(c16, pk[k][1][0], bias=(b.detach() if b is not None else None)) for k, (_, b) in enumerate(gates)]
+        ctx.ring = bool(GRU_RING and ac and V >= 2 and D * H * W * 64 < 2 ** 31)
+        if ctx.ring:
+            ctx.z32 = zz.dtype != torch.bfloat16
+            z_in = zz
+            if ctx.z32:                                           # (the convolutions round x to bf16 while staging anyway: same numbers)
+                zz = zz.to(torch.bfloat16)
+            # ---- round 6: the multi-output ring kernels (csrc/conv_gru.hip).  The per-step tensors are STACKED blocks
+            # [V-1]: UP / RP / CA are first filled with the state-independent parts of the three gates (one launch over all
+            # views: x feeds three gates), then overwritten in place by the pre-activations / the candidate of their step;
+            # the backward overwrites them once more with the gate GRADIENTS, which the weight gradients then read as
+            # multi-volume launches -- no per-step allocation, no element-wise stage launch in the forward at all.
+            wz = (torch.stack((pk[0][0][0], pk[1][0][0])), pk[2][0][0].reshape(1, 14, 16, 32))     # packs back to back: [u | r], [o]
+            wh = (torch.stack((pk[0][2][0], pk[1][2][0])), pk[2][2][0].reshape(1, 14, 16, 32))
+            blk = lambda: empty_cl16((V - 1, 16, D, H, W), zz.device, True)      # noqa: E731
+            UP, RP, CA, RH = blk(), blk(), blk(), blk()
+            HS = empty_cl((V - 1, 16, D, H, W), zz.device)                       # h_0 .. h_{V-2} (fp32 state)
+            HS[0:1].copy_(z_in[0:1])                              # (h_0 = view 0, un-rounded when the stack is fp32)
+            if GRU_RING_GROUPS == 2:
+                ring_multi(zz[1:], wz[0], he, [(UP, base[0], False), (RP, base[1], False)], addend_per_sample=False)
+            else:
+                for k_, blk_ in enumerate((UP, RP)):
+                    ring_multi(zz[1:], pk[k_][0][0].reshape(1, 14, 16, 32), he, [(blk_, base[k_], False)], addend_per_sample=False)
+            ring_multi(zz[1:], wz[1], he, [(CA, base[2], False)], addend_per_sample=False)
+            out = empty_cl(HS[0:1].shape, zz.device)
+            whu, whr = pk[0][2][0].reshape(1, 14, 16, 32), pk[1][2][0].reshape(1, 14, 16, 32)
+            for i in range(1, V):
+                h, j = HS[i - 1:i], slice(i - 1, i)
+                if GRU_RING_GROUPS == 2:
+                    ring_multi(h, wh[0], he, [(UP[j], UP[j], False), (RP[j], RP[j], False)], extra=_lib.LF_RING_EX_RH, o2=RH[j])
+                else:                                             # (two one-output launches: two workgroups per CU overlap their phases)
+                    ring_multi(h, whu, he, [(UP[j], UP[j], False)])
+                    ring_multi(h, whr, he, [(RP[j], RP[j], False)], extra=_lib.LF_RING_EX_RH, o2=RH[j])
+                ring_multi(RH[j], wh[1], he, [(CA[j], CA[j], False)], extra=_lib.LF_RING_EX_BLEND, e0=h, e1=UP[j],
+                           o2=HS[i:i + 1] if i < V - 1 else out)
+            ctx.ac, ctx.T16, ctx.he, ctx.pk = ac, T16, he, pk
+            ctx.blocks = [UP, RP, CA, RH, HS]
+            ctx.zshape = tuple(z.shape)
+            ctx.save_for_backward(zz, c16, wu, wr, wo)
+            ctx.has_bias = tuple(b is not None for _, b in gates)
+            return out
         hs, saved = [_f32(zz[0:1])], []                            # (the state is fp32; view 0 seeds it)
         for i in range(1, V):
             zi, h = zz[i:i + 1], hs[-1]
@@ -539,6 +621,8 @@ class _GruFuse(torch.autograd.Function):
         need_z = ctx.needs_input_grad[0]
         need_w = any(ctx.needs_input_grad[i] for i in (2, 3, 4, 5, 6, 7))
         g = cl(g.reshape(shape1))
+        if ctx.ring:
+            return _GruFuse._backward_ring(ctx, g, zz, c16, (wu, wr, wo), need_z, need_w)
 
         def conv(x, pack, addend=None, out=None, out16=False, rnd=0):
             if ac:
@@ -643,6 +727,123 @@ class _GruFuse(torch.autograd.Function):
         else:
             outs += [None] * 6
         return tuple(outs)
+
+
+def _gru_backward_ring(ctx, g, zz, c16, ws, need_z, need_w):
+    """Backward of the recurrence on the multi-output ring kernels (see the forward): per step ONE element-wise launch
+    (lf_gru_train_stage_b_bwd, gate gradients written over the saved pre-activations) and three convolution launches --
+        gc    -> (g_rh with the reset gate's backward in its epilogue, g_x)
+        gupre -> (g_x +=, g_h = gh12 +)          grpre -> (g_x +=, g_h +=)
+    (was: two stage kernels + six convolutions + six weight-gradient launches).  The weight gradients run afterwards over the
+    STORED gate gradients as multi-volume launches, in chunks of GRU_WGRAD_CHUNK steps on the side stream beside the chain;
+    the sums over the steps that the bias / coordinate-channel gradients need come from lf_sum_views_bf16 over the same blocks."""
+    L = _lib.lib()
+    if ctx.blocks is None:
+        raise RuntimeError('the fused GRU recurrence overwrites its activations during backward: a second backward through '
+                           'the same graph is not supported')
+    UP, RP, CA, RH, HS = ctx.blocks
+    ctx.blocks = None
+    V = zz.shape[0]
+    he, pk = ctx.he, ctx.pk
+    dev = zz.device
+    D, H, W = zz.shape[2:]
+    shape1 = (1,) + tuple(zz.shape[1:])
+    n = zz[0].numel()
+    s = _stream()
+    wu, wr, wo = ws
+    # transposed packs: [o: towards r h | towards x], [u: towards x | towards h], [r: towards x | towards h]
+    tp = tuple(torch.stack(p) for p in ((pk[2][2][1], pk[2][0][1]), (pk[0][0][1], pk[0][2][1]), (pk[1][0][1], pk[1][2][1])))
+    gz = empty_cl16((V, 16, D, H, W), dev, True)
+    gh1, gh12 = empty_cl(shape1, dev), empty_cl(shape1, dev)
+    gbuf = [empty_cl(shape1, dev), empty_cl(shape1, dev)]
+    main = torch.cuda.current_stream()
+    side = side_stream(dev) if (WGRAD_STREAM and need_w and ops.KERNEL_TIMER is None) else None
+    chunks = []                                                   # (first step, one past the last step) in launch order
+    hi = V
+    while hi > 1:
+        lo = max(1, hi - GRU_WGRAD_CHUNK) if GRU_WGRAD_CHUNK > 0 else 1
+        chunks.append((lo, hi))
+        hi = lo
+    gwb = torch.zeros(len(chunks), 3, 2, 27, 16, 16, device=dev, dtype=torch.float32) if need_w else None
+    acc = [empty_cl(shape1, dev) for _ in range(3)] if need_w else None
+    nbytes = L.lf_conv_bwd_weight_scratch_bytes(3, V, D, H, W, 16, 16)
+    scratch = torch.empty(nbytes // 4 + 1, device=dev, dtype=torch.float32) if need_w else None     # (one: the launches are in order)
+    if side is not None:
+        side.wait_stream(main)                                    # (the allocations above)
+        for t in [gwb, zz, UP, RP, CA, RH, HS, scratch] + acc:
+            t.record_stream(side)
+
+    def weight_grads(ci, lo, hi):
+        """The six weight gradients of steps lo .. hi-1 (their gate gradients are final) + this chunk's share of the sums."""
+        nv = hi - lo
+        j = slice(lo - 1, hi - 1)
+        for k, (gp, xh) in enumerate(((UP, HS), (RP, HS), (CA, RH))):
+            for q, x in enumerate((zz[lo:hi], xh[j])):
+                io = (1 if x.dtype == torch.bfloat16 else 0) | 2
+                check(L.lf_conv_bwd_weight_bf16_io(_ptr(x), _ptr(gp[j]), _ptr(gwb[ci, k, q]), _ptr(scratch, True), scratch.numel() * 4, 3, nv, D, H, W,
+                                                   16, 16, he, io, _stream()), 'lf_conv_bwd_weight_bf16_io')
+            check(L.lf_sum_views_bf16(_ptr(gp[j]), _ptr(acc[k]), n, nv, int(ci > 0), _stream()), 'lf_sum_views_bf16')
+
+    def on_side(fn, *a):
+        if side is not None:
+            ready = torch.cuda.Event()
+            ready.record(main)                                    # the gate gradients the launches read are complete
+            side.wait_event(ready)
+            with torch.cuda.stream(side):
+                fn(*a)
+        else:
+            fn(*a)
+    two = GRU_RING_GROUPS == 2
+    one = lambda p: p.reshape(1, 14, 16, 32)                      # noqa: E731
+    for ci, (lo, hi) in enumerate(chunks):
+        for i in range(hi - 1, lo - 1, -1):
+            j = slice(i - 1, i)
+            h = HS[j]
+            gnext = gbuf[i & 1]
+            check(L.lf_gru_train_stage_b_bwd(_ptr(g), _ptr(h), _ptr(UP[j]), _ptr(CA[j]), _ptr(gh1), _ptr(UP[j]), _ptr(CA[j]),
+                                             None, None, n, 1, s), 'lf_gru_train_stage_b_bwd')
+            if two:
+                ring_multi(CA[j], tp[0], he, [(RP[j], RP[j], True), (gz[i:i + 1], None, True)], extra=_lib.LF_RING_EX_ABWD,
+                           e0=h, e1=gh1, o2=gh12)
+                ring_multi(UP[j], tp[1], he, [(gz[i:i + 1], gz[i:i + 1], False), (gnext, gh12, False)])
+                ring_multi(RP[j], tp[2], he, [(gz[i:i + 1], gz[i:i + 1], False), (gnext, gnext, False)])
+            else:
+                # one-output launches on the chain (the state's gradient only); the gradients of the views follow the loop
+                ring_multi(CA[j], one(tp[0][0]), he, [(RP[j], RP[j], True)], extra=_lib.LF_RING_EX_ABWD, e0=h, e1=gh1, o2=gh12)
+                ring_multi(UP[j], one(tp[1][1]), he, [(gnext, gh12, False)])
+                ring_multi(RP[j], one(tp[2][1]), he, [(gnext, gnext, False)])
+            g = gnext
+        if need_w:
+            on_side(weight_grads, ci, lo, hi)
+    if not two:
+        if need_z:                                                # the views' gradients, from the stored gate gradients of all steps
+            gzs = gz[1:]
+            ring_multi(CA, one(tp[0][1]), he, [(gzs, None, True)])
+            ring_multi(UP, one(tp[1][0]), he, [(gzs, gzs, False)])
+            ring_multi(RP, one(tp[2][0]), he, [(gzs, gzs, False)])
+    if side is not None:
+        main.wait_stream(side)
+    if ctx.z32:
+        gz = gz.float()
+    gz[0:1].copy_(g)
+    outs = [gz.view(ctx.zshape) if need_z else None, None]
+    if need_w:
+        gsum = gwb.sum(dim=0)                                     # [gate][z | state][27][16][16], fixed order
+        for k, w in enumerate((wu, wr, wo)):
+            gwt = torch.empty(27, 16, w.shape[1], device=dev, dtype=torch.float32)
+            gwt[:, :, :16] = gsum[k, 0]
+            gwt[:, :, 19:] = gsum[k, 1]
+            gc_, _ = conv_bwd_weight(c16, acc[k], 3, 16, he, want_bias=False, bf16=True)
+            gwt[:, :, 16:19] = gc_[:, :, :3]
+            gw = round_bf16(gwt.reshape(3, 3, 3, 16, w.shape[1]).permute(3, 4, 0, 1, 2).contiguous())
+            outs.append(gw if ctx.needs_input_grad[2 + 2 * k] else None)
+            outs.append(bias_grad(acc[k], 3) if (ctx.has_bias[k] and ctx.needs_input_grad[3 + 2 * k]) else None)
+    else:
+        outs += [None] * 6
+    return tuple(outs)
+
+
+_GruFuse._backward_ring = staticmethod(_gru_backward_ring)
 
 
 def gru_fuse(z, c16, cell):

@@ -1,0 +1,165 @@
+"""lf_conv3d_c16_ring_multi (csrc/conv_gru.hip: the multi-output bf16 ring convolution with the ConvGRU's element-wise stages
+in its epilogue) against the one-output ring kernel + the stage kernels it replaces, and against plain torch (fp32 conv3d on the
+bf16-rounded operands).  Tolerances: a bf16-stored result may differ by one bf16 ulp (at most 2^-7 relative) where the fused epilogue
+rounds once instead of twice; fp32 results 1e-5."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(1, 6, 16, 32), (2, 5, 11, 19), (1, 4, 8, 16)]          # (N, D, H, W): tile-aligned, ragged, a single tile column
+
+
+def _setup(N, D, H, W, seed=0, x_bf16=True):
+    from latentfusion_amd import ops
+    g = torch.Generator().manual_seed(seed)
+    dev = 'cuda'
+    x = torch.randn(N, 16, D, H, W, generator=g).to(dev).contiguous(memory_format=torch.channels_last_3d)
+    if x_bf16:
+        x = x.to(torch.bfloat16)
+    w = [torch.randn(16, 16, 3, 3, 3, generator=g).to(dev) for _ in range(2)]
+    packs = torch.stack([ops.pack_conv3d_c16_ring_bf16(t) for t in w]).contiguous()
+    he = float((2.0 / (16 * 27)) ** 0.5)
+    return x, w, packs, he, g
+
+
+def _vol(g, N, D, H, W, dtype, scale=1.0):
+    return (torch.randn(N, 16, D, H, W, generator=g) * scale).cuda().contiguous(memory_format=torch.channels_last_3d).to(dtype)
+
+
+def _close_bf16(a, b, ulps=1.01):
+    a, b = a.float(), b.float()
+    tol = ulps * 2.0 ** -7 * torch.maximum(a.abs(), b.abs()) + 1e-30       # one bf16 ulp is 2^-8 .. 2^-7 of the value
+    bad = ((a - b).abs() > tol)
+    assert not bad.any(), f'{int(bad.sum())} of {a.numel()} beyond one bf16 ulp, max diff {float((a - b).abs().max())}'
+
+
+@pytest.mark.parametrize('N,D,H,W', SHAPES)
+def test_two_groups_addend_forms_equal_the_one_output_kernel(N, D, H, W):
+    from latentfusion_amd import ops, ops_train
+    x, w, packs, he, g = _setup(N, D, H, W)
+    base = _vol(g, 1, D, H, W, torch.float32)                       # one fp32 addend volume for all samples (the coordinate part)
+    addb = _vol(g, N, D, H, W, torch.bfloat16)                      # a per-sample bf16 addend
+    y0 = ops.empty_cl16((N, 16, D, H, W), 'cuda', True)
+    ops_train.ring_multi(x, packs, he, [(y0, base, False), (y0.clone(), None, False)], addend_per_sample=False)
+    want0, _ = ops.conv3d_c16_ring_bf16_io(x, packs[0], None, he, 0, 0, addend=base.expand(N, -1, -1, -1, -1).contiguous(memory_format=torch.channels_last_3d), out_bf16=True)
+    _close_bf16(y0, want0)
+    # group 0: bf16 addend -> bf16, in place; group 1: fp32 addend -> fp32
+    acc = addb.clone()
+    add32 = _vol(g, N, D, H, W, torch.float32)
+    y1 = ops.empty_cl16((N, 16, D, H, W), 'cuda', False)
+    ops_train.ring_multi(x, packs, he, [(acc, acc, False), (y1, add32, False)])
+    want_a, _ = ops.conv3d_c16_ring_bf16_io(x, packs[0], None, he, 0, 0, addend=addb, out_bf16=True)
+    want_b, _ = ops.conv3d_c16_ring_bf16_io(x, packs[1], None, he, 0, 0, addend=add32, out_bf16=False)
+    _close_bf16(acc, want_a)
+    torch.testing.assert_close(y1, want_b, atol=1e-5, rtol=1e-5)
+    # against plain torch: fp32 convolution of the bf16-rounded operands
+    ref = torch.nn.functional.conv3d(x.float(), w[1].to(torch.bfloat16).float(), padding=1) * he + add32
+    torch.testing.assert_close(y1, ref.contiguous(memory_format=torch.channels_last_3d), atol=2e-4, rtol=2e-4)
+
+
+@pytest.mark.parametrize('N,D,H,W', SHAPES)
+def test_rounded_forms_and_single_group(N, D, H, W):
+    from latentfusion_amd import ops, ops_train
+    x, w, packs, he, g = _setup(N, D, H, W, seed=1)
+    y0 = ops.empty_cl16((N, 16, D, H, W), 'cuda', True)
+    ops_train.ring_multi(x, packs[:1].contiguous(), he, [(y0, None, True)])
+    want, _ = ops.conv3d_c16_ring_bf16_io(x, packs[0], None, he, 0, 1, out_bf16=True)
+    assert torch.equal(y0, want)                                    # the same sums, the same roundings
+    base = _vol(g, N, D, H, W, torch.float32)
+    ops_train.ring_multi(x, packs[1:].contiguous(), he, [(y0, base, False)])
+    want, _ = ops.conv3d_c16_ring_bf16_io(x, packs[1], None, he, 0, 0, addend=base, out_bf16=True)
+    _close_bf16(y0, want)
+
+
+@pytest.mark.parametrize('N,D,H,W', SHAPES)
+def test_reset_gate_epilogue(N, D, H, W):
+    """(h -> upre, rpre) with r h in the epilogue == two addend convolutions + lf_gru_train_stage_a."""
+    from latentfusion_amd import _lib, ops, ops_train
+    h, w, packs, he, g = _setup(N, D, H, W, seed=2, x_bf16=False)
+    uz, rz = _vol(g, N, D, H, W, torch.bfloat16), _vol(g, N, D, H, W, torch.bfloat16)
+    upre, rpre, rh = (ops.empty_cl16((N, 16, D, H, W), 'cuda', True) for _ in range(3))
+    ops_train.ring_multi(h, packs, he, [(upre, uz, False), (rpre, rz, False)], extra=_lib.LF_RING_EX_RH, o2=rh)
+    wu, _ = ops.conv3d_c16_ring_bf16_io(h, packs[0], None, he, 0, 0, addend=uz, out_bf16=True)
+    wr, _ = ops.conv3d_c16_ring_bf16_io(h, packs[1], None, he, 0, 0, addend=rz, out_bf16=True)
+    _close_bf16(upre, wu)
+    _close_bf16(rpre, wr)
+    want = (h * torch.sigmoid(rpre.float())).to(torch.bfloat16)     # from rpre AS STORED by the fused launch
+    _close_bf16(rh, want)
+
+
+@pytest.mark.parametrize('N,D,H,W', SHAPES)
+def test_blend_epilogue(N, D, H, W):
+    """(r h -> cand) with h' = h (1 - u) + cand u in the epilogue == addend convolution + lf_gru_train_stage_b."""
+    from latentfusion_amd import _lib, ops, ops_train
+    rh, w, packs, he, g = _setup(N, D, H, W, seed=3)
+    oz, upre = _vol(g, N, D, H, W, torch.bfloat16), _vol(g, N, D, H, W, torch.bfloat16, 2.0)
+    h = _vol(g, N, D, H, W, torch.float32)
+    cand = ops.empty_cl16((N, 16, D, H, W), 'cuda', True)
+    hn = ops.empty_cl16((N, 16, D, H, W), 'cuda', False)
+    ops_train.ring_multi(rh, packs[:1].contiguous(), he, [(cand, oz, False)], extra=_lib.LF_RING_EX_BLEND, e0=h, e1=upre, o2=hn)
+    wc, _ = ops.conv3d_c16_ring_bf16_io(rh, packs[0], None, he, 0, 0, addend=oz, out_bf16=True)
+    _close_bf16(cand, wc)
+    u = torch.sigmoid(upre.float())
+    torch.testing.assert_close(hn, h * (1 - u) + cand.float() * u, atol=2e-6, rtol=2e-6)
+    L = _lib.lib()                                                  # and the stage kernel it replaces, on the same stored tensors
+    hn2 = torch.empty_like(hn)
+    _lib.check(L.lf_gru_train_stage_b(h.data_ptr(), upre.data_ptr(), cand.data_ptr(), hn2.data_ptr(), h.numel(), 1,
+                                      torch.cuda.current_stream().cuda_stream), 'lf_gru_train_stage_b')
+    torch.testing.assert_close(hn, hn2, atol=2e-6, rtol=2e-6)
+
+
+@pytest.mark.parametrize('N,D,H,W', SHAPES)
+def test_reset_backward_epilogue(N, D, H, W):
+    """(gc -> g_rh, g_x) with grpre / gh12 in the epilogue == two rounded convolutions + lf_gru_train_stage_a_bwd."""
+    from latentfusion_amd import _lib, ops, ops_train
+    gc, w, packs, he, g = _setup(N, D, H, W, seed=4)
+    rpre = _vol(g, N, D, H, W, torch.bfloat16, 2.0)
+    h, gh1 = _vol(g, N, D, H, W, torch.float32), _vol(g, N, D, H, W, torch.float32)
+    grpre = rpre.clone()                                            # written in place over the saved pre-activation
+    gz = ops.empty_cl16((N, 16, D, H, W), 'cuda', True)
+    gh12 = ops.empty_cl16((N, 16, D, H, W), 'cuda', False)
+    ops_train.ring_multi(gc, packs, he, [(grpre, grpre, True), (gz, None, True)], extra=_lib.LF_RING_EX_ABWD, e0=h, e1=gh1, o2=gh12)
+    grh, _ = ops.conv3d_c16_ring_bf16_io(gc, packs[0], None, he, 0, 1, out_bf16=True)
+    wz, _ = ops.conv3d_c16_ring_bf16_io(gc, packs[1], None, he, 0, 1, out_bf16=True)
+    assert torch.equal(gz, wz)
+    L = _lib.lib()
+    want_p, want_h = torch.empty_like(rpre), torch.empty_like(gh12)
+    _lib.check(L.lf_gru_train_stage_a_bwd(grh.data_ptr(), rpre.data_ptr(), h.data_ptr(), gh1.data_ptr(), want_p.data_ptr(),
+                                          want_h.data_ptr(), None, h.numel(), 1, torch.cuda.current_stream().cuda_stream),
+               'lf_gru_train_stage_a_bwd')
+    torch.testing.assert_close(gh12, want_h, atol=2e-6, rtol=2e-5)
+    _close_bf16(grpre, want_p)
+
+
+@pytest.mark.parametrize('N,D,H,W', SHAPES)
+def test_one_group_forms_of_the_fused_epilogues(N, D, H, W):
+    """The one-output launches the recurrence runs on its sequential chain: (h -> rpre, r h), (gc -> grpre, gh12), (h -> upre)
+    equal the corresponding group of the two-output launches bit for bit (same staging, same sums, same epilogue)."""
+    from latentfusion_amd import _lib, ops, ops_train
+    h, w, packs, he, g = _setup(N, D, H, W, seed=5, x_bf16=False)
+    uz, rz = _vol(g, N, D, H, W, torch.bfloat16), _vol(g, N, D, H, W, torch.bfloat16)
+    e = lambda: ops.empty_cl16((N, 16, D, H, W), 'cuda', True)     # noqa: E731
+    up2, rp2, rh2, up1, rp1, rh1 = e(), e(), e(), e(), e(), e()
+    ops_train.ring_multi(h, packs, he, [(up2, uz, False), (rp2, rz, False)], extra=_lib.LF_RING_EX_RH, o2=rh2)
+    ops_train.ring_multi(h, packs[:1].contiguous(), he, [(up1, uz, False)])
+    ops_train.ring_multi(h, packs[1:].contiguous(), he, [(rp1, rz, False)], extra=_lib.LF_RING_EX_RH, o2=rh1)
+    assert torch.equal(up1, up2) and torch.equal(rp1, rp2) and torch.equal(rh1, rh2)
+    gc = _vol(g, N, D, H, W, torch.bfloat16)
+    rpre = _vol(g, N, D, H, W, torch.bfloat16, 2.0)
+    hh, gh1 = _vol(g, N, D, H, W, torch.float32), _vol(g, N, D, H, W, torch.float32)
+    gp2, gp1, gz = rpre.clone(), rpre.clone(), e()
+    o2, o1 = ops.empty_cl16((N, 16, D, H, W), 'cuda', False), ops.empty_cl16((N, 16, D, H, W), 'cuda', False)
+    ops_train.ring_multi(gc, packs, he, [(gp2, gp2, True), (gz, None, True)], extra=_lib.LF_RING_EX_ABWD, e0=hh, e1=gh1, o2=o2)
+    ops_train.ring_multi(gc, packs[:1].contiguous(), he, [(gp1, gp1, True)], extra=_lib.LF_RING_EX_ABWD, e0=hh, e1=gh1, o2=o1)
+    assert torch.equal(gp1, gp2) and torch.equal(o1, o2)
+
+
+def test_refused_combinations():
+    from latentfusion_amd import _lib, ops, ops_train
+    x, w, packs, he, g = _setup(1, 4, 8, 16, x_bf16=False)
+    y = ops.empty_cl16((1, 16, 4, 8, 16), 'cuda', True)
+    with pytest.raises(_lib.LFHipError):                            # fp32 input without the reset-gate epilogue is not instantiated
+        ops_train.ring_multi(x, packs, he, [(y, None, True), (y.clone(), None, True)])
+    with pytest.raises(_lib.LFHipError):                            # the blend epilogue needs h / upre / an output
+        ops_train.ring_multi(x.to(torch.bfloat16), packs[:1].contiguous(), he, [(y, None, False)], extra=_lib.LF_RING_EX_BLEND)
