@@ -12,6 +12,7 @@
 // x == NULL stands for an all-ones single-channel input: gw[0][co][0] is then the bias gradient.
 #include <type_traits>
 #include "lf_common.h"
+#include "ring_tile.h"
 
 namespace {
 
@@ -227,6 +228,11 @@ __global__ void __launch_bounds__(512) wgrad3d_c16_kernel(
 // Products of bf16 operands are exact in fp32 and accumulation is fp32 as on the fp32 kernel: same result up to
 // summation order.  Partials: one 27 x 256 block per workgroup, summed by wgrad_reduce_kernel (fixed order, fp64).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+template <int I> struct WIC { static constexpr int v = I; };
+template <int B, int E, typename F>
+__device__ __forceinline__ void wstatic_for(F&& f) {
+  if constexpr (B < E) { f(WIC<B>{}); wstatic_for<B + 1, E>(f); }
+}
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -477,6 +483,300 @@ __global__ void __launch_bounds__(256, 2) wgrad3d_c16_bf16_kernel(
   }
 }
 
+// ---- round 6: the same contraction with the operands read by the LDS TRANSPOSE load (ds_read_b64_tr_b16) ------------------
+// PMC on the kernel above: SQ_LDS_BANK_CONFLICT = 0.68 of SQ_LDS_IDX_ACTIVE, LDS issue stalls + waits = 0.7 of the wave cycles
+// -- its channel-major planes (strides chosen for 32 banks; ds_read_b128 sees 64) conflict two-fold on every operand read,
+// four-fold on the fifth-dword reads, and the transposing commit (v_perm + four ds_write_b32 per pair-piece) conflicts too;
+// the contraction alone takes 1.67 of the 1.92 ms per 32 volumes (tools/wgrad_ab.py, -DWG_ABL).  gfx950 can transpose on the
+// way OUT of LDS instead: the tile stays in LDS as it is in memory, bf16 channels-last records of 32 B (x: the six-slot
+// ring of 10 x 18-voxel halo planes of the ring convolutions, conv_split.hip; gpre: the 2 x 8 x 16 block, double-buffered),
+// written with plain 8-byte stores, and a lane gets "channel (lane & 15) of four consecutive voxels" from one
+// ds_read_b64_tr_b16 at the address of record (voxel + (lane >> 2 & 3)), channel quad (lane & 3).  Two of them = the
+// 8-voxel K run of v_mfma_f32_16x16x32_bf16; a stencil shift along x is 32 B of address, not a v_alignbyte.  Bank-conflict
+// free by construction: an instruction's two 16-lane groups of a half-wave read the 128-byte chunks x = 0..3 and 4..7
+// (then 8..11 and 12..15) of one row = disjoint halves of the 64 banks, whatever the row / tap offset -- so the K run of
+// lane group k is voxels {4 (k & 1) .. +3} and {4 (k & 1) + 8 .. +3} of row k >> 1 of the K group's two rows, for BOTH
+// operands.  Wave / accumulator assignment, partials and the reduce kernel are those of the kernel above (bit-compatible
+// up to the order of the products inside one MFMA's K = 32, which is exact in fp32: same results).
+typedef __bf16 bf16x4t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) bf16x4t lds_bf16x4t;
+constexpr int TXP = RINGs * PLANE_B;                              // 34,560 B: the x ring
+constexpr int TGB = WTZ * WTY * WTX * 32;                         // 8,192 B per gpre buffer
+constexpr int TLDS = TXP + 2 * TGB + 1024;                        // + guard: a shifted K run of the last row reads past its plane
+
+__device__ __forceinline__ bf16x8 tr_pair(const unsigned char* p0, const unsigned char* p1) {
+  const bf16x4t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4t*)p0);
+  const bf16x4t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4t*)p1);
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+#ifndef WG_ABL
+#define WG_ABL 0                                                 // ablations of the kernel below (tools/wgrad_ab.py): 1 no contraction, 2 no commit to LDS, 4 no loads
+#endif
+#ifndef WG_TR_PF
+#define WG_TR_PF 1                                                // contraction steps whose operand reads are in flight ahead of the MFMAs
+#endif
+#ifndef WG_TR_WGS
+#define WG_TR_WGS 2                                               // resident workgroups per CU (8 waves each: 53 KB of LDS, <= 128 VGPRs)
+#endif
+template <int IO>
+__global__ void __launch_bounds__(512, 2 * WG_TR_WGS) wgrad3d_c16_tr_kernel(
+    const float* __restrict__ x, const float* __restrict__ gp, float* __restrict__ partial,
+    int N, int D, int H, int W, int tiles_x, int tiles_y, int tiles_z, int ntiles) {
+  constexpr bool X16 = (IO & 1) != 0, G16 = (IO & 2) != 0;
+  constexpr int XSH = X16 ? 5 : 6, GSH = G16 ? 5 : 6;
+  constexpr int OOB = (int)0x80000000;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15, k = lane >> 4;
+  const int nb = gridDim.x;
+  const int lb = (nb % 8 == 0) ? (blockIdx.x % 8) * (nb / 8) + blockIdx.x / 8 : blockIdx.x;
+  const int per = (ntiles + nb - 1) / nb;
+  const int t_begin = lb * per;
+  const int t_end = min(t_begin + per, ntiles);
+  const long nvox = (long)D * H * W;
+
+  f32x4 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (t_begin < t_end) {
+    for (int i = tid; i < TLDS / 16; i += 512) ((u32x4*)smem)[i] = (u32x4){0u, 0u, 0u, 0u};
+    __syncthreads();
+    // ---- staging (waves 4..7).  x: staging wave w fetches rows 5 (w >> 1) .. +4 of incoming plane w & 1 as six pieces
+    // (conv_split.hip); gpre: the tile's 256 voxels x 4 quarters = 4 pieces per staging thread, piece j of thread t = quarter
+    // t & 3 of voxel (t >> 2) + 64 j
+    const bool producer = wave >= 4;                                // (wave-uniform)
+    const int pw = wave & 3, ptid = tid & 255;
+    const int pzw = pw & 1, ryw = pw >> 1, frow0 = 5 * ryw;
+    const int erow = frow0 + (lane >> 3), ecol = 16 + ((lane >> 2) & 1);
+    const bool e_ok = lane < 40;
+    const int eldso = e_ok ? (erow * HXs + ecol) * 32 + (lane & 3) * 8 : -1;
+    const int xplane_b = (H * W) << XSH, gplane_b = (H * W) << GSH;
+    int foff[NPIECE], goff[4];
+    const unsigned char *fx = (const unsigned char*)x, *fg = (const unsigned char*)gp;
+    auto column = [&](int bx, int by, int bn) {
+      const int ox = bx * WTX - 1, oy = by * WTY - 1;
+      const int col = ox + (lane >> 2);
+#pragma unroll
+      for (int it = 0; it < 5; ++it) {
+        const int row = oy + frow0 + it;
+        foff[it] = ((unsigned)col < (unsigned)W && (unsigned)row < (unsigned)H) ? ((row * W + col) << XSH) + ((lane & 3) << (XSH - 2)) : OOB;
+      }
+      const int row = oy + erow, c2 = ox + ecol;
+      foff[5] = (e_ok && (unsigned)c2 < (unsigned)W && (unsigned)row < (unsigned)H) ? ((row * W + c2) << XSH) + ((lane & 3) << (XSH - 2)) : OOB;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int v = (ptid >> 2) + 64 * j, lx = v & 15, ly = (v >> 4) & 7;      // (lz = v >> 7 goes into the plane offset)
+        const int gx = bx * WTX + lx, gy = by * WTY + ly;
+        goff[j] = (gx < W && gy < H) ? ((gy * W + gx) << GSH) + ((ptid & 3) << (GSH - 2)) : OOB;
+      }
+      fx = (const unsigned char*)x + ((long)bn * nvox << XSH);
+      fg = (const unsigned char*)gp + ((long)bn * nvox << GSH);
+    };
+    u32x4 sx[NPIECE], sg[4];
+    auto fetch_x = [&](int z, bool on) {
+      const bool v = on && (unsigned)z < (unsigned)D;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)fx, 0, v ? (unsigned)(nvox << XSH) : 0u, 0x00020000);
+      const int soff = v ? z * xplane_b : 0;
+#pragma unroll
+      for (int it = 0; it < NPIECE; ++it) {
+        if constexpr (X16) { const u32x2 h = __builtin_amdgcn_raw_buffer_load_b64(rs, foff[it], soff, 0); sx[it] = (u32x4){h[0], h[1], 0u, 0u}; }
+        else sx[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, foff[it], soff, 0);
+      }
+    };
+    auto fetch_g = [&](int z0, bool on) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int z = z0 + (j >> 1);                               // pieces 0, 1: plane 0 of the tile; 2, 3: plane 1
+        const bool v = on && z < D;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)fg, 0, v ? (unsigned)(nvox << GSH) : 0u, 0x00020000);
+        const int soff = v ? z * gplane_b : 0;
+        if constexpr (G16) { const u32x2 h = __builtin_amdgcn_raw_buffer_load_b64(rs, goff[j], soff, 0); sg[j] = (u32x4){h[0], h[1], 0u, 0u}; }
+        else sg[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, goff[j], soff, 0);
+      }
+    };
+    auto to_bf16 = [&](const u32x4 v, bool is16) {
+      if (is16) return __builtin_bit_cast(bf16x4t, (u32x2){v[0], v[1]});
+      return __builtin_convertvector(__builtin_bit_cast(f32x4, v), bf16x4t);
+    };
+    auto commit_x = [&](int slot) {
+      unsigned char* const dst = smem + slot * PLANE_B;
+#pragma unroll
+      for (int it = 0; it < 5; ++it) *(bf16x4t*)(dst + (frow0 + it) * (HXs * 32) + lane * 8) = to_bf16(sx[it], X16);
+      if (e_ok) *(bf16x4t*)(dst + eldso) = to_bf16(sx[5], X16);
+    };
+    auto commit_g = [&](int gsel) {
+      unsigned char* const dst = smem + TXP + gsel * TGB;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *(bf16x4t*)(dst + (ptid + 256 * j) * 8) = to_bf16(sg[j], G16);
+    };
+    // ---- operands.  lane (channel m, lane group k): record of voxel (row k >> 1, x = 4 (k & 1) + (m >> 2)) of a K group's two
+    // rows, channel quad m & 3; the second transpose load of a K run sits 8 voxels (256 B) further along x
+    const int a_lane = TXP + (((k >> 1) * WTX + 4 * (k & 1) + (m >> 2)) * 32) + (m & 3) * 8;      // + gsel*TGB + (z*8 + 2 rp) * 512
+    const int b_lane = (((k >> 1) * HXs + 4 * (k & 1) + (m >> 2)) * 32) + (m & 3) * 8;            // + slot*PLANE_B + (2 rp + ky) * 576 + kx*32
+    const int kz0 = (2 * wave) / 3, ky0 = (2 * wave) % 3, kz1 = (2 * wave + 1) / 3, ky1 = (2 * wave + 1) % 3;
+    // Ten contraction steps per tile (K groups 0..7 for this wave's two stencil rows, then K groups 2w, 2w+1 for row 8);
+    // the operands of step s + WG_TR_PF are read before the MFMAs of step s (pinned: the scheduler otherwise sinks a read to
+    // its use and the wave waits out the LDS latency per operand)
+    struct Step { bf16x8 a, b[6]; };
+    auto contract = [&](int rot, int gsel) {
+      const unsigned char* ab = smem + a_lane + gsel * TGB;
+      const unsigned char* r0[2], *r1[2], *r8[2];
+#pragma unroll
+      for (int z = 0; z < 2; ++z) {
+        r0[z] = smem + b_lane + bmod6(rot + z + kz0) * PLANE_B + ky0 * (HXs * 32);
+        r1[z] = smem + b_lane + bmod6(rot + z + kz1) * PLANE_B + ky1 * (HXs * 32);
+        r8[z] = smem + b_lane + bmod6(rot + z + 2) * PLANE_B + 2 * (HXs * 32);
+      }
+      Step st[WG_TR_PF + 1];
+      auto load = [&](auto sc) {
+        constexpr int sidx = decltype(sc)::v;
+        Step& o = st[sidx % (WG_TR_PF + 1)];
+        if constexpr (sidx < 8) {
+          constexpr int z = sidx >> 2, rp = sidx & 3;
+          const unsigned char* ap = ab + (z * WTY + 2 * rp) * (WTX * 32);
+          o.a = tr_pair(ap, ap + 256);
+          const unsigned char* p0 = r0[z] + 2 * rp * (HXs * 32);
+          const unsigned char* p1 = r1[z] + 2 * rp * (HXs * 32);
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            o.b[kx] = tr_pair(p0 + kx * 32, p0 + kx * 32 + 256);
+            o.b[3 + kx] = tr_pair(p1 + kx * 32, p1 + kx * 32 + 256);
+          }
+        } else {
+          const int kg = 2 * wave + (sidx - 8), z = kg >> 2, rp = kg & 3;      // (wave-uniform)
+          const unsigned char* ap = ab + (z * WTY + 2 * rp) * (WTX * 32);
+          o.a = tr_pair(ap, ap + 256);
+          const unsigned char* p0 = (z ? r8[1] : r8[0]) + 2 * rp * (HXs * 32);
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) o.b[kx] = tr_pair(p0 + kx * 32, p0 + kx * 32 + 256);
+        }
+      };
+      wstatic_for<0, WG_TR_PF>([&](auto sc) { load(sc); });
+      wstatic_for<0, 10>([&](auto sc) {
+        constexpr int sidx = decltype(sc)::v;
+        if constexpr (sidx + WG_TR_PF < 10) load(WIC<sidx + WG_TR_PF>{});
+        if constexpr (WG_TR_PF > 0) __builtin_amdgcn_sched_barrier(0);
+        if constexpr (WG_TR_PF == 0) load(sc);
+        const Step& o = st[sidx % (WG_TR_PF + 1)];
+        if constexpr (sidx < 8) {
+#pragma unroll
+          for (int j = 0; j < 6; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(o.a, o.b[j], acc[j], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 3; ++j) acc[6 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(o.a, o.b[j], acc[6 + j], 0, 0, 0);
+        }
+        if constexpr (WG_TR_PF > 0) __builtin_amdgcn_sched_barrier(0);
+      });
+    };
+
+    int cx, cy, cz, cn;
+    {
+      int tt = t_begin;
+      cz = tt % tiles_z; tt /= tiles_z;
+      cx = tt % tiles_x; tt /= tiles_x;
+      cy = tt % tiles_y; cn = tt / tiles_y;
+    }
+    auto step = [&](int& x_, int& y_, int& z_, int& n_) {         // the tile after (x_, y_, z_, n_): z fastest
+      if (++z_ == tiles_z) { z_ = 0; if (++x_ == tiles_x) { x_ = 0; if (++y_ == tiles_y) { y_ = 0; ++n_; } } }
+    };
+    int rot = 0;
+    if (producer) {
+      // ---- waves 4..7: loads -> LDS, one tile ahead of the contraction.  Entering iteration t the incoming planes / gpre
+      // block of tile t + 1 are in flight; they are committed at once (their slots / buffer were last read by tile t - 1),
+      // then the loads of tile t + 2 are issued, then the workgroup barrier of tile t.
+      auto prefetch = [&](int tx, int ty, int tz, int tn, bool on_, bool slide_) {
+        if (on_ && !slide_) column(tx, ty, tn);
+        if (!(WG_ABL & 4)) {
+          fetch_x(tz * WTZ - 1 + (slide_ ? 2 : 0) + pzw, on_);
+          fetch_g(tz * WTZ, on_);
+        }
+      };
+      column(cx, cy, cn);
+      fetch_x(cz * WTZ - 1 + pzw, true);
+      fetch_g(cz * WTZ, true);
+      commit_x(pzw);
+      commit_g(0);
+      fetch_x(cz * WTZ + 1 + pzw, true);
+      commit_x(2 + pzw);
+      lds_barrier_s();
+      int ax = cx, ay = cy, az = cz, an = cn;                       // tile t + 1 (then t + 2)
+      step(ax, ay, az, an);
+      prefetch(ax, ay, az, an, t_begin + 1 < t_end, t_begin + 1 < t_end && az != 0);
+      for (int t = t_begin; t < t_end; ++t) {
+        const int gsel = (t - t_begin) & 1;
+        const bool on = t + 1 < t_end;
+        const int nz = az;                                          // (tile t + 1)
+        const bool slide = on && nz != 0;
+        if (on && !(WG_ABL & 2)) {
+          commit_x(bmod6(rot + 4 + pzw));
+          commit_g(gsel ^ 1);
+        }
+        step(ax, ay, az, an);                                       // -> tile t + 2
+        const bool on2 = t + 2 < t_end, slide2 = on2 && az != 0;
+        if (!on || slide) prefetch(ax, ay, az, an, on2, slide2);
+        lds_barrier_s();
+        if (on && !slide) {
+          // tile t + 1 starts a column: what was committed are its planes 0, 1 (slots rot + 4, rot + 5); planes 2, 3 go to
+          // the slots tile t has just released (exposed once per column), only then the loads of tile t + 2
+          rot = bmod6(rot + 4);
+          fetch_x(nz * WTZ + 1 + pzw, true);
+          commit_x(bmod6(rot + 2 + pzw));
+          lds_barrier_s();
+          prefetch(ax, ay, az, an, on2, slide2);
+        } else {
+          rot = bmod6(rot + 2);
+        }
+      }
+    } else {
+      // ---- waves 0..3: the contraction of tile t while the other four waves stage tile t + 1
+      lds_barrier_s();
+      int az = cz;
+      for (int t = t_begin; t < t_end; ++t) {
+        const int gsel = (t - t_begin) & 1;
+        const bool on = t + 1 < t_end;
+        if (++az == tiles_z) az = 0;
+        const bool slide = on && az != 0;
+        if (!(WG_ABL & 1)) contract(rot, gsel);
+        lds_barrier_s();
+        if (on && !slide) {
+          rot = bmod6(rot + 4);
+          lds_barrier_s();
+        } else {
+          rot = bmod6(rot + 2);
+        }
+      }
+    }
+  }
+  // row 8 (taps 24..26): waves 1..3 hand their shares to wave 0 through LDS, summed in wave order
+  f32x4* red = (f32x4*)smem;
+  __syncthreads();
+  if (wave > 0 && wave < 4) {
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) red[((wave - 1) * 3 + kx) * 64 + lane] = acc[6 + kx];
+  }
+  __syncthreads();
+  if (wave >= 4) return;                                          // (the staging waves hold no sums)
+  if (wave == 0) {
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) acc[6 + kx] += red[(w * 3 + kx) * 64 + lane];
+  }
+  float* out = partial + (long)blockIdx.x * 27 * 256;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    if (r == 2 && wave != 0) break;
+    const int zy = r == 2 ? 8 : 2 * wave + r;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) out[(zy * 3 + kx) * 256 + (4 * k + i) * 16 + m] = acc[r * 3 + kx][i];
+  }
+}
+
 // ---- bias gradient of a 16-channel layer: column sums of gpre [rows][16] ------------------------------
 // A streaming reduction (the generic path runs it as a GEMM against a vector of ones with at most 512 blocks,
 // 250 us for 134 MB; this takes ~40).  Fixed order: rows strided inside a block, blocks summed in fp64.
@@ -631,21 +931,35 @@ static int wgrad_bf16_launch(const void* x, const void* gpre, float* gw, void* s
   if (!wgrad_fast3d(dims, N, D, H, W, Cin, Cout) || !lf_aligned16(x) || !lf_aligned16(gpre)) return LF_EINVAL;
   // the kernel's 32-bit offsets reach three planes past the sample (halo planes of the last tile + the pair's second plane)
   if ((long)(D + 3) * H * W * 64 > 0xffffffffL) return LF_EINVAL;
+#ifdef WG_OLD
   const int nb = 2 * wgrad_cus();
+#else
+  const int nb = WG_TR_WGS * wgrad_cus();
+#endif
   if (scratch_bytes < (size_t)nb * 27 * 256 * sizeof(float)) return LF_ENOSPC;
   const int ptx = (W + WTX - 1) / WTX, pty = (H + WTY - 1) / WTY, ptz = (D + WTZ - 1) / WTZ;
   const long pt = (long)ptx * pty * ptz * N;
   if (pt > 0x7fffffffL) return LF_EINVAL;
-  const size_t shmem = (size_t)BLDS;
   typedef void (*kern_t)(const float*, const float*, float*, int, int, int, int, int, int, int, int);
+#ifdef WG_OLD                                                      // (A/B: the channel-major kernel of rounds 2-5, tools/wgrad_ab.py)
+  const size_t shmem = (size_t)BLDS;
   static const kern_t kerns[4] = {wgrad3d_c16_bf16_kernel<0>, wgrad3d_c16_bf16_kernel<1>, wgrad3d_c16_bf16_kernel<2>, wgrad3d_c16_bf16_kernel<3>};
+#else
+  const size_t shmem = (size_t)TLDS;
+  static const kern_t kerns[4] = {wgrad3d_c16_tr_kernel<0>, wgrad3d_c16_tr_kernel<1>, wgrad3d_c16_tr_kernel<2>, wgrad3d_c16_tr_kernel<3>};
+#endif
   static lf_devmask_t attr_set[4];
   {
     hipError_t e = lf_ensure_dyn_lds(attr_set[io], (const void*)kerns[io], (int)shmem);
     if (e != hipSuccess) return (int)e;
   }
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(kerns[io], dim3(nb), dim3(256), shmem, s, (const float*)x, (const float*)gpre, (float*)scratch, N, D, H, W, ptx, pty, ptz, (int)pt);
+#ifdef WG_OLD
+  const unsigned threads = 256;
+#else
+  const unsigned threads = 512;                                   // four contraction waves + four staging waves
+#endif
+  hipLaunchKernelGGL(kerns[io], dim3(nb), dim3(threads), shmem, s, (const float*)x, (const float*)gpre, (float*)scratch, N, D, H, W, ptx, pty, ptz, (int)pt);
   int st = lf_launch_status();
   if (st) return st;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(27, 1, 4), dim3(256), 0, s, (const float*)scratch, gw, nb, 27, 1, 1, 16, 16, scale);

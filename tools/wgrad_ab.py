@@ -44,4 +44,5 @@ for N in (1, 32):
         outs.append(gw.clone())
         print(f'N={N} {path}: median {sorted(ts)[3] * 1e3:.1f} us per launch (incl. the reduce kernel)  '
               f'= {2 * N * S ** 3 * 32 / sorted(ts)[3] / 1e6:.0f} GB/s of bf16 operands')
-    print('  identical results:', all(torch.equal(o, outs[0]) for o in outs))
+    print('  identical results:', all(torch.equal(o, outs[0]) for o in outs), ' max |diff| / max |ref|:',
+          [float((o - outs[0]).abs().max() / outs[0].abs().max()) for o in outs[1:]])
