@@ -255,7 +255,8 @@ def test_cfg2_headline_loop_vs_reference_fixture():
     HIP end to end against it (tools/headline_trace_probe.py; measured numbers: profiles/r05_headline_trace_vs_reference.json):
       * the reconstructed volume (sub-sampled) and the iteration-0 renders: 1e-3 relative (measured 3e-6 / 2e-6 rel-L2);
       * the loop: fp32 rounding differences are amplified by Adam's first steps (1e-7 -> 4e-3 over iterations 0-8) and then
-        stay BOUNDED (<= 5e-3 relative over all 100 iterations, asserted <= 2e-2); the argmin pose index is identical for the
+        stay BOUNDED (<= 5e-3 relative over all 100 iterations; asserted against the reference's OWN thread-count noise,
+        fixture g26n, see below); the argmin pose index is identical for the
         first 10 iterations (measured: 14) and at EVERY iteration where the reference separates its best two hypotheses by
         more than twice that iteration's loss deviation; the final best loss agrees to 1e-3 (measured 1e-4).
     The reference's own top-2 gap falls below 1e-3 relative in 66 of the 100 iterations (down to 4e-7): there the index of
@@ -274,9 +275,26 @@ def test_cfg2_headline_loop_vs_reference_fixture():
     t = res['trace']
     rows = t['per_iteration']
     assert t['iterations'] == res['fixture']['T']
-    assert t['max_rel_diff_first_5'] <= 1e-3 and t['max_rel_diff_all'] <= 2e-2, (t['max_rel_diff_first_5'], t['max_rel_diff_all'])
+    # ---- tolerances ANCHORED to the reference's own noise floor (round 6): g26n = the same reference run on the same seeds with
+    # 3 instead of 8 threads (oracle/make_golden_headline.py --threads 3; 32 iterations).  The reference deviates from ITSELF by
+    # 2e-7 -> 1.1e-3 over iterations 1-9 and up to 2.4e-3 after (its argmin differs at iterations 13, 14, 28).  HIP must stay
+    # within 8 x the control's deviation, taken over a +-2-iteration window (Adam amplifies a rounding difference
+    # exponentially at first, so single iterations of the control dip: 4e-5 at iteration 7 between 1e-4 and 7e-4);
+    # measured: 5.3 x (Winograd kernels; 4.1 x with the direct fp32 convolution, profiles/r06_headline_trace_vs_control.json).
+    sd = t['reference_self_deviation']
+    ctl = sd['per_iteration']
+    assert sd['control_threads'] != res['fixture']['reference_threads'] and len(ctl) >= 30
+    for i, r in enumerate(rows):
+        floor = max(ctl[max(0, i - 2):i + 3]) if i < len(ctl) else max(ctl)
+        assert r['rank_loss_max_rel_diff'] <= 8.0 * floor + 1e-6, (i, r['rank_loss_max_rel_diff'], floor)
+    assert sd['max_hip_dev_over_windowed_ref_dev'] <= 8.0
     assert all(r['argmin_equal'] for r in rows[:10]), t['first_iteration_argmin_differs']
-    decided = [r for r in rows if r['reference_top2_rel_gap'] > 2.0 * r['rank_loss_max_rel_diff']]
+    # argmin: asserted wherever BOTH reference runs agree on it and the reference separates its best two hypotheses by more
+    # than twice that iteration's HIP deviation.  (Where the two references agree but the gap is BELOW the deviation -- the
+    # cross-over of hypotheses 3 and 7, iterations 26-30: gap 1.2e-3 -> 6e-5, the control itself switches one iteration before
+    # the fixture -- the index is decided by rounding; those iterations are reported, not asserted.)
+    decided = [r for r in rows if r['reference_top2_rel_gap'] > 2.0 * r['rank_loss_max_rel_diff']
+               and r.get('references_agree_on_argmin', True)]
     assert len(decided) >= 5 and all(r["argmin_equal"] for r in decided), [r['iteration'] for r in decided if not r['argmin_equal']]
     assert abs(t['final_best_loss_hip'] - t['final_best_loss_reference']) <= 1e-3 * abs(t['final_best_loss_reference'])
 
