@@ -265,12 +265,16 @@ int lf_wino3d_input_transform(const float* x, float* V, int N, int D, int H, int
  * lf_wino3d_input_transform; dims = 2 (D = 1): V [16][T][Cin] from lf_wino2d_input_transform.
  * U2: [F][CoutP][Cin], CoutP = lf_wino_fused_cout_padded(Cout) (zero padded), U2[f][co][ci] = ((G (x) ..) w)[co][ci][f]
  * -- output-channel major so that both GEMM operands stream along the contraction axis.  Cin, Cout multiples of 4.
- * flags: LF_EPI_LRELU only; for PixelNorm run lf_pixelnorm_fwd on y afterwards (y is 1/8 resp. 1/4 of V).
+ * flags: LF_EPI_LRELU only; for PixelNorm run lf_pixelnorm_fwd on y afterwards (y is 1/8 resp. 1/4 of V);
+ * | LF_OUT_DEPTH_INNER (dims = 3): y is written as [N][H][W][D][Cout] instead of [N][D][H][W][Cout] -- a pixel's depth column
+ * of the last camera block becomes ONE contiguous row of D*Cout floats, so the factor projection 3-D -> 2-D that follows
+ * (modules/geometry.py:744-749; K = D*Cout = 4096 in the released model) is a plain row-major GEMM.
  * Also the data gradient of the same convolution (transposed / flipped U2, flags = 0, bias = NULL).
  * Replaces Equalized.forward + LeakyReLU of modules/equalized.py:57-64, blocks.py:152-158 for >= 64-channel layers.
  * Problems with few tile / channel blocks are split over the frequencies (more workgroups): each part writes its raw
  * partial outputs to `scratch` (lf_wino_fused_scratch_bytes(...) bytes, 0 when no split is used) and a second launch
  * adds them in a fixed order and applies the epilogue -- deterministic, no atomics. */
+#define LF_OUT_DEPTH_INNER 0x100u
 int lf_wino_fused_cout_padded(int Cout);
 size_t lf_wino_fused_scratch_bytes(int dims, int N, int D, int H, int W, int Cout);
 int lf_wino_fused_gemm(const float* V, const float* U2, const float* bias, float* y, void* scratch, size_t scratch_bytes,

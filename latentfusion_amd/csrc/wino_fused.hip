@@ -257,7 +257,8 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) wino_fus
       for (int o = 0; o < NO; ++o) {
         const int gx = 2 * bx + (o & 1), gy = 2 * by + ((o >> 1) & 1), gz = 2 * bz + (DIMS == 3 ? ((o >> 2) & 1) : 0);
         if (gx >= W || gy >= H || gz >= D) continue;
-        const long vox = ((n * D + gz) * H + gy) * W + gx;
+        // LF_OUT_DEPTH_INNER: y as [N][H][W][D][Cout] -- the factor projection then reads a pixel's D x Cout column as ONE row
+        const long vox = (flags & LF_OUT_DEPTH_INNER) ? ((n * H + gy) * W + gx) * D + gz : ((n * D + gz) * H + gy) * W + gx;
         if (partial != nullptr) {                                // frequency-split launch: raw partial sums
           *(f32x4*)(partial + (long)blockIdx.z * ysize + vox * Cout + co) = Y[o][a][b];
           continue;
@@ -363,7 +364,7 @@ extern "C" int lf_wino_fused_gemm(const float* V, const float* U2, const float* 
                                   unsigned flags, float slope, void* stream) {
   lf_clear_error();
   if ((dims != 2 && dims != 3) || N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return LF_EINVAL;
-  if ((Cin & 3) || (Cout & 3) || (dims == 2 && D != 1) || (flags & ~LF_EPI_LRELU)) return LF_EINVAL;
+  if ((Cin & 3) || (Cout & 3) || (dims == 2 && D != 1) || (flags & ~(LF_EPI_LRELU | LF_OUT_DEPTH_INNER))) return LF_EINVAL;
   if (!lf_aligned16(V) || !lf_aligned16(U2) || !lf_aligned16(y) || (bias && !lf_aligned16(bias))) return LF_EALIGN;
   const int tz = dims == 3 ? (D + 1) / 2 : 1, ty = (H + 1) / 2, tx = (W + 1) / 2;
   const long T = (long)N * tz * ty * tx;
@@ -391,7 +392,7 @@ extern "C" int lf_wino_fused_gemm(const float* V, const float* U2, const float* 
   if (st || zs == 1) return st;
   const long n4 = ysize / 4;
   hipLaunchKernelGGL(wino_fused_finish_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (const f32x4*)partial, bias, (f32x4*)y,
-                     n4, n4, zs, Cout / 4, he, flags, slope);
+                     n4, n4, zs, Cout / 4, he, flags & LF_EPI_LRELU, slope);
   return lf_launch_status();
 }
 

@@ -210,6 +210,8 @@ class RenderLoopEngine:
         if photographer.projection_type == 'factor':
             pw = photographer.projection_block.conv.module.weight
             cout = pw.shape[0]
+            # [D*C][cout], K = d*C + c: the projection as one row-major GEMM over depth-innermost rows (PROJ_GEMM)
+            self.proj_rows_t = pw.detach().reshape(cout, C, D).permute(2, 1, 0).reshape(D * C, cout).contiguous()
             self.proj = (pw, photographer.projection_block.conv.bias, ops.he_constant(pw),
                          ops.pack_conv1x1(pw.reshape(cout, C, D).permute(0, 2, 1).reshape(cout, D * C)),
                          ops.pack_conv1x1(pw.reshape(cout, C, D).permute(2, 1, 0).reshape(D * C, cout)))
@@ -314,9 +316,13 @@ class RenderLoopEngine:
         return self._forward_backward_group(params, intr, z_span, need_grad, 1.0, zt, masked_depth)
 
     # ---- per-layer launches of the camera blocks (the experimental subclass adds kernel variants here) ----
-    def _conv_fwd(self, li, x, flags):
+    PROJ_GEMM = True        # wide blocks, ranking only: depth-innermost last block + library GEMM for the factor projection
+
+    def _conv_fwd(self, li, x, flags, depth_inner=False):
         """Forward of camera-block convolution `li`: (y, norm, (zp, pnorm) when the factor projection rode along, else None)."""
         w, b, he, wp, _wt = self.convs[li]
+        if depth_inner:
+            return ops.wide_conv(x, self.wgemm[li], b, he, flags, depth_inner=True) + (None,)
         if self.split is not None:
             return ops.conv3d_c16_split(x, self.split[li][0], b, he, flags) + (None,)
         if self.wino is not None and li == len(self.convs) - 1 and 'fwd' in self.fuse_projection:
@@ -474,13 +480,18 @@ class RenderLoopEngine:
                   'lf_resample3d_fwd')
         acts, norms = [x0], []
         flags = LF_EPI_LRELU | LF_EPI_PIXELNORM
+        # wide blocks, ranking only (the released architecture under the cross-entropy search): the last block writes its output
+        # depth-innermost, so that the factor projection K = D * C -> C2 below is ONE row-major GEMM for the library
+        # (128 renders: 32768 x 4096 x 256, 0.5 ms on hipBLASLt's fp32 MFMA kernel against 1.27 ms of lf_conv1x1_fwd's K slices)
+        proj_gemm = (self.PROJ_GEMM and self.wgemm is not None and not need_grad and self.occ is None and not self.generic_tail
+                     and self.proj is not None and 'fwd' not in self.fuse_projection)
         for li_ in range(len(self.convs)):
-            y, nrm, rode = self._conv_fwd(li_, acts[-1], flags)
+            y, nrm, rode = self._conv_fwd(li_, acts[-1], flags, depth_inner=proj_gemm and li_ == len(self.convs) - 1)
             if rode is not None:
                 zp, pnorm = rode
             acts.append(y)
             norms.append(nrm)
-        Cl = acts[-1].shape[1]
+        Cl = acts[-1].shape[-1] if proj_gemm else acts[-1].shape[1]
         act_leaf = occ_saved = zs_leaf = None
         if self.occ is not None:
             # occlusion weights on explicit kernels; the composite behind them: the factor projection as in the plain renderer
@@ -517,7 +528,18 @@ class RenderLoopEngine:
         else:
             pw, pb, phe, ppack, ppack_t = self.proj
             cout = pw.shape[0]
-            if 'fwd' not in self.fuse_projection:
+            if proj_gemm:
+                with ops._timed('factor_project_fwd'):
+                    x2 = acts[-1].view(n * S * S, S * Cl)
+                    if pb is not None:
+                        rows = torch.addmm(pb.detach(), x2, self.proj_rows_t, alpha=phe)        # he * (x W^T) + b
+                    else:
+                        rows = torch.mm(x2, self.proj_rows_t).mul_(phe)
+                    torch.nn.functional.leaky_relu_(rows, ops.SLOPE)
+                    pnorm = torch.empty(n * S * S, device=dev, dtype=torch.float32)
+                    check(L.lf_pixelnorm_fwd(rows.data_ptr(), rows.data_ptr(), pnorm.data_ptr(), n * S * S, cout, ops.PN_EPS, s), 'lf_pixelnorm_fwd')
+                zp = rows.view(n, S, S, cout).permute(0, 3, 1, 2)                # channels-last (n, cout, S, S)
+            elif 'fwd' not in self.fuse_projection:
                 zp = ops.empty_cl((n, cout, S, S), dev)
                 with ops._timed('factor_project_fwd'):
                     pnorm = ops._conv1x1_raw(acts[-1], ppack, pb, n, S * S, Cl, S, S * S * S * Cl, S * S * Cl, cout, zp, phe, flags)

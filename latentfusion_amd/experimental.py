@@ -189,11 +189,11 @@ def make_engine_x():
             self._packs_built = False
             self._graph = None
 
-        def _conv_fwd(self, li, x, flags):
+        def _conv_fwd(self, li, x, flags, depth_inner=False):
             if self.conv_mode == 'winograd_f16x3':
                 _w, b, he, _wp, _wt = self.convs[li]
                 return conv3d_c16_wino_split(x, self.split[li][0], b, he, flags, amax_in=self.z_amax if li == 0 else None) + (None,)
-            return super()._conv_fwd(li, x, flags)
+            return super()._conv_fwd(li, x, flags, depth_inner)
 
         def _conv_bwd(self, i, g, prev, amax):
             if self.conv_mode == 'winograd_f16x3':

@@ -420,10 +420,11 @@ def pack_conv_wino_fused(weight, transpose=False):
     return out.contiguous()
 
 
-def conv_wino_fused(x, U2, cout, bias, he, flags):
+def conv_wino_fused(x, U2, cout, bias, he, flags, depth_inner=False):
     """Wide 2-D / 3-D conv: Winograd input transform, then ONE launch for the per-frequency fp32-MFMA products, the
     output transform, He scale, bias and LeakyReLU (lf_wino_fused_gemm); PixelNorm as a pass over the (small) output.
-    Returns (y, norm or None)."""
+    depth_inner (3-D only): y comes back as a plain (N, H, W, D, cout) tensor (LF_OUT_DEPTH_INNER): the layout the factor
+    projection that follows the last camera block wants.  Returns (y, norm or None)."""
     L = _lib.lib()
     dims = x.dim() - 2
     N, cin = x.shape[0], x.shape[1]
@@ -438,13 +439,18 @@ def conv_wino_fused(x, U2, cout, bias, he, flags):
         V = torch.empty(16, T, cin, device=x.device, dtype=torch.float32)
         with _timed('wino2d_input'):
             check(L.lf_wino2d_input_transform(_ptr(x), _ptr(V), N, H, W, cin, _stream()), 'lf_wino2d_input_transform')
-    y = empty_cl((N, cout) + tuple(x.shape[2:]), x.device)
+    if depth_inner:
+        assert dims == 3
+        y = torch.empty((N, H, W, D, cout), device=x.device, dtype=torch.float32)
+    else:
+        y = empty_cl((N, cout) + tuple(x.shape[2:]), x.device)
     nscr = L.lf_wino_fused_scratch_bytes(dims, N, D, H, W, cout)
     scr = torch.empty(nscr // 4, device=x.device, dtype=torch.float32) if nscr else None
     with _timed(f'wino{dims}d_fused'):
         check(L.lf_wino_fused_gemm(_ptr(V), _ptr(U2), _ptr(bias) if bias is not None else None, _ptr(y),
                                    _ptr(scr, True) if scr is not None else None, nscr, dims, N, D, H, W, cin,
-                                   cout, he, flags & LF_EPI_LRELU, SLOPE, _stream()), 'lf_wino_fused_gemm')
+                                   cout, he, (flags & LF_EPI_LRELU) | (_lib.LF_OUT_DEPTH_INNER if depth_inner else 0), SLOPE, _stream()),
+              'lf_wino_fused_gemm')
     del V
     norm = None
     if flags & LF_EPI_PIXELNORM:
@@ -453,12 +459,12 @@ def conv_wino_fused(x, U2, cout, bias, he, flags):
     return y, norm
 
 
-def wide_conv(x, weight, bias, he, flags, transpose=False):
+def wide_conv(x, weight, bias, he, flags, transpose=False, depth_inner=False):
     """Dispatch of a wide (>= 64-channel) 3x3(x3) convolution or its data gradient (transpose=True) by WIDE_CONV_MODE."""
     cout = weight.shape[1] if transpose else weight.shape[0]
     if WIDE_CONV_MODE == 'fused':
         U2 = _pk(weight, 'wfb' if transpose else 'wff', lambda w: pack_conv_wino_fused(w, transpose=transpose))
-        return conv_wino_fused(x, U2, cout, bias, he, flags)
+        return conv_wino_fused(x, U2, cout, bias, he, flags, depth_inner)
     from . import experimental                     # 'bmm': the three-stage form on the library GEMM (A/B reference)
     U = _pk(weight, 'g3b' if transpose else 'g3f', lambda w: experimental.pack_conv3d_wino_gemm(w, transpose=transpose))
     return experimental.conv3d_wino_gemm(x, U, bias, he, flags)

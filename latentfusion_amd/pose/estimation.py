@@ -339,10 +339,18 @@ class CrossEntropyPoseEstimator(PoseEstimator):
             parallel.broadcast_(params)
         return params
 
+    # 'fast': pose/gmm.DiagGMM (scikit-learn's diag-covariance EM and sampling order without the estimator framework: 0.3 instead
+    # of ~3 ms per fit with the GPU idle); 'sklearn': sklearn.mixture.GaussianMixture as the reference calls it (:412-420)
+    gmm_backend = 'fast'
+
     def _create_gmm(self, params=None):
-        import sklearn.mixture
-        gmm = sklearn.mixture.GaussianMixture(covariance_type='diag', n_components=self.num_gmm_components,
-                                              reg_covar=1e-5)
+        if self.gmm_backend == 'sklearn':
+            import sklearn.mixture
+            gmm = sklearn.mixture.GaussianMixture(covariance_type='diag', n_components=self.num_gmm_components,
+                                                  reg_covar=1e-5)
+        else:
+            from .gmm import DiagGMM
+            gmm = DiagGMM(self.num_gmm_components, reg_covar=1e-5)
         if params is not None:
             gmm.fit(params.numpy() if torch.is_tensor(params) else params)
         return gmm

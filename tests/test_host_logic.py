@@ -655,3 +655,47 @@ def test_torch_library_registration():
         torch.ops.lf.pixelnorm(torch.randn(2, 4, 3, 3))
     with pytest.raises(LFHipError):
         torch.ops.lf.conv_block(torch.randn(1, 4, 5, 5), torch.randn(4, 4, 3, 3), None, True, True)
+
+
+def test_diag_gmm_is_sklearns_algorithm():
+    """pose/gmm.DiagGMM (the cross-entropy search's mixture fit without the estimator framework) against
+    sklearn.mixture.GaussianMixture(covariance_type='diag', reg_covar=1e-5): from the same start the EM reaches the same
+    mixture, and `sample` draws the same numbers from numpy's global generator."""
+    import warnings
+    import numpy as np
+    import sklearn.mixture
+    from latentfusion_amd.pose.gmm import DiagGMM
+    rng = np.random.RandomState(3)
+    for k, n in ((6, 48), (2, 9), (3, 17)):
+        X = np.concatenate([rng.randn(n // k + 1, 6) * 0.07 + rng.randn(1, 6) for _ in range(k)])[:n].astype(np.float32)
+        labels = rng.randint(0, k, size=n)
+        labels[:k] = np.arange(k)                                   # every component owns a point
+        resp = np.zeros((n, k))
+        resp[np.arange(n), labels] = 1.0
+        mine = DiagGMM(k, reg_covar=1e-5).fit(X, resp=resp)
+        # the same start for scikit-learn: the parameters of the first M step
+        start = DiagGMM(k, reg_covar=1e-5)
+        start._m_step(X.astype(np.float64), resp)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            ref = sklearn.mixture.GaussianMixture(covariance_type='diag', n_components=k, reg_covar=1e-5, weights_init=start.weights_,
+                                                  means_init=start.means_, precisions_init=1.0 / start.covariances_).fit(X.astype(np.float64))
+        assert mine.n_iter_ == ref.n_iter_ and mine.converged_ == ref.converged_
+        np.testing.assert_allclose(mine.weights_, ref.weights_, rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(mine.means_, ref.means_, rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(mine.covariances_, ref.covariances_, rtol=1e-5, atol=1e-10)
+        np.testing.assert_allclose(mine.precisions_cholesky_, ref.precisions_cholesky_, rtol=1e-5)
+        np.random.seed(11)
+        a, ya = mine.sample(32)
+        ref.weights_, ref.means_, ref.covariances_ = mine.weights_, mine.means_, mine.covariances_
+        np.random.seed(11)
+        b, yb = ref.sample(32)
+        np.testing.assert_allclose(a, b, rtol=1e-12, atol=0)
+        assert (ya == yb).all()
+    # the default start (k-means labels) gives a valid mixture; fewer samples than components is an error as in scikit-learn
+    np.random.seed(0)
+    g = DiagGMM(6).fit(X)
+    assert g.converged_ and abs(g.weights_.sum() - 1.0) < 1e-12 and (g.covariances_ > 0).all()
+    import pytest
+    with pytest.raises(ValueError):
+        DiagGMM(6).fit(X[:3])

@@ -132,6 +132,18 @@ def test_g20_cross_entropy_evaluation(golden):
     close(loss, ce['loss'], atol=2e-5, rtol=1e-3)
     assert same_order_up_to_ties(loss, ce['loss'], 2e-5) and int(torch.argmin(loss)) == int(ce['order'][0])
     close(torch.sort(loss)[0][:8], ce['elite_loss'], atol=2e-5, rtol=1e-3)
+    # round 6: the ranking path writes the last camera block depth-innermost and runs the factor projection (K = D * C) as ONE
+    # row-major library GEMM (engine.PROJ_GEMM); the K-sliced lf_conv1x1_fwd form gives the same losses
+    from latentfusion_amd.engine import RenderLoopEngine
+    assert RenderLoopEngine.PROJ_GEMM
+    RenderLoopEngine.PROJ_GEMM = False
+    try:
+        est2 = estimation.CrossEntropyPoseEstimator(model=model, num_samples=24, num_elites=8, num_iters=1, num_gmm_components=2,
+                                                    learning_rate=0.9, sample_flipped=True, ranking_size=4, loss_weights=ce['weights'])
+        _, loss2 = est2.evaluate_samples(g['z_obj'].to(DEV), _target(t7), prod_camera(ce['cams']))
+    finally:
+        RenderLoopEngine.PROJ_GEMM = True
+    close(loss, loss2, atol=2e-6, rtol=2e-5)
 
 
 def same_order_up_to_ties(loss, ref_loss, tol):
