@@ -449,6 +449,21 @@ size_t lf_epilogue_bwd_c16_scratch_bytes(long rows);
 int lf_epilogue_bwd_c16(const void* gy, const void* y, const float* norm, void* gp, float* gbias, void* scratch,
                         size_t scratch_bytes, long rows, unsigned flags, float slope, int io, void* stream);
 
+/* The 2-D -> 3-D lift of the training step for 16 image channels and C0 = 16 volume channels as ONE kernel each way (round 6;
+ * reference modules/geometry.py:711-731 FactorProjection2d3d + autograd, bf16 autocast policy): rows x [R = V*P][16] fp32
+ * (bf16 values) -> pointwise conv to 16*S channels (channel = c*S + d), He scale, bias, LeakyReLU, PixelNorm over all 16*S
+ * channels -> bf16 channels-last volume records (v, d, p) of 16 channels + norm[R]; the 16*S-channel row is never stored.
+ * wtab: bf16 [S][16 c][16 cin] = W[c*S + d][cin]; btab: fp32 [S][16 c] or NULL.  R % 16 == 0, P % 16 == 0, R % P == 0.
+ * Backward: gvol / yvol = gradient and saved volume (bf16 records), wtab_t: bf16 [S][16 cin][16 c]; gx [R][16] fp32 (rounded to
+ * bf16 values if round_gx), gw [16*S][16] (scaled by he), gb [16*S]; S in {16, 32, 64, 128}; scratch of
+ * lf_lift16_bwd_scratch_bytes(S) bytes (per-workgroup partials, summed in a fixed order: deterministic). */
+int lf_lift16_fwd(const float* x, const void* wtab, const float* btab, void* vol, float* norm, long R, long P, int S,
+                  float he, float slope, float eps, void* stream);
+size_t lf_lift16_bwd_scratch_bytes(int S);
+int lf_lift16_bwd(const void* gvol, const void* yvol, const float* norm, const float* x, const void* wtab_t, float* gx, float* gw,
+                  float* gb, void* scratch, size_t scratch_bytes, long R, long P, int S, float he, float slope, int round_gx,
+                  void* stream);
+
 /* Standalone PixelNorm over the last (channel) axis of [rows][C], in place allowed.
  * norm_out[rows] receives sqrt(mean+eps).  modules/__init__.py:14-15. */
 int lf_pixelnorm_fwd(const float* x, float* y, float* norm_out, long rows, int C, float eps, void* stream);

@@ -24,11 +24,13 @@ GRU_WGRAD_CHUNK = 0                                               # steps per mu
 # on the state batched over the views before / after the loop; 2: two outputs per staged halo (one 8-wave workgroup per CU --
 # measured slower: its waves run in lock-step, profiles/r06_gru_ring_ab.txt)
 GRU_RING_GROUPS = 1
+LIFT_MFMA = True                                                  # the 16-channel lift as one MFMA kernel each way (csrc/lift_mfma.hip)
 RING_DGRAD = True                                                 # data gradients of the 16 -> 16 layers on the same kernel family
 import os as _os                                                  # (A/B switches of tools/train_probe.py)
 GRU_WGRAD_CHUNK = int(_os.environ.get('LF_GRU_WGRAD_CHUNK', GRU_WGRAD_CHUNK))
 GRU_RING_GROUPS = int(_os.environ.get('LF_GRU_RING_GROUPS', GRU_RING_GROUPS))
 RING_DGRAD = bool(int(_os.environ.get('LF_RING_DGRAD', int(RING_DGRAD))))
+LIFT_MFMA = bool(int(_os.environ.get('LF_LIFT_MFMA', int(LIFT_MFMA))))
 
 
 _SIDE = {}
@@ -915,6 +917,19 @@ class _LiftFused(torch.autograd.Function):
         c0 = cs // S
         P = H * W
         he = he_constant(weight)
+        ctx.mfma = bool(LIFT_MFMA and ctx.ac and storage_bf16() and c0 == 16 and cin == 16 and S in (16, 32, 64, 128) and P % 16 == 0)
+        if ctx.mfma:
+            # round 6 (csrc/lift_mfma.hip): K = 16 -- the 16*S-channel row is recomputed by MFMA instead of stored as fp32 rows
+            wtab = _pk(weight, 'l16f', lambda w: w.reshape(16, S, 16).permute(1, 0, 2).contiguous().to(torch.bfloat16))
+            btab = bias.detach().reshape(16, S).t().contiguous() if bias is not None else None
+            vol = empty_cl16((V, c0, S, H, W), x.device, True)
+            norm = torch.empty(V * P, device=x.device, dtype=torch.float32)
+            with _timed('lift16_fwd'):
+                check(L.lf_lift16_fwd(_ptr(x), _ptr(wtab), _ptr(btab) if btab is not None else None, _ptr(vol), _ptr(norm), V * P, P, S,
+                                      he, SLOPE, PN_EPS, _stream()), 'lf_lift16_fwd')
+            ctx.dims, ctx.he = (V, cin, H, W, c0, S), he
+            ctx.save_for_backward(vol, norm, weight, x)
+            return vol
         wpack = _pk(weight, 'c1f', lambda w: pack_conv1x1(w.reshape(cs, cin)))
         tmp = torch.empty(V * P, cs, device=x.device, dtype=torch.float32)
         _conv1x1_raw(x, wpack, bias.detach() if bias is not None else None, V, P, cin, 1, P * cin, 0, cs, tmp, he, LF_EPI_LRELU)
@@ -935,6 +950,18 @@ class _LiftFused(torch.autograd.Function):
         V, cin, H, W, c0, S = ctx.dims
         cs, P = c0 * S, H * W
         g = cl(g)
+        if ctx.mfma and g.dtype == torch.bfloat16 and vol.dtype == torch.bfloat16:
+            wtab_t = _pk(w, 'l16b', lambda t: t.reshape(16, S, 16).permute(1, 2, 0).contiguous().to(torch.bfloat16))
+            gx = empty_cl((V, cin, H, W), g.device)
+            gw = torch.empty(cs, cin, device=g.device, dtype=torch.float32)
+            gb = torch.empty(cs, device=g.device, dtype=torch.float32)
+            nb = L.lf_lift16_bwd_scratch_bytes(S)
+            scr = torch.empty(nb // 4 + 4, device=g.device, dtype=torch.float32)
+            with _timed('lift16_bwd'):
+                check(L.lf_lift16_bwd(_ptr(g), _ptr(vol), _ptr(norm), _ptr(x), _ptr(wtab_t), _ptr(gx), _ptr(gw), _ptr(gb), _ptr(scr, True),
+                                      scr.numel() * 4, V * P, P, S, ctx.he, SLOPE, 1, _stream()), 'lf_lift16_bwd')
+            return (gx if ctx.needs_input_grad[0] else None, _ac_in(gw.reshape(w.shape)) if ctx.needs_input_grad[1] else None,
+                    gb if ctx.needs_input_grad[2] else None, None)
         gp = torch.empty(V * P, cs, device=g.device, dtype=torch.float32)
         io = (1 if g.dtype == torch.bfloat16 else 0) | (2 if vol.dtype == torch.bfloat16 else 0)
         with _timed('lift_bwd'):
