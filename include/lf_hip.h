@@ -464,6 +464,17 @@ int lf_lift16_bwd(const void* gvol, const void* yvol, const float* norm, const f
                   float* gb, void* scratch, size_t scratch_bytes, long R, long P, int S, float he, float slope, int round_gx,
                   void* stream);
 
+/* The 3-D -> 2-D factor projection of the training step's renderer for 16 volume channels and 16 output channels on the same
+ * idea (reference modules/geometry.py:731-749 FactorProjection3d2d + autograd): vol = bf16 records (v, d, p); y fp32 rows
+ * [R][16] = PixelNorm(LeakyReLU(he * sum_{c,d} W[o][c*S + d] vol + b)), norm [R].  wtab: bf16 [S][16 o][16 c].
+ * Backward from gp (fp32 rows [R][16], rounded to bf16 inside): gxvol = bf16 records of he * W^T gp; gw [16][16*S] (scaled by
+ * he); wtab_t: bf16 [S][16 c][16 o]; S in {16, 32, 64, 128}; deterministic (per-workgroup partials, fixed order). */
+int lf_proj16_fwd(const void* vol, const void* wtab, const float* bias, float* y, float* norm, long R, long P, int S, float he,
+                  float slope, float eps, void* stream);
+size_t lf_proj16_bwd_scratch_bytes(int S);
+int lf_proj16_bwd(const float* gp, const void* vol, const void* wtab_t, void* gxvol, float* gw, void* scratch, size_t scratch_bytes,
+                  long R, long P, int S, float he, void* stream);
+
 /* Standalone PixelNorm over the last (channel) axis of [rows][C], in place allowed.
  * norm_out[rows] receives sqrt(mean+eps).  modules/__init__.py:14-15. */
 int lf_pixelnorm_fwd(const float* x, float* y, float* norm_out, long rows, int C, float eps, void* stream);

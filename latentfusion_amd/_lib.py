@@ -78,6 +78,9 @@ SIGNATURES = {
     'lf_lift16_fwd': (c_int, [P, P, P, P, P, c_long, c_long, c_int, c_float, c_float, c_float, P]),
     'lf_lift16_bwd_scratch_bytes': (c_size_t, [c_int]),
     'lf_lift16_bwd': (c_int, [P, P, P, P, P, P, P, P, P, c_size_t, c_long, c_long, c_int, c_float, c_float, c_int, P]),
+    'lf_proj16_fwd': (c_int, [P, P, P, P, P, c_long, c_long, c_int, c_float, c_float, c_float, P]),
+    'lf_proj16_bwd_scratch_bytes': (c_size_t, [c_int]),
+    'lf_proj16_bwd': (c_int, [P, P, P, P, P, P, c_size_t, c_long, c_long, c_int, c_float, P]),
     'lf_sum_views_bf16': (c_int, [P, P, c_long, c_int, c_int, P]),
     'lf_occ_input_fwd': (c_int, [P, P, P, P, P, c_int, c_int, c_long, c_float, P]),
     'lf_occ_input_bwd': (c_int, [P, P, P, P, P, P, P, c_long, c_float, P, P, c_uint, P]),

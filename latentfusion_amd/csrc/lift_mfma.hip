@@ -209,6 +209,116 @@ __global__ void __launch_bounds__(256) lift_bwd_reduce_kernel(const float* __res
   }
 }
 
+// ---- the 3-D -> 2-D factor projection of the training step's renderer (reference modules/geometry.py:731-749
+// FactorProjection3d2d: the depth axis folded into the channels, index c*S + d, of a pointwise conv K = 16*S -> 16, LeakyReLU,
+// PixelNorm) on the same idea, for 16 volume channels and 16 output channels: the volume is read as it lies (bf16 records),
+// one MFMA per depth accumulates a 16-pixel group's 16 outputs; backward: the volume gradient record by record
+// (gx_d[c][pixel] = W_d^T gp), the weight gradient per depth with both operands through the LDS transpose load.  Round 5:
+// fp32 copy of the volume + conv1x1 forward; conv1x1 into an fp32 volume + rounding pass + row copy of the volume + generic
+// weight gradient + cast backward (2.9 ms at 8 views of 128^3; now 0.4).
+// wtab: bf16 [S][16 o][16 c] = W[o][c*S + d]; y: fp32 rows [R][16]; norm [R].
+__global__ void __launch_bounds__(256, 2) proj16_fwd_kernel(const unsigned char* __restrict__ vol, const __bf16* __restrict__ wtab,
+                                                           const float* __restrict__ bias, float* __restrict__ y, float* __restrict__ norm,
+                                                           long R, long P, int S, float he, float slope, float eps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 15, kg = lane >> 4;
+  for (int i = tid; i < S * 32; i += 256) ((f32x4*)smem)[i] = ((const f32x4*)wtab)[i];
+  __syncthreads();
+  const long groups = R / 16;
+  const unsigned char* aw = smem + (n * 16 + kg * 4) * 2;          // A: row o = n, c 4 kg .. (+ d * 512)
+  f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (bias != nullptr) bv = *(const f32x4*)(bias + kg * 4);
+  for (long g = (long)blockIdx.x * 4 + wave; g < groups; g += (long)gridDim.x * 4) {
+    const long pix = g * 16 + n;
+    const long v = pix / P, p = pix - v * P;
+    const unsigned char* src = vol + ((v * S) * P + p) * 32 + kg * 8;
+    const long dstride = P * 32;
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int d = 0; d < S; ++d) acc = mfma16(*(const bf16x4m*)(aw + d * 512), *(const bf16x4m*)(src + d * dstride), acc);
+    f32x4 t;
+    float ss = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float u = __builtin_fmaf(acc[e], he, bv[e]);
+      u = fmaxf(u, u * slope);
+      t[e] = u;
+      ss = __builtin_fmaf(u, u, ss);
+    }
+    ss = quad_sum(ss);
+    const float rn = sqrtf(ss * (1.f / 16.f) + eps);
+    const float rinv = 1.f / rn;
+    *(f32x4*)(y + pix * 16 + kg * 4) = t * rinv;
+    if (kg == 0) norm[pix] = rn;
+  }
+}
+
+// gp: fp32 rows [R][16] (rounded to bf16 here); wtab_t: bf16 [S][16 c][16 o] = W[o][c*S + d]; gxvol: bf16 records;
+// pw: [gridDim.x][S][16 o][16 c] partial weight gradients.  SD = S / 8 depths per wave.
+template <int SD>
+__global__ void __launch_bounds__(512, 2) proj16_bwd_kernel(const float* __restrict__ gp, const unsigned char* __restrict__ vol,
+                                                           const __bf16* __restrict__ wtab_t, unsigned char* __restrict__ gxvol,
+                                                           float* __restrict__ pw, long R, long P, float he) {
+  constexpr int S = SD * 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* lw = smem;
+  unsigned char* scr = smem + S * 512;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, kg = lane >> 4;
+  for (int i = tid; i < S * 32; i += 512) ((f32x4*)lw)[i] = ((const f32x4*)wtab_t)[i];
+  __syncthreads();
+  unsigned char* gs = scr + wave * 1024;
+  unsigned char* xs = gs + 512;
+  const int own = (n * 16 + kg * 4) * 2;
+  const int trp = ((kg * 4 + (n >> 2)) * 16 + (n & 3) * 4) * 2;
+  f32x4 accw[SD];
+#pragma unroll
+  for (int j = 0; j < SD; ++j) accw[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const long groups = R / 16;
+  const long dstride = P * 32;
+  for (long g = blockIdx.x; g < groups; g += gridDim.x) {
+    const long pix = g * 16 + n;
+    const long v = pix / P, p = pix - v * P;
+    const long base = ((v * S + wave * SD) * P + p) * 32 + kg * 8;
+    const bf16x4m gpb = __builtin_convertvector(*(const f32x4*)(gp + pix * 16 + kg * 4), bf16x4m);    // lane (pixel n, o 4 kg ..)
+    bf16x4m xr[SD];
+#pragma unroll
+    for (int j = 0; j < SD; ++j) xr[j] = *(const bf16x4m*)(vol + base + j * dstride);
+    *(bf16x4m*)(gs + own) = gpb;
+    asm volatile("" ::: "memory");
+    const bf16x4m gt = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4m*)(gs + trp));          // lane (o n, pixels 4 kg ..)
+#pragma unroll
+    for (int j = 0; j < SD; ++j) {
+      const int d = wave * SD + j;
+      // gx_d[c][pixel] = W_d^T[c][o] gp[o][pixel]
+      const f32x4 o = mfma16(*(const bf16x4m*)(lw + d * 512 + own), gpb, (f32x4){0.f, 0.f, 0.f, 0.f}) * he;
+      *(bf16x4m*)(gxvol + base + j * dstride) = __builtin_convertvector(o, bf16x4m);
+      // gW_d[o][c] += gp[o][pixel] x_d[pixel][c]
+      *(bf16x4m*)(xs + own) = xr[j];
+      asm volatile("" ::: "memory");
+      const bf16x4m xt = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4m*)(xs + trp));        // lane (c n, pixels 4 kg ..)
+      accw[j] = mfma16(gt, xt, accw[j]);
+    }
+  }
+  float* ow = pw + ((long)blockIdx.x * S + wave * SD) * 256;
+#pragma unroll
+  for (int j = 0; j < SD; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ow[j * 256 + (kg * 4 + e) * 16 + n] = accw[j][e];
+}
+
+// gw[o][c*S + d] = he * sum_wg pw[wg][d][o][c]
+__global__ void __launch_bounds__(256) proj16_bwd_reduce_kernel(const float* __restrict__ pw, int nwg, int S, float he, float* __restrict__ gw) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int nw = S * 256;
+  if (i >= nw) return;
+  float s = 0.f;
+  for (int w = 0; w < nwg; ++w) s += pw[(long)w * nw + i];
+  const int d = i >> 8, o = (i >> 4) & 15, c = i & 15;
+  gw[o * (16 * S) + c * S + d] = s * he;
+}
+
 int lift_cus() {
   static int cus = 0;
   if (cus == 0) {
@@ -273,5 +383,55 @@ extern "C" int lf_lift16_bwd(const void* gvol, const void* yvol, const float* no
   if (st) return st;
   hipLaunchKernelGGL(lift_bwd_reduce_kernel, dim3((unsigned)((S * 272 + 255) / 256)), dim3(256), 0, s, (const float*)pw, (const float*)pb, nwg,
                      S, he, gw, gb);
+  return lf_launch_status();
+}
+
+extern "C" int lf_proj16_fwd(const void* vol, const void* wtab, const float* bias, float* y, float* norm, long R, long P, int S, float he,
+                             float slope, float eps, void* stream) {
+  lf_clear_error();
+  if (R <= 0 || P <= 0 || S <= 0 || S > 256 || (R % 16) || (P % 16) || (R % P) || vol == nullptr || wtab == nullptr || y == nullptr ||
+      norm == nullptr) return LF_EINVAL;
+  if (!lf_aligned16(vol) || !lf_aligned16(wtab) || !lf_aligned16(y) || (bias && !lf_aligned16(bias))) return LF_EALIGN;
+  const size_t shmem = (size_t)S * 512;
+  static lf_devmask_t attr;
+  if (shmem > 48 * 1024) {
+    hipError_t e = lf_ensure_dyn_lds(attr, (const void*)proj16_fwd_kernel, 150 * 1024);
+    if (e != hipSuccess) return (int)e;
+  }
+  const long groups = R / 16;
+  long nb = 2L * lift_cus();
+  if (nb * 4 > groups) nb = (groups + 3) / 4;
+  hipLaunchKernelGGL(proj16_fwd_kernel, dim3((unsigned)nb), dim3(256), shmem, (hipStream_t)stream, (const unsigned char*)vol,
+                     (const __bf16*)wtab, bias, y, norm, R, P, S, he, slope, eps);
+  return lf_launch_status();
+}
+
+extern "C" size_t lf_proj16_bwd_scratch_bytes(int S) { return (size_t)lift_cus() * (size_t)S * 256 * sizeof(float); }
+
+extern "C" int lf_proj16_bwd(const float* gp, const void* vol, const void* wtab_t, void* gxvol, float* gw, void* scratch,
+                             size_t scratch_bytes, long R, long P, int S, float he, void* stream) {
+  lf_clear_error();
+  if (R <= 0 || P <= 0 || (R % 16) || (P % 16) || (R % P) || gp == nullptr || vol == nullptr || wtab_t == nullptr || gxvol == nullptr ||
+      gw == nullptr) return LF_EINVAL;
+  if (S != 16 && S != 32 && S != 64 && S != 128) return LF_EINVAL;
+  if (!lf_aligned16(gp) || !lf_aligned16(vol) || !lf_aligned16(wtab_t) || !lf_aligned16(gxvol) || !lf_aligned16(scratch)) return LF_EALIGN;
+  const long groups = R / 16;
+  int nwg = lift_cus();
+  if (nwg > groups) nwg = (int)groups;
+  if (scratch == nullptr || scratch_bytes < (size_t)nwg * S * 256 * sizeof(float)) return LF_ENOSPC;
+  const size_t shmem = (size_t)S * 512 + 8 * 1024;
+  hipStream_t s = (hipStream_t)stream;
+  typedef void (*kern_t)(const float*, const unsigned char*, const __bf16*, unsigned char*, float*, long, long, float);
+  kern_t k = S == 128 ? proj16_bwd_kernel<16> : (S == 64 ? proj16_bwd_kernel<8> : (S == 32 ? proj16_bwd_kernel<4> : proj16_bwd_kernel<2>));
+  static lf_devmask_t attr[4];
+  if (shmem > 48 * 1024) {
+    hipError_t e = lf_ensure_dyn_lds(attr[S == 128 ? 0 : (S == 64 ? 1 : (S == 32 ? 2 : 3))], (const void*)k, 150 * 1024);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(512), shmem, s, gp, (const unsigned char*)vol, (const __bf16*)wtab_t, (unsigned char*)gxvol,
+                     (float*)scratch, R, P, he);
+  int st = lf_launch_status();
+  if (st) return st;
+  hipLaunchKernelGGL(proj16_bwd_reduce_kernel, dim3((unsigned)((S * 256 + 255) / 256)), dim3(256), 0, s, (const float*)scratch, nwg, S, he, gw);
   return lf_launch_status();
 }

@@ -766,9 +766,27 @@ class _FactorProject(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         ctx.x_bf16 = x.dtype == torch.bfloat16
+        ctx.ac = AUTOCAST is not None
+        ctx.mfma = bool(PROJ_MFMA and ctx.ac and ctx.x_bf16 and x.dim() == 5 and x.shape[1] == 16 and weight.shape[0] == 16
+                        and x.shape[2] in (16, 32, 64, 128) and (x.shape[3] * x.shape[4]) % 16 == 0 and x.is_cuda)
+        if ctx.mfma:
+            # round 6 (csrc/lift_mfma.hip): the bf16 volume read as it lies, one MFMA per depth; no fp32 copy of the volume
+            L = _lib.lib()
+            _req(weight, 'weight')
+            x = cl(x)
+            N, C, D, H, W = x.shape
+            he = he_constant(weight)
+            wtab = _pk(weight, 'p16f', lambda w: w.reshape(16, 16, D).permute(2, 0, 1).contiguous().to(torch.bfloat16))
+            y = empty_cl((N, 16, H, W), x.device)
+            norm = torch.empty(N * H * W, device=x.device, dtype=torch.float32)
+            with _timed('proj16_fwd'):
+                check(L.lf_proj16_fwd(_ptr(x), _ptr(wtab), _ptr(bias) if bias is not None else None, _ptr(y), _ptr(norm), N * H * W, H * W,
+                                      D, he, SLOPE, PN_EPS, _stream()), 'lf_proj16_fwd')
+            ctx.flags, ctx.he, ctx.xshape = LF_EPI_LRELU | LF_EPI_PIXELNORM, he, x.shape
+            ctx.save_for_backward(y, norm, weight, x)
+            return y
         x = _f32(x)
         _req(x, 'x'), _req(weight, 'weight')
-        ctx.ac = AUTOCAST is not None
         x = cl(x) if ctx.x_bf16 else _ac_in(cl(x))             # (a bf16-stored volume is already rounded)
         N, C, D, H, W = x.shape
         cout = weight.shape[0]
@@ -793,6 +811,21 @@ class _FactorProject(torch.autograd.Function):
         N, C, D, H, W = ctx.xshape
         cout = w.shape[0]
         gw = gb = None
+        if ctx.mfma:
+            L = _lib.lib()
+            wtab_t = _pk(w, 'p16b', lambda t: t.reshape(16, 16, D).permute(2, 1, 0).contiguous().to(torch.bfloat16))
+            gx = empty_cl16((N, 16, D, H, W), gp.device, True)
+            gwt = torch.empty(16, 16 * D, device=gp.device, dtype=torch.float32)
+            nb = L.lf_proj16_bwd_scratch_bytes(D)
+            scr = torch.empty(nb // 4 + 4, device=gp.device, dtype=torch.float32)
+            with _timed('proj16_bwd'):
+                check(L.lf_proj16_bwd(_ptr(gp), _ptr(x_saved), _ptr(wtab_t), _ptr(gx), _ptr(gwt), _ptr(scr, True), scr.numel() * 4,
+                                      N * H * W, H * W, D, ctx.he, _stream()), 'lf_proj16_bwd')
+            with autocast(True):
+                if ctx.needs_input_grad[2]:
+                    gb = _T().bias_grad(gp.permute(0, 2, 3, 1).reshape(N * H * W, cout), 0)
+                gw = _ac_in(gwt.reshape(w.shape))
+            return gx, gw if ctx.needs_input_grad[1] else None, gb if ctx.needs_input_grad[2] else None
         with autocast(ctx.ac):
             gp_full, gp = gp, _ac_in(gp)
             # gx[n,d,p,c] = he * sum_co gp[n,p,co] * W[co, c*D+d]  == pointwise conv with Cout' = D*C
@@ -822,6 +855,8 @@ def factor_project(x, weight, bias):
     return _FactorProject.apply(x, weight, bias)
 
 
+import os as _os
+PROJ_MFMA = bool(int(_os.environ.get('LF_PROJ_MFMA', '1')))   # the training step's 3-D -> 2-D factor projection as one MFMA kernel each way (csrc/lift_mfma.hip)
 LIFT_FUSED = True          # A/B switch of the fused training-path lift (_LiftFused); False: conv1x1 + PixelNorm + permutation
 
 

@@ -19,7 +19,7 @@ WGRAD_STREAM = True
 # The ConvGRU recurrence of the training step on the multi-output ring kernels (round 6, csrc/conv_gru.hip); False: the
 # one-output kernels + stage kernels of round 5 (kept: fp32 storage / no autocast take that path anyway)
 GRU_RING = True
-GRU_WGRAD_CHUNK = 0                                               # steps per multi-volume weight-gradient launch (0: one launch over all steps, after the chain)
+GRU_WGRAD_CHUNK = 16                                              # steps per multi-volume weight-gradient launch on the side stream (0: one launch over all steps, after the chain)
 # 1: one-output launches on the sequential chain (two workgroups per CU overlap their phases), everything that does not depend
 # on the state batched over the views before / after the loop; 2: two outputs per staged halo (one 8-wave workgroup per CU --
 # measured slower: its waves run in lock-step, profiles/r06_gru_ring_ab.txt)
