@@ -41,6 +41,8 @@ TRAIN_KERNELS = collections.OrderedDict([
     ('conv3d_c16_ring_bf16', (('conv3d_c16_f16x3_kernel<false, 1, 3>', 'conv3d_c16_f16x3_kernelILb0ELi1ELi3E'), V + V // 16)),
     ('conv3d_c16_ring_bf16_addend', (('conv3d_c16_f16x3_kernel<true, 1, 7>', 'conv3d_c16_f16x3_kernelILb1ELi1ELi7E'), 3 * V // 2)),
     ('wgrad3d_c16_bf16_kernel', (('wgrad3d_c16_bf16_kernel<3>', 'wgrad3d_c16_bf16_kernelILi3E'), V)),
+    # round 6: the transpose-load kernel (x + gpre, bf16 records)
+    ('wgrad3d_c16_tr_kernel', (('wgrad3d_c16_tr_kernel<3>', 'wgrad3d_c16_tr_kernelILi3E'), V)),
     ('epilogue_bwd_c16_kernel', (('epilogue_bwd_c16_kernel<7>', 'epilogue_bwd_c16_kernelILi7E'), 3 * V // 2 + V // 16)),
     ('resample_fwd_c16_kernel', (('resample_fwd_c16_kernel<1, 3>', 'resample_fwd_c16_kernelILi1ELi3E'), V)),
     ('splat_tile_kernel', (('splat_tile_kernel<1, 3>', 'splat_tile_kernelILi1ELi3E'), V)),
@@ -49,13 +51,21 @@ TRAIN_KERNELS = collections.OrderedDict([
     ('splat_bin_kernel_fill', (('splat_bin_kernel<1, true>', 'splat_bin_kernelILi1ELb1E'), 8 * 128 ** 3 * 7)),
     ('lift_norm_unfold_kernel', ('lift_norm_unfold_kernel', V + V // 2)),
     ('lift_bwd_fused_kernel', ('lift_bwd_fused_kernel', 2 * V)),
+    # round 6: one-group ring kernels with compile-time epilogues (bf16 in / out; in-place bf16 addend), the fused lift
+    # (forward: x rows + the bf16 volume; backward: two bf16 volumes in, gx rows out) and the fused 3-D -> 2-D projection
+    ('ring_multi_rounded', (('ring_multi_kernel<1, true, 0, 6>', 'ring_multi_kernelILi1ELb1ELi0ELi6E'), V)),
+    ('ring_multi_addend_inplace', (('ring_multi_kernel<1, true, 0, 11>', 'ring_multi_kernelILi1ELb1ELi0ELi11E'), 3 * V // 2)),
+    ('lift_fwd_mfma_kernel', ('lift_fwd_mfma_kernel', V // 2 + 8 * 128 ** 2 * 17 * 4)),
+    ('lift_bwd_mfma_kernel', ('lift_bwd_mfma_kernel', V + 8 * 128 ** 2 * 33 * 4)),
+    ('proj16_fwd_kernel', ('proj16_fwd_kernel', V // 2 + 8 * 128 ** 2 * 17 * 4)),
+    ('proj16_bwd_kernel', ('proj16_bwd_kernel', V + 8 * 128 ** 2 * 16 * 4)),
 ])
 # hbm_probe.py launches the Winograd kernel REP times in its forward form, then REP times as a data gradient with the
 # producer's epilogue backward fused (reads the saved activation and norm as well): reported separately
 SPLIT = {'conv3d_c16_wino_kernel': (('forward form', 2 * 8 * 16 * 128 ** 3 * 4 + 8 * 128 ** 3 * 4),
                                     ('data-gradient form + fused previous-layer backward', 3 * 8 * 16 * 128 ** 3 * 4 + 8 * 128 ** 3 * 4))}
 SOURCES = ['conv_wino.hip', 'conv.hip', 'conv_split.hip', 'resample.hip', 'pointwise.hip', 'reduce.hip']
-TRAIN_SOURCES = ['conv_split.hip', 'wgrad.hip', 'resample.hip', 'pointwise.hip', 'gru.hip']
+TRAIN_SOURCES = ['conv_split.hip', 'wgrad.hip', 'resample.hip', 'pointwise.hip', 'gru.hip', 'conv_gru.hip', 'lift_mfma.hip', 'ring_tile.h']
 # --cfg3: the released architecture's kernels inside the cross_entropy_linemod loop (tools/pmc_collect_cfg3.sh over
 # tools/cfg3_probe.py; no calibration copy in that run: FETCH_SIZE x 2, WRITE_SIZE x 1 as calibrated in the other two)
 CFG3_KERNELS = collections.OrderedDict([

@@ -64,4 +64,40 @@ for _ in range(REP):
     _lib.check(L.lf_lift_norm_unfold(rows.data_ptr(), vol.data_ptr(), norm.data_ptr(), N, S * S, C, S, 1e-8, 1, s), 'lift fwd')
     _lib.check(L.lf_lift_bwd(gp.data_ptr(), vol.data_ptr(), norm.data_ptr(), gpr.data_ptr(), N, S * S, C, S, 0.2, 1, 3, s), 'lift bwd')
 torch.cuda.synchronize()
+# round 6: the one-group ring kernels with compile-time epilogues (data gradient = rounded form; in-place bf16 addend form), the
+# fused lift and the renderer's fused 3-D -> 2-D projection (8 views of 128^2 pixels each)
+from latentfusion_amd import ops_train  # noqa: E402
+p1 = wp.reshape(1, 14, 16, 32)
+o16 = torch.empty_like(x)
+for _ in range(REP):
+    ops_train.ring_multi(x, p1, he, [(o16, None, True)])                                                         # <1,true,0,6>
+torch.cuda.synchronize()
+for _ in range(REP):
+    ops_train.ring_multi(x, p1, he, [(o16, o16, False)])                                                         # <1,true,0,11>
+torch.cuda.synchronize()
+xin = torch.randn(N * S * S, 16, generator=g).cuda()
+wl = torch.randn(16 * S, 16, generator=g).cuda()
+wtab = wl.reshape(16, S, 16).permute(1, 0, 2).contiguous().to(torch.bfloat16)
+wtab_t = wl.reshape(16, S, 16).permute(1, 2, 0).contiguous().to(torch.bfloat16)
+btab = torch.zeros(S, 16, device='cuda')
+gx = torch.empty(N * S * S, 16, device='cuda')
+gwl, gbl = torch.empty(16 * S, 16, device='cuda'), torch.empty(16 * S, device='cuda')
+scr2 = torch.empty(L.lf_lift16_bwd_scratch_bytes(S) // 4 + 4, device='cuda')
+for _ in range(REP):
+    _lib.check(L.lf_lift16_fwd(xin.data_ptr(), wtab.data_ptr(), btab.data_ptr(), vol.data_ptr(), norm.data_ptr(), N * S * S, S * S, S, 0.35, 0.2,
+                               1e-8, s), 'lift16 fwd')
+    _lib.check(L.lf_lift16_bwd(gp.data_ptr(), vol.data_ptr(), norm.data_ptr(), xin.data_ptr(), wtab_t.data_ptr(), gx.data_ptr(), gwl.data_ptr(),
+                               gbl.data_ptr(), scr2.data_ptr(), scr2.numel() * 4, N * S * S, S * S, S, 0.35, 0.2, 1, s), 'lift16 bwd')
+torch.cuda.synchronize()
+y2 = torch.empty(N * S * S, 16, device='cuda')
+wp2 = torch.randn(16, 16 * S, generator=g).cuda()
+ptab = wp2.reshape(16, 16, S).permute(2, 0, 1).contiguous().to(torch.bfloat16)
+ptab_t = wp2.reshape(16, 16, S).permute(2, 1, 0).contiguous().to(torch.bfloat16)
+gwp = torch.empty(16, 16 * S, device='cuda')
+scr3 = torch.empty(L.lf_proj16_bwd_scratch_bytes(S) // 4 + 4, device='cuda')
+for _ in range(REP):
+    _lib.check(L.lf_proj16_fwd(x.data_ptr(), ptab.data_ptr(), None, y2.data_ptr(), norm.data_ptr(), N * S * S, S * S, S, 0.03, 0.2, 1e-8, s), 'proj16 fwd')
+    _lib.check(L.lf_proj16_bwd(gx.data_ptr(), x.data_ptr(), ptab_t.data_ptr(), o16.data_ptr(), gwp.data_ptr(), scr3.data_ptr(), scr3.numel() * 4,
+                               N * S * S, S * S, S, 0.03, s), 'proj16 bwd')
+torch.cuda.synchronize()
 print('ok')
