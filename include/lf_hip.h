@@ -237,6 +237,11 @@ int lf_conv3d_c16_ring_bf16_io(const void* x, const void* wpack, const float* bi
  *   LF_RING_EX_ABWD  (group 0 = LF_RING_ROUND | LF_RING_ADD_BF16 with add_0 = reset pre-activation, NOT added;
  *                    e0 = h fp32, e1 = gh1 fp32): g = group 0's result is not stored; y_0 (bf16) = g h r (1 - r),
  *                    o2 (fp32) = e1 + g r,  r = sigmoid(add_0).  y_0 may alias add_0.
+ *   LF_RING_EX_PREV  (ngroups 1, bf16 x, flags LF_RING_ROUND | LF_RING_OUT_BF16: the data gradient of a 16 -> 16 layer) e0 = the
+ *                    bf16 activation of the layer that PRODUCED this layer's input, e1 = its PixelNorm norms (fp32 per voxel):
+ *                    y_0 = LeakyReLU'(PixelNorm'(g; e0, e1)) of the rounded result g, slope 0.2 -- that producer's pre-activation
+ *                    gradient; o2 = fp32 scratch of 16 * (1 + 2 * #CUs) floats, zero-filled by the caller: o2[0..15] receives the
+ *                    producer's bias gradient (sums of the un-rounded y_0, fixed order).  Autograd of modules/blocks.py:152-158.
  * In-place addends (y_g == add_g) are allowed.  Only the combinations the recurrence launches are instantiated (LF_EINVAL
  * otherwise): no extra with (bf16 x, 1 or 2 groups) or (fp32 x, 1 group); EX_RH and EX_ABWD with 1 or 2 groups; EX_BLEND with 1.
  * D*H*W*64 < 2^31. */
@@ -247,6 +252,7 @@ int lf_conv3d_c16_ring_bf16_io(const void* x, const void* wpack, const float* bi
 #define LF_RING_EX_RH 1
 #define LF_RING_EX_BLEND 2
 #define LF_RING_EX_ABWD 3
+#define LF_RING_EX_PREV 5
 int lf_conv3d_c16_ring_multi(const void* x, int x_bf16, const void* wpack, int ngroups,
                              void* y0, const void* add0, unsigned flags0, void* y1, const void* add1, unsigned flags1,
                              int extra, const void* e0, const void* e1, void* o2,

@@ -68,9 +68,9 @@ class Equalized(nn.Module):
         """sqrt(2 / fan_in) (reference equalized.py:66-74)."""
         return ops.he_constant(self.module.weight)
 
-    def forward(self, x, fuse_act=False, fuse_norm=False):
+    def forward(self, x, fuse_act=False, fuse_norm=False, chain=False):
         if self.kernel_size == 3:
-            return ops.conv3x3(x, self.module.weight, self.bias, lrelu=fuse_act, pixelnorm=fuse_norm)
+            return ops.conv3x3(x, self.module.weight, self.bias, lrelu=fuse_act, pixelnorm=fuse_norm, chain=chain)
         return ops.conv1x1(x, self.module.weight, self.bias, lrelu=fuse_act, pixelnorm=fuse_norm)
 
 

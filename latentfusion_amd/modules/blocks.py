@@ -101,5 +101,5 @@ class Block(nn.Module):
         """rescale=False leaves the block's resize to the caller (a nearest up-sampling commutes with the pointwise layers behind
         it: Photographer.decode_features)."""
         x = self.conv1(x, fuse_act=True, fuse_norm=True)
-        x = self.conv2(x, fuse_act=True, fuse_norm=True)
+        x = self.conv2(x, fuse_act=True, fuse_norm=True, chain=True)     # (conv1's output has no other consumer)
         return self.interpolate(x) if (self.interpolate and rescale) else x

@@ -682,10 +682,11 @@ class _Conv3x3(torch.autograd.Function):
         return gx, gw if ctx.needs_input_grad[1] else None, gb if ctx.needs_input_grad[2] else None, None
 
 
-def conv3x3(x, weight, bias, lrelu=True, pixelnorm=True):
+def conv3x3(x, weight, bias, lrelu=True, pixelnorm=True, chain=False):
+    """chain: x is the output of the previous convolution of the same Block and has no other consumer (ops_train._Conv16AC)."""
     flags = (LF_EPI_LRELU if lrelu else 0) | (LF_EPI_PIXELNORM if pixelnorm else 0)
     if _T()._conv16_ac_ok(x, weight):
-        return _T()._Conv16AC.apply(x, weight, bias, flags)
+        return _T()._Conv16AC.apply(x, weight, bias, flags, chain)
     return _Conv3x3.apply(_f32(x), weight, bias, flags)
 
 
@@ -755,7 +756,7 @@ class _Conv1x1(torch.autograd.Function):
 def conv1x1(x, weight, bias, lrelu=False, pixelnorm=False):
     flags = (LF_EPI_LRELU if lrelu else 0) | (LF_EPI_PIXELNORM if pixelnorm else 0)
     if _T()._conv16_ac_ok(x, weight):                       # (the encoder's 16 -> 16 output layer: the ring kernel's centre tap)
-        return _T()._Conv16AC.apply(x, weight, bias, flags)
+        return _T()._Conv16AC.apply(x, weight, bias, flags, False)
     return _Conv1x1.apply(_f32(x), weight, bias, flags)
 
 

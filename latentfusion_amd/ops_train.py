@@ -24,6 +24,7 @@ GRU_WGRAD_CHUNK = 16                                              # steps per mu
 # on the state batched over the views before / after the loop; 2: two outputs per staged halo (one 8-wave workgroup per CU --
 # measured slower: its waves run in lock-step, profiles/r06_gru_ring_ab.txt)
 GRU_RING_GROUPS = 1
+CHAIN_EPILOGUE = bool(int(__import__('os').environ.get('LF_CHAIN_EPILOGUE', '1')))   # Block conv2's data gradient applies conv1's epilogue backward (LF_RING_EX_PREV)
 LIFT_MFMA = True                                                  # the 16-channel lift as one MFMA kernel each way (csrc/lift_mfma.hip)
 RING_DGRAD = True                                                 # data gradients of the 16 -> 16 layers on the same kernel family
 import os as _os                                                  # (A/B switches of tools/train_probe.py)
@@ -234,12 +235,18 @@ def epilogue_bwd_c16(gy, y, norm, flags, want_bias, out_bf16=True):
 class _Conv16AC(torch.autograd.Function):
     """A 3-D 16 -> 16 layer (3x3x3, or 1x1x1 on the centre tap) of the training step under the bf16 autocast + storage policy:
     x (fp32 or bf16 storage) -> epilogue(conv(x, W) * he + b) in bf16 storage on lf_conv3d_c16_ring_bf16_io.  Backward: one
-    pass for LeakyReLU' / PixelNorm' and the bias gradient (lf_epilogue_bwd_c16), the data gradient on the same ring kernel
-    in the input's storage type, the weight gradient on lf_conv_bwd_weight_bf16_io -- every volume moves as bf16."""
+    pass for LeakyReLU' / PixelNorm' and the bias gradient (lf_epilogue_bwd_c16), the data gradient on the ring kernel
+    in the input's storage type, the weight gradient on lf_conv_bwd_weight_bf16_io -- every volume moves as bf16.
+
+    chain (round 6): the caller states that x is the output of ANOTHER _Conv16AC layer with LeakyReLU + PixelNorm that nothing else
+    consumes (the two convolutions of a Block, modules/blocks.py:152-158).  This layer's data gradient then applies that layer's
+    epilogue backward in its store and sums its bias gradient (LF_RING_EX_PREV): the producer receives its PRE-activation
+    gradient and skips its own lf_epilogue_bwd_c16 pass (1.28 ms and 4.3 GB per Block at 32 views)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, flags):
+    def forward(ctx, x, weight, bias, flags, chain=False):
         _req(weight, 'weight')
+        link = getattr(x, '_lf_link', None) if (chain and CHAIN_EPILOGUE) else None
         x = cl(x)
         he = he_constant(weight)
         one = weight.shape[2] == 1
@@ -250,6 +257,15 @@ class _Conv16AC(torch.autograd.Function):
         need_w = weight.requires_grad or (bias is not None and bias.requires_grad)
         ctx.save_for_backward(y if flags else None, norm, weight, x if need_w else None)
         ctx.xdtype = x.dtype
+        # the producer's side of the chain: what a consumer needs to run this layer's epilogue backward (its activation reaches
+        # the consumer as that layer's input), and the box through which the consumer reports having done so
+        ctx.box = None
+        if CHAIN_EPILOGUE and flags == (LF_EPI_LRELU | LF_EPI_PIXELNORM) and not one:
+            ctx.box = {'done': False, 'gb': None}
+            y._lf_link = (norm, ctx.box)
+        ctx.link = None
+        if link is not None and x.dtype == torch.bfloat16 and need_w and not one and x.shape[2] * x.shape[3] * x.shape[4] * 64 < 2 ** 31:
+            ctx.link = link                                       # (norm of the producer, its box)
         return y
 
     @staticmethod
@@ -257,7 +273,11 @@ class _Conv16AC(torch.autograd.Function):
         y, norm, w, x_saved = ctx.saved_tensors
         gy = cl(gy)
         want_b = ctx.needs_input_grad[2]
-        if ctx.flags == 0 and not want_b and gy.dtype == torch.bfloat16:
+        if ctx.box is not None and ctx.box['done']:
+            gp, gb = gy, ctx.box['gb']                            # the consumer's data gradient already applied this layer's epilogue backward
+            if gp.dtype != torch.bfloat16:
+                gp = gp.to(torch.bfloat16)
+        elif ctx.flags == 0 and not want_b and gy.dtype == torch.bfloat16:
             gp, gb = gy, None
         else:
             gp, gb = epilogue_bwd_c16(gy, y, norm, ctx.flags, want_b)
@@ -288,7 +308,16 @@ class _Conv16AC(torch.autograd.Function):
                             t.record_stream(side)
             if ctx.needs_input_grad[0]:
                 pack_t = _pk(w, 'a3b', lambda t: pack_conv3d_c16_ring_bf16(w3(t), transpose=True))
-                if RING_DGRAD and gp.dtype == torch.bfloat16 and ctx.xdtype == torch.bfloat16:
+                if ctx.link is not None and gp.dtype == torch.bfloat16:
+                    # this layer's data gradient + the PRODUCER's epilogue backward and bias sums in one launch: x_saved is the
+                    # producer's activation
+                    pnorm, pbox = ctx.link
+                    gx = torch.empty_like(gp)
+                    gbuf = torch.zeros(16 * 1025, device=gp.device, dtype=torch.float32)
+                    ring_multi(gp, pack_t.reshape(1, 14, 16, 32), ctx.he, [(gx, None, True)], extra=_lib.LF_RING_EX_PREV, e0=x_saved, e1=pnorm,
+                               o2=gbuf)
+                    pbox['done'], pbox['gb'] = True, gbuf[:16]
+                elif RING_DGRAD and gp.dtype == torch.bfloat16 and ctx.xdtype == torch.bfloat16:
                     # the same sums and roundings on the one-group ring kernel with a compile-time epilogue (csrc/conv_gru.hip):
                     # bit-identical, 32 instead of 53 us per 128^3 volume
                     gx = torch.empty_like(gp)
@@ -305,7 +334,7 @@ class _Conv16AC(torch.autograd.Function):
                     gw = round_bf16(gwt[13].reshape(w.shape).contiguous())
                 else:
                     gw = round_bf16(gwt.reshape(3, 3, 3, 16, 16).permute(3, 4, 0, 1, 2).contiguous())
-        return gx, gw, gb, None
+        return gx, gw, gb, None, None
 
 
 def _conv16_ac_ok(x, weight):

@@ -163,3 +163,59 @@ def test_refused_combinations():
         ops_train.ring_multi(x, packs, he, [(y, None, True), (y.clone(), None, True)])
     with pytest.raises(_lib.LFHipError):                            # the blend epilogue needs h / upre / an output
         ops_train.ring_multi(x.to(torch.bfloat16), packs[:1].contiguous(), he, [(y, None, False)], extra=_lib.LF_RING_EX_BLEND)
+
+
+@pytest.mark.parametrize('N,D,H,W', SHAPES)
+def test_previous_layer_backward_in_the_data_gradient_store(N, D, H, W):
+    """LF_RING_EX_PREV: the data gradient of a 16 -> 16 layer with the PRODUCER's LeakyReLU' / PixelNorm' and bias sums in its
+    store == the rounded data gradient followed by lf_epilogue_bwd_c16 on the producer's activation."""
+    from latentfusion_amd import _lib, ops, ops_train
+    from latentfusion_amd._lib import LF_EPI_LRELU, LF_EPI_PIXELNORM
+    gp, w, packs, he, g = _setup(N, D, H, W, seed=7)
+    # a producer activation: PixelNorm output with its norms
+    t = torch.randn(N, 16, D, H, W, generator=g).cuda().contiguous(memory_format=torch.channels_last_3d)
+    t = torch.nn.functional.leaky_relu(t, 0.2)
+    nrm = torch.sqrt((t * t).mean(dim=1) + 1e-8).reshape(-1).contiguous()
+    y = (t / nrm.view(N, 1, D, H, W)).to(torch.bfloat16).contiguous(memory_format=torch.channels_last_3d)
+    out = torch.empty_like(gp)
+    gbuf = torch.zeros(16 * 1025, device='cuda')
+    ops_train.ring_multi(gp, packs[:1].contiguous(), he, [(out, None, True)], extra=_lib.LF_RING_EX_PREV, e0=y, e1=nrm, o2=gbuf)
+    gy, _ = ops.conv3d_c16_ring_bf16_io(gp, packs[0], None, he, 0, 1, out_bf16=True)
+    want, gb = ops_train.epilogue_bwd_c16(gy, y, nrm, LF_EPI_LRELU | LF_EPI_PIXELNORM, True)
+    _close_bf16(out, want)
+    torch.testing.assert_close(gbuf[:16], gb, atol=1e-4 * float(gb.abs().max()) + 1e-6, rtol=2e-3)
+
+
+def test_block_chain_equals_separate_epilogue_backward():
+    """A Block of two 16 -> 16 layers under the bf16 policy: conv2's data gradient applies conv1's epilogue backward
+    (ops_train.CHAIN_EPILOGUE) -- same output, same gradients as with conv1's own lf_epilogue_bwd_c16 pass."""
+    from latentfusion_amd import ops, ops_train
+    from latentfusion_amd.modules.blocks import Block
+    torch.manual_seed(5)
+    blk = Block(16, 16).cuda()
+    with torch.no_grad():
+        for p in blk.parameters():
+            if p.dim() == 1:
+                p.normal_(0.0, 0.2)
+    g = torch.Generator().manual_seed(9)
+    x0 = torch.randn(2, 16, 12, 16, 32, generator=g).cuda().contiguous(memory_format=torch.channels_last_3d).to(torch.bfloat16)
+    gout = torch.randn(2, 16, 12, 16, 32, generator=g).cuda().contiguous(memory_format=torch.channels_last_3d)
+    res = []
+    for chain in (True, False, True):
+        ops_train.CHAIN_EPILOGUE = chain
+        try:
+            blk.zero_grad()
+            x = x0.clone().requires_grad_(True)
+            with ops.autocast(True):
+                y = blk(x)
+            (y.float() * gout).sum().backward()
+        finally:
+            ops_train.CHAIN_EPILOGUE = True
+        res.append((y.detach(), x.grad.clone(), {k: p.grad.clone() for k, p in blk.named_parameters()}))
+    a, b, c = res
+    assert torch.equal(a[0], b[0]) and torch.equal(a[0], c[0]) and torch.equal(a[1], c[1])
+    _close_bf16(a[1], b[1], ulps=2.02)
+    for k in a[2]:
+        assert torch.equal(a[2][k], c[2][k])
+        cos = torch.nn.functional.cosine_similarity(a[2][k].reshape(1, -1).double(), b[2][k].reshape(1, -1).double()).item()
+        assert cos > 0.99999, (k, cos)
