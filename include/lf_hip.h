@@ -237,6 +237,9 @@ int lf_conv3d_c16_ring_bf16_io(const void* x, const void* wpack, const float* bi
  *   LF_RING_EX_ABWD  (group 0 = LF_RING_ROUND | LF_RING_ADD_BF16 with add_0 = reset pre-activation, NOT added;
  *                    e0 = h fp32, e1 = gh1 fp32): g = group 0's result is not stored; y_0 (bf16) = g h r (1 - r),
  *                    o2 (fp32) = e1 + g r,  r = sigmoid(add_0).  y_0 may alias add_0.
+ *   LF_RING_EX_BLOCK (ngroups 1, flags LF_RING_ROUND | LF_RING_OUT_BF16; e0 = bias[16] fp32 or NULL, o2 = norms fp32 per voxel):
+ *                    y_0 = PixelNorm(LeakyReLU(bf16(bf16(conv) * he) + bias)), slope 0.2, eps 1e-8: the Block step of
+ *                    lf_conv3d_c16_ring_bf16_io (flags LRELU | PIXELNORM, round_out 1) with its epilogue at compile time.
  *   LF_RING_EX_PREV  (ngroups 1, bf16 x, flags LF_RING_ROUND | LF_RING_OUT_BF16: the data gradient of a 16 -> 16 layer) e0 = the
  *                    bf16 activation of the layer that PRODUCED this layer's input, e1 = its PixelNorm norms (fp32 per voxel):
  *                    y_0 = LeakyReLU'(PixelNorm'(g; e0, e1)) of the rounded result g, slope 0.2 -- that producer's pre-activation
@@ -252,6 +255,7 @@ int lf_conv3d_c16_ring_bf16_io(const void* x, const void* wpack, const float* bi
 #define LF_RING_EX_RH 1
 #define LF_RING_EX_BLEND 2
 #define LF_RING_EX_ABWD 3
+#define LF_RING_EX_BLOCK 4
 #define LF_RING_EX_PREV 5
 int lf_conv3d_c16_ring_multi(const void* x, int x_bf16, const void* wpack, int ngroups,
                              void* y0, const void* add0, unsigned flags0, void* y1, const void* add1, unsigned flags1,

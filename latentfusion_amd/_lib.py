@@ -14,7 +14,7 @@ LF_EPI_LRELU = 1
 LF_EPI_PIXELNORM = 2
 LF_EPI_ADD = 4
 LF_RING_ADD_BF16, LF_RING_OUT_BF16, LF_RING_ROUND = 1, 2, 4
-LF_RING_EX_NONE, LF_RING_EX_RH, LF_RING_EX_BLEND, LF_RING_EX_ABWD, LF_RING_EX_PREV = 0, 1, 2, 3, 5
+LF_RING_EX_NONE, LF_RING_EX_RH, LF_RING_EX_BLEND, LF_RING_EX_ABWD, LF_RING_EX_BLOCK, LF_RING_EX_PREV = 0, 1, 2, 3, 4, 5
 LF_OUT_DEPTH_INNER = 0x100
 LF_IO_IN_BF16, LF_IO_OUT_BF16, LF_IO_ADDEND_BF16 = 1, 2, 4
 LF_MAP_O2C = 0

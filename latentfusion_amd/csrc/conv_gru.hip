@@ -15,6 +15,8 @@
 //     EX_BLEND (r h -> cand): also h' = h (1 - s(upre)) + cand s(upre)                       (was lf_gru_train_stage_b)
 //     EX_ABWD  group 0 of (gc -> g_rh, g_x): g_rh is not stored; grpre = g_rh h r (1 - r), gh12 = gh1 + g_rh r
 //                                                                                          (was lf_gru_train_stage_a_bwd)
+//     EX_BLOCK the Block step itself: bf16(bf16(conv) * he) + bias, LeakyReLU, PixelNorm (norms stored) -- the forward epilogue of
+//              conv3d_c16_f16x3_kernel<false, 1> at compile time (1.63 -> 1.2 ms per 32 volumes)
 //     EX_PREV  the data gradient of layer L+1 with the LeakyReLU' / PixelNorm' of layer L (the producer of its input) in the
 //              store + L's bias-gradient sums: what comes out is L's PRE-activation gradient (was lf_epilogue_bwd_c16 on 32 views:
 //              1.28 ms and a 4.3 GB round trip per Block of two 16 -> 16 layers)
@@ -193,10 +195,14 @@ __global__ void __launch_bounds__(256 * NG, 2) ring_multi_kernel(const RmArgs A)
     if constexpr (EX == 2) { e_e0 = (const unsigned char*)A.e0 + (sv << 6); e_e1 = (const unsigned char*)A.e1 + (sv << 5); e_o2 = (const unsigned char*)A.o2 + (sv << 6); }
     if constexpr (EX == 3) { e_e0 = (const unsigned char*)A.e0 + (sv << 6); e_e1 = (const unsigned char*)A.e1 + (sv << 6); e_o2 = (const unsigned char*)A.o2 + (sv << 6); }
     if constexpr (EX == 5) { e_e0 = (const unsigned char*)A.e0 + (sv << 5); e_e1 = (const unsigned char*)A.e1 + (sv << 2); }
+    if constexpr (EX == 4) e_o2 = (const unsigned char*)A.o2 + (sv << 2);
   };
   struct Epi { int soff; bool zv; };
   f32x4 ev[RYs], adv[RYs], x1[RYs], x2[RYs];
   f32x4 bacc = (f32x4){0.f, 0.f, 0.f, 0.f};                      // (EX_PREV) this lane's share of the producer's bias gradient
+  f32x4 bias4 = (f32x4){0.f, 0.f, 0.f, 0.f};                     // (EX_BLOCK) bias of channels 4 kg .. +3
+  if constexpr (EX == 4) { if (A.e0 != nullptr) bias4 = *(const f32x4*)((const float*)A.e0 + kg * 4); }
+  float etv[RYs];
   auto rsrc = [&](const void* p, bool zv, bool half) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (zv && p != nullptr) ? (half ? sample_bytes >> 1 : sample_bytes) : 0u, 0x00020000);
   };
@@ -239,9 +245,28 @@ __global__ void __launch_bounds__(256 * NG, 2) ring_multi_kernel(const RmArgs A)
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = has_add ? __builtin_fmaf(a[r][e], he, adv[r][e]) : a[r][e] * he;
       }
+      if constexpr (EX == 4) {
+        float ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float u = v[e] + bias4[e];
+          u = fmaxf(u, u * A.slope);
+          v[e] = u;
+          ss += u * u;
+        }
+        etv[r] = quarter_sum(ss) * (1.f / 16.f) + 1e-8f;
+      }
       ev[r] = v;
     } else {
       const f32x4 v = ev[r];
+      if constexpr (EX == 4) {
+        const float rinv = fast_rsqrt_s(etv[r]);
+        const float rn = etv[r] * rinv;
+        st16(e_y, E.zv, eoff[r], E.soff, v * rinv);
+        const __amdgpu_buffer_rsrc_t rsn = __builtin_amdgcn_make_buffer_rsrc((void*)e_o2, 0, E.zv ? (sample_bytes >> 4) : 0u, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, rn), rsn, (eoff[r] >> 4) | (kg == 0 ? 0 : OOB), E.soff >> 4, 0);
+        return;
+      }
       if constexpr (EX == 3) {
         if (ex_ab) {                                     // v = g_rh (bf16-exact); adv = rpre, x1 = h, x2 = gh1
           const f32x4 rr = sigmoid4_fast(adv[r]);
@@ -397,7 +422,7 @@ extern "C" int lf_conv3d_c16_ring_multi(const void* x, int x_bf16, const void* w
                                         int extra, const void* e0, const void* e1, void* o2,
                                         int N, int D, int H, int W, float he, int addend_per_sample, void* stream) {
   lf_clear_error();
-  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || ngroups < 1 || ngroups > 2 || extra < 0 || extra > 5 || extra == 4) return LF_EINVAL;
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || ngroups < 1 || ngroups > 2 || extra < 0 || extra > 5) return LF_EINVAL;
   if ((long)D * H * W * 64 >= 0x7fffffffL) return LF_EINVAL;
   if (x == nullptr || wpack == nullptr || y0 == nullptr || (ngroups == 2 && y1 == nullptr)) return LF_EINVAL;
   const unsigned known = LF_RING_ADD_BF16 | LF_RING_OUT_BF16 | LF_RING_ROUND;
@@ -428,11 +453,14 @@ extern "C" int lf_conv3d_c16_ring_multi(const void* x, int x_bf16, const void* w
     kern = fl == 15 ? ring_multi_kernel<1, true, 3, 15> : ring_multi_kernel<1, true, 3>;
   } else if (extra == LF_RING_EX_PREV && x_bf16 && fl == 6) {
     kern = ring_multi_kernel<1, true, 5, 6>;
+  } else if (extra == LF_RING_EX_BLOCK && fl == 6) {
+    kern = x_bf16 ? ring_multi_kernel<1, true, 4, 6> : ring_multi_kernel<1, false, 4, 6>;
   }
   if (kern == nullptr) return LF_EINVAL;
   const unsigned flags_last = ngroups == 2 ? flags1 : flags0;
   if (extra == LF_RING_EX_RH && (o2 == nullptr || !(flags_last & LF_RING_OUT_BF16))) return LF_EINVAL;
   if (extra == LF_RING_EX_BLEND && (e0 == nullptr || e1 == nullptr || o2 == nullptr || !(flags0 & LF_RING_OUT_BF16))) return LF_EINVAL;
+  if (extra == LF_RING_EX_BLOCK && (o2 == nullptr || ngroups != 1)) return LF_EINVAL;
   if (extra == LF_RING_EX_PREV && (e0 == nullptr || e1 == nullptr || o2 == nullptr || ngroups != 1)) return LF_EINVAL;
   if (extra == LF_RING_EX_ABWD && (e0 == nullptr || e1 == nullptr || o2 == nullptr || add0 == nullptr ||
                                    !(flags0 & LF_RING_ROUND) || !(flags0 & LF_RING_ADD_BF16))) return LF_EINVAL;

@@ -24,6 +24,7 @@ GRU_WGRAD_CHUNK = 16                                              # steps per mu
 # on the state batched over the views before / after the loop; 2: two outputs per staged halo (one 8-wave workgroup per CU --
 # measured slower: its waves run in lock-step, profiles/r06_gru_ring_ab.txt)
 GRU_RING_GROUPS = 1
+RING_BLOCK_FWD = bool(int(__import__('os').environ.get('LF_RING_BLOCK_FWD', '1')))      # forward Block steps on ring_multi (LF_RING_EX_BLOCK)
 CHAIN_EPILOGUE = bool(int(__import__('os').environ.get('LF_CHAIN_EPILOGUE', '1')))   # Block conv2's data gradient applies conv1's epilogue backward (LF_RING_EX_PREV)
 LIFT_MFMA = True                                                  # the 16-channel lift as one MFMA kernel each way (csrc/lift_mfma.hip)
 RING_DGRAD = True                                                 # data gradients of the 16 -> 16 layers on the same kernel family
@@ -252,7 +253,14 @@ class _Conv16AC(torch.autograd.Function):
         one = weight.shape[2] == 1
         w3 = (lambda t: pack_center_tap(t)) if one else (lambda t: t)
         pack = _pk(weight, 'a3f', lambda t: pack_conv3d_c16_ring_bf16(w3(t)))
-        y, norm = conv3d_c16_ring_bf16_io(x, pack, bias.detach() if bias is not None else None, he, flags, 1, out_bf16=True)
+        if RING_BLOCK_FWD and flags == (LF_EPI_LRELU | LF_EPI_PIXELNORM) and x.shape[2] * x.shape[3] * x.shape[4] * 64 < 2 ** 31:
+            # the same arithmetic on the one-group ring kernel with its epilogue at compile time (LF_RING_EX_BLOCK): bit-identical
+            y = empty_cl16(tuple(x.shape), x.device, True)
+            norm = torch.empty(x.shape[0] * x.shape[2] * x.shape[3] * x.shape[4], device=x.device, dtype=torch.float32)
+            ring_multi(x, pack.reshape(1, 14, 16, 32), he, [(y, None, True)], extra=_lib.LF_RING_EX_BLOCK,
+                       e0=bias.detach() if bias is not None else None, o2=norm)
+        else:
+            y, norm = conv3d_c16_ring_bf16_io(x, pack, bias.detach() if bias is not None else None, he, flags, 1, out_bf16=True)
         ctx.flags, ctx.he, ctx.one = flags, he, one
         need_w = weight.requires_grad or (bias is not None and bias.requires_grad)
         ctx.save_for_backward(y if flags else None, norm, weight, x if need_w else None)

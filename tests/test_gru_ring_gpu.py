@@ -219,3 +219,18 @@ def test_block_chain_equals_separate_epilogue_backward():
         assert torch.equal(a[2][k], c[2][k])
         cos = torch.nn.functional.cosine_similarity(a[2][k].reshape(1, -1).double(), b[2][k].reshape(1, -1).double()).item()
         assert cos > 0.99999, (k, cos)
+
+
+@pytest.mark.parametrize('N,D,H,W', SHAPES)
+@pytest.mark.parametrize('x_bf16', [True, False])
+def test_block_epilogue_form_is_bit_identical(N, D, H, W, x_bf16):
+    """LF_RING_EX_BLOCK == lf_conv3d_c16_ring_bf16_io with LeakyReLU + PixelNorm and round_out = 1 (activation and norms)."""
+    from latentfusion_amd import _lib, ops, ops_train
+    from latentfusion_amd._lib import LF_EPI_LRELU, LF_EPI_PIXELNORM
+    x, w, packs, he, g = _setup(N, D, H, W, seed=8, x_bf16=x_bf16)
+    bias = (torch.randn(16, generator=g) * 0.3).cuda()
+    y = ops.empty_cl16((N, 16, D, H, W), 'cuda', True)
+    nrm = torch.empty(N * D * H * W, device='cuda')
+    ops_train.ring_multi(x, packs[:1].contiguous(), he, [(y, None, True)], extra=_lib.LF_RING_EX_BLOCK, e0=bias, o2=nrm)
+    wy, wn = ops.conv3d_c16_ring_bf16_io(x, packs[0], bias, he, LF_EPI_LRELU | LF_EPI_PIXELNORM, 1, out_bf16=True)
+    assert torch.equal(y, wy) and torch.equal(nrm, wn)
