@@ -231,7 +231,8 @@ int lf_conv3d_c16_ring_bf16_io(const void* x, const void* wpack, const float* bi
  *     y_g = bf16(bf16(conv_g) * he)                      LF_RING_ROUND: what autocast's half-precision convolution returns
  * stored as fp32 or (LF_RING_OUT_BF16) bf16 records; addend_per_sample = 0: one addend volume for all N samples.
  * `extra` folds an element-wise stage of the recurrence into the epilogue of the convolution that owns the same voxels:
- *   LF_RING_EX_RH    (fp32 x = h, the LAST group = reset gate stored as bf16): o2 = bf16(h * sigmoid(y_last as stored))
+ *   LF_RING_EX_RH    (x = h: fp32, or its bf16 copy with e0 = the fp32 h; the LAST group = reset gate stored as bf16):
+ *                    o2 = bf16(h * sigmoid(y_last as stored))
  *   LF_RING_EX_BLEND (ngroups 1, y_0 = candidate stored as bf16; e0 = h fp32, e1 = update pre-activation bf16):
  *                    o2 (fp32) = h (1 - u) + y_0 u,  u = sigmoid(e1)
  *   LF_RING_EX_ABWD  (group 0 = LF_RING_ROUND | LF_RING_ADD_BF16 with add_0 = reset pre-activation, NOT added;
@@ -261,6 +262,11 @@ int lf_conv3d_c16_ring_multi(const void* x, int x_bf16, const void* wpack, int n
                              void* y0, const void* add0, unsigned flags0, void* y1, const void* add1, unsigned flags1,
                              int extra, const void* e0, const void* e1, void* o2,
                              int N, int D, int H, int W, float he, int addend_per_sample, void* stream);
+/* The LF_RING_EX_BLEND launch spelled out, with an optional second output: cand (bf16, may alias `addend`) = conv(rh) * he +
+ * addend (bf16); h_new (fp32) = h (1 - u) + cand u, u = sigmoid(upre as stored, bf16); h_new_bf16 (or NULL) = the same state
+ * rounded to bf16 -- what the next step's gate convolutions and the weight gradients stage, at half the bytes. */
+int lf_conv3d_c16_ring_blend(const void* rh, const void* wpack, void* cand, const void* addend, const float* h, const void* upre,
+                             float* h_new, void* h_new_bf16, int N, int D, int H, int W, float he, void* stream);
 
 /* Winograd F(2x2x2,3x3x3) for wide (>= 64-channel) 3-D convolutions, stage 1: the input transform.  x channels-last;
  * V [64][T][Cin], T = lf_wino3d_tiles(N, D, H, W), frequency f = (a*4 + b)*4 + c (z, y, x).  Cin a multiple of 4.

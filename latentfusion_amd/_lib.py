@@ -58,6 +58,7 @@ SIGNATURES = {
     'lf_conv3d_c16_ring_bf16': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint, c_float, c_float, P, c_int, P]),
     'lf_conv3d_c16_ring_bf16_io': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint, c_float, c_float, P, c_int, c_int, P]),
     'lf_conv3d_c16_ring_multi': (c_int, [P, c_int, P, c_int, P, P, c_uint, P, P, c_uint, c_int, P, P, P, c_int, c_int, c_int, c_int, c_float, c_int, P]),
+    'lf_conv3d_c16_ring_blend': (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     'lf_wino3d_tiles': (c_long, [c_int, c_int, c_int, c_int]),
     'lf_wino3d_input_transform': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'lf_wino_fused_cout_padded': (c_int, [c_int]),

@@ -41,7 +41,7 @@ struct RmGroup { void* y; const void* add; unsigned flags; };
 struct RmArgs {
   const void* x; const void* wpack;
   RmGroup g[2];
-  const void* e0; const void* e1; void* o2;
+  const void* e0; const void* e1; void* o2; void* o3;
   int N, D, H, W, tiles_x, tiles_y, tiles_z, ntiles;
   float he;
   int add_per_sample;
@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(256 * NG, 2) ring_multi_kernel(const RmArgs A)
   int eoff[RYs];
 #pragma unroll
   for (int r = 0; r < RYs; ++r) eoff[r] = OOB;
-  const unsigned char *e_y = nullptr, *e_add = nullptr, *e_x = nullptr, *e_e0 = nullptr, *e_e1 = nullptr, *e_o2 = nullptr;
+  const unsigned char *e_y = nullptr, *e_add = nullptr, *e_x = nullptr, *e_e0 = nullptr, *e_e1 = nullptr, *e_o2 = nullptr, *e_o3 = nullptr;
   auto epi_column = [&](int bx, int by, int bn) {
     const int gx = bx * TXs + n, gy0 = by * TYs + RYs * ry;
 #pragma unroll
@@ -191,8 +191,9 @@ __global__ void __launch_bounds__(256 * NG, 2) ring_multi_kernel(const RmArgs A)
     const long sv = (long)bn * nvox;
     e_y = (const unsigned char*)G.y + (sv << (out16 ? 5 : 6));
     e_add = has_add ? (const unsigned char*)G.add + ((A.add_per_sample ? sv : 0L) << (add16 ? 5 : 6)) : nullptr;
-    if constexpr (EX == 1) { e_x = (const unsigned char*)A.x + (sv << 6); e_o2 = (const unsigned char*)A.o2 + (sv << 5); }
-    if constexpr (EX == 2) { e_e0 = (const unsigned char*)A.e0 + (sv << 6); e_e1 = (const unsigned char*)A.e1 + (sv << 5); e_o2 = (const unsigned char*)A.o2 + (sv << 6); }
+    if constexpr (EX == 1) { e_x = (const unsigned char*)(A.e0 != nullptr ? A.e0 : A.x) + (sv << 6); e_o2 = (const unsigned char*)A.o2 + (sv << 5); }
+    if constexpr (EX == 2) { e_e0 = (const unsigned char*)A.e0 + (sv << 6); e_e1 = (const unsigned char*)A.e1 + (sv << 5); e_o2 = (const unsigned char*)A.o2 + (sv << 6);
+                             e_o3 = A.o3 != nullptr ? (const unsigned char*)A.o3 + (sv << 5) : nullptr; }
     if constexpr (EX == 3) { e_e0 = (const unsigned char*)A.e0 + (sv << 6); e_e1 = (const unsigned char*)A.e1 + (sv << 6); e_o2 = (const unsigned char*)A.o2 + (sv << 6); }
     if constexpr (EX == 5) { e_e0 = (const unsigned char*)A.e0 + (sv << 5); e_e1 = (const unsigned char*)A.e1 + (sv << 2); }
     if constexpr (EX == 4) e_o2 = (const unsigned char*)A.o2 + (sv << 2);
@@ -304,6 +305,7 @@ __global__ void __launch_bounds__(256 * NG, 2) ring_multi_kernel(const RmArgs A)
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = __fadd_rn(__fmul_rn(x1[r][e], __fsub_rn(1.f, uu[e])), __fmul_rn(c[e], uu[e]));
         st32(e_o2, E.zv, eoff[r], E.soff, o);
+        if (e_o3 != nullptr) st16(e_o3, E.zv, eoff[r], E.soff, o);     // (a bf16 copy of the new state: what the next step's convolutions stage)
       }
     }
   };
@@ -417,10 +419,29 @@ __global__ void __launch_bounds__(64) bias_partials_sum_kernel(float* __restrict
 
 }  // namespace
 
+static int ring_multi_launch(const void* x, int x_bf16, const void* wpack, int ngroups,
+                             void* y0, const void* add0, unsigned flags0, void* y1, const void* add1, unsigned flags1,
+                             int extra, const void* e0, const void* e1, void* o2, void* o3,
+                             int N, int D, int H, int W, float he, int addend_per_sample, void* stream);
+
 extern "C" int lf_conv3d_c16_ring_multi(const void* x, int x_bf16, const void* wpack, int ngroups,
                                         void* y0, const void* add0, unsigned flags0, void* y1, const void* add1, unsigned flags1,
                                         int extra, const void* e0, const void* e1, void* o2,
                                         int N, int D, int H, int W, float he, int addend_per_sample, void* stream) {
+  return ring_multi_launch(x, x_bf16, wpack, ngroups, y0, add0, flags0, y1, add1, flags1, extra, e0, e1, o2, nullptr, N, D, H, W, he,
+                           addend_per_sample, stream);
+}
+
+extern "C" int lf_conv3d_c16_ring_blend(const void* rh, const void* wpack, void* cand, const void* addend, const float* h, const void* upre,
+                                        float* h_new, void* h_new_bf16, int N, int D, int H, int W, float he, void* stream) {
+  return ring_multi_launch(rh, 1, wpack, 1, cand, addend, LF_RING_ADD_BF16 | LF_RING_OUT_BF16, nullptr, nullptr, 0, LF_RING_EX_BLEND, h, upre,
+                           h_new, h_new_bf16, N, D, H, W, he, 1, stream);
+}
+
+static int ring_multi_launch(const void* x, int x_bf16, const void* wpack, int ngroups,
+                             void* y0, const void* add0, unsigned flags0, void* y1, const void* add1, unsigned flags1,
+                             int extra, const void* e0, const void* e1, void* o2, void* o3,
+                             int N, int D, int H, int W, float he, int addend_per_sample, void* stream) {
   lf_clear_error();
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || ngroups < 1 || ngroups > 2 || extra < 0 || extra > 5) return LF_EINVAL;
   if ((long)D * H * W * 64 >= 0x7fffffffL) return LF_EINVAL;
@@ -447,6 +468,8 @@ extern "C" int lf_conv3d_c16_ring_multi(const void* x, int x_bf16, const void* w
     kern = fl == 11 ? ring_multi_kernel<1, false, 0, 11> : ring_multi_kernel<1, false, 0>;
   } else if (extra == LF_RING_EX_RH && !x_bf16) {
     kern = fl == 11 ? ring_multi_kernel<1, false, 1, 11> : ring_multi_kernel<1, false, 1>;
+  } else if (extra == LF_RING_EX_RH && x_bf16 && fl == 11 && e0 != nullptr) {
+    kern = ring_multi_kernel<1, true, 1, 11>;                      // (x = the bf16 copy of h; e0 = h itself for r h)
   } else if (extra == LF_RING_EX_BLEND && x_bf16) {
     kern = fl == 11 ? ring_multi_kernel<1, true, 2, 11> : ring_multi_kernel<1, true, 2>;
   } else if (extra == LF_RING_EX_ABWD && x_bf16) {
@@ -464,14 +487,14 @@ extern "C" int lf_conv3d_c16_ring_multi(const void* x, int x_bf16, const void* w
   if (extra == LF_RING_EX_PREV && (e0 == nullptr || e1 == nullptr || o2 == nullptr || ngroups != 1)) return LF_EINVAL;
   if (extra == LF_RING_EX_ABWD && (e0 == nullptr || e1 == nullptr || o2 == nullptr || add0 == nullptr ||
                                    !(flags0 & LF_RING_ROUND) || !(flags0 & LF_RING_ADD_BF16))) return LF_EINVAL;
-  const void* ps[] = {x, wpack, y0, add0, y1, add1, e0, e1, o2};
+  const void* ps[] = {x, wpack, y0, add0, y1, add1, e0, e1, o2, o3};
   for (const void* p : ps)
     if (p != nullptr && !lf_aligned16(p)) return LF_EALIGN;
   RmArgs A;
   A.x = x; A.wpack = wpack;
   A.g[0] = RmGroup{y0, add0, flags0};
   A.g[1] = RmGroup{y1, add1, flags1};
-  A.e0 = e0; A.e1 = e1; A.o2 = o2;
+  A.e0 = e0; A.e1 = e1; A.o2 = o2; A.o3 = o3;
   A.N = N; A.D = D; A.H = H; A.W = W;
   A.tiles_x = (W + TXs - 1) / TXs; A.tiles_y = (H + TYs - 1) / TYs; A.tiles_z = (D + TZs - 1) / TZs;
   const long pt = (long)A.tiles_x * A.tiles_y * A.tiles_z * N;

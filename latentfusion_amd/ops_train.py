@@ -24,6 +24,7 @@ GRU_WGRAD_CHUNK = 16                                              # steps per mu
 # on the state batched over the views before / after the loop; 2: two outputs per staged halo (one 8-wave workgroup per CU --
 # measured slower: its waves run in lock-step, profiles/r06_gru_ring_ab.txt)
 GRU_RING_GROUPS = 1
+GRU_STATE_BF16 = bool(int(__import__('os').environ.get('LF_GRU_STATE_BF16', '0')))      # a bf16 copy of the recurrent state for the staged operands: measured -0.2 ms for +1.9 GB, off
 RING_BLOCK_FWD = bool(int(__import__('os').environ.get('LF_RING_BLOCK_FWD', '1')))      # forward Block steps on ring_multi (LF_RING_EX_BLOCK)
 CHAIN_EPILOGUE = bool(int(__import__('os').environ.get('LF_CHAIN_EPILOGUE', '1')))   # Block conv2's data gradient applies conv1's epilogue backward (LF_RING_EX_PREV)
 LIFT_MFMA = True                                                  # the 16-channel lift as one MFMA kernel each way (csrc/lift_mfma.hip)
@@ -596,6 +597,12 @@ class _GruFuse(torch.autograd.Function):
             UP, RP, CA, RH = blk(), blk(), blk(), blk()
             HS = empty_cl((V - 1, 16, D, H, W), zz.device)                       # h_0 .. h_{V-2} (fp32 state)
             HS[0:1].copy_(z_in[0:1])                              # (h_0 = view 0, un-rounded when the stack is fp32)
+            # a bf16 copy of every state (round 6): what the gate convolutions and the weight gradients STAGE -- they round h to
+            # bf16 while staging anyway, so reading the rounded copy is the same arithmetic at half the bytes; the fp32 state
+            # stays what the element-wise stages (r h, the blend and their backward) use
+            H16 = blk() if GRU_STATE_BF16 else None
+            if H16 is not None:
+                H16[0:1].copy_(z_in[0:1])
             if GRU_RING_GROUPS == 2:
                 ring_multi(zz[1:], wz[0], he, [(UP, base[0], False), (RP, base[1], False)], addend_per_sample=False)
             else:
@@ -604,17 +611,22 @@ class _GruFuse(torch.autograd.Function):
             ring_multi(zz[1:], wz[1], he, [(CA, base[2], False)], addend_per_sample=False)
             out = empty_cl(HS[0:1].shape, zz.device)
             whu, whr = pk[0][2][0].reshape(1, 14, 16, 32), pk[1][2][0].reshape(1, 14, 16, 32)
+            L = _lib.lib()
             for i in range(1, V):
                 h, j = HS[i - 1:i], slice(i - 1, i)
+                hx = H16[j] if H16 is not None else h            # the staged operand
                 if GRU_RING_GROUPS == 2:
                     ring_multi(h, wh[0], he, [(UP[j], UP[j], False), (RP[j], RP[j], False)], extra=_lib.LF_RING_EX_RH, o2=RH[j])
                 else:                                             # (two one-output launches: two workgroups per CU overlap their phases)
-                    ring_multi(h, whu, he, [(UP[j], UP[j], False)])
-                    ring_multi(h, whr, he, [(RP[j], RP[j], False)], extra=_lib.LF_RING_EX_RH, o2=RH[j])
-                ring_multi(RH[j], wh[1], he, [(CA[j], CA[j], False)], extra=_lib.LF_RING_EX_BLEND, e0=h, e1=UP[j],
-                           o2=HS[i:i + 1] if i < V - 1 else out)
+                    ring_multi(hx, whu, he, [(UP[j], UP[j], False)])
+                    ring_multi(hx, whr, he, [(RP[j], RP[j], False)], extra=_lib.LF_RING_EX_RH, e0=h if H16 is not None else None, o2=RH[j])
+                hn = HS[i:i + 1] if i < V - 1 else out
+                with _timed('conv3d_c16_ring_multi', '1:2:1'):
+                    check(L.lf_conv3d_c16_ring_blend(_ptr(RH[j]), _ptr(wh[1]), _ptr(CA[j]), _ptr(CA[j]), _ptr(h), _ptr(UP[j]), _ptr(hn),
+                                                     _ptr(H16[i:i + 1]) if (H16 is not None and i < V - 1) else None, 1, D, H, W, he, _stream()),
+                          'lf_conv3d_c16_ring_blend')
             ctx.ac, ctx.T16, ctx.he, ctx.pk = ac, T16, he, pk
-            ctx.blocks = [UP, RP, CA, RH, HS]
+            ctx.blocks = [UP, RP, CA, RH, HS, H16]
             ctx.zshape = tuple(z.shape)
             ctx.save_for_backward(zz, c16, wu, wr, wo)
             ctx.has_bias = tuple(b is not None for _, b in gates)
@@ -780,7 +792,8 @@ def _gru_backward_ring(ctx, g, zz, c16, ws, need_z, need_w):
     if ctx.blocks is None:
         raise RuntimeError('the fused GRU recurrence overwrites its activations during backward: a second backward through '
                            'the same graph is not supported')
-    UP, RP, CA, RH, HS = ctx.blocks
+    UP, RP, CA, RH, HS, H16 = ctx.blocks
+    HX = H16 if H16 is not None else HS                          # the state as the weight gradients stage it
     ctx.blocks = None
     V = zz.shape[0]
     he, pk = ctx.he, ctx.pk
@@ -809,14 +822,14 @@ def _gru_backward_ring(ctx, g, zz, c16, ws, need_z, need_w):
     scratch = torch.empty(nbytes // 4 + 1, device=dev, dtype=torch.float32) if need_w else None     # (one: the launches are in order)
     if side is not None:
         side.wait_stream(main)                                    # (the allocations above)
-        for t in [gwb, zz, UP, RP, CA, RH, HS, scratch] + acc:
+        for t in [gwb, zz, UP, RP, CA, RH, HS, HX, scratch] + acc:
             t.record_stream(side)
 
     def weight_grads(ci, lo, hi):
         """The six weight gradients of steps lo .. hi-1 (their gate gradients are final) + this chunk's share of the sums."""
         nv = hi - lo
         j = slice(lo - 1, hi - 1)
-        for k, (gp, xh) in enumerate(((UP, HS), (RP, HS), (CA, RH))):
+        for k, (gp, xh) in enumerate(((UP, HX), (RP, HX), (CA, RH))):
             for q, x in enumerate((zz[lo:hi], xh[j])):
                 io = (1 if x.dtype == torch.bfloat16 else 0) | 2
                 check(L.lf_conv_bwd_weight_bf16_io(_ptr(x), _ptr(gp[j]), _ptr(gwb[ci, k, q]), _ptr(scratch, True), scratch.numel() * 4, 3, nv, D, H, W,

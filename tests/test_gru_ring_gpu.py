@@ -234,3 +234,32 @@ def test_block_epilogue_form_is_bit_identical(N, D, H, W, x_bf16):
     ops_train.ring_multi(x, packs[:1].contiguous(), he, [(y, None, True)], extra=_lib.LF_RING_EX_BLOCK, e0=bias, o2=nrm)
     wy, wn = ops.conv3d_c16_ring_bf16_io(x, packs[0], bias, he, LF_EPI_LRELU | LF_EPI_PIXELNORM, 1, out_bf16=True)
     assert torch.equal(y, wy) and torch.equal(nrm, wn)
+
+
+@pytest.mark.parametrize('N,D,H,W', SHAPES)
+def test_bf16_state_copy_forms(N, D, H, W):
+    """lf_conv3d_c16_ring_blend writes the new state also rounded to bf16; the gate convolutions staged from that copy (reset gate:
+    r h still from the fp32 state, e0) give bit for bit what they give staged from the fp32 state."""
+    from latentfusion_amd import _lib, ops, ops_train
+    rh, w, packs, he, g = _setup(N, D, H, W, seed=11)
+    oz, upre = _vol(g, N, D, H, W, torch.bfloat16), _vol(g, N, D, H, W, torch.bfloat16, 2.0)
+    h = _vol(g, N, D, H, W, torch.float32)
+    cand, cand2, h16 = oz.clone(), oz.clone(), ops.empty_cl16((N, 16, D, H, W), 'cuda', True)
+    hn, hn2 = ops.empty_cl16((N, 16, D, H, W), 'cuda', False), ops.empty_cl16((N, 16, D, H, W), 'cuda', False)
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    p0 = packs[:1].contiguous()
+    _lib.check(L.lf_conv3d_c16_ring_blend(rh.data_ptr(), p0.data_ptr(), cand.data_ptr(), cand.data_ptr(), h.data_ptr(), upre.data_ptr(),
+                                          hn.data_ptr(), h16.data_ptr(), N, D, H, W, he, st), 'blend')
+    ops_train.ring_multi(rh, p0, he, [(cand2, cand2, False)], extra=_lib.LF_RING_EX_BLEND, e0=h, e1=upre, o2=hn2)
+    assert torch.equal(cand, cand2) and torch.equal(hn, hn2) and torch.equal(h16, hn.to(torch.bfloat16))
+    # the next step's gates staged from the bf16 copy
+    uz, rz = _vol(g, N, D, H, W, torch.bfloat16), _vol(g, N, D, H, W, torch.bfloat16)
+    e = lambda: ops.empty_cl16((N, 16, D, H, W), 'cuda', True)     # noqa: E731
+    ua, ub, ra, rb, rha, rhb = e(), e(), e(), e(), e(), e()
+    p1 = packs[1:].contiguous()
+    ops_train.ring_multi(hn, p0, he, [(ua, uz, False)])
+    ops_train.ring_multi(h16, p0, he, [(ub, uz, False)])
+    ops_train.ring_multi(hn, p1, he, [(ra, rz, False)], extra=_lib.LF_RING_EX_RH, o2=rha)
+    ops_train.ring_multi(h16, p1, he, [(rb, rz, False)], extra=_lib.LF_RING_EX_RH, e0=hn, o2=rhb)
+    assert torch.equal(ua, ub) and torch.equal(ra, rb) and torch.equal(rha, rhb)
