@@ -380,7 +380,7 @@ def cfg5_report(a, dev):
     32 input views encoded and fused, 8 output views rendered, hard smooth-L1 depth + BCE mask losses, backward through every
     kernel (data, weight and bias gradients, deterministic volume splat), flat Adam -- under the bf16 autocast policy
     (ops.autocast; `--use-amp` of the reference).  One GPU: the data-parallel half (bucketed RCCL gradient all-reduce) needs
-    more devices.  Reported: wall time per step (MEDIAN of `--cfg5-steps` steps after one warm-up; every step time is listed), peak device memory, the
+    more devices.  Reported: wall time per step (MEDIAN of `--cfg5-steps` steps after three warm-up steps; every step time is listed), peak device memory, the
     launch time and HBM fraction of the dominant training kernel from HIP events in one extra step, and whether two fresh
     runs of the same steps agree bit for bit."""
     from latentfusion_amd import ops, synth
@@ -406,15 +406,19 @@ def cfg5_report(a, dev):
             times.append(time.perf_counter() - t0)
             losses.append(float(l_['total']))
         return times, losses
+    import gc
+    gc.collect()
     torch.cuda.empty_cache()
     torch.cuda.reset_peak_memory_stats()
+    resident_before = torch.cuda.memory_allocated() / 2 ** 30      # what earlier blocks of this process still hold (headline volume, ...)
     step, batch = fresh()
     K = max(1, a.cfg5_steps)
-    times, losses = run(step, batch, 1 + K)
+    WU = 3                                                        # warm-up steps: the caching allocator re-grows its 30 GB pool over the first steps
+    times, losses = run(step, batch, WU + K)                      # (one full bench run of round 6 showed 117 / 112 / 103 / 87 / 86 ms after a single warm-up step)
     peak = torch.cuda.max_memory_allocated() / 2 ** 30
     params_after = step.flat.data.clone()
     # HIP events around the bf16 ring convolution (forward / data-gradient / ConvGRU addend forms) in one extra, untimed step
-    ops.KERNEL_TIMER_TAGS = {'conv3d_c16_ring_bf16'}
+    ops.KERNEL_TIMER_TAGS = {'conv3d_c16_ring_bf16', 'conv3d_c16_ring_multi'}
     ops.KERNEL_TIMER = []
     step.run_iteration(batch)
     torch.cuda.synchronize()
@@ -429,18 +433,19 @@ def cfg5_report(a, dev):
     n_par = sum(q.numel() for q in step.flat.params)
     del step, batch
     torch.cuda.empty_cache()
-    # the same 1 + K steps from a fresh model: identical losses and identical parameters, bit for bit
+    # the same WU + K steps from a fresh model: identical losses and identical parameters, bit for bit
     step2, batch2 = fresh()
-    _, losses2 = run(step2, batch2, 1 + K)
+    _, losses2 = run(step2, batch2, WU + K)
     identical = losses == losses2 and bool(torch.equal(params_after, step2.flat.data))
     del step2, batch2, params_after
     torch.cuda.empty_cache()
-    ms = sorted(times[1:])[(K - 1) // 2] * 1e3                     # median step (a single step can catch an allocator / clock hiccup)
+    ms = sorted(times[WU:])[(K - 1) // 2] * 1e3                    # median step (a single step can catch an allocator / clock hiccup)
     out = {'workload': f'one generator training step (reference tools/train/train_reconstruct.py:421-535) on SYN({S},{C}), GRU fuser: '
                        f'{Vi} input views + {Vo} output views, bf16 autocast policy, flat Adam; 1 GPU (no data-parallel all-reduce)',
-           'ms_per_step': ms, 'steps_per_s': 1e3 / ms, 'steps_timed': K, 'step_ms': [t * 1e3 for t in times[1:]],
-           'mean_step_ms': sum(times[1:]) / K * 1e3,
-           'first_step_ms': times[0] * 1e3, 'peak_mem_GB': peak, 'params': n_par, 'loss': losses,
+           'ms_per_step': ms, 'steps_per_s': 1e3 / ms, 'steps_timed': K, 'warmup_steps': WU, 'step_ms': [t * 1e3 for t in times[WU:]],
+           'warmup_step_ms': [t * 1e3 for t in times[:WU]], 'mean_step_ms': sum(times[WU:]) / K * 1e3,
+           'first_step_ms': times[0] * 1e3, 'peak_mem_GB': peak, 'resident_before_GB': resident_before,
+           'peak_mem_step_GB': peak - resident_before, 'params': n_par, 'loss': losses,
            'run_to_run_identical': bool(identical), 'dtype': 'bf16 MFMA operands (autocast policy), fp32 accumulation / master weights / Adam'}
     step_bytes = float(sum(v[1] for v in byte_log.values()))
     top = sorted(byte_log.items(), key=lambda kv: -kv[1][1])[:12]
@@ -455,15 +460,27 @@ def cfg5_report(a, dev):
     # launches it ~370 times per step); algorithmic bytes = input + output (+ the addend of the gates' sum form), fp32
     vol = C * S ** 3 * 4
     forms = {}
+    # (with the timer on the weight gradients stay on the main stream: launch times without a neighbour on the side stream)
+    EXTRA = {0: 'plain', 1: 'reset gate + r h', 2: 'candidate + blend', 3: 'reset-gate backward', 4: 'Block step (bias, LeakyReLU, PixelNorm)',
+             5: 'data gradient + producer epilogue backward'}
+    EXTRA_BYTES = {0: 0, 1: 64 + 32, 2: 64 + 32 + 64, 3: 64 + 64 + 64, 4: 4, 5: 32 + 4}     # per voxel, beyond x / y / addend
     for n_, e0, e1 in timer:
-        form, nb, io = n_.detail.split(':')
-        forms.setdefault((form, int(nb), int(io[2:])), []).append(e0.elapsed_time(e1))
+        if n_ == 'conv3d_c16_ring_multi':
+            ng, ex, nb, fl, xb = (int(v) for v in n_.detail.split(':'))
+            if ng != 1:
+                continue
+            per_vox = 16 * xb + 16 * (2 if fl & 2 else 4) + (16 * (2 if fl & 1 else 4) if fl & 8 else 0) + EXTRA_BYTES[ex]
+            forms.setdefault((f'ring_multi<1,{"bf16" if xb == 2 else "fp32"} x,{ex},{fl}> {EXTRA[ex]}', nb, per_vox), []).append(e0.elapsed_time(e1))
+        else:
+            form, nb, io = n_.detail.split(':')
+            io = int(io[2:])
+            per_vox = 64 * ((0.5 if io & 1 else 1.0) + (0.5 if io & 2 else 1.0) + ((0.5 if io & 4 else 1.0) if form == 'add' else 0.0))
+            forms.setdefault((f'conv3d_c16_f16x3<{"true" if form == "add" else "false"},1,{io}> {form}', int(nb), per_vox), []).append(e0.elapsed_time(e1))
     table = {}
-    for (form, nb, io), d in sorted(forms.items()):
-        # input + output (+ addend) records: 64 B per voxel in fp32 storage, 32 B in bf16 storage (io bits 0 / 1 / 2)
-        alg = nb * vol * ((0.5 if io & 1 else 1.0) + (0.5 if io & 2 else 1.0) + ((0.5 if io & 4 else 1.0) if form == 'add' else 0.0))
+    for (form, nb, per_vox), d in sorted(forms.items()):
+        alg = nb * (S ** 3) * per_vox                               # input + output (+ addend / epilogue operands) records, each once
         m_ = sum(d) / len(d)
-        table[f'{form}:io={io}:N={nb}'] = {'launches': len(d), 'avg_launch_ms': m_, 'total_ms': sum(d), 'algorithmic_bytes_per_launch': alg,
+        table[f'{form}:N={nb}'] = {'launches': len(d), 'avg_launch_ms': m_, 'total_ms': sum(d), 'algorithmic_bytes_per_launch': alg,
                                    'hbm_frac': alg / (m_ * 1e-3) / 1e9 / HBM_PEAK_GBS}
     out['ring_conv_launches'] = table
     dom = max(table.items(), key=lambda kv: kv[1]['total_ms']) if table else None
@@ -472,22 +489,21 @@ def cfg5_report(a, dev):
         tr, trs = None, None
         import glob
         import hashlib
+        pmc_key = ('ring_multi_block' if ',4,6>' in key else 'ring_multi_rounded' if ',0,6>' in key else 'ring_multi_addend_inplace' if ',0,11>' in key
+                   else 'conv3d_c16_ring_bf16' if 'false,1,3>' in key else 'conv3d_c16_ring_bf16_addend' if 'true,1,7>' in key else None)
         for tpath in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_train_hbm_bytes.json')), reverse=True):
             try:
                 tj = json.load(open(tpath))
                 fresh_ = all(hashlib.sha256(open(os.path.join(ROOT, 'latentfusion_amd', 'csrc', f), 'rb').read()).hexdigest() == h
                              for f, h in tj['source_sha256'].items())
-                kk = 'conv3d_c16_ring_bf16_addend' if key.startswith('add') else 'conv3d_c16_ring_bf16'
-                # (the PMC probe measures the bf16-storage forms: plain io = 3, addend io = 7)
-                if fresh_ and kk in tj['kernels'] and (':io=7:' in key if key.startswith('add') else ':io=3:' in key):
+                if fresh_ and pmc_key in tj['kernels']:
                     # the PMC probe launches the kernel on 8 volumes: per-volume bytes x the volumes of this launch
-                    tr = tj['kernels'][kk]['bytes_per_launch'] / 8.0 * int(key.split('N=')[1])
+                    tr = tj['kernels'][pmc_key]['bytes_per_launch'] / 8.0 * int(key.split('N=')[1])
                     trs = os.path.basename(tpath)
                     break
             except Exception:                                       # noqa: BLE001
                 continue
-        out['roofline'] = {'bound': 'hbm', 'kernel': f'conv3d_c16_f16x3_kernel<{"true" if key.startswith("add") else "false"}, 1> '
-                                                     f'(bf16 ring convolution 16 -> 16, form {key})',
+        out['roofline'] = {'bound': 'hbm', 'kernel': f'bf16 ring convolution 16 -> 16, dominant form of the step: {key}',
                            'achieved': t_['algorithmic_bytes_per_launch'] / (t_['avg_launch_ms'] * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS,
                            'unit': 'GB/s', 'frac': t_['hbm_frac'], 'traffic': tr, 'traffic_source': trs,
                            'avg_launch_ms': t_['avg_launch_ms'], 'launches_timed': t_['launches'],
@@ -1055,7 +1071,7 @@ def main():
         'cpu_baseline_iters_per_s': dig(out, 'cpu_baseline', 'value'),
         'cfg3_iters_per_s': dig(cfg3, 'value'), 'cfg3_roofline_frac': dig(cfg3, 'roofline', 'frac'),
         'cfg3_scored_on_fused_engine': dig(cfg3, 'scored_on_fused_engine'),
-        'cfg5_ms_per_step': dig(cfg5, 'ms_per_step'), 'cfg5_peak_mem_GB': dig(cfg5, 'peak_mem_GB'),
+        'cfg5_ms_per_step': dig(cfg5, 'ms_per_step'), 'cfg5_peak_mem_GB': dig(cfg5, 'peak_mem_GB'), 'cfg5_peak_mem_step_GB': dig(cfg5, 'peak_mem_step_GB'),
         'cfg5_roofline_step_frac': dig(cfg5, 'roofline_step', 'frac'), 'cfg5_step_GB': (dig(cfg5, 'roofline_step', 'algorithmic_bytes_per_step') or 0) / 1e9 or None,
         'cfg5_run_to_run_identical': dig(cfg5, 'run_to_run_identical'),
         'renderer_variants_iters_per_s': {k: dig(variants, k, 'iters_per_s') for k in ('sum', 'occlusion')} if variants else None,

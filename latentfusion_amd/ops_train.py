@@ -447,7 +447,8 @@ def ring_multi(x, wpacks, he, outs, extra=0, e0=None, e1=None, o2=None, addend_p
         args += [_ptr(y), _ptr(add) if add is not None else None, fl]
     if ng == 1:
         args += [None, None, 0]
-    with _timed('conv3d_c16_ring_multi', f'{ng}:{extra}:{N}'):
+    fl0 = args[2] | (8 if outs[0][1] is not None else 0)           # group 0's epilogue form, as the kernel template sees it
+    with _timed('conv3d_c16_ring_multi', f'{ng}:{extra}:{N}:{fl0}:{x.element_size()}'):
         check(L.lf_conv3d_c16_ring_multi(_ptr(x), int(x.dtype == torch.bfloat16), _ptr(wpacks), ng, *args, extra,
                                          _ptr(e0) if e0 is not None else None, _ptr(e1) if e1 is not None else None,
                                          _ptr(o2) if o2 is not None else None, N, D, H, W, he, int(bool(addend_per_sample)), _stream()),
@@ -621,7 +622,7 @@ class _GruFuse(torch.autograd.Function):
                     ring_multi(hx, whu, he, [(UP[j], UP[j], False)])
                     ring_multi(hx, whr, he, [(RP[j], RP[j], False)], extra=_lib.LF_RING_EX_RH, e0=h if H16 is not None else None, o2=RH[j])
                 hn = HS[i:i + 1] if i < V - 1 else out
-                with _timed('conv3d_c16_ring_multi', '1:2:1'):
+                with _timed('conv3d_c16_ring_multi', '1:2:1:11:2'):
                     check(L.lf_conv3d_c16_ring_blend(_ptr(RH[j]), _ptr(wh[1]), _ptr(CA[j]), _ptr(CA[j]), _ptr(h), _ptr(UP[j]), _ptr(hn),
                                                      _ptr(H16[i:i + 1]) if (H16 is not None and i < V - 1) else None, 1, D, H, W, he, _stream()),
                           'lf_conv3d_c16_ring_blend')

@@ -54,6 +54,7 @@ TRAIN_KERNELS = collections.OrderedDict([
     # round 6: one-group ring kernels with compile-time epilogues (bf16 in / out; in-place bf16 addend), the fused lift
     # (forward: x rows + the bf16 volume; backward: two bf16 volumes in, gx rows out) and the fused 3-D -> 2-D projection
     ('ring_multi_rounded', (('ring_multi_kernel<1, true, 0, 6>', 'ring_multi_kernelILi1ELb1ELi0ELi6E'), V)),
+    ('ring_multi_block', (('ring_multi_kernel<1, true, 4, 6>', 'ring_multi_kernelILi1ELb1ELi4ELi6E'), V + V // 16)),
     ('ring_multi_addend_inplace', (('ring_multi_kernel<1, true, 0, 11>', 'ring_multi_kernelILi1ELb1ELi0ELi11E'), 3 * V // 2)),
     ('lift_fwd_mfma_kernel', ('lift_fwd_mfma_kernel', V // 2 + 8 * 128 ** 2 * 17 * 4)),
     ('lift_bwd_mfma_kernel', ('lift_bwd_mfma_kernel', V + 8 * 128 ** 2 * 33 * 4)),

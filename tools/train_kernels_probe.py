@@ -75,6 +75,10 @@ torch.cuda.synchronize()
 for _ in range(REP):
     ops_train.ring_multi(x, p1, he, [(o16, o16, False)])                                                         # <1,true,0,11>
 torch.cuda.synchronize()
+nrm2 = torch.empty(N * S ** 3, device='cuda')
+for _ in range(REP):
+    ops_train.ring_multi(x, p1, he, [(o16, None, True)], extra=_lib.LF_RING_EX_BLOCK, e0=b, o2=nrm2)            # <1,true,4,6>
+torch.cuda.synchronize()
 xin = torch.randn(N * S * S, 16, generator=g).cuda()
 wl = torch.randn(16 * S, 16, generator=g).cuda()
 wtab = wl.reshape(16, S, 16).permute(1, 0, 2).contiguous().to(torch.bfloat16)
