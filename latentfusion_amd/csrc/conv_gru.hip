@@ -48,17 +48,10 @@ struct RmArgs {
   float slope;
 };
 
-#ifndef RM_SIG
-#define RM_SIG 1
-#endif
 __device__ __forceinline__ float sigmoid_fast(float v) {
-#if RM_SIG == 0
-  return __builtin_amdgcn_rcpf(1.f + __expf(-v));
-#else
   const float d = 1.f + __expf(-v);
   const float r = __builtin_amdgcn_rcpf(d);
-  return r * (2.f - d * r);                                // (one Newton step: also keeps d live past the v_rcp_f32, see below)
-#endif
+  return r * (2.f - d * r);                                // (v_rcp_f32 + one Newton step)
 }
 __device__ __forceinline__ f32x4 sigmoid4_fast(const f32x4 v) {
   return (f32x4){sigmoid_fast(v[0]), sigmoid_fast(v[1]), sigmoid_fast(v[2]), sigmoid_fast(v[3])};
@@ -296,11 +289,7 @@ __global__ void __launch_bounds__(256 * NG, 2) ring_multi_kernel(const RmArgs A)
         if (ex_rh) st16(e_o2, E.zv, eoff[r], E.soff, x1[r] * sigmoid4_fast(rb16x4(v)));   // r from rpre AS STORED (bf16)
       }
       if constexpr (EX == 2) {                           // v = cand; x1 = h, x2 = upre (as stored)
-#ifdef RM_DBG
-        const f32x4 uu = x2[r] * 0.25f, c = rb16x4(v);
-#else
         const f32x4 uu = sigmoid4_fast(x2[r]), c = rb16x4(v);
-#endif
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = __fadd_rn(__fmul_rn(x1[r][e], __fsub_rn(1.f, uu[e])), __fmul_rn(c[e], uu[e]));

@@ -16,24 +16,30 @@ from .ops import (PN_EPS, SLOPE, _ac_in, _cached, _conv1x1_raw, _dense_views, _f
 # workgroups (62 KB of LDS each) plus one ring-convolution workgroup (35 KB): the weight gradient of a layer -- nothing in the
 # backward chain waits for it -- runs beside the data-gradient convolution of the same layer instead of in front of it.
 WGRAD_STREAM = True
-# The ConvGRU recurrence of the training step on the multi-output ring kernels (round 6, csrc/conv_gru.hip); False: the
-# one-output kernels + stage kernels of round 5 (kept: fp32 storage / no autocast take that path anyway)
-GRU_RING = True
-GRU_WGRAD_CHUNK = 16                                              # steps per multi-volume weight-gradient launch on the side stream (0: one launch over all steps, after the chain)
+# ---- round-6 forms of the training step, each with its A/B switch (module attribute; LF_<NAME>=0/1 in the environment sets the
+# default for a fresh process: tools/train_probe.py A/Bs, profiles/r06_*) --------------------------------------------------
+import os as _os
+
+
+def _env(name, default):
+    return type(default)(int(_os.environ.get('LF_' + name, int(default))))
+
+
+# the ConvGRU recurrence on the ring kernels with fused epilogues (csrc/conv_gru.hip); False: round 5's one-output kernels + stage
+# kernels (kept: fp32 storage / no autocast take that path anyway)
+GRU_RING = _env('GRU_RING', True)
 # 1: one-output launches on the sequential chain (two workgroups per CU overlap their phases), everything that does not depend
 # on the state batched over the views before / after the loop; 2: two outputs per staged halo (one 8-wave workgroup per CU --
-# measured slower: its waves run in lock-step, profiles/r06_gru_ring_ab.txt)
-GRU_RING_GROUPS = 1
-GRU_STATE_BF16 = bool(int(__import__('os').environ.get('LF_GRU_STATE_BF16', '0')))      # a bf16 copy of the recurrent state for the staged operands: measured -0.2 ms for +1.9 GB, off
-RING_BLOCK_FWD = bool(int(__import__('os').environ.get('LF_RING_BLOCK_FWD', '1')))      # forward Block steps on ring_multi (LF_RING_EX_BLOCK)
-CHAIN_EPILOGUE = bool(int(__import__('os').environ.get('LF_CHAIN_EPILOGUE', '1')))   # Block conv2's data gradient applies conv1's epilogue backward (LF_RING_EX_PREV)
-LIFT_MFMA = True                                                  # the 16-channel lift as one MFMA kernel each way (csrc/lift_mfma.hip)
-RING_DGRAD = True                                                 # data gradients of the 16 -> 16 layers on the same kernel family
-import os as _os                                                  # (A/B switches of tools/train_probe.py)
-GRU_WGRAD_CHUNK = int(_os.environ.get('LF_GRU_WGRAD_CHUNK', GRU_WGRAD_CHUNK))
-GRU_RING_GROUPS = int(_os.environ.get('LF_GRU_RING_GROUPS', GRU_RING_GROUPS))
-RING_DGRAD = bool(int(_os.environ.get('LF_RING_DGRAD', int(RING_DGRAD))))
-LIFT_MFMA = bool(int(_os.environ.get('LF_LIFT_MFMA', int(LIFT_MFMA))))
+# measured slower: its waves run in lock-step, profiles/r06_gru_ring_probe.json)
+GRU_RING_GROUPS = _env('GRU_RING_GROUPS', 1)
+# steps per multi-volume weight-gradient launch of the recurrence on the side stream (0: one launch over all steps, after the chain)
+GRU_WGRAD_CHUNK = _env('GRU_WGRAD_CHUNK', 16)
+# a bf16 copy of the recurrent state for the staged operands: bit-identical, measured -0.2 ms for +1.9 GB: off
+GRU_STATE_BF16 = _env('GRU_STATE_BF16', False)
+RING_BLOCK_FWD = _env('RING_BLOCK_FWD', True)          # forward Block steps on ring_multi (LF_RING_EX_BLOCK, bit-identical)
+RING_DGRAD = _env('RING_DGRAD', True)                  # data gradients of the 16 -> 16 layers on ring_multi (bit-identical)
+CHAIN_EPILOGUE = _env('CHAIN_EPILOGUE', True)          # a Block's conv2 data gradient applies conv1's epilogue backward (LF_RING_EX_PREV)
+LIFT_MFMA = _env('LIFT_MFMA', True)                    # the 16-channel lift as one MFMA kernel each way (csrc/lift_mfma.hip)
 
 
 _SIDE = {}
