@@ -5,6 +5,7 @@
 // The sampling grid is evaluated per voxel from a per-sample coefficient block (see lf_hip.h);
 // volumes are channels-last so that every trilinear tap is one contiguous C-float record.
 #include "lf_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -876,7 +877,18 @@ __device__ __forceinline__ float fixed_scale(const unsigned* amax) {
 // round-to-nearest-even of v (|v| < 2^39) as a 64-bit integer, in 8 VALU instructions instead of the ~20 of the generic
 // float -> int64 conversion (half of the tiled kernel's arithmetic): r = rint(v) is an integer-valued float; its value
 // splits exactly into hi * 2^24 + lo with lo in [0, 2^24), both exact in fp32 and in range of the 32-bit converts.
+#ifndef LF_FIXED_MAGIC
+#define LF_FIXED_MAGIC 1
+#endif
 __device__ __forceinline__ unsigned long long fixed_round(float v) {
+#if LF_FIXED_MAGIC
+  // round 6: the same integer in 3 instructions.  v is exact in fp64; adding 1.5 * 2^52 leaves a double in [2^52, 2^53) whose
+  // unit in the last place is 1, so the fp64 add itself rounds v to the nearest integer (ties to even, the mode of rintf) and
+  // the mantissa field then holds 2^51 + that integer.  Subtracting the bit pattern of the constant (its low word is zero: one
+  // 32-bit add on the high word) leaves the integer in two's complement.
+  const double d = (double)v + 6755399441055744.0;
+  return (unsigned long long)__double_as_longlong(d) - 0x4338000000000000ull;
+#endif
   const float r = __builtin_rintf(v);
   const float hi = __builtin_floorf(r * 5.9604644775390625e-08f);          // 2^-24
   const float lo = __builtin_fmaf(hi, -16777216.f, r);
@@ -916,7 +928,7 @@ __global__ void __launch_bounds__(256) fixed_to_float_kernel(const long long* __
                                                             float* __restrict__ out, long n) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  out[i] = (float)((double)acc[i] / (double)fixed_scale(amax));
+  out[i] = (float)((double)acc[i] * (1.0 / (double)fixed_scale(amax)));   // (the scale is a power of two: its reciprocal is exact)
 }
 
 // ---- the same sums without global atomics (C == 16): every SOURCE tile is owned by one workgroup ---------------------
@@ -1062,12 +1074,12 @@ __global__ void __launch_bounds__(256) splat_tile_kernel(const float* __restrict
   if (x < W && y < H && z < D) {
     constexpr int OREC = (IO & 2) ? 32 : 64;
     char* dst = (char*)gvol + ((vol_n == 1 ? 0 : (long)blockIdx.y * nvox) + (((long)z * H + y) * W + x)) * OREC;
-    const double inv = (double)scale;
+    const double inv = 1.0 / (double)scale;                       // exact: the scale is a power of two (2^-90 .. 2^126)
 #pragma unroll
     for (int c4 = 0; c4 < 4; ++c4) {
       f32x4 o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (float)((double)(long long)acc[tid * SACC + c4 * 4 + e] / inv);
+      for (int e = 0; e < 4; ++e) o[e] = (float)((double)(long long)acc[tid * SACC + c4 * 4 + e] * inv);
       if constexpr ((IO & 2) != 0) *(bf16x4r*)(dst + c4 * 8) = __builtin_convertvector(o, bf16x4r);
       else *(f32x4*)(dst + c4 * 16) = o;
     }
@@ -1184,14 +1196,28 @@ __global__ void __launch_bounds__(256) splat_binned_tile_kernel(const float* __r
     const char* gs = (const char*)gout + (long)(n0 + nl) * nvox * ((IO & 1) ? 32 : 64);
     const unsigned count = cnt[(long)nl * ntiles + tile];
     const unsigned* mine = list + (long)nl * cap + off[(long)nl * ntiles + tile];
-    for (unsigned i = tid >> 2; i < count; i += 64) {
-      const unsigned pk = mine[i];                                  // z << 20 | y << 10 | x
+    // two list entries ahead, one gradient record ahead (round 6): the chain list word -> record address -> record is two HBM / L2
+    // latencies long and a workgroup holds only four waves; with the loads of the next entries in flight behind the arithmetic of
+    // this one the pass is no longer latency-bound (tools/splat_ab.py)
+    typedef typename std::conditional<(IO & 1) != 0, bf16x4r, f32x4>::type graw_t;
+    auto g_of = [&](unsigned pk_) -> graw_t {
+      const long v_ = ((long)(pk_ >> 20) * H + (long)((pk_ >> 10) & 1023u)) * W + (long)(pk_ & 1023u);
+      return *(const graw_t*)(gs + v_ * ((IO & 1) ? 32 : 64) + q * ((IO & 1) ? 8 : 16));
+    };
+    const unsigned i0 = tid >> 2;
+    unsigned pk1 = i0 < count ? mine[i0] : 0u, pk2 = i0 + 64 < count ? mine[i0 + 64] : 0u;
+    graw_t gnext = g_of(pk1);
+    for (unsigned i = i0; i < count; i += 64) {
+      const unsigned pk = pk1;                                      // z << 20 | y << 10 | x
+      const graw_t graw = gnext;
+      pk1 = pk2;
+      if (i + 64 < count) gnext = g_of(pk1);
+      pk2 = i + 128 < count ? mine[i + 128] : 0u;
       const int x = (int)(pk & 1023u), y = (int)((pk >> 10) & 1023u), z = (int)(pk >> 20);
-      const long v = ((long)z * H + y) * W + x;
       const SplatTap t = splat_eval<KIND>(cf, x, y, z, W, H, D, st);
       f32x4 g4;
-      if constexpr ((IO & 1) != 0) g4 = __builtin_convertvector(*(const bf16x4r*)(gs + (long)v * 32 + q * 8), f32x4);
-      else g4 = *(const f32x4*)(gs + (long)v * 64 + q * 16);
+      if constexpr ((IO & 1) != 0) g4 = __builtin_convertvector(graw, f32x4);
+      else g4 = graw;
       g4 = g4 * scale;
 #define SPLAT_B(Z, Y, X, WI) do { \
         const int lz_ = (Z) - tz0, ly_ = (Y) - ty0, lx_ = (X) - tx0; \
@@ -1212,14 +1238,134 @@ __global__ void __launch_bounds__(256) splat_binned_tile_kernel(const float* __r
   if (x < W && y < H && z < D) {
     constexpr int OREC = (IO & 2) ? 32 : 64;
     char* dst = (char*)gvol + (n_out * nvox + (((long)z * H + y) * W + x)) * OREC;
-    const double inv = (double)scale;
+    const double inv = 1.0 / (double)scale;                       // exact: the scale is a power of two (2^-90 .. 2^126)
 #pragma unroll
     for (int c4 = 0; c4 < 4; ++c4) {
       f32x4 o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (float)((double)(long long)acc[tid * SACC + c4 * 4 + e] / inv);
+      for (int e = 0; e < 4; ++e) o[e] = (float)((double)(long long)acc[tid * SACC + c4 * 4 + e] * inv);
       if constexpr ((IO & 2) != 0) *(bf16x4r*)(dst + c4 * 8) = __builtin_convertvector(o, bf16x4r);
       else *(f32x4*)(dst + c4 * 16) = o;
+    }
+  }
+}
+
+// ---- round 6 A/B (NOT the default: lf_set_tuning(4, 4)): the binned tile pass with ONE LANE PER CHANNEL (16 lanes per entry) ------
+// tools/ub/lds_atomic2.hip: 64-bit LDS atomics retire at 8-9 lane-atomics per clock and CU whatever the shape of the access -- as
+// long as the lanes of one instruction do not meet on an address.  The quad-per-entry form above puts 16 list entries into one
+// instruction; neighbouring entries come from one 4x4x4 block of output voxels and land on the same few source voxels, clamped
+// samples pile up on border records: on ONE record it falls to 2.0 per clock.  With 16 lanes per entry an instruction covers
+// 4 entries x 128 contiguous bytes, which the LDS serves at 8.0 per clock even when all four are the SAME record.  To keep the
+// arithmetic per entry from growing 4x with the lanes, a wave works in two phases per 64 entries: (A) lane-per-entry: list word,
+// the sample's gradient record, splat_eval, in-tile test -> a table in LDS (8 weights, 8 record numbers or 0xffff, the record);
+// (B) 16 lanes per entry read their entry's row (broadcast reads) and issue the 8 adds.  Same quantisation, same integer totals,
+// same conversion => bit-identical to the other forms.
+// MEASURED (profiles/r06_splat_ab.txt, 8 x 128^3 x 16, training geometry): 2.82 ms against 2.50 ms of the quad form before its
+// loads were pipelined (2.36 after).  Ablations of THIS kernel: without the atomics -0.30 ms, without splat_eval -0.42 ms, without
+// the conversion -0.07 ms of 1.9 ms: the atomics were never the bound -- the dependent loads (list word -> record) and the
+// per-entry arithmetic at four waves per workgroup are; which is what the pipelined loads in the quad form address.
+template <int KIND, int IO>
+__global__ void __launch_bounds__(256) splat_binned_tile16_kernel(const float* __restrict__ gout, const float* __restrict__ coef,
+                                                                  const unsigned* __restrict__ cnt, const unsigned* __restrict__ off,
+                                                                  const unsigned* __restrict__ list, const unsigned* __restrict__ amax,
+                                                                  float* __restrict__ gvol, int n0, int m, int shared, long nvox, long cap,
+                                                                  int ntiles, int ntx, int nty, int D, int H, int W, Steps st) {
+  constexpr bool IN16 = (IO & 1) != 0, OUT16 = (IO & 2) != 0;
+  constexpr int NREC = STZ * STY * STX, GREC = IN16 ? 32 : 64;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  __shared__ unsigned long long acc[NREC * 16];                    // 32 KB: record stride 128 B (the shape is conflict-free as it is)
+  __shared__ __attribute__((aligned(16))) float tw[4][64][8];      // per wave and entry: the 8 corner weights
+  __shared__ __attribute__((aligned(16))) unsigned short tr[4][64][8];   // the 8 records (0xffff: outside the tile or weight zero)
+  __shared__ __attribute__((aligned(16))) unsigned char tg[4][64][GREC]; // the sample's 16-channel gradient record as stored
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, grp = lane >> 4, ch = lane & 15;
+  const int tile = blockIdx.x;
+  const int nl_first = shared ? 0 : (int)blockIdx.y, nl_last = shared ? m : (int)blockIdx.y + 1;
+  const long n_out = shared ? 0 : n0 + (long)blockIdx.y;
+  const int tx0 = (tile % ntx) * STX, ty0 = ((tile / ntx) % nty) * STY, tz0 = (tile / (ntx * nty)) * STZ;
+  constexpr int OREC = OUT16 ? 32 : 64;
+  unsigned total = 0;
+  for (int nl = nl_first; nl < nl_last; ++nl) total |= cnt[(long)nl * ntiles + tile];
+  if (total == 0) {
+    const int lx = tid % STX, ly = (tid / STX) % STY, lz = tid / (STX * STY);
+    const int x = tx0 + lx, y = ty0 + ly, z = tz0 + lz;
+    if (x < W && y < H && z < D) {
+      f32x4* dst = (f32x4*)((char*)gvol + (n_out * nvox + (((long)z * H + y) * W + x)) * OREC);
+#pragma unroll
+      for (int k = 0; k < OREC / 16; ++k) dst[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    return;
+  }
+  for (int i = tid; i < NREC * 16; i += 256) acc[i] = 0ull;
+  const float scale = fixed_scale(amax);
+  __syncthreads();
+  for (int nl = nl_first; nl < nl_last; ++nl) {
+    const float* cf = coef + (long)(n0 + nl) * LF_MAP_COEFS;
+    const char* gs = (const char*)gout + (long)(n0 + nl) * nvox * GREC;
+    const unsigned count = cnt[(long)nl * ntiles + tile];
+    const unsigned* mine = list + (long)nl * cap + off[(long)nl * ntiles + tile];
+    for (unsigned b0 = (unsigned)wv * 64u; b0 < count; b0 += 256u) {
+      // ---- phase A: lane = list entry
+      if (b0 + lane < count) {
+        const unsigned pk = mine[b0 + lane];                        // z << 20 | y << 10 | x
+        const int x = (int)(pk & 1023u), y = (int)((pk >> 10) & 1023u), z = (int)(pk >> 20);
+        const u32x4* src = (const u32x4*)(gs + (((long)z * H + y) * W + x) * GREC);
+        u32x4 rec[GREC / 16];
+#pragma unroll
+        for (int k = 0; k < GREC / 16; ++k) rec[k] = src[k];
+        const SplatTap t = splat_eval<KIND>(cf, x, y, z, W, H, D, st);
+        const int lz[2] = {t.z0 - tz0, t.z1 - tz0}, ly[2] = {t.y0 - ty0, t.y1 - ty0}, lx[2] = {t.x0 - tx0, t.x1 - tx0};
+        unsigned r16[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const int cz = lz[c >> 2], cy = ly[(c >> 1) & 1], cx = lx[c & 1];
+          const bool in = t.w[c] != 0.f && (unsigned)cz < (unsigned)STZ && (unsigned)cy < (unsigned)STY && (unsigned)cx < (unsigned)STX;
+          r16[c] = in ? (unsigned)((cz * STY + cy) * STX + cx) : 0xffffu;
+        }
+        *(f32x4*)&tw[wv][lane][0] = (f32x4){t.w[0], t.w[1], t.w[2], t.w[3]};
+        *(f32x4*)&tw[wv][lane][4] = (f32x4){t.w[4], t.w[5], t.w[6], t.w[7]};
+        *(u32x4*)&tr[wv][lane][0] = (u32x4){r16[0] | (r16[1] << 16), r16[2] | (r16[3] << 16), r16[4] | (r16[5] << 16), r16[6] | (r16[7] << 16)};
+#pragma unroll
+        for (int k = 0; k < GREC / 16; ++k) *(u32x4*)&tg[wv][lane][k * 16] = rec[k];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // ---- phase B: 16 lanes = the channels of one entry, four entries per instruction
+      const int nb = (int)min(64u, count - b0);
+#pragma unroll 4
+      for (int j = 0; j < 16; ++j) {
+        const int e = j * 4 + grp;
+        if (e < nb) {
+          const f32x4 w0 = *(const f32x4*)&tw[wv][e][0], w1 = *(const f32x4*)&tw[wv][e][4];
+          const u32x4 r4 = *(const u32x4*)&tr[wv][e][0];
+          float g;
+          if constexpr (IN16) g = __uint_as_float((unsigned)(*(const unsigned short*)&tg[wv][e][ch * 2]) << 16);
+          else g = *(const float*)&tg[wv][e][ch * 4];
+          g = g * scale;
+          const float w8[8] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            const unsigned r = (r4[c >> 1] >> (16 * (c & 1))) & 0xffffu;
+            if (r != 0xffffu) atomicAdd(acc + r * 16 + ch, fixed_round(g * w8[c]));
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();                             // (the table is rewritten by the next batch)
+    }
+  }
+  __syncthreads();
+  // conversion and store, 16 lanes per record (a record's 128 bytes in one access; four x-neighbours per instruction)
+  const double inv = 1.0 / (double)scale;                       // exact: the scale is a power of two (2^-90 .. 2^126)
+#pragma unroll 4
+  for (int j = 0; j < 16; ++j) {
+    const int r = wv * 64 + j * 4 + grp;
+    const int lx = r % STX, ly = (r / STX) % STY, lz = r / (STX * STY);
+    const int x = tx0 + lx, y = ty0 + ly, z = tz0 + lz;
+    if (x < W && y < H && z < D) {
+      char* dst = (char*)gvol + (n_out * nvox + (((long)z * H + y) * W + x)) * OREC;
+      const float o = (float)((double)(long long)acc[r * 16 + ch] * inv);
+      if constexpr (OUT16) ((__bf16*)dst)[ch] = __builtin_convertvector((f32x4){o, o, o, o}, bf16x4r)[0];
+      else ((float*)dst)[ch] = o;
     }
   }
 }
@@ -1234,7 +1380,8 @@ inline int splat_bin_chunk(int N, long nvox) {
 }
 
 int g_splat_variant = 2;      // deterministic splat (lf_set_tuning key 4): 1 = global 64-bit atomics, 2 = source tiles in LDS (C == 16;
-                              // lf_resample3d_bwd_vol_det_io: binned lists when every sample has its own volume), 3 = as 2 without the binned form
+                              // lf_resample3d_bwd_vol_det_io: binned lists, a lane quad per list entry), 3 = as 2 without the binned form,
+                              // 4 = as 2 with 16 lanes per list entry (round-6 A/B: slower)
 
 bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
@@ -1435,7 +1582,7 @@ extern "C" int lf_set_tuning(int key, int value) {
   }
   if (key == 4) {
     const int prev = g_splat_variant;
-    if (value >= 1 && value <= 3) g_splat_variant = value;
+    if (value >= 1 && value <= 4) g_splat_variant = value;
     return prev;
   }
   if (key == 6) {
@@ -1596,6 +1743,11 @@ extern "C" int lf_resample3d_bwd_vol_det_io(const void* gout, const float* coef,
          splat_binned_tile_kernel<LF_MAP_O2C, 3>},
         {splat_binned_tile_kernel<LF_MAP_C2O, 0>, splat_binned_tile_kernel<LF_MAP_C2O, 1>, splat_binned_tile_kernel<LF_MAP_C2O, 2>,
          splat_binned_tile_kernel<LF_MAP_C2O, 3>}};
+    static const tile_t tiles16[2][4] = {
+        {splat_binned_tile16_kernel<LF_MAP_O2C, 0>, splat_binned_tile16_kernel<LF_MAP_O2C, 1>, splat_binned_tile16_kernel<LF_MAP_O2C, 2>,
+         splat_binned_tile16_kernel<LF_MAP_O2C, 3>},
+        {splat_binned_tile16_kernel<LF_MAP_C2O, 0>, splat_binned_tile16_kernel<LF_MAP_C2O, 1>, splat_binned_tile16_kernel<LF_MAP_C2O, 2>,
+         splat_binned_tile16_kernel<LF_MAP_C2O, 3>}};
     for (int n0 = 0; n0 < N; n0 += cv) {
       const int m = min(cv, N - n0);
       e = hipMemsetAsync(cnt, 0, (size_t)2 * cv * nt * 4, s);
@@ -1611,7 +1763,7 @@ extern "C" int lf_resample3d_bwd_vol_det_io(const void* gout, const float* coef,
         hipLaunchKernelGGL((splat_bin_kernel<LF_MAP_C2O, true>), gbin, dim3(256), 0, s, coef, cur, off, list, n0, nvox, cap, (int)nt, ntx, nty, D, H, W, stp);
       }
       const int shared = vol_n == 1 && N > 1;
-      hipLaunchKernelGGL(tiles[kind == LF_MAP_O2C ? 0 : 1][io], dim3((unsigned)nt, (unsigned)(shared ? 1 : m)), dim3(256), 0, s, (const float*)gout,
+      hipLaunchKernelGGL((g_splat_variant == 4 ? tiles16 : tiles)[kind == LF_MAP_O2C ? 0 : 1][io], dim3((unsigned)nt, (unsigned)(shared ? 1 : m)), dim3(256), 0, s, (const float*)gout,
                          coef, cnt, off, list, amax, (float*)gvol, n0, m, shared, nvox, cap, (int)nt, ntx, nty, D, H, W, stp);
     }
     return lf_launch_status();

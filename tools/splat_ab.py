@@ -13,6 +13,8 @@ from latentfusion_amd.modules.geometry import Camera, c2o_coefficients  # noqa: 
 from latentfusion_amd.pose import utils as pu  # noqa: E402
 
 N, S = int(sys.argv[1]) if len(sys.argv) > 1 else 8, 128
+if os.environ.get('LF_HIP_LIB'):                                    # A/B of two BUILDS of the library (tool only)
+    _lib.LIB_PATH = os.environ['LF_HIP_LIB']
 L = _lib.lib()
 s = torch.cuda.current_stream().cuda_stream
 g = torch.Generator().manual_seed(0)
@@ -34,7 +36,7 @@ cf[:, :coef.shape[1]] = coef
 nb = max(L.lf_resample3d_bwd_vol_det_io_scratch_bytes(N, N, S, S, S), L.lf_resample3d_bwd_vol_det_io_scratch_bytes(1, N, S, S, S))
 scr = torch.empty(nb // 8 + 1, device='cuda', dtype=torch.int64)
 outs = {}
-for name, variant in (('tile form (box culling)', 3), ('binned form', 2)):
+for name, variant in (('tile form (box culling)', 3), ('binned, 16 lanes per entry', 4), ('binned, quad per entry', 2)):
     prev = L.lf_set_tuning(4, variant)
     gv = ops.empty_cl16((N, 16, S, S, S), 'cuda', True)
     ts = []
@@ -49,15 +51,16 @@ for name, variant in (('tile form (box culling)', 3), ('binned form', 2)):
     L.lf_set_tuning(4, prev)
     outs[name] = gv
     print(f'{name:28s} N = {N}: {min(ts[1:]):8.3f} ms  (runs {", ".join("%.3f" % t for t in ts)}), scratch {nb / 2**20:.0f} MiB')
-a, b = outs.values()
-print('bit-identical:', bool(torch.equal(a, b)))
+a, q, b = outs.values()
+print('bit-identical:', bool(torch.equal(a, b)), bool(torch.equal(q, b)))
+print('checksum C2O:', int(b.view(torch.int16).to(torch.int64).sum().item()), float(b.float().abs().sum().item()))
 # the renderer's direction: object -> camera, ONE volume shared by the N samples
 from latentfusion_amd.modules.geometry import o2c_coefficients  # noqa: E402
 coef = o2c_coefficients(cams, 1.0).cuda()
 cf = torch.zeros(N, _lib.LF_MAP_COEFS, device='cuda')
 cf[:, :coef.shape[1]] = coef
 outs = {}
-for name, variant in (('O2C shared: tile form', 3), ('O2C shared: binned form', 2)):
+for name, variant in (('O2C shared: tile form', 3), ('O2C shared: binned 16 lanes', 4), ('O2C shared: binned quad', 2)):
     prev = L.lf_set_tuning(4, variant)
     gv = ops.empty_cl16((1, 16, S, S, S), 'cuda', True)
     ts = []
@@ -72,5 +75,6 @@ for name, variant in (('O2C shared: tile form', 3), ('O2C shared: binned form', 
     L.lf_set_tuning(4, prev)
     outs[name] = gv
     print(f'{name:28s} N = {N}: {min(ts[1:]):8.3f} ms  (runs {", ".join("%.3f" % t for t in ts)})')
-a, b = outs.values()
-print('bit-identical:', bool(torch.equal(a, b)))
+a, q, b = outs.values()
+print('bit-identical:', bool(torch.equal(a, b)), bool(torch.equal(q, b)))
+print('checksum O2C:', int(b.view(torch.int16).to(torch.int64).sum().item()), float(b.float().abs().sum().item()))
