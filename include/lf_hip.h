@@ -36,6 +36,8 @@ extern "C" {
 #define LF_EPI_LRELU     1u   /* y = max(y, slope*y)                                         */
 #define LF_EPI_PIXELNORM 2u   /* y = y / sqrt(mean_c(y^2) + eps); also writes the norm       */
 #define LF_EPI_ADD       4u   /* (prev_flags of lf_conv3d_c16_wino only) prev_y is an addend  */
+#define LF_EPI_DOT       8u   /* (prev_flags of lf_conv1x1_bwd_data only, alone) gx is stored as it is; prev_norm is an OUTPUT:
+                                 prev_norm[record] = sum_c gx[record][c] * prev_y[record][c] per 16-channel record            */
 
 /* grid-map kinds of the 3-D resampler */
 #define LF_MAP_O2C 0   /* bilinear polynomial map (ObjectToCameraTransform)                  */
@@ -122,6 +124,15 @@ int lf_conv1x1_fwd(const float* x, const float* wpack, const float* bias, float*
                    int Cout, long y_batch_stride, int y_row_stride, int y_slice_channels,
                    long y_slice_stride,
                    float he, unsigned flags, float slope, float eps, void* stream);
+/* The same with every input slice scaled by a per-pixel factor first: element (p, k = s*Cin + c) is
+ * x[...] * xscale[(n*ksl + s)*P + p], the product rounded to fp32 as a separate scaling pass would round it (Cin % 4 == 0).
+ * Replaces `z = z * depth_weights_resized` ahead of the factor projection (reference recon/models.py:427-430 -> modules/
+ * geometry.py:744-749) without the scaled volume (round 6; was lf_column_scale_fwd + lf_conv1x1_fwd). */
+int lf_conv1x1_fwd_scaled(const float* x, const float* xscale, const float* wpack, const float* bias, float* y, float* norm_out,
+                          int N, int P, int Cin, int ksl, long x_batch_stride, long x_slice_stride,
+                          int Cout, long y_batch_stride, int y_row_stride, int y_slice_channels,
+                          long y_slice_stride,
+                          float he, unsigned flags, float slope, float eps, void* stream);
 
 /* Data gradients of the two convolutions: gx = conv^T(gy) * he with the host-packed transposed
  * weights (taps flipped / in-out swapped).  When prev_y != NULL the epilogue backward of the layer

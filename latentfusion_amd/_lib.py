@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'liblf_hip.so')
 LF_EPI_LRELU = 1
 LF_EPI_PIXELNORM = 2
 LF_EPI_ADD = 4
+LF_EPI_DOT = 8
 LF_RING_ADD_BF16, LF_RING_OUT_BF16, LF_RING_ROUND = 1, 2, 4
 LF_RING_EX_NONE, LF_RING_EX_RH, LF_RING_EX_BLEND, LF_RING_EX_ABWD, LF_RING_EX_BLOCK, LF_RING_EX_PREV = 0, 1, 2, 3, 4, 5
 LF_OUT_DEPTH_INNER = 0x100
@@ -39,6 +40,8 @@ SIGNATURES = {
                                c_float, c_uint, c_float, c_float, P]),
     'lf_conv1x1_fwd': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_long, c_long, c_int, c_long, c_int,
                                c_int, c_long, c_float, c_uint, c_float, c_float, P]),
+    'lf_conv1x1_fwd_scaled': (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_long, c_long, c_int, c_long, c_int,
+                                      c_int, c_long, c_float, c_uint, c_float, c_float, P]),
     'lf_conv3x3_bwd_data': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, P, P, c_uint,
                                     c_float, P]),
     'lf_conv1x1_bwd_data': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_long, c_int, c_int, c_long, c_float, P, P,

@@ -84,6 +84,31 @@ __device__ __forceinline__ void epilogue_store(f32x4 (&acc)[NT][NR], const long 
       constexpr bool whole = WHOLE;
       f32x4 ypv[NT];
       float nrv[NT];
+      if (!whole && (prev_flags & LF_EPI_DOT)) {
+        // (round 6, lf_conv1x1_bwd_data with LF_EPI_DOT) the gradient is stored as it is; on the side, per 16-channel record,
+        // dot[record] = sum_c g[c] * prev_y[c] goes to the buffer passed as prev_norm: the gradient w.r.t. a per-voxel FACTOR
+        // that scaled prev_y ahead of this convolution (the occlusion weights ahead of the factor projection) without a pass
+        // over the two volumes (was lf_column_scale_bwd)
+        float* dot_out = const_cast<float*>(prev_norm);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int co = co_base + t * 16 + cq * 4;
+          const bool ok = rowoff[j] >= 0 && co < Cout;
+          const long off = ok ? rowoff[j] + (long)(co / ysc) * yss + (co % ysc) : 0;
+          ypv[t] = ok ? *(const f32x4*)(prev_y + off) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int co = co_base + t * 16 + cq * 4;
+          const bool ok = rowoff[j] >= 0 && co < Cout;
+          const long off = ok ? rowoff[j] + (long)(co / ysc) * yss + (co % ysc) : 0;
+          const f32x4 g = acc[t][j], yp = ypv[t];
+          float dot = g[0] * yp[0] + g[1] * yp[1] + g[2] * yp[2] + g[3] * yp[3];
+          dot += __shfl_xor(dot, 16, 64);
+          dot += __shfl_xor(dot, 32, 64);
+          if (ok && cq == 0) dot_out[off >> 4] = dot;
+        }
+      } else {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int co = co_base + t * 16 + cq * 4;
@@ -124,6 +149,7 @@ __device__ __forceinline__ void epilogue_store(f32x4 (&acc)[NT][NR], const long 
         acc[t][j] = g;
         if (amax_out != nullptr && rowoff[j] >= 0)
           lane_amax = fmaxf(lane_amax, fmaxf(fmaxf(fabsf(g[0]), fabsf(g[1])), fmaxf(fabsf(g[2]), fabsf(g[3]))));
+      }
       }
     }
     if (rowoff[j] >= 0) {
@@ -615,7 +641,7 @@ __global__ void __launch_bounds__(256) conv1x1_kernel(
     long y_batch_stride, int y_row_stride, int y_slice_channels, long y_slice_stride,
     float he, unsigned flags, float slope, float eps,
     const float* __restrict__ prev_y, const float* __restrict__ prev_norm, unsigned prev_flags,
-    float* __restrict__ amax_out) {
+    float* __restrict__ amax_out, const float* __restrict__ xscale) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, cq = lane >> 4;
   const int n = blockIdx.z;
@@ -640,6 +666,9 @@ __global__ void __launch_bounds__(256) conv1x1_kernel(
       const float* src = xrow + (long)s * x_slice_stride + c0;
       if (vec_in) {
         bfrag = *(const f32x4*)src;
+        // (lf_conv1x1_fwd_scaled) one factor per (sample, slice, pixel): the product is rounded as the separate scaling pass
+        // rounded it (lf_column_scale_fwd), so the sums are the same bits without the scaled volume ever existing
+        if (xscale != nullptr) bfrag = bfrag * xscale[((long)n * ksl + s) * P + p];
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -782,13 +811,16 @@ static int conv1x1_launch(const float* x, const float* wpack, const float* bias,
                           int Cout, long y_batch_stride, int y_row_stride, int y_slice_channels,
                           long y_slice_stride,
                           float he, unsigned flags, float slope, float eps, void* stream,
-                          const float* prev_y, const float* prev_norm, unsigned prev_flags, float* amax_out = nullptr) {
+                          const float* prev_y, const float* prev_norm, unsigned prev_flags, float* amax_out = nullptr,
+                          const float* xscale = nullptr) {
   if (N <= 0 || P <= 0 || Cin <= 0 || ksl <= 0 || Cout <= 0 || y_slice_channels <= 0) return LF_EINVAL;
+  if (xscale != nullptr && (Cin & 3)) return LF_EALIGN;
   if (prev_y != nullptr) {
     if (flags != 0 || bias != nullptr || y_slice_channels != 16 || y_row_stride != 16 || (Cout & 15) ||
         !lf_aligned16(prev_y) || ((y_batch_stride | y_slice_stride) & 15))
       return LF_EINVAL;
     if ((prev_flags & LF_EPI_PIXELNORM) && prev_norm == nullptr) return LF_EINVAL;
+    if ((prev_flags & LF_EPI_DOT) && (prev_flags != LF_EPI_DOT || prev_norm == nullptr)) return LF_EINVAL;
   }
   if (y_row_stride < (y_slice_channels < Cout ? y_slice_channels : Cout)) return LF_EINVAL;
   if (ksl > 1 && (Cin & 3)) return LF_EALIGN;     // a lane's 4-channel group must not straddle slices
@@ -810,7 +842,7 @@ static int conv1x1_launch(const float* x, const float* wpack, const float* bias,
 #define LAUNCH(T) hipLaunchKernelGGL((conv1x1_kernel<T>), grid, block, 0, s, x, wpack, bias, y, norm_out, \
                                      P, Cin, ksl, x_batch_stride, x_slice_stride, Cout, Kp, y_batch_stride, y_row_stride, \
                                      y_slice_channels, y_slice_stride, he, flags, slope, eps, prev_y, prev_norm, prev_flags, \
-                                     amax_out)
+                                     amax_out, xscale)
   switch (NT) {
     case 1: LAUNCH(1); break;
     case 2: LAUNCH(2); break;
@@ -831,6 +863,17 @@ extern "C" int lf_conv1x1_fwd(const float* x, const float* wpack, const float* b
   return conv1x1_launch(x, wpack, bias, y, norm_out, N, P, Cin, ksl, x_batch_stride, x_slice_stride, Cout,
                         y_batch_stride, y_row_stride, y_slice_channels, y_slice_stride, he, flags, slope, eps, stream,
                         nullptr, nullptr, 0);
+}
+
+extern "C" int lf_conv1x1_fwd_scaled(const float* x, const float* xscale, const float* wpack, const float* bias, float* y,
+                                     float* norm_out, int N, int P, int Cin, int ksl, long x_batch_stride, long x_slice_stride,
+                                     int Cout, long y_batch_stride, int y_row_stride, int y_slice_channels, long y_slice_stride,
+                                     float he, unsigned flags, float slope, float eps, void* stream) {
+  lf_clear_error();
+  if (xscale == nullptr) return LF_EINVAL;
+  return conv1x1_launch(x, wpack, bias, y, norm_out, N, P, Cin, ksl, x_batch_stride, x_slice_stride, Cout,
+                        y_batch_stride, y_row_stride, y_slice_channels, y_slice_stride, he, flags, slope, eps, stream,
+                        nullptr, nullptr, 0, nullptr, xscale);
 }
 
 extern "C" int lf_conv1x1_bwd_data(const float* gy, const float* wpack_t, float* gx, int N, int P, int Cin, int Cout,

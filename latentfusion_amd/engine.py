@@ -317,6 +317,7 @@ class RenderLoopEngine:
 
     # ---- per-layer launches of the camera blocks (the experimental subclass adds kernel variants here) ----
     PROJ_GEMM = True        # wide blocks, ranking only: depth-innermost last block + library GEMM for the factor projection
+    OCC_FUSE_SCALE = True   # occlusion weights: the factor projection scales its operand / sums the weights' gradient itself (r06)
 
     def _conv_fwd(self, li, x, flags, depth_inner=False):
         """Forward of camera-block convolution `li`: (y, norm, (zp, pnorm) when the factor projection rode along, else None)."""
@@ -418,11 +419,14 @@ class RenderLoopEngine:
         wocc = torch.empty_like(logits)
         with ops._timed('column_softmax'):
             check(L.lf_column_softmax_fwd(logits.data_ptr(), wocc.data_ptr(), None, n, D, P, s), 'lf_column_softmax_fwd')
+        if self.proj is not None and self.OCC_FUSE_SCALE:
+            # (round 6) the factor projection scales its operand itself (lf_conv1x1_fwd_scaled): the scaled volume is never written
+            return None, (ta, t16, ys, ns, wocc)
         zs = ops.empty_cl(zc.shape, dev)
         check(L.lf_column_scale_fwd(zc.data_ptr(), wocc.data_ptr(), zs.data_ptr(), n * D * P, 16, s), 'lf_column_scale_fwd')
         return zs, (ta, t16, ys, ns, wocc)
 
-    def _occlusion_bwd(self, g_zs, zc, saved, flags, prev=None):
+    def _occlusion_bwd(self, g_zs, zc, saved, flags, prev=None, gw=None):
         """d/d(zs) -> d/d(zc): the scaling, the softmax, the output block, the four convolutions (each data-gradient launch folds
         in the LeakyReLU' / PixelNorm' of the layer it lands on) and the input block, plus the direct term of the scaling.
         prev = (zc, norm, flags) of the camera-block layer that produced zc: its epilogue backward is applied on the way out."""
@@ -431,10 +435,11 @@ class RenderLoopEngine:
         ta, t16, ys, ns, wocc = saved
         n, _, D, H, W = zc.shape
         P = H * W
-        gw = torch.empty_like(wocc)
         # (the direct term g_zs * wocc of the scaling joins the input block's backward below: no volume is written for it)
-        check(L.lf_column_scale_bwd(g_zs.data_ptr(), zc.data_ptr(), wocc.data_ptr(), None, gw.data_ptr(), n * D * P, 16, s),
-              'lf_column_scale_bwd')
+        if gw is None:                                            # (else: the projection's data gradient already summed g_zs * zc per voxel)
+            gw = torch.empty_like(wocc)
+            check(L.lf_column_scale_bwd(g_zs.data_ptr(), zc.data_ptr(), wocc.data_ptr(), None, gw.data_ptr(), n * D * P, 16, s),
+                  'lf_column_scale_bwd')
         gl = torch.empty_like(wocc)
         check(L.lf_column_softmax_bwd(wocc.data_ptr(), gw.data_ptr(), None, gl.data_ptr(), n, D, P, s), 'lf_column_softmax_bwd')
         _hb, hhe, _hpk, hpkt = o['head']
@@ -502,7 +507,11 @@ class RenderLoopEngine:
                 cout = pw.shape[0]
                 zp = ops.empty_cl((n, cout, S, S), dev)
                 with ops._timed('factor_project_fwd'):
-                    pnorm = ops._conv1x1_raw(zs, ppack, pb, n, S * S, Cl, S, S * S * S * Cl, S * S * Cl, cout, zp, phe, flags)
+                    if zs is None:
+                        pnorm = ops._conv1x1_raw(acts[-1], ppack, pb, n, S * S, Cl, S, S * S * S * Cl, S * S * Cl, cout, zp, phe, flags,
+                                                 xscale=occ_saved[4])
+                    else:
+                        pnorm = ops._conv1x1_raw(zs, ppack, pb, n, S * S, Cl, S, S * S * S * Cl, S * S * Cl, cout, zp, phe, flags)
                 zp_leaf = zp.detach().requires_grad_(need_grad)
             else:
                 zs_leaf = zs.detach().requires_grad_(need_grad)
@@ -652,13 +661,24 @@ class RenderLoopEngine:
                 if self.proj is not None:
                     gp = gp_explicit if (explicit and gp_explicit is not None) else ops._epilogue_bwd(ops.cl(g_zp), zp, pnorm, flags)
                     g_zs = ops.empty_cl((n, Cl, S, S, S), dev)
+                    gw_occ = None
                     with ops._timed('factor_project_bwd'):
-                        ops._conv1x1_raw(gp, ppack_t, None, n, S * S, cout, 1, S * S * cout, 0, S * Cl, g_zs, phe, 0,
-                                         yaddr=(S * S * S * Cl, Cl, Cl, S * S * Cl))
+                        if self.OCC_FUSE_SCALE and Cl == 16:
+                            # the same launch also sums g_zs * zc over the channels of every voxel (LF_EPI_DOT): the gradient of the
+                            # occlusion weights, without lf_column_scale_bwd's pass over both volumes
+                            gw_occ = torch.empty(n, 1, S, S, S, device=dev, dtype=torch.float32)
+                            check(L.lf_conv1x1_bwd_data(gp.data_ptr(), ppack_t.data_ptr(), g_zs.data_ptr(), n, S * S, cout, S * Cl,
+                                                        S * S * S * Cl, Cl, Cl, S * S * Cl, phe, acts[-1].data_ptr(), gw_occ.data_ptr(),
+                                                        _lib.LF_EPI_DOT, ops.SLOPE, None, s), 'lf_conv1x1_bwd_data')
+                        else:
+                            ops._conv1x1_raw(gp, ppack_t, None, n, S * S, cout, 1, S * S * cout, 0, S * Cl, g_zs, phe, 0,
+                                             yaddr=(S * S * S * Cl, Cl, Cl, S * S * Cl))
                 else:
                     g_zs = ops.cl(g_zp)
+                    gw_occ = None
                 landed = fuse and nconv > 0
-                g_zp = self._occlusion_bwd(g_zs, acts[-1], occ_saved, flags, (acts[nconv], norms[nconv - 1], flags) if landed else None)
+                g_zp = self._occlusion_bwd(g_zs, acts[-1], occ_saved, flags, (acts[nconv], norms[nconv - 1], flags) if landed else None,
+                                           gw=gw_occ)
             # g_zp is d/d(output of the last camera block); from here the explicit data-gradient chain
             g = ops.cl(g_zp)
             if fuse and nconv:

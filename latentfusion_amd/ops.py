@@ -690,18 +690,26 @@ def conv3x3(x, weight, bias, lrelu=True, pixelnorm=True, chain=False):
     return _Conv3x3.apply(_f32(x), weight, bias, flags)
 
 
-def _conv1x1_raw(x_ptr_tensor, wpack, bias, N, P, cin, ksl, xbs, xss, cout, y2d, he, flags, yaddr=None):
+def _conv1x1_raw(x_ptr_tensor, wpack, bias, N, P, cin, ksl, xbs, xss, cout, y2d, he, flags, yaddr=None, xscale=None):
     """y2d: output buffer; yaddr = (batch_stride, row_stride, slice_channels, slice_stride) or None
-    for plain [N*P][cout] rows.  Returns norm or None."""
+    for plain [N*P][cout] rows.  xscale: a factor per (sample, slice, pixel) applied to the operand (lf_conv1x1_fwd_scaled).
+    Returns norm or None."""
     L = _lib.lib()
     ybs, yrs, ysc, yss = yaddr if yaddr is not None else (P * cout, cout, 1 << 30, 0)
     fuse_pn = bool(flags & LF_EPI_PIXELNORM) and cout <= 128
     kflags = flags if fuse_pn else (flags & ~LF_EPI_PIXELNORM)
     norm = torch.empty(N * P, device=y2d.device, dtype=torch.float32) if (flags & LF_EPI_PIXELNORM) else None
-    check(L.lf_conv1x1_fwd(_ptr(x_ptr_tensor), _ptr(wpack), _ptr(bias) if bias is not None else None, _ptr(y2d),
-                           _ptr(norm) if (norm is not None and fuse_pn) else None,
-                           N, P, cin, ksl, xbs, xss, cout, ybs, yrs, ysc, yss, he, kflags, SLOPE, PN_EPS, _stream()),
-          'lf_conv1x1_fwd')
+    if xscale is not None:
+        assert xscale.numel() == N * ksl * P and xscale.dtype == torch.float32 and xscale.is_contiguous()
+        check(L.lf_conv1x1_fwd_scaled(_ptr(x_ptr_tensor), _ptr(xscale), _ptr(wpack), _ptr(bias) if bias is not None else None, _ptr(y2d),
+                                      _ptr(norm) if (norm is not None and fuse_pn) else None,
+                                      N, P, cin, ksl, xbs, xss, cout, ybs, yrs, ysc, yss, he, kflags, SLOPE, PN_EPS, _stream()),
+              'lf_conv1x1_fwd_scaled')
+    else:
+        check(L.lf_conv1x1_fwd(_ptr(x_ptr_tensor), _ptr(wpack), _ptr(bias) if bias is not None else None, _ptr(y2d),
+                               _ptr(norm) if (norm is not None and fuse_pn) else None,
+                               N, P, cin, ksl, xbs, xss, cout, ybs, yrs, ysc, yss, he, kflags, SLOPE, PN_EPS, _stream()),
+              'lf_conv1x1_fwd')
     if (flags & LF_EPI_PIXELNORM) and not fuse_pn:
         check(L.lf_pixelnorm_fwd(_ptr(y2d), _ptr(y2d), _ptr(norm), N * P, cout, PN_EPS, _stream()), 'lf_pixelnorm_fwd')
     return norm
