@@ -402,6 +402,11 @@ int lf_occ_conv17_bwd(const float* g, const float* t16, const float* w27, float*
 int lf_column_reduce_sum_fwd(const float* x, float* y, int N, int D, long P, int C, void* stream);
 int lf_column_reduce_sum_bwd(const float* gy, float* gx, int N, int D, long P, int C, void* stream);
 int lf_column_softmax_fwd(const float* logits, float* weights, float* zdepth, int N, int D, long P, void* stream);
+/* The same with the logits formed on the way in: logit[n][d][p] = (sum_c y[n][d][p][c] * w16[c]) * he + bias[0] over a channels-last
+ * 16-channel volume y (the occlusion module's 16 -> 1 output block without activation, reference recon/models.py:378-388 over
+ * modules/unet.py / blocks.py OutputBlock); the logits volume is not written.  D <= 256; y and w16 16-byte aligned. */
+int lf_column_softmax_head_fwd(const float* y, const float* w16, const float* bias, float he, float* weights, float* zdepth,
+                               int N, int D, long P, void* stream);
 int lf_column_softmax_bwd(const float* weights, const float* gweights, const float* gzdepth, float* glogits,
                           int N, int D, long P, void* stream);
 int lf_column_scale_fwd(const float* z, const float* w, float* out, long rows, int C, void* stream);

@@ -93,6 +93,7 @@ SIGNATURES = {
     'lf_column_reduce_sum_fwd': (c_int, [P, P, c_int, c_int, c_long, c_int, P]),
     'lf_column_reduce_sum_bwd': (c_int, [P, P, c_int, c_int, c_long, c_int, P]),
     'lf_column_softmax_fwd': (c_int, [P, P, P, c_int, c_int, c_long, P]),
+    'lf_column_softmax_head_fwd': (c_int, [P, P, P, c_float, P, P, c_int, c_int, c_long, P]),
     'lf_column_softmax_bwd': (c_int, [P, P, P, P, c_int, c_int, c_long, P]),
     'lf_column_scale_fwd': (c_int, [P, P, P, c_long, c_int, P]),
     'lf_column_scale_bwd': (c_int, [P, P, P, P, P, c_long, c_int, P]),

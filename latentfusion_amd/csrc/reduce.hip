@@ -132,6 +132,72 @@ __global__ void __launch_bounds__(256) column_softmax_fwd_kernel(const float* __
   }
 }
 
+// The same with the logits formed on the way in (round 6): logit[n][d][p] = (sum_c y[n][d][p][c] * w[c]) * he + bias, the occlusion
+// module's 16 -> 1 output block (reference modules/blocks.py OutputBlock without activation) over a channels-last 16-channel
+// volume.  Every record is read ONCE (a thread keeps the <= 16 logits of its depth slices in registers: D <= 256) and the
+// logits volume is never written -- the pointwise launch that produced it read the same 64 bytes per voxel for 4 bytes out.
+constexpr int CSH_MAX = 16;                                        // depth values per thread at most
+__global__ void __launch_bounds__(256) column_softmax_head_fwd_kernel(const f32x4* __restrict__ y, const float* __restrict__ w16,
+                                                                      const float* __restrict__ bias, float he,
+                                                                      float* __restrict__ wout, float* __restrict__ zdepth,
+                                                                      int D, long P, float step) {
+  __shared__ float lds[4][16];
+  ColRed cr;
+  cr.lds = lds; cr.lane = threadIdx.x & 63; cr.w = threadIdx.x >> 6; cr.col = cr.lane & 15;
+  const int slice = cr.w * 4 + (cr.lane >> 4);
+  const long p = (long)blockIdx.x * 16 + cr.col;
+  const long n = blockIdx.y;
+  const bool live = p < P;
+  const f32x4 w0 = *(const f32x4*)w16, w1 = *(const f32x4*)(w16 + 4), w2 = *(const f32x4*)(w16 + 8), w3 = *(const f32x4*)(w16 + 12);
+  const float b = bias != nullptr ? bias[0] : 0.f;
+  const f32x4* src = y + ((n * D) * P + (live ? p : 0)) * 4;
+  float lg[CSH_MAX];
+  float m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < CSH_MAX; ++i) {
+    const int d = slice + 16 * i;
+    lg[i] = -INFINITY;
+    if (live && d < D) {
+      const f32x4* r = src + (long)d * P * 4;
+      const f32x4 a0 = r[0], a1 = r[1], a2 = r[2], a3 = r[3];
+      float sum = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) sum += a0[c] * w0[c];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) sum += a1[c] * w1[c];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) sum += a2[c] * w2[c];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) sum += a3[c] * w3[c];
+      lg[i] = sum * he + b;
+      m = fmaxf(m, lg[i]);
+    }
+  }
+  m = column_allreduce<true>(m, cr);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < CSH_MAX; ++i)
+    if (live && slice + 16 * i < D) { lg[i] = expf(lg[i] - m); s += lg[i]; }
+  s = column_allreduce<false>(s, cr);
+  float mom = 0.f;
+  if (live) {
+    float* dst = wout ? wout + (n * D) * P + p : nullptr;
+#pragma unroll
+    for (int i = 0; i < CSH_MAX; ++i) {
+      const int d = slice + 16 * i;
+      if (d < D) {
+        const float wv = lg[i] / s;
+        if (dst) dst[(long)d * P] = wv;
+        mom += depth_coord(d, D, step) * wv;
+      }
+    }
+  }
+  if (zdepth != nullptr) {
+    mom = column_allreduce<false>(mom, cr);
+    if (live && threadIdx.x < 16) zdepth[n * P + p] = mom;
+  }
+}
+
 // glogits_d = w_d (t_d - sum_e w_e t_e),  t_d = gw_d + gz * coord_d
 __global__ void __launch_bounds__(256) column_softmax_bwd_kernel(const float* __restrict__ wts, const float* __restrict__ gw,
                                                                  const float* __restrict__ gz, float* __restrict__ glogits,
@@ -382,6 +448,17 @@ extern "C" int lf_column_softmax_fwd(const float* logits, float* weights, float*
   if (N <= 0 || D <= 0 || P <= 0 || N > 65535 || (weights == nullptr && zdepth == nullptr)) return LF_EINVAL;
   hipLaunchKernelGGL(column_softmax_fwd_kernel, dim3((unsigned)((P + 15) / 16), N), dim3(256), 0, (hipStream_t)stream, logits,
                      weights, zdepth, D, P, lin_step(D));
+  return lf_launch_status();
+}
+
+extern "C" int lf_column_softmax_head_fwd(const float* y, const float* w16, const float* bias, float he, float* weights, float* zdepth,
+                                         int N, int D, long P, void* stream) {
+  lf_clear_error();
+  if (N <= 0 || D <= 0 || P <= 0 || N > 65535 || D > 16 * CSH_MAX || y == nullptr || w16 == nullptr ||
+      (weights == nullptr && zdepth == nullptr)) return LF_EINVAL;
+  if (!lf_aligned16(y) || !lf_aligned16(w16)) return LF_EALIGN;
+  hipLaunchKernelGGL(column_softmax_head_fwd_kernel, dim3((unsigned)((P + 15) / 16), N), dim3(256), 0, (hipStream_t)stream, (const f32x4*)y,
+                     w16, bias, he, weights, zdepth, D, P, lin_step(D));
   return lf_launch_status();
 }
 

@@ -391,7 +391,7 @@ class RenderLoopEngine:
         rest = [(c.bias, ops.he_constant(c.module.weight), pk(c.module.weight), pk(c.module.weight, transpose=True)) for c in convs[1:]]
         wo2 = wo.detach().reshape(1, 16)
         head = (ob.conv.bias, ops.he_constant(wo), ops.pack_conv1x1(wo2), ops.pack_conv1x1(wo2.t().contiguous()))
-        return dict(wi=wi.contiguous(), bi=bi, first=first, rest=rest, head=head)
+        return dict(wi=wi.contiguous(), bi=bi, first=first, rest=rest, head=head, head_w16=wo2.reshape(16).float().contiguous())
 
     def _occlusion_fwd(self, zc, flags):
         """zc: output of the last camera block (n,16,S,S,S).  Returns (zs = zc * softmax_D(occlusion logits), saved)."""
@@ -414,11 +414,17 @@ class RenderLoopEngine:
             ys.append(y)
             ns.append(nrm)
         hb, hhe, hpk, _hpkt = o['head']
-        logits = torch.empty(n, 1, D, H, W, device=dev, dtype=torch.float32)
-        ops._conv1x1_raw(ys[-1], hpk, hb, n, D * P, 16, 1, D * P * 16, 0, 1, logits, hhe, 0)
-        wocc = torch.empty_like(logits)
-        with ops._timed('column_softmax'):
-            check(L.lf_column_softmax_fwd(logits.data_ptr(), wocc.data_ptr(), None, n, D, P, s), 'lf_column_softmax_fwd')
+        wocc = torch.empty(n, 1, D, H, W, device=dev, dtype=torch.float32)
+        if self.OCC_FUSE_SCALE and D <= 256:
+            # (round 6) output block + softmax over the depth column in one pass over the last activation: no logits volume
+            with ops._timed('column_softmax_head'):
+                check(L.lf_column_softmax_head_fwd(ys[-1].data_ptr(), o['head_w16'].data_ptr(), hb.data_ptr() if hb is not None else None,
+                                                   hhe, wocc.data_ptr(), None, n, D, P, s), 'lf_column_softmax_head_fwd')
+        else:
+            logits = torch.empty(n, 1, D, H, W, device=dev, dtype=torch.float32)
+            ops._conv1x1_raw(ys[-1], hpk, hb, n, D * P, 16, 1, D * P * 16, 0, 1, logits, hhe, 0)
+            with ops._timed('column_softmax'):
+                check(L.lf_column_softmax_fwd(logits.data_ptr(), wocc.data_ptr(), None, n, D, P, s), 'lf_column_softmax_fwd')
         if self.proj is not None and self.OCC_FUSE_SCALE:
             # (round 6) the factor projection scales its operand itself (lf_conv1x1_fwd_scaled): the scaled volume is never written
             return None, (ta, t16, ys, ns, wocc)
