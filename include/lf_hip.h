@@ -387,7 +387,8 @@ int lf_resample3d_bwd_vol_det_io(const void* gout, const float* coef, int kind, 
  *   lf_occ_conv17_bwd  gp16[u] = LeakyReLU'(t16[u]) * sum_taps sum_co w27[tap][co] * g[u - (tap - 1)][co]
  *                      (both on v_mfma_f32_16x16x4_f32: the forward as a 16 x 27 by 27 x voxels product, the backward as
  *                      h[tap][voxel] = W g per z plane into LDS followed by the shifted sums)
- *   lf_occ_input_bwd   gz = g_zs * wocc[row] + W1[:16]^T (gta * LeakyReLU'(ta)) + W1[16] * gp16   (g_zs / wocc: the direct term of
+ *   lf_occ_input_bwd   gz = g_zs * wocc[row] + W1[:16]^T (gta * LeakyReLU'(ta)) + W1[16] * gp16   (ta == NULL: gta already carries
+ *                      LeakyReLU'(ta) -- the data gradient that produced it applied it, prev_y = ta; g_zs / wocc: the direct term of
  *                      the occlusion scaling z * wocc, both NULL to leave it out); prev_y != NULL: followed by the epilogue
  *                      backward of the layer that produced z (saved output prev_y, norm prev_norm, prev_flags), as in
  *                      lf_conv3x3_bwd_data */
@@ -396,6 +397,18 @@ int lf_occ_input_fwd(const float* z, const float* w, const float* b, float* ta, 
 int lf_occ_input_bwd(const float* gta, const float* ta, const float* gp16, const float* w, const float* g_zs, const float* wocc,
                      float* gz, long rows, float slope, const float* prev_y, const float* prev_norm, unsigned prev_flags,
                      void* stream);
+/* lf_occ_input_bwd with the factor projection's data gradient recomputed instead of read (round 6): the direct term of the scaling is
+ * ((Wp_d^T gp2d[n][pixel]) * he_p) * wocc[voxel] with wpack_t = the transposed projection pack lf_conv1x1_bwd_data takes
+ * ([D * 16 rows (d, c)][16 cout]) and gp2d the (N, H*W, 16) gradient of the projection's pre-activation; gta must already carry
+ * LeakyReLU'(ta) (the data gradient that produced it ran with prev_y = ta).  P % 16 == 0, N*D*P < 2^31. */
+int lf_occ_input_bwd_proj(const float* gta, const float* gp16, const float* w, const float* gp2d, const float* wpack_t, float he_p,
+                          const float* wocc, float* gz, int N, int D, long P, float slope,
+                          const float* prev_y, const float* prev_norm, unsigned prev_flags, void* stream);
+/* Data gradient of the occlusion module's 16 -> 1 output block (no activation) onto the 16-channel activation y that fed it, with
+ * the LeakyReLU' / PixelNorm' of the layer that produced y (its norm, flags) applied in the store:
+ *   g[v][c] = epilogue'( (gl[v] * w16[c]) * he )          (rows voxels; what lf_conv1x1_bwd_data(Cin = 1, prev_y = y) computes, same bits) */
+int lf_occ_head_bwd(const float* gl, const float* w16, float he, const float* y, const float* norm, unsigned flags, float slope,
+                    float* g, long rows, void* stream);
 int lf_occ_conv17_fwd(const float* t16, const float* w27, float* pre, int N, int D, int H, int W, void* stream);
 int lf_occ_conv17_bwd(const float* g, const float* t16, const float* w27, float* gp16, int N, int D, int H, int W, float slope,
                       void* stream);

@@ -152,7 +152,7 @@ __device__ __forceinline__ void epilogue_store(f32x4 (&acc)[NT][NR], const long 
       }
       }
     }
-    if (rowoff[j] >= 0) {
+    if (rowoff[j] >= 0 && y != nullptr) {                          // (y == NULL: LF_EPI_DOT launches that only want the sums)
       float* dst = y + rowoff[j];
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
@@ -826,6 +826,7 @@ static int conv1x1_launch(const float* x, const float* wpack, const float* bias,
   if (ksl > 1 && (Cin & 3)) return LF_EALIGN;     // a lane's 4-channel group must not straddle slices
   if ((flags & LF_EPI_PIXELNORM) && Cout > 128) return LF_EINVAL;
   if (!lf_aligned16(x) || !lf_aligned16(y) || !lf_aligned16(wpack)) return LF_EALIGN;
+  if (y == nullptr && !(prev_y != nullptr && (prev_flags & LF_EPI_DOT))) return LF_EINVAL;
   if ((Cin & 3) == 0 && ((x_batch_stride | x_slice_stride) & 3)) return LF_EALIGN;
   const int K = ksl * Cin, Kp = (K + 15) & ~15;
   const int CoutP = lf_conv1x1_cout_padded(Cout);

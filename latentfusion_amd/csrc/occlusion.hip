@@ -129,7 +129,9 @@ __global__ void __launch_bounds__(256) occ_input_bwd_kernel(const f32x4* __restr
   if (g_zs != nullptr) acc = g_zs[row * 4 + q] * wocc[row];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const f32x4 g = gta[row * 4 + k], t = ta[row * 4 + k];
+    const f32x4 g = gta[row * 4 + k];
+    f32x4 t = (f32x4){1.f, 1.f, 1.f, 1.f};                          // (ta == NULL: gta already carries lrelu'(ta))
+    if (ta != nullptr) t = ta[row * 4 + k];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const float gp = t[c] > 0.f ? g[c] : g[c] * slope;
@@ -154,6 +156,111 @@ __global__ void __launch_bounds__(256) occ_input_bwd_kernel(const f32x4* __restr
     }
   }
   if (live) gz[row * 4 + q] = acc;
+}
+
+// The input block's backward on the fp32 matrix pipe, with the factor projection's data gradient recomputed instead of read
+// (round 6).  The lane-per-quarter form above is bound by its own loads and LDS-fed FMAs (0.96 ms per 8 x 128^3 launch; taking
+// one of its five volume reads away moved it by 2 %).  Here lane (n = voxel, kg) loads ITS quarter of each record once:
+//   W1[:16]^T gta   four v_mfma_f32_16x16x4_f32 steps, A = W1[j = 4 kg + i][c = n]  (gta already carries LeakyReLU'(ta))
+//   g_zs            = (Wp_d^T gp2d[pixel]) * he_p for the voxel's depth d: four more steps, A = wpt[(d * 16 + n) * 16 + 4 kg + i],
+//                   B = the lane's quarter of the 2-D gradient row (8 MB in all: L2) -- the 1 GB gradient volume the projection's
+//                   data gradient used to write, and this kernel to read, does not exist; times wocc[voxel] it is the direct term
+//   + W1[16][c] * gp16, then the epilogue backward of the layer that produced z, and the quarter record is stored.
+__global__ void __launch_bounds__(256) occ_input_bwd_mfma_kernel(const f32x4* __restrict__ gta, const float* __restrict__ gp16,
+                                                                 const float* __restrict__ w, const f32x4* __restrict__ gp2d,
+                                                                 const float* __restrict__ wpt, float he_p,
+                                                                 const float* __restrict__ wocc, f32x4* __restrict__ gz,
+                                                                 unsigned rows, unsigned D, unsigned P, float slope,
+                                                                 const f32x4* __restrict__ prev_y, const float* __restrict__ prev_norm,
+                                                                 unsigned prev_flags) {
+  const int lane = threadIdx.x & 63, n = lane & 15, kg = lane >> 4;
+  const unsigned g0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * (unsigned)OIF_GPW;
+  const unsigned groups = (rows + 15u) >> 4;
+  if (g0 >= groups) return;                                        // (wave-uniform)
+  float a1[4];                                                    // W1[4 kg + i][n]
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a1[i] = w[(kg * 4 + i) * 20 + n];
+  const f32x4 w16 = *(const f32x4*)(w + 16 * 20 + kg * 4);        // W1[16][4 kg .. +3]
+  const unsigned ng = min((unsigned)OIF_GPW, groups - g0);
+  f32x4 xg[OIF_GPW], xp[OIF_GPW], xy[OIF_GPW], aw[OIF_GPW];
+  float s16[OIF_GPW], so[OIF_GPW], sn[OIF_GPW];
+#pragma unroll
+  for (int gi = 0; gi < OIF_GPW; ++gi) {
+    const unsigned v = min((g0 + gi) * 16u + n, rows - 1u);        // (dead lanes shadow the last row)
+    const bool on = gi < (int)ng;
+    const unsigned smp = v / (D * P), pix = v % P, d = (v / P) % D;
+    xg[gi] = on ? gta[(size_t)v * 4 + kg] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    xp[gi] = on ? gp2d[((size_t)smp * P + pix) * 4 + kg] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    aw[gi] = on ? *(const f32x4*)(wpt + ((size_t)d * 16 + n) * 16 + kg * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    xy[gi] = (on && prev_y != nullptr) ? prev_y[(size_t)v * 4 + kg] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    s16[gi] = on ? gp16[v] : 0.f;
+    so[gi] = on ? wocc[v] : 0.f;
+    sn[gi] = (on && (prev_flags & LF_EPI_PIXELNORM)) ? prev_norm[v] : 1.f;
+  }
+#pragma unroll
+  for (int gi = 0; gi < OIF_GPW; ++gi) {
+    if (gi >= (int)ng) break;                                      // (wave-uniform)
+    const unsigned v = (g0 + gi) * 16u + n;
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, gzs = acc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i], xg[gi][i], acc, 0, 0, 0);
+      gzs = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[gi][i], xp[gi][i], gzs, 0, 0, 0);
+    }
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = ((gzs[j] * he_p) * so[gi] + acc[j]) + w16[j] * s16[gi];
+    if (prev_y != nullptr) {
+      const f32x4 vb = xy[gi];
+      if (prev_flags & LF_EPI_PIXELNORM) {
+        float dot = o[0] * vb[0] + o[1] * vb[1] + o[2] * vb[2] + o[3] * vb[3];
+        dot += __shfl_xor(dot, 16, 64);
+        dot += __shfl_xor(dot, 32, 64);
+        dot *= (1.f / 16.f);
+        const float r = sn[gi];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (o[e] - vb[e] * dot) / r;
+      }
+      if (prev_flags & LF_EPI_LRELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = vb[e] > 0.f ? o[e] : o[e] * slope;
+      }
+    }
+    if (v < rows) gz[(size_t)v * 4 + kg] = o;
+  }
+}
+
+// Data gradient of the 16 -> 1 output block onto the last 16-channel activation, with that layer's epilogue backward in the store
+// (round 6; was lf_conv1x1_bwd_data with K = 1 padded to an MFMA step: 0.55 ms per 8 x 128^3 launch for 2.3 GB):
+//   g[v][c] = lrelu'(y[v][c]) * (t[c] - y[v][c] * mean_c(t * y[v])) / norm[v],   t[c] = (gl[v] * w[c]) * he
+// One lane per quarter record, the same products, the same order of the partial sums => the same bits.
+__global__ void __launch_bounds__(256) occ_head_bwd_kernel(const float* __restrict__ gl, const float* __restrict__ w16, float he,
+                                                           const f32x4* __restrict__ y, const float* __restrict__ norm, unsigned flags,
+                                                           float slope, f32x4* __restrict__ g, long rows) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const int q = (int)(i & 3);
+  const bool live = (i >> 2) < rows;
+  const long row = live ? (i >> 2) : rows - 1;                    // (dead lanes shadow the last row: the shuffles stay defined)
+  const f32x4 wq = *(const f32x4*)(w16 + q * 4);
+  const f32x4 yp = y[row * 4 + q];
+  const float gv = gl[row];
+  f32x4 t;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) t[e] = (gv * wq[e]) * he;
+  if (flags & LF_EPI_PIXELNORM) {
+    float dot = t[0] * yp[0] + t[1] * yp[1] + t[2] * yp[2] + t[3] * yp[3];
+    dot += __shfl_xor(dot, 1, 64);
+    dot += __shfl_xor(dot, 2, 64);
+    dot *= (1.f / 16.f);
+    const float rinv = 1.0f / norm[row];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) t[e] = (t[e] - yp[e] * dot) * rinv;
+  }
+  if (flags & LF_EPI_LRELU) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) t[e] = yp[e] > 0.f ? t[e] : t[e] * slope;
+  }
+  if (live) g[row * 4 + q] = t;
 }
 
 // pre[v][co] = sum_taps w27[tap][co] * t16[v + tap - 1]  (zero padding), w27 = W2[:, 16] * he as [kz*9 + ky*3 + kx][16].
@@ -182,23 +289,21 @@ __global__ void __launch_bounds__(256) occ_conv17_fwd_kernel(const float* __rest
     dx[s] = kx - 1;
     dl[s] = ((kz - 1) * H + (ky - 1)) * W + (kx - 1);
   }
-  long v = g0 * 16 + n;
-  int x = (int)(v % W), y = (int)((v / W) % H), z = (int)((v / ((long)W * H)) % D);
+  const long v0 = g0 * 16 + n;
+  int x = (int)(v0 % W), y = (int)((v0 / W) % H), z = (int)((v0 / ((long)W * H)) % D);
+  // (round 6) all neighbour values of the wave's 8 groups are requested first (56 loads in flight per lane instead of 7 behind
+  // each group's stores)
+  float b[C17_GPW][7];
+#pragma unroll
   for (int gi = 0; gi < C17_GPW; ++gi) {
-    if (g0 + gi >= groups) break;                                  // (wave-uniform)
-    const bool live = v < rows;
-    float b[7];
+    const long v = v0 + 16 * gi;
+    const bool live = g0 + gi < groups && v < rows;
 #pragma unroll
     for (int s = 0; s < 7; ++s) {
       const bool ok = live && (unsigned)(z + dz[s]) < (unsigned)D && (unsigned)(y + dy[s]) < (unsigned)H && (unsigned)(x + dx[s]) < (unsigned)W;
-      const float t = t16[ok ? v + dl[s] : (live ? v : 0)];
-      b[s] = ok ? t : 0.f;
+      b[gi][s] = 0.f;
+      if (ok) b[gi][s] = t16[v + dl[s]];
     }
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < 7; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
-    if (live) pre[v * 4 + kg] = acc;
-    v += 16;
     x += 16;
     while (x >= W) {
       x -= W;
@@ -207,6 +312,15 @@ __global__ void __launch_bounds__(256) occ_conv17_fwd_kernel(const float* __rest
         if (++z >= D) z = 0;
       }
     }
+  }
+#pragma unroll
+  for (int gi = 0; gi < C17_GPW; ++gi) {
+    if (g0 + gi >= groups) break;                                  // (wave-uniform)
+    const long v = v0 + 16 * gi;
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 7; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[gi][s], acc, 0, 0, 0);
+    if (v < rows) pre[v * 4 + kg] = acc;
   }
 }
 
@@ -220,10 +334,11 @@ __global__ void __launch_bounds__(256) occ_conv17_fwd_kernel(const float* __rest
 // A workgroup walks C17_ZR output planes down z, so every gradient record is loaded (18 / 16)^2 (1 + 2 / C17_ZR) = 1.4 times
 // instead of 13.5 times by the lane-per-quarter form it replaces (0.89 ms at 8 x 64^3, bound by those loads).
 constexpr int C17_ZR = 16, C17_HS = 336;                         // planes per workgroup; LDS slots per tap (324 halo voxels, padded to 21 x 16)
+constexpr int C17_LS = 340;                                       // LDS row stride per tap: 4 rows apart = 16 banks apart (stage A's four lane groups write two-way, not four-way)
 __global__ void __launch_bounds__(256) occ_conv17_bwd_kernel(const f32x4* __restrict__ g, const float* __restrict__ t16,
                                                              const float* __restrict__ w27, float* __restrict__ gp16,
                                                              int D, int H, int W, int nzr, int nty, int ntx, float slope) {
-  __shared__ float hT[28 * C17_HS];
+  __shared__ float hT[28 * C17_LS];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, kg = lane >> 4;
   int b = blockIdx.x;
   const int bx = b % ntx; b /= ntx;
@@ -244,17 +359,34 @@ __global__ void __launch_bounds__(256) occ_conv17_bwd_kernel(const f32x4* __rest
   const bool col_ok = y0 + ty < H && x0 + tx < W;
   const long vol = (long)D * H * W;
   float accm = 0.f, acc0 = 0.f, accp = 0.f;                        // sums of output planes p - 1, p, p + 1
+  // (round 6) a wave's <= 6 record groups of a plane are requested together, and the NEXT plane's before this plane's barrier and
+  // stage B: the kernel ran one dependent load per group and wave at a time (0.51 ms per 8 x 128^3 launch = 2.2 TB/s of the
+  // gradient volume it reads)
+  constexpr int NGW = (C17_HS / 16 + 3) / 4;                       // groups per wave: 6 (waves 0: 0, 4, .., 20)
+  f32x4 rg[NGW];
+  auto load_plane = [&](int p) {
+    const bool pin = p >= 0 && p < D;
+#pragma unroll
+    for (int k = 0; k < NGW; ++k) {
+      const int grp = wv + 4 * k;
+      const int q = grp * 16 + n;
+      const int yy = y0 - 1 + q / 18, xx = x0 - 1 + q % 18;
+      const bool ok = pin && grp < C17_HS / 16 && q < 324 && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+      rg[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (ok) rg[k] = g[(smp * vol + ((long)p * H + yy) * W + xx) * 4 + kg];
+    }
+  };
+  load_plane(z0 - 1);
   for (int p = z0 - 1; p <= z0 + C17_ZR && p <= D; ++p) {
     const bool plane_in = p >= 0 && p < D;                         // (workgroup-uniform)
     if (plane_in) {
       // ---- stage A: 21 groups of 16 halo voxels, wave wv takes groups wv, wv + 4, ...
-      for (int grp = wv; grp < C17_HS / 16; grp += 4) {
+#pragma unroll
+      for (int k = 0; k < NGW; ++k) {
+        const int grp = wv + 4 * k;
+        if (grp >= C17_HS / 16) break;                             // (wave-uniform)
         const int q = grp * 16 + n;                                // halo slot of this lane's voxel
-        const int yy = y0 - 1 + q / 18, xx = x0 - 1 + q % 18;
-        const bool ok = q < 324 && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
-        const long v = smp * vol + ((long)p * H + (ok ? yy : 0)) * W + (ok ? xx : 0);
-        f32x4 r = g[v * 4 + kg];
-        if (!ok) r = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const f32x4 r = rg[k];
         f32x4 d0 = (f32x4){0.f, 0.f, 0.f, 0.f}, d1 = d0;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -263,11 +395,12 @@ __global__ void __launch_bounds__(256) occ_conv17_bwd_kernel(const f32x4* __rest
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          hT[(4 * kg + i) * C17_HS + q] = d0[i];                   // taps 0..15
-          if (16 + 4 * kg + i < 28) hT[(16 + 4 * kg + i) * C17_HS + q] = d1[i];   // taps 16..27 (27 = the zero slot)
+          hT[(4 * kg + i) * C17_LS + q] = d0[i];                   // taps 0..15
+          if (16 + 4 * kg + i < 28) hT[(16 + 4 * kg + i) * C17_LS + q] = d1[i];   // taps 16..27 (27 = the zero slot)
         }
       }
     }
+    if (p + 1 <= z0 + C17_ZR && p + 1 <= D) load_plane(p + 1);     // in flight across the barrier and stage B
     __syncthreads();
     if (plane_in) {
       // ---- stage B: source voxel of tap (kz, ky, kx) for output (ty, tx) = halo slot (ty + 2 - ky, tx + 2 - kx) of this plane
@@ -277,9 +410,9 @@ __global__ void __launch_bounds__(256) occ_conv17_bwd_kernel(const f32x4* __rest
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
           const int slot = (ty + 2 - ky) * 18 + (tx + 2 - kx);
-          sm += hT[(0 * 9 + ky * 3 + kx) * C17_HS + slot];
-          s0 += hT[(1 * 9 + ky * 3 + kx) * C17_HS + slot];
-          sp += hT[(2 * 9 + ky * 3 + kx) * C17_HS + slot];
+          sm += hT[(0 * 9 + ky * 3 + kx) * C17_LS + slot];
+          s0 += hT[(1 * 9 + ky * 3 + kx) * C17_LS + slot];
+          sp += hT[(2 * 9 + ky * 3 + kx) * C17_LS + slot];
         }
       accm += sm;
       acc0 += s0;
@@ -322,14 +455,43 @@ extern "C" int lf_occ_input_bwd(const float* gta, const float* ta, const float* 
                                 const float* wocc, float* gz, long rows, float slope, const float* prev_y, const float* prev_norm,
                                 unsigned prev_flags, void* stream) {
   lf_clear_error();
-  if (rows <= 0 || !gta || !ta || !gp16 || !w || !gz || ((g_zs == nullptr) != (wocc == nullptr))) return LF_EINVAL;
+  if (rows <= 0 || !gta || !gp16 || !w || !gz || ((g_zs == nullptr) != (wocc == nullptr))) return LF_EINVAL;
   if ((prev_flags & ~(LF_EPI_LRELU | LF_EPI_PIXELNORM)) || (prev_y == nullptr && prev_flags != 0) ||
       ((prev_flags & LF_EPI_PIXELNORM) && prev_norm == nullptr)) return LF_EINVAL;
-  if (!lf_aligned16(gta) || !lf_aligned16(ta) || !lf_aligned16(gz) || (g_zs && !lf_aligned16(g_zs)) ||
+  if (!lf_aligned16(gta) || (ta && !lf_aligned16(ta)) || !lf_aligned16(gz) || (g_zs && !lf_aligned16(g_zs)) ||
       (prev_y && !lf_aligned16(prev_y))) return LF_EALIGN;
   hipLaunchKernelGGL(occ_input_bwd_kernel, dim3((unsigned)((rows * 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const f32x4*)gta,
                      (const f32x4*)ta, gp16, w, (const f32x4*)g_zs, wocc, (f32x4*)gz, rows, slope, (const f32x4*)prev_y, prev_norm,
                      prev_flags);
+  return lf_launch_status();
+}
+
+extern "C" int lf_occ_input_bwd_proj(const float* gta, const float* gp16, const float* w, const float* gp2d, const float* wpack_t,
+                                     float he_p, const float* wocc, float* gz, int N, int D, long P, float slope,
+                                     const float* prev_y, const float* prev_norm, unsigned prev_flags, void* stream) {
+  lf_clear_error();
+  if (N <= 0 || D <= 0 || P <= 0 || !gta || !gp16 || !w || !gp2d || !wpack_t || !wocc || !gz) return LF_EINVAL;
+  if ((prev_flags & ~(LF_EPI_LRELU | LF_EPI_PIXELNORM)) || (prev_y == nullptr && prev_flags != 0) ||
+      ((prev_flags & LF_EPI_PIXELNORM) && prev_norm == nullptr)) return LF_EINVAL;
+  const long rows = (long)N * D * P;
+  if (rows >= 0x7fffffffL || (P & 15)) return LF_EINVAL;             // (a group of 16 voxels lies in one depth plane)
+  if (!lf_aligned16(gta) || !lf_aligned16(gz) || !lf_aligned16(gp2d) || !lf_aligned16(wpack_t) || !lf_aligned16(w) ||
+      (prev_y && !lf_aligned16(prev_y))) return LF_EALIGN;
+  const long groups = (rows + 15) / 16;
+  hipLaunchKernelGGL(occ_input_bwd_mfma_kernel, dim3((unsigned)((groups + 4 * OIF_GPW - 1) / (4 * OIF_GPW))), dim3(256), 0, (hipStream_t)stream,
+                     (const f32x4*)gta, gp16, w, (const f32x4*)gp2d, wpack_t, he_p, wocc, (f32x4*)gz, (unsigned)rows, (unsigned)D,
+                     (unsigned)P, slope, (const f32x4*)prev_y, prev_norm, prev_flags);
+  return lf_launch_status();
+}
+
+extern "C" int lf_occ_head_bwd(const float* gl, const float* w16, float he, const float* y, const float* norm, unsigned flags,
+                               float slope, float* g, long rows, void* stream) {
+  lf_clear_error();
+  if (rows <= 0 || !gl || !w16 || !y || !g || (flags & ~(LF_EPI_LRELU | LF_EPI_PIXELNORM)) ||
+      ((flags & LF_EPI_PIXELNORM) && norm == nullptr)) return LF_EINVAL;
+  if (!lf_aligned16(y) || !lf_aligned16(g) || !lf_aligned16(w16)) return LF_EALIGN;
+  hipLaunchKernelGGL(occ_head_bwd_kernel, dim3((unsigned)((rows * 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gl, w16, he,
+                     (const f32x4*)y, norm, flags, slope, (f32x4*)g, rows);
   return lf_launch_status();
 }
 

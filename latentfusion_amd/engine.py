@@ -432,7 +432,7 @@ class RenderLoopEngine:
         check(L.lf_column_scale_fwd(zc.data_ptr(), wocc.data_ptr(), zs.data_ptr(), n * D * P, 16, s), 'lf_column_scale_fwd')
         return zs, (ta, t16, ys, ns, wocc)
 
-    def _occlusion_bwd(self, g_zs, zc, saved, flags, prev=None, gw=None):
+    def _occlusion_bwd(self, g_zs, zc, saved, flags, prev=None, gw=None, proj_bwd=None):
         """d/d(zs) -> d/d(zc): the scaling, the softmax, the output block, the four convolutions (each data-gradient launch folds
         in the LeakyReLU' / PixelNorm' of the layer it lands on) and the input block, plus the direct term of the scaling.
         prev = (zc, norm, flags) of the camera-block layer that produced zc: its epilogue backward is applied on the way out."""
@@ -450,20 +450,36 @@ class RenderLoopEngine:
         check(L.lf_column_softmax_bwd(wocc.data_ptr(), gw.data_ptr(), None, gl.data_ptr(), n, D, P, s), 'lf_column_softmax_bwd')
         _hb, hhe, _hpk, hpkt = o['head']
         g = ops.empty_cl(zc.shape, dev)
-        check(L.lf_conv1x1_bwd_data(gl.data_ptr(), hpkt.data_ptr(), g.data_ptr(), n, D * P, 1, 16, D * P * 16, 16, 16, 0, hhe,
-                                    ys[-1].data_ptr(), ns[-1].data_ptr(), flags, ops.SLOPE, None, s), 'lf_conv1x1_bwd_data')
+        if self.OCC_FUSE_SCALE:
+            with ops._timed('occ_head_bwd'):
+                check(L.lf_occ_head_bwd(gl.data_ptr(), o['head_w16'].data_ptr(), hhe, ys[-1].data_ptr(), ns[-1].data_ptr(), flags, ops.SLOPE,
+                                        g.data_ptr(), n * D * P, s), 'lf_occ_head_bwd')
+        else:
+            check(L.lf_conv1x1_bwd_data(gl.data_ptr(), hpkt.data_ptr(), g.data_ptr(), n, D * P, 1, 16, D * P * 16, 16, 16, 0, hhe,
+                                        ys[-1].data_ptr(), ns[-1].data_ptr(), flags, ops.SLOPE, None, s), 'lf_conv1x1_bwd_data')
         for i in range(len(o['rest']) - 1, -1, -1):
             _b, he, _pk, pkt = o['rest'][i]
             g = ops.conv3d_c16_wino(g, pkt, None, he, 0, prev=(ys[i], ns[i], flags))[0]
         _b2, he2, _pa, pat, w27 = o['first']
-        gta = ops.conv3d_c16_wino(g, pat, None, he2, 0)[0]
+        # (round 6) LeakyReLU' of the input block's outputs 0..15 rides in the store of this data gradient (prev = ta, no norm): the
+        # input block's backward then does not read ta
+        ta_in_store = self.OCC_FUSE_SCALE or proj_bwd is not None
+        gta = ops.conv3d_c16_wino(g, pat, None, he2, 0, prev=(ta, None, LF_EPI_LRELU) if ta_in_store else None)[0]
         gp16 = torch.empty_like(t16)
         with ops._timed('occ_conv17_bwd'):
             check(L.lf_occ_conv17_bwd(g.data_ptr(), t16.data_ptr(), w27.data_ptr(), gp16.data_ptr(), n, D, H, W, ops.SLOPE, s),
                   'lf_occ_conv17_bwd')
         gz = ops.empty_cl(zc.shape, dev)
+        if proj_bwd is not None:
+            gp2d, ppack_t, phe = proj_bwd
+            with ops._timed('occ_input_bwd'):
+                check(L.lf_occ_input_bwd_proj(gta.data_ptr(), gp16.data_ptr(), o['wi'].data_ptr(), gp2d.data_ptr(), ppack_t.data_ptr(), phe,
+                                              wocc.data_ptr(), gz.data_ptr(), n, D, P, ops.SLOPE, zc.data_ptr() if prev is not None else None,
+                                              prev[1].data_ptr() if prev is not None else None, prev[2] if prev is not None else 0, s),
+                      'lf_occ_input_bwd_proj')
+            return gz
         with ops._timed('occ_input_bwd'):
-            check(L.lf_occ_input_bwd(gta.data_ptr(), ta.data_ptr(), gp16.data_ptr(), o['wi'].data_ptr(), g_zs.data_ptr(),
+            check(L.lf_occ_input_bwd(gta.data_ptr(), None if ta_in_store else ta.data_ptr(), gp16.data_ptr(), o['wi'].data_ptr(), g_zs.data_ptr(),
                                      wocc.data_ptr(), gz.data_ptr(), n * D * P, ops.SLOPE, zc.data_ptr() if prev is not None else None,
                                      prev[1].data_ptr() if prev is not None else None, prev[2] if prev is not None else 0, s),
                   'lf_occ_input_bwd')
@@ -666,25 +682,29 @@ class RenderLoopEngine:
                 # then the occlusion module's explicit backward
                 if self.proj is not None:
                     gp = gp_explicit if (explicit and gp_explicit is not None) else ops._epilogue_bwd(ops.cl(g_zp), zp, pnorm, flags)
-                    g_zs = ops.empty_cl((n, Cl, S, S, S), dev)
-                    gw_occ = None
+                    gw_occ = proj_bwd = None
                     with ops._timed('factor_project_bwd'):
-                        if self.OCC_FUSE_SCALE and Cl == 16:
-                            # the same launch also sums g_zs * zc over the channels of every voxel (LF_EPI_DOT): the gradient of the
-                            # occlusion weights, without lf_column_scale_bwd's pass over both volumes
+                        if self.OCC_FUSE_SCALE and Cl == 16 and cout == 16 and (S * S) % 16 == 0:
+                            # the projection's data gradient is NOT stored: this launch only sums g_zs * zc over the channels of every
+                            # voxel (LF_EPI_DOT, gx = NULL) -- the gradient of the occlusion weights, without lf_column_scale_bwd's
+                            # pass over two volumes -- and the input block's backward recomputes g_zs where it needs it
+                            # (lf_occ_input_bwd_proj)
+                            g_zs = None
                             gw_occ = torch.empty(n, 1, S, S, S, device=dev, dtype=torch.float32)
-                            check(L.lf_conv1x1_bwd_data(gp.data_ptr(), ppack_t.data_ptr(), g_zs.data_ptr(), n, S * S, cout, S * Cl,
+                            check(L.lf_conv1x1_bwd_data(gp.data_ptr(), ppack_t.data_ptr(), None, n, S * S, cout, S * Cl,
                                                         S * S * S * Cl, Cl, Cl, S * S * Cl, phe, acts[-1].data_ptr(), gw_occ.data_ptr(),
                                                         _lib.LF_EPI_DOT, ops.SLOPE, None, s), 'lf_conv1x1_bwd_data')
+                            proj_bwd = (gp, ppack_t, phe)
                         else:
+                            g_zs = ops.empty_cl((n, Cl, S, S, S), dev)
                             ops._conv1x1_raw(gp, ppack_t, None, n, S * S, cout, 1, S * S * cout, 0, S * Cl, g_zs, phe, 0,
                                              yaddr=(S * S * S * Cl, Cl, Cl, S * S * Cl))
                 else:
                     g_zs = ops.cl(g_zp)
-                    gw_occ = None
+                    gw_occ = proj_bwd = None
                 landed = fuse and nconv > 0
                 g_zp = self._occlusion_bwd(g_zs, acts[-1], occ_saved, flags, (acts[nconv], norms[nconv - 1], flags) if landed else None,
-                                           gw=gw_occ)
+                                           gw=gw_occ, proj_bwd=proj_bwd)
             # g_zp is d/d(output of the last camera block); from here the explicit data-gradient chain
             g = ops.cl(g_zp)
             if fuse and nconv:
