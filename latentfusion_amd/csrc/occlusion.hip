@@ -83,12 +83,14 @@ __global__ void __launch_bounds__(256) occ_input_fwd_mfma_kernel(const f32x4* __
     const unsigned v = (g0 + gi) * 16u + n;
     x[gi] = (gi < (int)ng && v < rows) ? z[(size_t)v * 4 + kg] : (f32x4){0.f, 0.f, 0.f, 0.f};
   }
+  // (P % 16 == 0: the 16 voxels of a group share their depth plane; one division per WAVE, then the plane index is stepped --
+  //  with three integer divisions per lane and group these kernels were bound by their VALU, not by the HBM)
+  unsigned pb = (g0 * 16u) % P, d = ((g0 * 16u) / P) % D;
 #pragma unroll
   for (int gi = 0; gi < OIF_GPW; ++gi) {
     if (gi >= (int)ng) break;                                      // (wave-uniform)
     const unsigned v = (g0 + gi) * 16u + n;
     const bool live = v < rows;
-    const unsigned d = (v / P) % D;
     // torch.linspace(-1, 1, D): start + step * i in the first half, end - step * (D - 1 - i) in the second
     const float dc = D > 1 ? ((d < D / 2) ? -1.f + dstep * (float)d : 1.f - dstep * (float)(D - 1 - d)) : -1.f;
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -106,6 +108,8 @@ __global__ void __launch_bounds__(256) occ_input_fwd_mfma_kernel(const f32x4* __
     s16 += __shfl_xor(s16, 32, 64);
     s16 += b16 + wd16 * dc;
     if (live && kg == 0) t16[v] = s16 > 0.f ? s16 : s16 * slope;
+    pb += 16u;
+    if (pb >= P) { pb = 0u; if (++d >= D) d = 0u; }
   }
 }
 
@@ -184,11 +188,12 @@ __global__ void __launch_bounds__(256) occ_input_bwd_mfma_kernel(const f32x4* __
   const unsigned ng = min((unsigned)OIF_GPW, groups - g0);
   f32x4 xg[OIF_GPW], xp[OIF_GPW], xy[OIF_GPW], aw[OIF_GPW];
   float s16[OIF_GPW], so[OIF_GPW], sn[OIF_GPW];
+  unsigned smp = (g0 * 16u) / (D * P), d = ((g0 * 16u) / P) % D, pb = (g0 * 16u) % P;   // (wave-uniform; stepped per group)
 #pragma unroll
   for (int gi = 0; gi < OIF_GPW; ++gi) {
     const unsigned v = min((g0 + gi) * 16u + n, rows - 1u);        // (dead lanes shadow the last row)
     const bool on = gi < (int)ng;
-    const unsigned smp = v / (D * P), pix = v % P, d = (v / P) % D;
+    const unsigned pix = pb + n;
     xg[gi] = on ? gta[(size_t)v * 4 + kg] : (f32x4){0.f, 0.f, 0.f, 0.f};
     xp[gi] = on ? gp2d[((size_t)smp * P + pix) * 4 + kg] : (f32x4){0.f, 0.f, 0.f, 0.f};
     aw[gi] = on ? *(const f32x4*)(wpt + ((size_t)d * 16 + n) * 16 + kg * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -196,6 +201,8 @@ __global__ void __launch_bounds__(256) occ_input_bwd_mfma_kernel(const f32x4* __
     s16[gi] = on ? gp16[v] : 0.f;
     so[gi] = on ? wocc[v] : 0.f;
     sn[gi] = (on && (prev_flags & LF_EPI_PIXELNORM)) ? prev_norm[v] : 1.f;
+    pb += 16u;
+    if (pb >= P) { pb = 0u; if (++d >= D) { d = 0u; ++smp; } }
   }
 #pragma unroll
   for (int gi = 0; gi < OIF_GPW; ++gi) {
@@ -227,6 +234,45 @@ __global__ void __launch_bounds__(256) occ_input_bwd_mfma_kernel(const f32x4* __
       }
     }
     if (v < rows) gz[(size_t)v * 4 + kg] = o;
+  }
+}
+
+// Gradient of the occlusion weights through the factor projection (round 6): gw[v] = sum_c z[v][c] * g_zs[v][c] with
+// g_zs = (Wp_d^T gp2d[pixel]) * he_p recomputed per 16 voxels as in the kernel above -- one read of z, 4 bytes out per voxel
+// (was lf_conv1x1_bwd_data with LF_EPI_DOT: the generic pointwise kernel, 0.32 ms; before that lf_column_scale_bwd over two volumes).
+__global__ void __launch_bounds__(256) occ_weight_grad_kernel(const f32x4* __restrict__ z, const f32x4* __restrict__ gp2d,
+                                                              const float* __restrict__ wpt, float he_p, float* __restrict__ gw,
+                                                              unsigned rows, unsigned D, unsigned P) {
+  const int lane = threadIdx.x & 63, n = lane & 15, kg = lane >> 4;
+  const unsigned g0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * (unsigned)OIF_GPW;
+  const unsigned groups = (rows + 15u) >> 4;
+  if (g0 >= groups) return;                                        // (wave-uniform)
+  const unsigned ng = min((unsigned)OIF_GPW, groups - g0);
+  f32x4 xz[OIF_GPW], xp[OIF_GPW], aw[OIF_GPW];
+  unsigned smp = (g0 * 16u) / (D * P), d = ((g0 * 16u) / P) % D, pb = (g0 * 16u) % P;   // (wave-uniform; stepped per group)
+#pragma unroll
+  for (int gi = 0; gi < OIF_GPW; ++gi) {
+    const unsigned v = min((g0 + gi) * 16u + n, rows - 1u);
+    const bool on = gi < (int)ng;
+    const unsigned pix = pb + n;
+    xz[gi] = on ? z[(size_t)v * 4 + kg] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    xp[gi] = on ? gp2d[((size_t)smp * P + pix) * 4 + kg] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    aw[gi] = on ? *(const f32x4*)(wpt + ((size_t)d * 16 + n) * 16 + kg * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    pb += 16u;
+    if (pb >= P) { pb = 0u; if (++d >= D) { d = 0u; ++smp; } }
+  }
+#pragma unroll
+  for (int gi = 0; gi < OIF_GPW; ++gi) {
+    if (gi >= (int)ng) break;                                      // (wave-uniform)
+    const unsigned v = (g0 + gi) * 16u + n;
+    f32x4 gzs = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gzs = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[gi][i], xp[gi][i], gzs, 0, 0, 0);
+    const f32x4 zq = xz[gi];
+    float dot = (gzs[0] * he_p) * zq[0] + (gzs[1] * he_p) * zq[1] + (gzs[2] * he_p) * zq[2] + (gzs[3] * he_p) * zq[3];
+    dot += __shfl_xor(dot, 16, 64);
+    dot += __shfl_xor(dot, 32, 64);
+    if (kg == 0 && v < rows) gw[v] = dot;
   }
 }
 
@@ -440,7 +486,7 @@ extern "C" int lf_occ_input_fwd(const float* z, const float* w, const float* b, 
   if (!lf_aligned16(z) || !lf_aligned16(ta)) return LF_EALIGN;
   const long rows = (long)N * D * P;
   const float dstep = D > 1 ? 2.f / (float)(D - 1) : 0.f;
-  if (rows < 0x7fffffffL && P < 0x7fffffffL && lf_aligned16(w)) {
+  if (rows < 0x7fffffffL && P < 0x7fffffffL && (P & 15) == 0 && lf_aligned16(w)) {
     const long groups = (rows + 15) / 16;
     hipLaunchKernelGGL(occ_input_fwd_mfma_kernel, dim3((unsigned)((groups + 4 * OIF_GPW - 1) / (4 * OIF_GPW))), dim3(256), 0, (hipStream_t)stream,
                        (const f32x4*)z, w, b, (f32x4*)ta, t16, (unsigned)rows, (unsigned)D, (unsigned)P, dstep, slope);
@@ -481,6 +527,19 @@ extern "C" int lf_occ_input_bwd_proj(const float* gta, const float* gp16, const 
   hipLaunchKernelGGL(occ_input_bwd_mfma_kernel, dim3((unsigned)((groups + 4 * OIF_GPW - 1) / (4 * OIF_GPW))), dim3(256), 0, (hipStream_t)stream,
                      (const f32x4*)gta, gp16, w, (const f32x4*)gp2d, wpack_t, he_p, wocc, (f32x4*)gz, (unsigned)rows, (unsigned)D,
                      (unsigned)P, slope, (const f32x4*)prev_y, prev_norm, prev_flags);
+  return lf_launch_status();
+}
+
+extern "C" int lf_occ_weight_grad(const float* z, const float* gp2d, const float* wpack_t, float he_p, float* gw, int N, int D, long P,
+                                  void* stream) {
+  lf_clear_error();
+  if (N <= 0 || D <= 0 || P <= 0 || !z || !gp2d || !wpack_t || !gw) return LF_EINVAL;
+  const long rows = (long)N * D * P;
+  if (rows >= 0x7fffffffL || (P & 15)) return LF_EINVAL;
+  if (!lf_aligned16(z) || !lf_aligned16(gp2d) || !lf_aligned16(wpack_t)) return LF_EALIGN;
+  const long groups = (rows + 15) / 16;
+  hipLaunchKernelGGL(occ_weight_grad_kernel, dim3((unsigned)((groups + 4 * OIF_GPW - 1) / (4 * OIF_GPW))), dim3(256), 0, (hipStream_t)stream,
+                     (const f32x4*)z, (const f32x4*)gp2d, wpack_t, he_p, gw, (unsigned)rows, (unsigned)D, (unsigned)P);
   return lf_launch_status();
 }
 

@@ -685,15 +685,13 @@ class RenderLoopEngine:
                     gw_occ = proj_bwd = None
                     with ops._timed('factor_project_bwd'):
                         if self.OCC_FUSE_SCALE and Cl == 16 and cout == 16 and (S * S) % 16 == 0:
-                            # the projection's data gradient is NOT stored: this launch only sums g_zs * zc over the channels of every
-                            # voxel (LF_EPI_DOT, gx = NULL) -- the gradient of the occlusion weights, without lf_column_scale_bwd's
-                            # pass over two volumes -- and the input block's backward recomputes g_zs where it needs it
-                            # (lf_occ_input_bwd_proj)
+                            # the projection's data gradient is NOT stored: lf_occ_weight_grad sums g_zs * zc over the channels of every
+                            # voxel -- the gradient of the occlusion weights, one read of zc instead of lf_column_scale_bwd's pass over
+                            # two volumes -- and the input block's backward recomputes g_zs where it needs it (lf_occ_input_bwd_proj)
                             g_zs = None
                             gw_occ = torch.empty(n, 1, S, S, S, device=dev, dtype=torch.float32)
-                            check(L.lf_conv1x1_bwd_data(gp.data_ptr(), ppack_t.data_ptr(), None, n, S * S, cout, S * Cl,
-                                                        S * S * S * Cl, Cl, Cl, S * S * Cl, phe, acts[-1].data_ptr(), gw_occ.data_ptr(),
-                                                        _lib.LF_EPI_DOT, ops.SLOPE, None, s), 'lf_conv1x1_bwd_data')
+                            check(L.lf_occ_weight_grad(acts[-1].data_ptr(), gp.data_ptr(), ppack_t.data_ptr(), phe, gw_occ.data_ptr(),
+                                                       n, S, S * S, s), 'lf_occ_weight_grad')
                             proj_bwd = (gp, ppack_t, phe)
                         else:
                             g_zs = ops.empty_cl((n, Cl, S, S, S), dev)
