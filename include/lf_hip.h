@@ -407,6 +407,10 @@ int lf_occ_input_bwd_proj(const float* gta, const float* gp16, const float* w, c
 /* Gradient of the occlusion weights through `z * w` -> factor projection: gw[n][d][p] = sum_c z[n][d][p][c] * g_zs[n][d][p][c],
  * g_zs = (Wp_d^T gp2d[n][p]) * he_p recomputed on the matrix pipe (wpack_t, gp2d as for lf_occ_input_bwd_proj); one read of z. */
 int lf_occ_weight_grad(const float* z, const float* gp2d, const float* wpack_t, float he_p, float* gw, int N, int D, long P, void* stream);
+/* lf_occ_weight_grad followed by the depth softmax's backward in one launch: glogits[d] = w[d] * (gw[d] - sum_e w[e] gw[e]) per pixel
+ * column (weights = the softmax output lf_column_softmax(_head)_fwd stored); no gw volume.  D <= 256, P % 16 == 0. */
+int lf_occ_weight_grad_softmax_bwd(const float* z, const float* gp2d, const float* wpack_t, float he_p, const float* weights,
+                                   float* glogits, int N, int D, long P, void* stream);
 /* Data gradient of the occlusion module's 16 -> 1 output block (no activation) onto the 16-channel activation y that fed it, with
  * the LeakyReLU' / PixelNorm' of the layer that produced y (its norm, flags) applied in the store:
  *   g[v][c] = epilogue'( (gl[v] * w16[c]) * he )          (rows voxels; what lf_conv1x1_bwd_data(Cin = 1, prev_y = y) computes, same bits) */

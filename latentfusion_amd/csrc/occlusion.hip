@@ -276,6 +276,52 @@ __global__ void __launch_bounds__(256) occ_weight_grad_kernel(const f32x4* __res
   }
 }
 
+// The same followed by the depth softmax's backward in one kernel (round 6): a wave takes 16 pixels of one sample and walks ALL
+// depths, so the column sum of the softmax gradient is a running sum in registers; the weights' gradients of the column wait in LDS
+// (D x 16 floats per wave) for it:   glogits[d] = w[d] * (gw[d] - sum_e w[e] gw[e]).   No gw volume, no lf_column_softmax_bwd launch.
+constexpr int OWS_CH = 8;                                         // depths per batch of loads
+__global__ void __launch_bounds__(256) occ_weight_grad_softmax_kernel(const f32x4* __restrict__ z, const f32x4* __restrict__ gp2d,
+                                                                      const float* __restrict__ wpt, float he_p,
+                                                                      const float* __restrict__ wocc, float* __restrict__ glogits,
+                                                                      unsigned D, unsigned P, unsigned ngroups) {
+  extern __shared__ float sgw[];                                  // [4 waves][D][16]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, n = lane & 15, kg = lane >> 4;
+  const unsigned grp = blockIdx.x * 4u + wv;                      // group of 16 pixels over all samples
+  if (grp >= ngroups) return;                                      // (wave-uniform)
+  const unsigned smp = grp / (P >> 4), pix = (grp % (P >> 4)) * 16u + n;
+  float* mine = sgw + (size_t)wv * D * 16;
+  const f32x4 xp = gp2d[((size_t)smp * P + pix) * 4 + kg];
+  const size_t col = (size_t)smp * D * P + pix;                   // voxel (d = 0) of this lane's pixel
+  float dotc = 0.f;
+  for (unsigned d0 = 0; d0 < D; d0 += OWS_CH) {
+    f32x4 xz[OWS_CH], aw[OWS_CH];
+    float wd[OWS_CH];
+#pragma unroll
+    for (int i = 0; i < OWS_CH; ++i) {
+      const unsigned d = min(d0 + i, D - 1u);
+      xz[i] = z[(col + (size_t)d * P) * 4 + kg];
+      aw[i] = *(const f32x4*)(wpt + ((size_t)d * 16 + n) * 16 + kg * 4);
+      wd[i] = wocc[col + (size_t)d * P];
+    }
+#pragma unroll
+    for (int i = 0; i < OWS_CH; ++i) {
+      if (d0 + i >= D) break;                                      // (wave-uniform)
+      f32x4 gzs = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) gzs = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[i][k], xp[k], gzs, 0, 0, 0);
+      const f32x4 zq = xz[i];
+      float dot = (gzs[0] * he_p) * zq[0] + (gzs[1] * he_p) * zq[1] + (gzs[2] * he_p) * zq[2] + (gzs[3] * he_p) * zq[3];
+      dot += __shfl_xor(dot, 16, 64);
+      dot += __shfl_xor(dot, 32, 64);
+      if (kg == 0) mine[(d0 + i) * 16 + n] = dot;
+      dotc += wd[i] * dot;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  for (unsigned d = kg; d < D; d += 4) glogits[col + (size_t)d * P] = wocc[col + (size_t)d * P] * (mine[d * 16 + n] - dotc);
+}
+
 // Data gradient of the 16 -> 1 output block onto the last 16-channel activation, with that layer's epilogue backward in the store
 // (round 6; was lf_conv1x1_bwd_data with K = 1 padded to an MFMA step: 0.55 ms per 8 x 128^3 launch for 2.3 GB):
 //   g[v][c] = lrelu'(y[v][c]) * (t[c] - y[v][c] * mean_c(t * y[v])) / norm[v],   t[c] = (gl[v] * w[c]) * he
@@ -540,6 +586,20 @@ extern "C" int lf_occ_weight_grad(const float* z, const float* gp2d, const float
   const long groups = (rows + 15) / 16;
   hipLaunchKernelGGL(occ_weight_grad_kernel, dim3((unsigned)((groups + 4 * OIF_GPW - 1) / (4 * OIF_GPW))), dim3(256), 0, (hipStream_t)stream,
                      (const f32x4*)z, (const f32x4*)gp2d, wpack_t, he_p, gw, (unsigned)rows, (unsigned)D, (unsigned)P);
+  return lf_launch_status();
+}
+
+extern "C" int lf_occ_weight_grad_softmax_bwd(const float* z, const float* gp2d, const float* wpack_t, float he_p, const float* weights,
+                                              float* glogits, int N, int D, long P, void* stream) {
+  lf_clear_error();
+  if (N <= 0 || D <= 0 || P <= 0 || !z || !gp2d || !wpack_t || !weights || !glogits) return LF_EINVAL;
+  const long rows = (long)N * D * P;
+  if (rows >= 0x7fffffffL || (P & 15) || D > 256) return LF_EINVAL;    // (D <= 256: the columns of four waves fit the default 64 KB of LDS)
+  if (!lf_aligned16(z) || !lf_aligned16(gp2d) || !lf_aligned16(wpack_t)) return LF_EALIGN;
+  const long ngroups = (long)N * (P / 16);
+  const size_t lds = (size_t)4 * D * 16 * sizeof(float);
+  hipLaunchKernelGGL(occ_weight_grad_softmax_kernel, dim3((unsigned)((ngroups + 3) / 4)), dim3(256), lds, (hipStream_t)stream,
+                     (const f32x4*)z, (const f32x4*)gp2d, wpack_t, he_p, weights, glogits, (unsigned)D, (unsigned)P, (unsigned)ngroups);
   return lf_launch_status();
 }
 

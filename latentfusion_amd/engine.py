@@ -442,12 +442,23 @@ class RenderLoopEngine:
         n, _, D, H, W = zc.shape
         P = H * W
         # (the direct term g_zs * wocc of the scaling joins the input block's backward below: no volume is written for it)
-        if gw is None:                                            # (else: the projection's data gradient already summed g_zs * zc per voxel)
-            gw = torch.empty_like(wocc)
-            check(L.lf_column_scale_bwd(g_zs.data_ptr(), zc.data_ptr(), wocc.data_ptr(), None, gw.data_ptr(), n * D * P, 16, s),
-                  'lf_column_scale_bwd')
         gl = torch.empty_like(wocc)
-        check(L.lf_column_softmax_bwd(wocc.data_ptr(), gw.data_ptr(), None, gl.data_ptr(), n, D, P, s), 'lf_column_softmax_bwd')
+        if proj_bwd is not None and D <= 256:
+            # (round 6) the weights' gradient sum_c zc * g_zs, g_zs recomputed from the projection's 2-D gradient, and the softmax
+            # backward over each pixel's depth column in one launch: one read of zc; neither g_zs nor gw exist as volumes
+            with ops._timed('occ_weight_grad_softmax_bwd'):
+                check(L.lf_occ_weight_grad_softmax_bwd(zc.data_ptr(), proj_bwd[0].data_ptr(), proj_bwd[1].data_ptr(), proj_bwd[2], wocc.data_ptr(),
+                                                       gl.data_ptr(), n, D, P, s), 'lf_occ_weight_grad_softmax_bwd')
+        else:
+            if gw is None and proj_bwd is not None:
+                gw = torch.empty_like(wocc)
+                check(L.lf_occ_weight_grad(zc.data_ptr(), proj_bwd[0].data_ptr(), proj_bwd[1].data_ptr(), proj_bwd[2], gw.data_ptr(), n, D, P, s),
+                      'lf_occ_weight_grad')
+            if gw is None:                                        # (else: the gradient of the weights is already summed per voxel)
+                gw = torch.empty_like(wocc)
+                check(L.lf_column_scale_bwd(g_zs.data_ptr(), zc.data_ptr(), wocc.data_ptr(), None, gw.data_ptr(), n * D * P, 16, s),
+                      'lf_column_scale_bwd')
+            check(L.lf_column_softmax_bwd(wocc.data_ptr(), gw.data_ptr(), None, gl.data_ptr(), n, D, P, s), 'lf_column_softmax_bwd')
         _hb, hhe, _hpk, hpkt = o['head']
         g = ops.empty_cl(zc.shape, dev)
         if self.OCC_FUSE_SCALE:
@@ -464,8 +475,11 @@ class RenderLoopEngine:
         # (round 6) LeakyReLU' of the input block's outputs 0..15 rides in the store of this data gradient (prev = ta, no norm): the
         # input block's backward then does not read ta
         ta_in_store = self.OCC_FUSE_SCALE or proj_bwd is not None
-        gta = ops.conv3d_c16_wino(g, pat, None, he2, 0, prev=(ta, None, LF_EPI_LRELU) if ta_in_store else None)[0]
         gp16 = torch.empty_like(t16)
+        # (measured, round 6: this launch on a second stream BESIDE the Winograd data gradient that reads the same g is slower -- the
+        # persistent Winograd workgroups hold every CU, the side kernel took 1.33 ms instead of 0.38 and stretched its neighbour:
+        # 63.4 against 64.4 it/s)
+        gta = ops.conv3d_c16_wino(g, pat, None, he2, 0, prev=(ta, None, LF_EPI_LRELU) if ta_in_store else None)[0]
         with ops._timed('occ_conv17_bwd'):
             check(L.lf_occ_conv17_bwd(g.data_ptr(), t16.data_ptr(), w27.data_ptr(), gp16.data_ptr(), n, D, H, W, ops.SLOPE, s),
                   'lf_occ_conv17_bwd')
@@ -689,9 +703,6 @@ class RenderLoopEngine:
                             # voxel -- the gradient of the occlusion weights, one read of zc instead of lf_column_scale_bwd's pass over
                             # two volumes -- and the input block's backward recomputes g_zs where it needs it (lf_occ_input_bwd_proj)
                             g_zs = None
-                            gw_occ = torch.empty(n, 1, S, S, S, device=dev, dtype=torch.float32)
-                            check(L.lf_occ_weight_grad(acts[-1].data_ptr(), gp.data_ptr(), ppack_t.data_ptr(), phe, gw_occ.data_ptr(),
-                                                       n, S, S * S, s), 'lf_occ_weight_grad')
                             proj_bwd = (gp, ppack_t, phe)
                         else:
                             g_zs = ops.empty_cl((n, Cl, S, S, S), dev)
