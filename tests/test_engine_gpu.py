@@ -958,6 +958,94 @@ def test_occlusion_seventeenth_channel_kernels():
         close(gz3, want3.float(), atol=2e-5, rtol=2e-5)
 
 
+def test_occlusion_tail_round6_kernels():
+    """The round-6 kernels around the occlusion module against the launches they replace and fp64 expressions (reference
+    recon/models.py:378-395,427-430): the factor projection that scales its operand (lf_conv1x1_fwd_scaled == lf_column_scale_fwd +
+    lf_conv1x1_fwd, same bits), LF_EPI_DOT of lf_conv1x1_bwd_data, output block + depth softmax in one pass
+    (lf_column_softmax_head_fwd), the output block's backward (lf_occ_head_bwd == lf_conv1x1_bwd_data with K = 1, same bits), the
+    weights' gradient with the projection's data gradient recomputed (lf_occ_weight_grad, lf_occ_weight_grad_softmax_bwd) and the
+    input block's backward in that form (lf_occ_input_bwd_proj)."""
+    from latentfusion_amd import _lib, ops
+    F = torch.nn.functional
+    L = _lib.lib()
+    gen = torch.Generator().manual_seed(11)
+    s = torch.cuda.current_stream().cuda_stream
+    for (n, D, H, W) in ((2, 8, 8, 8), (1, 5, 4, 12), (3, 16, 16, 16)):
+        P = H * W
+        zc = ops.cl(torch.randn(n, 16, D, H, W, generator=gen).to(DEV))
+        wocc = torch.softmax(torch.randn(n, 1, D, H, W, generator=gen), dim=2).to(DEV).contiguous()
+        pw = (torch.randn(16, 16 * D, 1, 1, generator=gen) * 0.2).to(DEV)          # projection weight [cout][C * D] (channel-major K)
+        pb = (torch.randn(16, generator=gen) * 0.1).to(DEV)
+        phe = ops.he_constant(pw)
+        ppack = ops.pack_conv1x1(pw.reshape(16, 16, D).permute(0, 2, 1).reshape(16, D * 16))
+        ppack_t = ops.pack_conv1x1(pw.reshape(16, 16, D).permute(2, 1, 0).reshape(D * 16, 16))
+        flags = _lib.LF_EPI_LRELU | _lib.LF_EPI_PIXELNORM
+        # 1. scaled projection == scale pass + projection, bit for bit
+        zs = ops.empty_cl(zc.shape, DEV)
+        _lib.check(L.lf_column_scale_fwd(zc.data_ptr(), wocc.data_ptr(), zs.data_ptr(), n * D * P, 16, s), 'scale')
+        zp_a, zp_b = ops.empty_cl((n, 16, H, W), DEV), ops.empty_cl((n, 16, H, W), DEV)
+        na = ops._conv1x1_raw(zs, ppack, pb, n, P, 16, D, D * P * 16, P * 16, 16, zp_a, phe, flags)
+        nb = ops._conv1x1_raw(zc, ppack, pb, n, P, 16, D, D * P * 16, P * 16, 16, zp_b, phe, flags, xscale=wocc)
+        assert torch.equal(zp_a, zp_b) and torch.equal(na, nb)
+        # 2. data gradient of the projection + the per-voxel sums g_zs . zc (LF_EPI_DOT), with and without the gradient volume
+        gp = ops.cl(torch.randn(n, 16, H, W, generator=gen).to(DEV))
+        g_ref = ops.empty_cl(zc.shape, DEV)
+        ops._conv1x1_raw(gp, ppack_t, None, n, P, 16, 1, P * 16, 0, D * 16, g_ref, phe, 0, yaddr=(D * P * 16, 16, 16, P * 16))
+        g_dot, gw = ops.empty_cl(zc.shape, DEV), torch.empty(n, 1, D, H, W, device=DEV)
+        _lib.check(L.lf_conv1x1_bwd_data(gp.data_ptr(), ppack_t.data_ptr(), g_dot.data_ptr(), n, P, 16, D * 16, D * P * 16, 16, 16, P * 16,
+                                         phe, zc.data_ptr(), gw.data_ptr(), _lib.LF_EPI_DOT, 0.2, None, s), 'dot')
+        assert torch.equal(g_dot, g_ref)
+        want_gw = (g_ref.double() * zc.double()).sum(1, keepdim=True)
+        close(gw, want_gw.float(), atol=2e-5, rtol=1e-5)
+        gw2 = torch.empty_like(gw)
+        _lib.check(L.lf_conv1x1_bwd_data(gp.data_ptr(), ppack_t.data_ptr(), None, n, P, 16, D * 16, D * P * 16, 16, 16, P * 16,
+                                         phe, zc.data_ptr(), gw2.data_ptr(), _lib.LF_EPI_DOT, 0.2, None, s), 'dot only')
+        assert torch.equal(gw2, gw)
+        # 3. output block (16 -> 1, no activation) + softmax over the depth column
+        hw = (torch.randn(16, generator=gen) * 0.5).to(DEV).contiguous()
+        hb = (torch.randn(1, generator=gen) * 0.3).to(DEV)
+        hhe = 0.35
+        w_out = torch.empty(n, 1, D, H, W, device=DEV)
+        _lib.check(L.lf_column_softmax_head_fwd(zc.data_ptr(), hw.data_ptr(), hb.data_ptr(), hhe, w_out.data_ptr(), None, n, D, P, s), 'head softmax')
+        logits = (zc.double() * hw.double().view(1, 16, 1, 1, 1)).sum(1, keepdim=True) * hhe + hb.double()
+        close(w_out, torch.softmax(logits, dim=2).float(), atol=2e-6, rtol=1e-5)
+        # 4. output block backward with the producer's epilogue backward == the K = 1 pointwise data gradient, bit for bit
+        nrm = (torch.rand(n * D * P, generator=gen) + 0.5).to(DEV)
+        gl = torch.randn(n, 1, D, H, W, generator=gen).to(DEV)
+        hpkt = ops.pack_conv1x1(hw.reshape(16, 1))
+        g_a, g_b = ops.empty_cl(zc.shape, DEV), ops.empty_cl(zc.shape, DEV)
+        _lib.check(L.lf_conv1x1_bwd_data(gl.data_ptr(), hpkt.data_ptr(), g_a.data_ptr(), n, D * P, 1, 16, D * P * 16, 16, 16, 0, hhe,
+                                         zc.data_ptr(), nrm.data_ptr(), flags, 0.2, None, s), 'head bwd (pointwise)')
+        _lib.check(L.lf_occ_head_bwd(gl.data_ptr(), hw.data_ptr(), hhe, zc.data_ptr(), nrm.data_ptr(), flags, 0.2, g_b.data_ptr(), n * D * P, s),
+                   'head bwd')
+        assert torch.equal(g_a, g_b)
+        if P % 16:
+            continue                                              # (the matrix-pipe forms take whole groups of 16 voxels per depth plane)
+        # 5. the weights' gradient with g_zs recomputed; followed by the softmax backward
+        gw3 = torch.empty_like(gw)
+        _lib.check(L.lf_occ_weight_grad(zc.data_ptr(), gp.data_ptr(), ppack_t.data_ptr(), phe, gw3.data_ptr(), n, D, P, s), 'weight grad')
+        close(gw3, want_gw.float(), atol=2e-5, rtol=1e-5)
+        glz = torch.empty_like(gw)
+        _lib.check(L.lf_occ_weight_grad_softmax_bwd(zc.data_ptr(), gp.data_ptr(), ppack_t.data_ptr(), phe, wocc.data_ptr(), glz.data_ptr(), n, D, P, s),
+                   'weight grad + softmax bwd')
+        wd = wocc.double()
+        want_gl = wd * (want_gw - (wd * want_gw).sum(2, keepdim=True))
+        close(glz, want_gl.float(), atol=2e-5, rtol=2e-5)
+        # 6. input block backward with the direct term recomputed == the form that reads g_zs (ta = NULL in both)
+        wi = torch.zeros(17, 20, device=DEV)
+        wi[:, :17] = torch.randn(17, 17, generator=gen).to(DEV) * 0.4
+        gta = ops.cl(torch.randn(n, 16, D, H, W, generator=gen).to(DEV))
+        gp16 = torch.randn(n, 1, D, H, W, generator=gen).to(DEV)
+        for prev in (None, (zc, nrm, flags)):
+            gz_a, gz_b = ops.empty_cl(zc.shape, DEV), ops.empty_cl(zc.shape, DEV)
+            py, pn, pf = (prev[0].data_ptr(), prev[1].data_ptr(), prev[2]) if prev else (None, None, 0)
+            _lib.check(L.lf_occ_input_bwd(gta.data_ptr(), None, gp16.data_ptr(), wi.data_ptr(), g_ref.data_ptr(), wocc.data_ptr(), gz_a.data_ptr(),
+                                          n * D * P, 0.2, py, pn, pf, s), 'input bwd')
+            _lib.check(L.lf_occ_input_bwd_proj(gta.data_ptr(), gp16.data_ptr(), wi.data_ptr(), gp.data_ptr(), ppack_t.data_ptr(), phe, wocc.data_ptr(),
+                                               gz_b.data_ptr(), n, D, P, 0.2, py, pn, pf, s), 'input bwd proj')
+            close(gz_b, gz_a, atol=3e-5, rtol=2e-5)
+
+
 @pytest.mark.parametrize('projection', ['factor', 'sum'])
 def test_engine_occlusion_module_on_explicit_kernels(golden, projection):
     """The 16-channel occlusion renderer (UNet3d(17, 1, [[17, 16], [16, 16]]), reference recon/models.py:305-306,378-395,427-430)

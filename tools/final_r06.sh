@@ -19,6 +19,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_c -o cfg3 -- p
 f=$(find /tmp/prof_c -name "*kernel_stats.csv" | head -1)
 python $R/tools/kernel_stats_txt.py $f $O/r06_released_arch_kernel_stats.txt "BASELINE cfg 3 (released architecture, cross_entropy_linemod, 128 renders per iteration): tools/cfg3_probe.py 10 = 30 iterations + 2 reconstructions" 30 > /dev/null
 cd $R
+bash tools/occ_profile.sh r06 > $O/log_occ.txt 2>&1
+cd $R
 bash tools/pmc_collect.sh r06_pmc > $O/log_pmc1.txt 2>&1
 bash tools/pmc_collect_train.sh r06_pmc_train > $O/log_pmc2.txt 2>&1
 find gpurun_out/r06_pmc gpurun_out/r06_pmc_train -name "*_kernel_trace.csv" ! -name "trace_*" -delete
