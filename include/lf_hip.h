@@ -413,7 +413,7 @@ int lf_occ_weight_grad_softmax_bwd(const float* z, const float* gp2d, const floa
                                    float* glogits, int N, int D, long P, void* stream);
 /* Data gradient of the occlusion module's 16 -> 1 output block (no activation) onto the 16-channel activation y that fed it, with
  * the LeakyReLU' / PixelNorm' of the layer that produced y (its norm, flags) applied in the store:
- *   g[v][c] = epilogue'( (gl[v] * w16[c]) * he )          (rows voxels; what lf_conv1x1_bwd_data(Cin = 1, prev_y = y) computes, same bits) */
+ *   g[v][c] = epilogue'( (gl[v] * w16[c]) * he )          (rows voxels; what lf_conv1x1_bwd_data(Cin = 1, prev_y = y) computes) */
 int lf_occ_head_bwd(const float* gl, const float* w16, float he, const float* y, const float* norm, unsigned flags, float slope,
                     float* g, long rows, void* stream);
 int lf_occ_conv17_fwd(const float* t16, const float* w27, float* pre, int N, int D, int H, int W, void* stream);

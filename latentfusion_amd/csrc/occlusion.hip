@@ -325,7 +325,8 @@ __global__ void __launch_bounds__(256) occ_weight_grad_softmax_kernel(const f32x
 // Data gradient of the 16 -> 1 output block onto the last 16-channel activation, with that layer's epilogue backward in the store
 // (round 6; was lf_conv1x1_bwd_data with K = 1 padded to an MFMA step: 0.55 ms per 8 x 128^3 launch for 2.3 GB):
 //   g[v][c] = lrelu'(y[v][c]) * (t[c] - y[v][c] * mean_c(t * y[v])) / norm[v],   t[c] = (gl[v] * w[c]) * he
-// One lane per quarter record, the same products, the same order of the partial sums => the same bits.
+// One lane per quarter record, the same products and order of the partial sums (the results differ from the pointwise kernel's in
+// the last bit where the compiler contracts a multiply-add differently).
 __global__ void __launch_bounds__(256) occ_head_bwd_kernel(const float* __restrict__ gl, const float* __restrict__ w16, float he,
                                                            const f32x4* __restrict__ y, const float* __restrict__ norm, unsigned flags,
                                                            float slope, f32x4* __restrict__ g, long rows) {
