@@ -527,6 +527,21 @@ size_t lf_proj16_bwd_scratch_bytes(int S);
 int lf_proj16_bwd(const float* gp, const void* vol, const void* wtab_t, void* gxvol, float* gw, void* scratch, size_t scratch_bytes,
                   long R, long P, int S, float he, void* stream);
 
+/* ---- pointwise 16 -> 16 layers of the training step (round 6; csrc/pw16.hip) ------------------------------------------------------------
+ * 1x1x1 convolutions under the bf16 autocast + storage policy (the sculptor's output block, reference recon/models.py:143,222 over
+ * modules/blocks.py:108-119): one v_mfma_f32_16x16x16_bf16 per 16 voxels instead of the 3x3x3 ring kernels with the weights on the
+ * centre tap.  rows = N*D*H*W voxels, channels-last 16-channel records.
+ *   lf_pw16_fwd   y = act( bf16(bf16(W x) * he) + bias ) stored as bf16; x in bf16 (x_bf16 = 1) or fp32 storage (rounded on load);
+ *                 w_bf16 = bf16 [cout][cin]; flags: 0 or LF_EPI_LRELU
+ *   lf_pw16_bwd   gx = bf16(bf16(W^T gy) * he) stored as bf16 (gx_bf16 = 1) or fp32; wt_bf16 = bf16 [cin][cout]; gy in bf16 storage;
+ *                 gbias != NULL: also gbias[c] = sum over the voxels of gy[.][c] (per-workgroup partial sums in `scratch`, reduced in
+ *                 a fixed order: deterministic) */
+int lf_pw16_fwd(const void* x, int x_bf16, const void* w_bf16, const float* bias, float he, unsigned flags, float slope, void* y,
+                long rows, void* stream);
+size_t lf_pw16_bwd_scratch_bytes(long rows);
+int lf_pw16_bwd(const void* gy_bf16, const void* wt_bf16, float he, void* gx, int gx_bf16, float* gbias, void* scratch,
+                size_t scratch_bytes, long rows, void* stream);
+
 /* Standalone PixelNorm over the last (channel) axis of [rows][C], in place allowed.
  * norm_out[rows] receives sqrt(mean+eps).  modules/__init__.py:14-15. */
 int lf_pixelnorm_fwd(const float* x, float* y, float* norm_out, long rows, int C, float eps, void* stream);

@@ -95,6 +95,9 @@ SIGNATURES = {
     'lf_column_softmax_fwd': (c_int, [P, P, P, c_int, c_int, c_long, P]),
     'lf_occ_input_bwd_proj': (c_int, [P, P, P, P, P, c_float, P, P, c_int, c_int, c_long, c_float, P, P, c_uint, P]),
     'lf_occ_weight_grad': (c_int, [P, P, P, c_float, P, c_int, c_int, c_long, P]),
+    'lf_pw16_fwd': (c_int, [P, c_int, P, P, c_float, c_uint, c_float, P, c_long, P]),
+    'lf_pw16_bwd_scratch_bytes': (c_size_t, [c_long]),
+    'lf_pw16_bwd': (c_int, [P, P, c_float, P, c_int, P, P, c_size_t, c_long, P]),
     'lf_occ_weight_grad_softmax_bwd': (c_int, [P, P, P, c_float, P, P, c_int, c_int, c_long, P]),
     'lf_occ_head_bwd': (c_int, [P, P, c_float, P, P, c_uint, c_float, P, c_long, P]),
     'lf_column_softmax_head_fwd': (c_int, [P, P, P, c_float, P, P, c_int, c_int, c_long, P]),

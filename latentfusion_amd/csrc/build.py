@@ -5,7 +5,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ['resample.hip', 'conv.hip', 'pointwise.hip', 'image.hip', 'optim.hip', 'resize.hip', 'conv_split.hip', 'conv_wino.hip', 'wgrad.hip', 'sample2d.hip', 'gru.hip', 'wino_gemm.hip', 'reduce.hip', 'wino_fused.hip', 'conv_bf16.hip', 'occlusion.hip', 'conv_gru.hip', 'lift_mfma.hip']
+SOURCES = ['resample.hip', 'conv.hip', 'pointwise.hip', 'image.hip', 'optim.hip', 'resize.hip', 'conv_split.hip', 'conv_wino.hip', 'wgrad.hip', 'sample2d.hip', 'gru.hip', 'wino_gemm.hip', 'reduce.hip', 'wino_fused.hip', 'conv_bf16.hip', 'occlusion.hip', 'conv_gru.hip', 'lift_mfma.hip', 'pw16.hip']
 LIB = os.path.join(HERE, 'liblf_hip.so')
 # per-file extras (conv_split.hip: see split_piece there; conv_gru.hip: see the note on packed fp32 arithmetic at its top)
 EXTRA = {'conv_split.hip': ['-fno-slp-vectorize'], 'conv_gru.hip': ['-fno-slp-vectorize']}

@@ -40,6 +40,7 @@ RING_BLOCK_FWD = _env('RING_BLOCK_FWD', True)          # forward Block steps on 
 RING_DGRAD = _env('RING_DGRAD', True)                  # data gradients of the 16 -> 16 layers on ring_multi (bit-identical)
 CHAIN_EPILOGUE = _env('CHAIN_EPILOGUE', True)          # a Block's conv2 data gradient applies conv1's epilogue backward (LF_RING_EX_PREV)
 LIFT_MFMA = _env('LIFT_MFMA', True)                    # the 16-channel lift as one MFMA kernel each way (csrc/lift_mfma.hip)
+PW16 = _env('PW16', True)                              # 1x1x1 16 -> 16 layers on the pointwise MFMA kernels (csrc/pw16.hip), not on the centre tap of the ring kernels
 
 
 _SIDE = {}
@@ -259,14 +260,26 @@ class _Conv16AC(torch.autograd.Function):
         he = he_constant(weight)
         one = weight.shape[2] == 1
         w3 = (lambda t: pack_center_tap(t)) if one else (lambda t: t)
-        pack = _pk(weight, 'a3f', lambda t: pack_conv3d_c16_ring_bf16(w3(t)))
-        if RING_BLOCK_FWD and flags == (LF_EPI_LRELU | LF_EPI_PIXELNORM) and x.shape[2] * x.shape[3] * x.shape[4] * 64 < 2 ** 31:
+        ctx.pw = bool(one and PW16 and flags in (0, LF_EPI_LRELU))
+        if ctx.pw:
+            # (round 6) a pointwise layer is one MFMA per 16 voxels, streamed: same products, same roundings as the ring kernel
+            L = _lib.lib()
+            wq = _pk(weight, 'p1f', lambda t: t.detach().reshape(16, 16).to(torch.bfloat16).contiguous())
+            y = empty_cl16(tuple(x.shape), x.device, True)
+            norm = None
+            b_ = bias.detach() if bias is not None else None
+            with _timed('pw16_fwd', f'{x.shape[0]}:{x.dtype == torch.bfloat16}'):
+                check(L.lf_pw16_fwd(_ptr(x), 1 if x.dtype == torch.bfloat16 else 0, _ptr(wq), _ptr(b_) if b_ is not None else None, he, flags,
+                                    SLOPE, _ptr(y), x.numel() // 16, _stream()), 'lf_pw16_fwd')
+        elif RING_BLOCK_FWD and flags == (LF_EPI_LRELU | LF_EPI_PIXELNORM) and x.shape[2] * x.shape[3] * x.shape[4] * 64 < 2 ** 31:
             # the same arithmetic on the one-group ring kernel with its epilogue at compile time (LF_RING_EX_BLOCK): bit-identical
+            pack = _pk(weight, 'a3f', lambda t: pack_conv3d_c16_ring_bf16(w3(t)))
             y = empty_cl16(tuple(x.shape), x.device, True)
             norm = torch.empty(x.shape[0] * x.shape[2] * x.shape[3] * x.shape[4], device=x.device, dtype=torch.float32)
             ring_multi(x, pack.reshape(1, 14, 16, 32), he, [(y, None, True)], extra=_lib.LF_RING_EX_BLOCK,
                        e0=bias.detach() if bias is not None else None, o2=norm)
         else:
+            pack = _pk(weight, 'a3f', lambda t: pack_conv3d_c16_ring_bf16(w3(t)))
             y, norm = conv3d_c16_ring_bf16_io(x, pack, bias.detach() if bias is not None else None, he, flags, 1, out_bf16=True)
         ctx.flags, ctx.he, ctx.one = flags, he, one
         need_w = weight.requires_grad or (bias is not None and bias.requires_grad)
@@ -288,7 +301,10 @@ class _Conv16AC(torch.autograd.Function):
         y, norm, w, x_saved = ctx.saved_tensors
         gy = cl(gy)
         want_b = ctx.needs_input_grad[2]
-        if ctx.box is not None and ctx.box['done']:
+        pw_bwd = ctx.pw and ctx.flags == 0 and gy.dtype == torch.bfloat16 and ctx.needs_input_grad[0]
+        if pw_bwd:
+            gp, gb = gy, None                                     # no activation: the pre-activation gradient IS gy; the bias sums ride in lf_pw16_bwd
+        elif ctx.box is not None and ctx.box['done']:
             gp, gb = gy, ctx.box['gb']                            # the consumer's data gradient already applied this layer's epilogue backward
             if gp.dtype != torch.bfloat16:
                 gp = gp.to(torch.bfloat16)
@@ -321,7 +337,22 @@ class _Conv16AC(torch.autograd.Function):
                         done.record(side)
                         for t in (x_saved, gp, gwt, scr):
                             t.record_stream(side)
-            if ctx.needs_input_grad[0]:
+            if ctx.needs_input_grad[0] and ctx.pw and gp.dtype == torch.bfloat16:
+                # pointwise data gradient (+ this layer's bias gradient when nothing ran before it): one streamed pass
+                L = _lib.lib()
+                wtq = _pk(w, 'p1b', lambda t: t.detach().reshape(16, 16).t().to(torch.bfloat16).contiguous())
+                rows = gp.numel() // 16
+                out16 = ctx.xdtype == torch.bfloat16
+                gx = torch.empty_like(gp, dtype=torch.bfloat16 if out16 else torch.float32, memory_format=torch.preserve_format)
+                need_gb = pw_bwd and want_b
+                if need_gb:
+                    gb = torch.empty(16, device=gp.device, dtype=torch.float32)
+                    nb = L.lf_pw16_bwd_scratch_bytes(rows)
+                    scr = torch.empty(nb // 4 + 4, device=gp.device, dtype=torch.float32)
+                with _timed('pw16_bwd', f'{gp.shape[0]}:{out16}'):
+                    check(L.lf_pw16_bwd(_ptr(gp), _ptr(wtq), ctx.he, _ptr(gx), 1 if out16 else 0, _ptr(gb) if need_gb else None,
+                                        _ptr(scr, True) if need_gb else None, scr.numel() * 4 if need_gb else 0, rows, _stream()), 'lf_pw16_bwd')
+            elif ctx.needs_input_grad[0]:
                 pack_t = _pk(w, 'a3b', lambda t: pack_conv3d_c16_ring_bf16(w3(t), transpose=True))
                 if ctx.link is not None and gp.dtype == torch.bfloat16:
                     # this layer's data gradient + the PRODUCER's epilogue backward and bias sums in one launch: x_saved is the
