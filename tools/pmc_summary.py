@@ -60,13 +60,15 @@ TRAIN_KERNELS = collections.OrderedDict([
     ('lift_bwd_mfma_kernel', ('lift_bwd_mfma_kernel', V + 8 * 128 ** 2 * 33 * 4)),
     ('proj16_fwd_kernel', ('proj16_fwd_kernel', V // 2 + 8 * 128 ** 2 * 17 * 4)),
     ('proj16_bwd_kernel', ('proj16_bwd_kernel', V + 8 * 128 ** 2 * 16 * 4)),
+    ('pw16_fwd_kernel', ('pw16_fwd_kernel', V)),
+    ('pw16_bwd_kernel', ('pw16_bwd_kernel', V)),
 ])
 # hbm_probe.py launches the Winograd kernel REP times in its forward form, then REP times as a data gradient with the
 # producer's epilogue backward fused (reads the saved activation and norm as well): reported separately
 SPLIT = {'conv3d_c16_wino_kernel': (('forward form', 2 * 8 * 16 * 128 ** 3 * 4 + 8 * 128 ** 3 * 4),
                                     ('data-gradient form + fused previous-layer backward', 3 * 8 * 16 * 128 ** 3 * 4 + 8 * 128 ** 3 * 4))}
 SOURCES = ['conv_wino.hip', 'conv.hip', 'conv_split.hip', 'resample.hip', 'pointwise.hip', 'reduce.hip']
-TRAIN_SOURCES = ['conv_split.hip', 'wgrad.hip', 'resample.hip', 'pointwise.hip', 'gru.hip', 'conv_gru.hip', 'lift_mfma.hip', 'ring_tile.h']
+TRAIN_SOURCES = ['conv_split.hip', 'wgrad.hip', 'resample.hip', 'pointwise.hip', 'gru.hip', 'conv_gru.hip', 'lift_mfma.hip', 'ring_tile.h', 'pw16.hip']
 # --cfg3: the released architecture's kernels inside the cross_entropy_linemod loop (tools/pmc_collect_cfg3.sh over
 # tools/cfg3_probe.py; no calibration copy in that run: FETCH_SIZE x 2, WRITE_SIZE x 1 as calibrated in the other two)
 CFG3_KERNELS = collections.OrderedDict([

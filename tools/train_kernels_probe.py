@@ -104,4 +104,14 @@ for _ in range(REP):
     _lib.check(L.lf_proj16_bwd(gx.data_ptr(), x.data_ptr(), ptab_t.data_ptr(), o16.data_ptr(), gwp.data_ptr(), scr3.data_ptr(), scr3.numel() * 4,
                                N * S * S, S * S, S, 0.03, s), 'proj16 bwd')
 torch.cuda.synchronize()
+# round 6: pointwise 16 -> 16 layer (bf16 records in and out; the data gradient with the bias sums)
+wq = torch.randn(16, 16, generator=g).cuda().to(torch.bfloat16)
+bq = torch.randn(16, generator=g).cuda()
+gbq = torch.empty(16, device='cuda')
+scr4 = torch.empty(L.lf_pw16_bwd_scratch_bytes(N * S ** 3) // 4 + 4, device='cuda')
+for _ in range(REP):
+    _lib.check(L.lf_pw16_fwd(x.data_ptr(), 1, wq.data_ptr(), bq.data_ptr(), 0.35, 0, 0.2, o16.data_ptr(), N * S ** 3, s), 'pw16 fwd')
+    _lib.check(L.lf_pw16_bwd(x.data_ptr(), wq.data_ptr(), 0.35, o16.data_ptr(), 1, gbq.data_ptr(), scr4.data_ptr(), scr4.numel() * 4, N * S ** 3, s),
+               'pw16 bwd')
+torch.cuda.synchronize()
 print('ok')
