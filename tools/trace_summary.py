@@ -52,6 +52,13 @@ def main(path, out, marker=None):
                       f'{"kernel":100s} {"calls":>7s} {"total_us":>12s} {"pct_busy":>8s}']
             for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1]))[:30]:
                 lines.append(f'{k:100s} {len(v):7d} {sum(v):12.1f} {100 * sum(v) / busy:8.2f}')
+            # the same iteration in launch order: where the idle time between dispatches sits
+            lines += ['', '# the same iteration in launch order: start (us from the marker), duration, idle gap before the dispatch',
+                      f'{"start_us":>10s} {"dur_us":>9s} {"gap_us":>8s}  kernel']
+            t0, prev_end = it[0][1], it[0][1]
+            for n, s_, e_ in it:
+                lines.append(f'{(s_ - t0) / 1e3:10.1f} {(e_ - s_) / 1e3:9.1f} {max(0, s_ - prev_end) / 1e3:8.1f}  {short(n)}')
+                prev_end = max(prev_end, e_)
     open(out, 'w').write('\n'.join(lines) + '\n')
     print('\n'.join(lines[:40]))
 
