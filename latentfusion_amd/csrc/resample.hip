@@ -833,6 +833,51 @@ __device__ __forceinline__ SplatTap splat_eval(const float* __restrict__ cf, int
   return s;
 }
 
+// The same evaluation shared by the four lanes of a quad that work on ONE sample (the binned tile pass: a lane quad per list entry,
+// round 6): lane q < 3 evaluates axis q -- its numerator, for the projective axes the denominator and the division, the un-normalise /
+// clip / floor chain -- lane 3 repeats axis 2; three quad broadcasts (v_mov_b32 dpp quad_perm) per value hand every lane all three
+// axes.  Every operation an axis sees is the one splat_eval performs for it, in the same order, contraction off: the same bits, for
+// about 55 % of the instructions (the evaluation was a quarter of the tile pass, profiles/r06_splat_ab.txt).
+template <int CTRL>
+__device__ __forceinline__ int quad_bcast_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL>
+__device__ __forceinline__ float quad_bcast_f(float v) { return __int_as_float(quad_bcast_i<CTRL>(__float_as_int(v))); }
+
+template <int KIND>
+__device__ __forceinline__ SplatTap splat_eval_quad(const float* __restrict__ cf, int x, int y, int z, int W, int H, int D, Steps st, int q) {
+#pragma clang fp contract(off)
+  const float a = (x < W / 2) ? st.w * (float)x : 1.f - st.w * (float)(W - 1 - x);
+  const float b = (y < H / 2) ? st.h * (float)y : 1.f - st.h * (float)(H - 1 - y);
+  const float k = (z < D / 2) ? st.d * (float)z : 1.f - st.d * (float)(D - 1 - z);
+  const int c = q < 3 ? q : 2;                                     // this lane's axis
+  float g;
+  if (KIND == LF_MAP_O2C) {
+    const float ak = a * k, bk = b * k;
+    g = ((((cf[c] + cf[3 + c] * a) + cf[6 + c] * b) + cf[9 + c] * k) + cf[12 + c] * ak) + cf[15 + c] * bk;
+  } else {
+    const float lx = 2.f * a - 1.f, ly = 2.f * b - 1.f, lz = 2.f * k - 1.f;
+    const float num = ((cf[4 * c] * lx + cf[4 * c + 1] * ly) + cf[4 * c + 2] * lz) + cf[4 * c + 3];
+    const float dn = ((cf[12] * lx + cf[13] * ly) + cf[14] * lz) + cf[15];
+    g = c < 2 ? num / dn : num;
+  }
+  const int size = c == 0 ? W : (c == 1 ? H : D);
+  float p = ((g + 1.f) * (float)size - 1.f) * 0.5f;               // grid_sampler_unnormalize (align_corners=False)
+  p = fminf(fmaxf(p, 0.f), (float)(size - 1));                    // border clip
+  if (!(p == p)) p = 0.f;                                         // NaN samples voxel 0 (ATen clip semantics)
+  const float f = floorf(p);
+  const float tm = p - f;
+  const int i0m = (int)f;
+  const int i1m = min(i0m + 1, size - 1);
+  SplatTap s;
+  s.x0 = quad_bcast_i<0x00>(i0m); s.y0 = quad_bcast_i<0x55>(i0m); s.z0 = quad_bcast_i<0xaa>(i0m);
+  s.x1 = quad_bcast_i<0x00>(i1m); s.y1 = quad_bcast_i<0x55>(i1m); s.z1 = quad_bcast_i<0xaa>(i1m);
+  const float t0 = quad_bcast_f<0x00>(tm), t1 = quad_bcast_f<0x55>(tm), t2 = quad_bcast_f<0xaa>(tm);
+  const float wx[2] = {1.f - t0, t0}, wy[2] = {1.f - t1, t1}, wz[2] = {1.f - t2, t2};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s.w[i] = (wx[i & 1] * wy[(i >> 1) & 1]) * wz[i >> 2];
+  return s;
+}
+
 // ---- deterministic splat: the same scatter, accumulated in 64-bit fixed point ----------------------------------
 // Float atomics make the result depend on the order in which the hardware retires them.  Integer addition is
 // associative, so accumulating round(contribution * 2^K) with 64-bit integer atomics gives bit-identical results
@@ -1221,7 +1266,7 @@ __global__ void __launch_bounds__(SBT_THREADS) splat_binned_tile_kernel(const fl
       if (i + EPI < count) gnext = g_of(pk1);
       pk2 = i + 2 * EPI < count ? mine[i + 2 * EPI] : 0u;
       const int x = (int)(pk & 1023u), y = (int)((pk >> 10) & 1023u), z = (int)(pk >> 20);
-      const SplatTap t = splat_eval<KIND>(cf, x, y, z, W, H, D, st);
+      const SplatTap t = splat_eval_quad<KIND>(cf, x, y, z, W, H, D, st, q);   // (the quad's lanes are all live or all past the list's end)
       f32x4 g4;
       if constexpr ((IO & 1) != 0) g4 = __builtin_convertvector(graw, f32x4);
       else g4 = graw;
