@@ -346,7 +346,7 @@ def variants_report(a, dev):
     cfg['args']['num_samples'] = cfg['args']['ranking_size'] = N
     torch.manual_seed(300)
     init = pu.sample_cameras_with_estimate(N, target.camera.to('cpu'))
-    out = {'workload': f'SYN({S},{C}) renderer with seeded random weights, N = {N}, adam_quick, {K} timed iterations after 2 warm-up'}
+    out = {'workload': f'SYN({S},{C}) renderer with seeded random weights, N = {N}, adam_quick, median of 3 blocks of {K} timed iterations after 3 warm-up'}
     for name, kw in (('sum', dict(projection_type='sum', object_config=[], occlusion_config=False)),
                      ('occlusion', dict(projection_type='factor', object_config=[16, 16], occlusion_config=[[17, 16], [16, 16]]))):
         torch.manual_seed(1)
@@ -359,15 +359,18 @@ def variants_report(a, dev):
             photographer, device, input_size, camera_dist = ph, torch.device(dev), S, cdist
         est = estimation.load_from_config(cfg, M, converge_patience=10 ** 6)
         st = est.start(z_obj, target, init.zoom(None, S, cdist).to(dev))
-        for _ in range(2):
+        for _ in range(3):
             est.iterate(st)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(K):
-            est.iterate(st)
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t0
-        out[name] = {'iters_per_s': K / el, 'ms_per_iteration': el / K * 1e3, 'on_engine': 'engine' in st,
+        els = []
+        for _blk in range(3):                                         # median of three blocks of K iterations
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(K):
+                est.iterate(st)
+            torch.cuda.synchronize()
+            els.append(time.perf_counter() - t0)
+        el = sorted(els)[1]
+        out[name] = {'iters_per_s': K / el, 'ms_per_iteration': el / K * 1e3, 'blocks_ms': [e / K * 1e3 for e in els], 'on_engine': 'engine' in st,
                      'explicit_occlusion_kernels': bool(getattr(st.get('engine'), 'occ', None) is not None)}
         del est, st, ph
         torch.cuda.empty_cache()
