@@ -85,6 +85,9 @@ def parse(argv=None):
     ap.add_argument('--no-cfg5', action='store_true',
                     help='skip the secondary cfg 5 block (one bf16-autocast generator training step, 32 + 8 views, SYN(128,16))')
     ap.add_argument('--cfg5-steps', type=int, default=5)
+    ap.add_argument('--no-live-pmc', action='store_true',
+                    help='do not run the two rocprofv3 counter passes for `roofline.traffic` (tools/pmc_live.py, ~10 s at N = 1); the '
+                         'committed profiles/r*_hbm_bytes.json is replayed instead')
     ap.add_argument('--no-variants', action='store_true',
                     help="skip the secondary block with the 'sum' and occlusion renderer variants on the engine")
     ap.add_argument('--launcher-selftest', action='store_true',
@@ -820,12 +823,25 @@ def main():
                 continue
         return None, None
     traffic, traffic_src = pmc_traffic(kname)
+    traffic_live = None
+    if world == 1 and not a.no_live_pmc and wino and S == 128 and C == 16 and N == 8:
+        # measured now, on this box: two counter passes over the same kernel at the same shape in a child process (the bench is idle
+        # meanwhile); the committed file is the fallback
+        try:
+            sys.path.insert(0, os.path.join(ROOT, 'tools'))
+            import pmc_live
+            torch.cuda.synchronize()
+            traffic_live = pmc_live.wino_traffic_live()
+        except Exception:                                           # noqa: BLE001
+            traffic_live = None
+        if traffic_live is not None:
+            traffic, traffic_src = traffic_live['forward_form_bytes_per_launch'], 'live: rocprofv3 --pmc passes inside this run (tools/pmc_live.py)'
     if alt is not None and 'roofline' in alt:
         alt['roofline']['traffic'], alt['roofline']['traffic_source'] = pmc_traffic('conv3d_c16_f16x3_kernel')
     roofline = {
         'bound': 'mfma', 'kernel': kname + ' (fused conv3d 16->16 + He + bias + LeakyReLU + PixelNorm; forward and data-gradient forms)',
         'achieved': exec_tflops, 'peak': peak, 'unit': 'TFLOP/s', 'frac': exec_tflops / peak,
-        'traffic': traffic, 'traffic_source': traffic_src,
+        'traffic': traffic, 'traffic_source': traffic_src, 'traffic_live': traffic_live,
         'avg_launch_ms': conv_ms, 'launches_timed': conv_launches, 'floor_ms': floor_ms, 'floor_over_measured': floor_ms / conv_ms if conv_ms else 0.0,
         'executed_flops_per_launch': exec_flops, 'algorithmic_flops_per_launch': alg_flops,
         'algorithmic_bytes_per_launch': alg_bytes, 'hbm_achieved_GBps': hbm_gbs, 'hbm_frac': hbm_gbs / HBM_PEAK_GBS,

@@ -7,7 +7,7 @@ O=$R/gpurun_out/r06
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_b /tmp/prof_t /tmp/prof_c
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b -o bench -- python $R/bench.py --no-cpu-baseline --no-cfg3 --no-cfg5 --no-alt --no-variants --repeats 5 > $O/stats_bench_line.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b -o bench -- python $R/bench.py --no-cpu-baseline --no-cfg3 --no-cfg5 --no-alt --no-variants --no-live-pmc --repeats 5 > $O/stats_bench_line.txt 2>&1
 f=$(find /tmp/prof_b -name "*kernel_trace.csv" | head -1)
 python $R/tools/trace_summary.py $f $O/r06_kernel_stats.txt adam_step > /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_t -o train -- python $R/tools/train_probe.py --views-in 32 --views-out 8 --amp --steps 3 > $O/stats_train_line.txt 2>&1
