@@ -509,9 +509,21 @@ def cfg5_report(a, dev):
                     break
             except Exception:                                       # noqa: BLE001
                 continue
+        tr_live = None
+        if pmc_key == 'ring_multi_block' and not getattr(a, 'no_live_pmc', False) and int(os.environ.get('WORLD_SIZE', '1')) == 1:
+            try:                                                      # measured now, on this box (tools/pmc_live.py); the file above is the fallback
+                sys.path.insert(0, os.path.join(ROOT, 'tools'))
+                import pmc_live
+                torch.cuda.synchronize()
+                tr_live = pmc_live.ring_block_traffic_live()
+            except Exception:                                       # noqa: BLE001
+                tr_live = None
+            if tr_live is not None:
+                tr = tr_live['bytes_per_launch_of_8_volumes'] / 8.0 * int(key.split('N=')[1])
+                trs = 'live: rocprofv3 --pmc passes inside this run (tools/pmc_live.py), 8-volume launch scaled to this launch'
         out['roofline'] = {'bound': 'hbm', 'kernel': f'bf16 ring convolution 16 -> 16, dominant form of the step: {key}',
                            'achieved': t_['algorithmic_bytes_per_launch'] / (t_['avg_launch_ms'] * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS,
-                           'unit': 'GB/s', 'frac': t_['hbm_frac'], 'traffic': tr, 'traffic_source': trs,
+                           'unit': 'GB/s', 'frac': t_['hbm_frac'], 'traffic': tr, 'traffic_source': trs, 'traffic_live': tr_live,
                            'avg_launch_ms': t_['avg_launch_ms'], 'launches_timed': t_['launches'],
                            'algorithmic_bytes_per_launch': t_['algorithmic_bytes_per_launch'],
                            'share_of_step': t_['total_ms'] / ms}

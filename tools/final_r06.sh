@@ -23,9 +23,11 @@ bash tools/occ_profile.sh r06 > $O/log_occ.txt 2>&1
 cd $R
 bash tools/pmc_collect.sh r06_pmc > $O/log_pmc1.txt 2>&1
 bash tools/pmc_collect_train.sh r06_pmc_train > $O/log_pmc2.txt 2>&1
-find gpurun_out/r06_pmc gpurun_out/r06_pmc_train -name "*_kernel_trace.csv" ! -name "trace_*" -delete
+bash tools/pmc_collect_cfg3.sh r06_pmc_cfg3 > $O/log_pmc3.txt 2>&1
+find gpurun_out/r06_pmc gpurun_out/r06_pmc_train gpurun_out/r06_pmc_cfg3 -name "*_kernel_trace.csv" ! -name "trace_*" -delete
 python tools/pmc_summary.py gpurun_out/r06_pmc $O/r06 > /dev/null 2>&1
 python tools/pmc_summary.py --train gpurun_out/r06_pmc_train $O/r06_train > /dev/null 2>&1
-rm -rf gpurun_out/r06_pmc gpurun_out/r06_pmc_train
+python tools/pmc_summary.py --cfg3 gpurun_out/r06_pmc_cfg3 $O/r06_released_arch > /dev/null 2>&1
+rm -rf gpurun_out/r06_pmc gpurun_out/r06_pmc_train gpurun_out/r06_pmc_cfg3
 ls -la $O | tail -20
 tail -2 $O/stats_train_line.txt | cut -c1-300
