@@ -60,8 +60,21 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) wino_fus
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = w / WN, wc = w % WN;
   const int lr = lane & 15, kg = lane >> 4;
-  const long m0 = (long)blockIdx.x * MTc;                        // first tile of this workgroup
-  const int n0 = blockIdx.y * NTc;                               // first output channel
+  // (round 6) XCD-aware order: the workgroups of ONE tile block -- one per output-channel block, all reading the same slice of V --
+  // are dispatched x-fastest, i.e. gridDim.x dispatches apart, and each re-read V from HBM (9.8 GB per 128-render launch of the
+  // released architecture against 4.8 GB of V + y).  Dispatch L goes to XCD L % 8: re-numbered so that the channel blocks of a tile
+  // block follow each other ON ONE XCD, they stream V through that XCD's L2 together.
+  int bxi = blockIdx.x, byi = blockIdx.y;
+#ifndef WF_XCD
+#define WF_XCD 1
+#endif
+  if (WF_XCD && gridDim.y > 1 && (gridDim.x & 7) == 0) {
+    const unsigned L = blockIdx.x + gridDim.x * blockIdx.y, slot = L >> 3;
+    byi = (int)(slot % gridDim.y);
+    bxi = (int)((slot / gridDim.y) * 8 + (L & 7));
+  }
+  const long m0 = (long)bxi * MTc;                               // first tile of this workgroup
+  const int n0 = byi * NTc;                                      // first output channel
 
   // ---- global -> LDS staging by LDS-DMA (buffer_load_dwordx4 ... lds): a wave-instruction deposits 64 x 16 B = 1 KiB
   // linearly at a wave-uniform LDS address, so the swizzle is applied on the GLOBAL side: the lane that lands on

@@ -15,5 +15,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
+if os.environ.get('LF_HIP_LIB'):                                    # A/B of two BUILDS of the library (tool only)
+    from latentfusion_amd import _lib
+    _lib.LIB_PATH = os.environ['LF_HIP_LIB']
+
 a = argparse.Namespace(cfg3_iters=int(sys.argv[1]) if len(sys.argv) > 1 else 10)
 print(json.dumps(bench.cfg3_report(a, 'cuda:0')))
