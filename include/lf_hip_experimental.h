@@ -23,7 +23,8 @@ extern "C" {
  * shape of lf_wino_fused_gemm (output channels x Winograd tiles): 0 = 64 x 64, 1 = 128 x 64, 2 = 64 x 128, 3 = 128 x 128,
  * 4 = 64 x 256 (3, 4: 2-D only), -1 = chosen from the problem shape (default).  key 4: lf_resample3d_bwd_vol_det, 1 = global
  * 64-bit atomics, 2 = source tiles accumulated in LDS (default; C == 16; bit-identical results; lf_resample3d_bwd_vol_det_io bins
- * the output voxels per tile when every sample has its own volume), 3 = as 2 without the binned form.  key 5: resident workgroups
+ * the output voxels per tile when every sample has its own volume), 3 = as 2 without the binned form, 4 = as 2 with the tile pass that
+ * gives a list entry 16 lanes instead of a lane quad (round-6 A/B: slower, profiles/r06_splat_ab.txt).  key 5: resident workgroups
  * per CU of lf_conv3d_c16_ring_bf16, 2 (default) or 3.  key 6: samples per pass of the binned splat at most (0 = default: as many
  * as 512 MB of lists hold; tests use 1 or 2 to walk the multi-pass path at small sizes).
  * Returns the previous value or LF_EINVAL. */
