@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'tools'))
 
 
-def wino_traffic_live(timeout=180, rep=2):
+def wino_traffic_live(timeout=60, rep=2):
     exe = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
     if exe is None:
         return None
@@ -60,7 +60,7 @@ def wino_traffic_live(timeout=180, rep=2):
         shutil.rmtree(wd, ignore_errors=True)
 
 
-def ring_block_traffic_live(timeout=180, rep=2):
+def ring_block_traffic_live(timeout=60, rep=2):
     """The same for the cfg 5 block's dominant kernel: the Block step of the bf16 ring convolution on 8 volumes (tools/pmc_live_probe_train.py).
     Returns bytes per launch OF 8 VOLUMES."""
     exe = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
