@@ -699,3 +699,23 @@ def test_diag_gmm_is_sklearns_algorithm():
     import pytest
     with pytest.raises(ValueError):
         DiagGMM(6).fit(X[:3])
+
+
+def test_wino_fused_xcd_order_is_a_permutation():
+    """csrc/wino_fused.hip re-numbers its workgroups so that the output-channel blocks of one tile block run side by side on one
+    XCD (dispatch L lands on XCD L mod 8): the same arithmetic here must visit every (tile block, channel block) exactly once, keep
+    a tile block's channel blocks on ONE XCD and put them next to each other in that XCD's dispatch order."""
+    for gx, gy in ((8, 2), (512, 2), (64, 4), (24, 3), (16, 16)):
+        seen, xcd_of, order = set(), {}, {}
+        for by in range(gy):
+            for bx in range(gx):
+                L = bx + gx * by                                     # hardware dispatch order: x fastest
+                slot = L >> 3
+                byi, bxi = slot % gy, (slot // gy) * 8 + (L & 7)
+                assert 0 <= bxi < gx and 0 <= byi < gy
+                seen.add((bxi, byi))
+                xcd_of.setdefault(bxi, set()).add(L & 7)
+                order.setdefault(bxi, []).append(slot)
+        assert len(seen) == gx * gy
+        assert all(len(v) == 1 for v in xcd_of.values())
+        assert all(max(v) - min(v) == gy - 1 for v in order.values())   # consecutive slots of that XCD
